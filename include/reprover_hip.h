@@ -1,0 +1,185 @@
+/*
+ * reprover_hip.h — C ABI of libreprover_hip.so, the MI355X (gfx950) premise-retrieval engine.
+ *
+ * Drop-in boundary for the hot path of lean-dojo/ReProver named by BASELINE.json:north_star:
+ *   retrieval/model.py::PremiseRetriever (_encode :92-114, reindex_corpus :183-210,
+ *   retrieve :338-375, predict hooks :274-336), common.py::Corpus.get_nearest_premises :299-326,
+ *   retrieval/index.py :13-41.
+ * The reference has no native code and no FFI of its own: it calls HuggingFace `transformers`
+ * (T5EncoderModel) and torch ops from Python.  These entry points are what a ctypes/cffi stub
+ * on the reference side binds instead (INTEGRATION.md shows the stub); the Python package
+ * `reprover_amd` is exactly such a stub plus the host-side mirror of the reference classes.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, POD structs; no torch / HIP C++ types.  `stream` is a
+ *     hipStream_t passed as void* (NULL = the legacy default stream).
+ *   - every pointer documented "device" must be a HIP device pointer valid on the current device.
+ *   - every call returns an RpStatus (0 = OK, < 0 = error); rp_last_error() gives the message
+ *     of the last failing call on the calling thread.
+ *   - launches are asynchronous on `stream`; no call synchronises the device unless documented.
+ *   - no hidden allocations after rp_encoder_create(); scratch comes from caller workspaces sized
+ *     by the matching *_workspace_bytes() function.
+ */
+#ifndef REPROVER_HIP_H
+#define REPROVER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t RpStatus;
+enum {
+  RP_OK = 0,
+  RP_E_INVALID = -1,      /* bad argument / unsupported shape                                   */
+  RP_E_HIP = -2,          /* a HIP runtime call failed                                          */
+  RP_E_WORKSPACE = -3,    /* caller workspace too small                                         */
+  RP_E_UNSUPPORTED = -4   /* model configuration outside what the kernels implement             */
+};
+
+enum { RP_DT_F32 = 0, RP_DT_BF16 = 1 };
+
+/* ABI / build identification; bumps when a signature changes. */
+int32_t rp_abi_version(void);
+/* Message of the last error returned on this thread ("" if none). */
+const char* rp_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Encoder: T5EncoderModel forward + masked mean-pool + L2 normalise
+ *   replaces retrieval/model.py:92-114 (_encode) and, beneath it, transformers
+ *   models/t5/modeling_t5.py T5Stack.forward :663-750 (what model.py:44-45,101-105 invoke).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct RpT5Config {
+  int32_t vocab_size;      /* rows of the embedding table (384 for ByT5)                        */
+  int32_t d_model;         /* 1472 (small) / 1536 (base); must be a multiple of 32              */
+  int32_t d_kv;            /* per-head width; kernels implement 64                              */
+  int32_t num_heads;       /* 6 / 12                                                            */
+  int32_t d_ff;            /* 3584 / 3968; multiple of 32; feed_forward_proj = gated-gelu       */
+  int32_t num_layers;      /* 12 / 18                                                           */
+  int32_t rel_num_buckets; /* 32                                                                */
+  int32_t rel_max_distance;/* 128                                                               */
+  float   layer_norm_eps;  /* 1e-6                                                              */
+} RpT5Config;
+
+/* Weights in HuggingFace layout (nn.Linear = [out, in] row-major), all device pointers of dtype
+ * `weight_dtype` (RP_DT_F32 or RP_DT_BF16); key names: SURVEY.md App. B.5.  The engine packs its
+ * own bf16 copies (fused QKV, gate/up-interleaved wi, padded) at create time; the caller may free
+ * the originals afterwards. */
+typedef struct RpT5LayerWeights {
+  const void* ln_attn;   /* encoder.block.i.layer.0.layer_norm.weight          [d_model]         */
+  const void* q;         /* ...layer.0.SelfAttention.q.weight                  [H*d_kv, d_model] */
+  const void* k;         /* ...k.weight                                        [H*d_kv, d_model] */
+  const void* v;         /* ...v.weight                                        [H*d_kv, d_model] */
+  const void* o;         /* ...o.weight                                        [d_model, H*d_kv] */
+  const void* ln_ff;     /* ...layer.1.layer_norm.weight                       [d_model]         */
+  const void* wi_0;      /* ...layer.1.DenseReluDense.wi_0.weight              [d_ff, d_model]   */
+  const void* wi_1;      /* ...wi_1.weight                                     [d_ff, d_model]   */
+  const void* wo;        /* ...wo.weight                                       [d_model, d_ff]   */
+} RpT5LayerWeights;
+
+typedef struct RpT5Weights {
+  const void* embed;            /* shared.weight                               [vocab, d_model]  */
+  const void* rel_bias;         /* block.0 relative_attention_bias.weight      [buckets, H]      */
+  const void* final_ln;         /* encoder.final_layer_norm.weight             [d_model]         */
+  const RpT5LayerWeights* layers; /* host array of num_layers entries                           */
+} RpT5Weights;
+
+typedef struct RpEncoder RpEncoder;
+
+/* Allocates and packs device weights (synchronises the device once). */
+RpStatus rp_encoder_create(const RpT5Config* cfg, const RpT5Weights* weights, int32_t weight_dtype,
+                           RpEncoder** out);
+void     rp_encoder_destroy(RpEncoder* enc);
+
+/* Scratch needed by rp_encode_varlen for `total_tokens` packed tokens in `batch` sequences. */
+size_t   rp_encoder_workspace_bytes(const RpEncoder* enc, int32_t total_tokens, int32_t batch);
+
+/* Encode `batch` sequences given as packed token ids (varlen, no padding):
+ *   ids        device int32 [total_tokens]  — ByT5 ids (byte+3, EOS=1 last), sequence b occupies
+ *                                             [cu_seqlens[b], cu_seqlens[b+1])
+ *   cu_seqlens device int32 [batch+1], cu_seqlens[0] = 0, cu_seqlens[batch] = total_tokens
+ *   max_len    longest sequence (host value; sizes the attention grid)
+ *   out        device [batch, d_model] of out_dtype (RP_DT_F32 / RP_DT_BF16): unit-norm rows,
+ *              = F.normalize(masked_mean(last_hidden_state))  (model.py:108-114)
+ * Equivalent to PremiseRetriever._encode(input_ids, attention_mask) with right-padded inputs:
+ * padding never influences a row, so it is not materialised. */
+RpStatus rp_encode_varlen(RpEncoder* enc, const int32_t* ids, const int32_t* cu_seqlens,
+                          int32_t batch, int32_t total_tokens, int32_t max_len,
+                          void* out, int32_t out_dtype,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* Host-only helper, exact restatement of T5Attention._relative_position_bucket (bidirectional)
+ * — modeling_t5.py:216-262; exported so the bucket table can be checked without a GPU. */
+int32_t  rp_relative_position_bucket(int32_t relative_position, int32_t num_buckets,
+                                     int32_t max_distance);
+
+/* ---------------------------------------------------------------------------------------------
+ * Retrieval: similarity GEMM + accessibility mask + exact top-k
+ *   replaces common.py:299-326 (Corpus.get_nearest_premises): `Q @ E.T`, full argsort, and the
+ *   per-query Python walk over accessible premises.
+ *
+ * Accessibility in array form (common.py:280-289; derivation SURVEY.md §8 a6'):
+ *   premise i is accessible to query j  iff
+ *       bit j of file_bits_t[file_of[i]]                       (file imported, transitively)
+ *    or (file_of[i] == own_file[j] and end_key[i] <= q_key[j]) (earlier in the same file)
+ *   with key = (line_nb << 20) | column_nb.  Passing file_of == NULL disables the mask.
+ * Ordering: (score descending, id ascending) — the reference's argsort leaves ties unspecified.
+ * ------------------------------------------------------------------------------------------- */
+enum { RP_TOPK_AUTO = 0, RP_TOPK_DENSE = 1 /* force the single-pass dense path */ };
+
+size_t   rp_sim_topk_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t k, int32_t flags);
+
+/*   Q            device bf16 [B, D]   query embeddings (unit norm)
+ *   E            device bf16 [N, D]   this rank's rows of the premise-embedding matrix
+ *   file_of      device int32 [N]     file index of each premise           (NULL = no mask)
+ *   end_key      device int64 [N]     end position key of each premise
+ *   file_bits_t  device uint32 [F, ceil(B/32)]  bit j of row f = query j may use file f
+ *   own_file     device int32 [B];  q_key device int64 [B]
+ *   id_offset    added to local row numbers to form the ids written (row-sharded corpus)
+ *   out_scores   device f32 [B, k];  out_ids device int32 [B, k]  (rows sorted best-first;
+ *                entries past out_count[j] are -inf / -1)
+ *   out_count    device int32 [B]: min(k, #accessible premises on this rank); the caller maps
+ *                a global count < k to the reference's ValueError (common.py:323-324).
+ *                -1 = internal candidate overflow: call again with RP_TOPK_DENSE.          */
+RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t N, int32_t D,
+                     const int32_t* file_of, const int64_t* end_key,
+                     const uint32_t* file_bits_t, int32_t F,
+                     const int32_t* own_file, const int64_t* q_key,
+                     int32_t id_offset, int32_t k, int32_t flags,
+                     float* out_scores, int32_t* out_ids, int32_t* out_count,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Merge R per-rank results (as gathered by an RCCL all-gather) into the global top-k.
+ *   scores device f32 [R, B, k], ids device int32 [R, B, k], counts device int32 [R, B]
+ *   workspace: rp_topk_merge_workspace_bytes(R, B, k) bytes.                                   */
+size_t   rp_topk_merge_workspace_bytes(int32_t R, int32_t B, int32_t k);
+RpStatus rp_topk_merge(const float* scores, const int32_t* ids, const int32_t* counts,
+                       int32_t R, int32_t B, int32_t k,
+                       float* out_scores, int32_t* out_ids, int32_t* out_count,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Kernel-level entry points used by the parity tests (tests/test_kernels_gpu.py) to check each
+ * HIP kernel against the oracle in isolation.  Same conventions as above.
+ * ------------------------------------------------------------------------------------------- */
+enum { RP_EPI_STORE_BF16 = 0, RP_EPI_RESID_F32 = 1, RP_EPI_GEGLU_BF16 = 2 };
+/* C = A[M,K] (bf16) x W[N,K]^T (bf16); M, N multiples of 128 (N may exceed n_valid: only the
+ * first n_valid columns are written), K multiple of 32.
+ *   STORE_BF16: out bf16 [M, n_valid]           RESID_F32: out f32 [M, n_valid] += C
+ *   GEGLU_BF16: W rows interleaved 32 gate / 32 up; out bf16 [M, n_valid/2] = gelu_new(g)*u  */
+RpStatus rp_dbg_gemm(const void* A, const void* W, void* out, int32_t M, int32_t N, int32_t K,
+                     int32_t n_valid, int32_t epilogue, void* stream);
+RpStatus rp_dbg_rmsnorm(const float* x, const float* w, void* out_bf16, int32_t rows, int32_t D,
+                        float eps, void* stream);
+RpStatus rp_dbg_attention(const void* qkv_bf16, const int32_t* cu_seqlens, const float* bias_tab,
+                          void* out_bf16, int32_t batch, int32_t max_len, int32_t num_heads,
+                          int32_t rows_total, void* stream);
+/* Tuning knobs (integers), e.g. "gemm_variant"; returns RP_E_INVALID for unknown names. */
+RpStatus rp_set_option(const char* name, int32_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REPROVER_HIP_H */

@@ -1,0 +1,135 @@
+"""ctypes binding of libreprover_hip.so (include/reprover_hip.h).
+
+This is the reference-side FFI stub: tensors are passed as raw device
+pointers (``tensor.data_ptr()``) plus sizes; the current torch HIP stream is passed as
+``void*``.  There is no CPU fallback: if the library is missing or a call fails, an exception
+is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libreprover_hip.so")
+
+RP_OK = 0
+RP_DT_F32, RP_DT_BF16 = 0, 1
+RP_TOPK_AUTO, RP_TOPK_DENSE = 0, 1
+RP_EPI_STORE_BF16, RP_EPI_RESID_F32, RP_EPI_GEGLU_BF16 = 0, 1, 2
+ABI_VERSION = 1
+
+
+class RpT5Config(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_int32),
+        ("d_model", C.c_int32),
+        ("d_kv", C.c_int32),
+        ("num_heads", C.c_int32),
+        ("d_ff", C.c_int32),
+        ("num_layers", C.c_int32),
+        ("rel_num_buckets", C.c_int32),
+        ("rel_max_distance", C.c_int32),
+        ("layer_norm_eps", C.c_float),
+    ]
+
+
+class RpT5LayerWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln_attn", "q", "k", "v", "o", "ln_ff", "wi_0", "wi_1", "wo")]
+
+
+class RpT5Weights(C.Structure):
+    _fields_ = [
+        ("embed", C.c_void_p),
+        ("rel_bias", C.c_void_p),
+        ("final_ln", C.c_void_p),
+        ("layers", C.POINTER(RpT5LayerWeights)),
+    ]
+
+
+class HipLibraryError(RuntimeError):
+    """A libreprover_hip call returned a non-zero status."""
+
+
+# name -> (restype, argtypes); every symbol declared in include/reprover_hip.h
+SIGNATURES = {
+    "rp_abi_version": (C.c_int32, []),
+    "rp_last_error": (C.c_char_p, []),
+    "rp_encoder_create": (C.c_int32, [C.POINTER(RpT5Config), C.POINTER(RpT5Weights), C.c_int32, C.POINTER(C.c_void_p)]),
+    "rp_encoder_destroy": (None, [C.c_void_p]),
+    "rp_encoder_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
+    "rp_encode_varlen": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+         C.c_size_t, C.c_void_p],
+    ),
+    "rp_relative_position_bucket": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
+    "rp_sim_topk_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "rp_sim_topk": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+         C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+         C.c_size_t, C.c_void_p],
+    ),
+    "rp_topk_merge_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "rp_topk_merge": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+         C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
+    "rp_dbg_gemm": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
+    ),
+    "rp_dbg_rmsnorm": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "rp_dbg_attention": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
+    ),
+    "rp_set_option": (C.c_int32, [C.c_char_p, C.c_int32]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the engine (once).  Raises if it has not been built — never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m reprover_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the retrieval path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.rp_abi_version()
+    if got != ABI_VERSION:
+        raise HipLibraryError(f"libreprover_hip ABI {got} != binding {ABI_VERSION}; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != RP_OK:
+        msg = load().rp_last_error().decode(errors="replace")
+        raise HipLibraryError(f"{what} failed with status {status}: {msg}")
+
+
+def ptr(t) -> Optional[int]:
+    """Device pointer of a torch tensor (None passes NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "libreprover_hip takes contiguous device tensors"
+    return t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

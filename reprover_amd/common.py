@@ -1,0 +1,459 @@
+"""Host-side corpus data model of the retrieval path, MI355X-native.
+
+Mirrors the interface of the reference's ``common.py`` (lean-dojo/ReProver) for the classes the
+retrieval hot path touches — ``Pos``, ``Context``, ``Premise``, ``File``, ``Corpus``,
+``IndexedCorpus`` — with the same names, argument meaning and error behaviour, but a different
+representation underneath:
+
+  * the import DAG's transitive closure is a packed bit matrix built in one topological sweep
+    (the reference uses ``networkx.transitive_closure_dag``, common.py:215);
+  * accessibility (common.py:280-289) is kept in array form — ``file_of[i]``, ``end_key[i]`` per
+    premise and one bit per (file, query) — which is what the HIP scan kernel consumes, so the
+    per-query Python ``PremiseSet`` walk of common.py:312-324 never happens;
+  * ``get_nearest_premises`` (common.py:299-326) runs on the GPU through ``rp_sim_topk``.
+"""
+from __future__ import annotations
+
+import json
+import re
+from dataclasses import dataclass, field
+from typing import Any, Dict, Generator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+MARK_START_SYMBOL = "<a>"  # common.py:25
+MARK_END_SYMBOL = "</a>"  # common.py:26
+
+POS_COL_BITS = 20  # key = (line_nb << 20) | column_nb, monotone in the lexicographic Pos order
+
+
+def remove_marks(s: str) -> str:
+    """common.py:29-31."""
+    return s.replace(MARK_START_SYMBOL, "").replace(MARK_END_SYMBOL, "")
+
+
+class Pos(tuple):
+    """Stand-in for ``lean_dojo.Pos`` (absent here): ``Pos(line_nb, column_nb)``, iterable,
+    hashable, totally ordered lexicographically."""
+
+    __slots__ = ()
+
+    def __new__(cls, line_nb: int, column_nb: int):
+        return super().__new__(cls, (int(line_nb), int(column_nb)))
+
+    @property
+    def line_nb(self) -> int:
+        return self[0]
+
+    @property
+    def column_nb(self) -> int:
+        return self[1]
+
+    def key(self) -> int:
+        assert 0 <= self[1] < (1 << POS_COL_BITS) and self[0] >= 0
+        return (self[0] << POS_COL_BITS) | self[1]
+
+    def __repr__(self) -> str:
+        return f"Pos(line_nb={self[0]}, column_nb={self[1]})"
+
+
+@dataclass(unsafe_hash=True)
+class Context:
+    """A retrieval query (common.py:34-56)."""
+
+    path: str
+    theorem_full_name: str
+    theorem_pos: Pos = field(compare=False)
+    state: str
+
+    def __post_init__(self) -> None:
+        assert isinstance(self.path, str)
+        assert isinstance(self.theorem_full_name, str)
+        assert isinstance(self.theorem_pos, Pos)
+        assert (
+            isinstance(self.state, str)
+            and "⊢" in self.state
+            and MARK_START_SYMBOL not in self.state
+            and MARK_END_SYMBOL not in self.state
+        )
+
+    def serialize(self) -> str:
+        return self.state
+
+
+_WS_LOOKBEHIND = r"(?<=\s)«?"
+
+
+@dataclass(unsafe_hash=True)
+class Premise:
+    """A retrievable document (common.py:59-106)."""
+
+    path: str
+    full_name: str
+    start: Pos = field(repr=False)
+    end: Pos = field(repr=False, compare=False)
+    code: str = field(compare=False)
+
+    def __post_init__(self) -> None:
+        assert isinstance(self.path, str)
+        assert isinstance(self.full_name, str)
+        assert isinstance(self.start, Pos) and isinstance(self.end, Pos) and self.start <= self.end
+        assert isinstance(self.code, str) and self.code != ""
+
+    def serialize(self) -> str:
+        """Text fed to the encoder: the code with the premise's own name wrapped in <a>…</a>
+        (byte-identical to common.py:93-106, fixture tests/golden/g2_serialize.json)."""
+        tagged = MARK_START_SYMBOL + self.full_name + MARK_END_SYMBOL
+        code = self.code.replace("_root_." + self.full_name, tagged)
+        name = self.full_name
+        while True:
+            # the reference interpolates the (unescaped) dotted suffix into the pattern
+            out = re.sub(_WS_LOOKBEHIND + name + "»?", tagged, code)
+            if out != code:
+                return out
+            dot = name.find(".")
+            if dot < 0:
+                return code
+            name = name[dot + 1 :]
+
+
+class PremiseSet:
+    """Premises indexed by (path, full_name) (common.py:109-138)."""
+
+    def __init__(self) -> None:
+        self.path2premises: Dict[str, Dict[str, Premise]] = {}
+
+    def __iter__(self) -> Generator[Premise, None, None]:
+        for group in self.path2premises.values():
+            yield from group.values()
+
+    def add(self, p: Premise) -> None:
+        self.path2premises.setdefault(p.path, {})[p.full_name] = p
+
+    def update(self, premises: Sequence[Premise]) -> None:
+        for p in premises:
+            self.add(p)
+
+    def __contains__(self, p: Premise) -> bool:
+        return p.full_name in self.path2premises.get(p.path, ())
+
+    def __len__(self) -> int:
+        return sum(len(g) for g in self.path2premises.values())
+
+
+@dataclass(frozen=True)
+class File:
+    """A Lean file and the premises it defines (common.py:141-178)."""
+
+    path: str
+    premises: List[Premise] = field(repr=False, compare=False)
+
+    @classmethod
+    def from_data(cls, file_data: Dict[str, Any]) -> "File":
+        path = file_data["path"]
+        kept = []
+        for rec in file_data["premises"]:
+            name = rec["full_name"]
+            if name is None or "user__.n" in name or rec["code"] == "":
+                continue  # ill-formed (common.py:160-164)
+            if name.startswith("[") and name.endswith("]"):
+                continue  # mutual definitions (common.py:165-167)
+            kept.append(Premise(path, name, Pos(*rec["start"]), Pos(*rec["end"]), rec["code"]))
+        return cls(path, kept)
+
+    @property
+    def is_empty(self) -> bool:
+        return self.premises == []
+
+
+class Corpus:
+    """The retrieval corpus: a DAG of files whose premises can be retrieved (common.py:181-326)."""
+
+    all_premises: List[Premise]
+
+    def __init__(self, jsonl_path: str) -> None:
+        self._files: List[File] = []
+        self._index: Dict[str, int] = {}
+        direct: List[List[int]] = []
+        self.all_premises = []
+        with open(jsonl_path) as fh:
+            for line in fh:
+                data = json.loads(line)
+                path = data["path"]
+                assert path not in self._index  # common.py:204
+                f = File.from_data(data)
+                deps = []
+                for imp in data["imports"]:
+                    assert imp in self._index  # imports must precede importers (common.py:211)
+                    deps.append(self._index[imp])
+                self._index[path] = len(self._files)
+                self._files.append(f)
+                direct.append(deps)
+                self.all_premises.extend(f.premises)
+        self._build_arrays(direct)
+
+    # -- array form -----------------------------------------------------------------------------
+    def _build_arrays(self, direct: List[List[int]]) -> None:
+        F = len(self._files)
+        W = (F + 63) // 64
+        reach = np.zeros((F, W), dtype=np.uint64)  # bit g of row f: f imports g (transitively)
+        for f, deps in enumerate(direct):  # files arrive in topological order
+            row = reach[f]
+            for g in deps:
+                row |= reach[g]
+                row[g >> 6] |= np.uint64(1) << np.uint64(g & 63)
+        self._reach = reach
+        N = len(self.all_premises)
+        self.file_of = np.zeros(N, dtype=np.int32)
+        self.end_key = np.zeros(N, dtype=np.int64)
+        self._file_start = np.zeros(F + 1, dtype=np.int64)
+        i = 0
+        for f, fl in enumerate(self._files):
+            self._file_start[f] = i
+            # PremiseSet membership is by (path, full_name): a later duplicate of a name is
+            # "accessible" as soon as ANY same-named premise of the file is (common.py:129-132),
+            # so each premise carries the smallest end key of its name group.
+            best: Dict[str, int] = {}
+            for p in fl.premises:
+                k = p.end.key()
+                if k < best.get(p.full_name, 1 << 62):
+                    best[p.full_name] = k
+            for p in fl.premises:
+                self.file_of[i] = f
+                self.end_key[i] = best[p.full_name]
+                i += 1
+        self._file_start[F] = i
+        self._dev: Dict[str, torch.Tensor] = {}
+
+    # -- reference interface --------------------------------------------------------------------
+    def _get_file(self, path: str) -> File:
+        return self._files[self._index[path]]
+
+    def __len__(self) -> int:
+        return len(self.all_premises)
+
+    def __contains__(self, path: str) -> bool:
+        return path in self._index
+
+    def __getitem__(self, idx: int) -> Premise:
+        return self.all_premises[idx]
+
+    @property
+    def files(self) -> List[File]:
+        return list(self._files)
+
+    @property
+    def num_files(self) -> int:
+        return len(self._files)
+
+    def _reach_ids(self, f: int) -> np.ndarray:
+        bits = np.unpackbits(self._reach[f].view(np.uint8), bitorder="little")[: len(self._files)]
+        return np.flatnonzero(bits)
+
+    def get_dependencies(self, path: str) -> List[str]:
+        """Direct and indirect imports of ``path`` (common.py:241-243)."""
+        return [self._files[g].path for g in self._reach_ids(self._index[path])]
+
+    def get_premises(self, path: str) -> List[Premise]:
+        return self._get_file(path).premises
+
+    def num_premises(self, path: str) -> int:
+        return len(self.get_premises(path))
+
+    def locate_premise(self, path: str, pos: Pos) -> Optional[Premise]:
+        """common.py:253-262."""
+        for p in self.get_premises(path):
+            if p.start <= pos <= p.end:
+                return p
+        return None
+
+    def _get_imported_premises(self, path: str) -> List[Premise]:
+        out: List[Premise] = []
+        for g in self._reach_ids(self._index[path]):
+            out.extend(self._files[g].premises)
+        return out
+
+    def get_accessible_premises(self, path: str, pos: Pos) -> PremiseSet:
+        """Premises of (transitively) imported files plus those ending at or before ``pos`` in
+        the same file (common.py:280-289)."""
+        s = PremiseSet()
+        for p in self.get_premises(path):
+            if p.end <= pos:
+                s.add(p)
+        s.update(self._get_imported_premises(path))
+        return s
+
+    def accessible_mask(self, path: str, pos: Pos) -> np.ndarray:
+        """bool [N]: the array form of ``p in get_accessible_premises(path, pos)``."""
+        f = self._index[path]
+        bits = np.unpackbits(self._reach[f].view(np.uint8), bitorder="little")[: len(self._files)].astype(bool)
+        return bits[self.file_of] | ((self.file_of == f) & (self.end_key <= pos.key()))
+
+    def get_accessible_premise_indexes(self, path: str, pos: Pos) -> List[int]:
+        """common.py:291-297 (index form: uses each premise's own end, not its name group's)."""
+        f = self._index[path]
+        reach = set(self._reach_ids(f).tolist())
+        return [
+            i
+            for i, p in enumerate(self.all_premises)
+            if (self.file_of[i] == f and p.end <= pos) or int(self.file_of[i]) in reach
+        ]
+
+    # -- GPU search ------------------------------------------------------------------------------
+    def query_masks(self, batch_context: Sequence[Context]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """Per-batch accessibility operands of ``rp_sim_topk``:
+        (file_bits_t uint32 [F, ceil(B/32)], own_file int32 [B], q_key int64 [B])."""
+        B, F = len(batch_context), len(self._files)
+        own = np.fromiter((self._index[c.path] for c in batch_context), dtype=np.int32, count=B)  # KeyError
+        qk = np.fromiter((c.theorem_pos.key() for c in batch_context), dtype=np.int64, count=B)
+        rows = np.unpackbits(self._reach[own].view(np.uint8), axis=1, bitorder="little")[:, :F]  # [B, F]
+        words = (B + 31) // 32
+        padded = np.zeros((F, words * 32), dtype=np.uint8)
+        padded[:, :B] = rows.T
+        bits_t = np.packbits(padded, axis=1, bitorder="little").view(np.uint32).reshape(F, words)
+        return np.ascontiguousarray(bits_t), own, qk
+
+    def _device_arrays(self, device: torch.device) -> Tuple[torch.Tensor, torch.Tensor]:
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (
+                torch.from_numpy(self.file_of).to(device),
+                torch.from_numpy(self.end_key).to(device),
+            )
+        return self._dev[key]
+
+    def nearest_premise_ids(
+        self,
+        premise_embeddings: torch.Tensor,
+        batch_context: Sequence[Context],
+        batch_context_emb: torch.Tensor,
+        k: int,
+        dense: bool = False,
+    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Device-side search: (ids int32 [B,k], scores f32 [B,k], counts int32 [B]) on the GPU."""
+        lib = _lib.load()
+        dev = batch_context_emb.device
+        if dev.type != "cuda":
+            raise _lib.HipLibraryError("nearest-premise search runs on the GPU only (no CPU fallback)")
+        E = as_bf16_matrix(premise_embeddings, dev)
+        Q = as_bf16_matrix(batch_context_emb, dev)
+        B, D = Q.shape
+        N = E.shape[0]
+        assert N == len(self.all_premises) and E.shape[1] == D
+        bits_t, own, qk = self.query_masks(batch_context)
+        file_of, end_key = self._device_arrays(dev)
+        d_bits = torch.from_numpy(bits_t.view(np.int32)).to(dev)
+        d_own = torch.from_numpy(own).to(dev)
+        d_qk = torch.from_numpy(qk).to(dev)
+        out_s = torch.empty((B, k), dtype=torch.float32, device=dev)
+        out_i = torch.empty((B, k), dtype=torch.int32, device=dev)
+        out_c = torch.empty((B,), dtype=torch.int32, device=dev)
+        flags = _lib.RP_TOPK_DENSE if dense else _lib.RP_TOPK_AUTO
+        ws_bytes = lib.rp_sim_topk_workspace_bytes(B, N, D, k, flags)
+        ws = _workspace(dev, ws_bytes)
+        _lib.check(
+            lib.rp_sim_topk(
+                _lib.ptr(Q), _lib.ptr(E), B, N, D, _lib.ptr(file_of), _lib.ptr(end_key), _lib.ptr(d_bits),
+                len(self._files), _lib.ptr(d_own), _lib.ptr(d_qk), 0, k, flags, _lib.ptr(out_s), _lib.ptr(out_i),
+                _lib.ptr(out_c), _lib.ptr(ws), ws_bytes, _lib.current_stream(),
+            ),
+            "rp_sim_topk",
+        )
+        return out_i, out_s, out_c
+
+    def get_nearest_premises(
+        self,
+        premise_embeddings: torch.Tensor,
+        batch_context: List[Context],
+        batch_context_emb: torch.Tensor,
+        k: int,
+    ) -> Tuple[List[List[Premise]], List[List[float]]]:
+        """Batch nearest-neighbour search restricted to accessible premises (common.py:299-326).
+        Raises ``ValueError`` when a query has fewer than ``k`` accessible premises, as the
+        reference does (common.py:323-324)."""
+        ids, scores, counts = self.nearest_premise_ids(premise_embeddings, batch_context, batch_context_emb, k)
+        counts_h = counts.cpu()
+        if bool((counts_h < 0).any()):  # candidate-list overflow: redo with the dense pass
+            ids, scores, counts = self.nearest_premise_ids(
+                premise_embeddings, batch_context, batch_context_emb, k, dense=True
+            )
+            counts_h = counts.cpu()
+        if bool((counts_h < k).any()):
+            raise ValueError
+        ids_h = ids.cpu().tolist()
+        scores_h = scores.cpu().tolist()
+        prem = self.all_premises
+        return [[prem[i] for i in row] for row in ids_h], scores_h
+
+
+_ws_cache: Dict[str, torch.Tensor] = {}
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """A grow-only scratch buffer per device (the C ABI never allocates after create)."""
+    key = str(device)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+_bf16_cache: Dict[Tuple[int, Tuple[int, ...], str], torch.Tensor] = {}
+
+
+def as_bf16_matrix(t: torch.Tensor, device: torch.device) -> torch.Tensor:
+    """Contiguous bf16 device view/copy of an embedding matrix; large conversions are cached by
+    storage so that ``retrieve`` does not re-cast the corpus every call (the reference caches
+    the cast in ``self.corpus_embeddings``, model.py:363-366)."""
+    if t.dtype == torch.bfloat16 and t.device == device and t.is_contiguous():
+        return t
+    if t.numel() < (1 << 20):
+        return t.to(device=device, dtype=torch.bfloat16).contiguous()
+    key = (t.data_ptr(), tuple(t.shape), str(t.dtype) + str(t.device) + str(t._version))
+    hit = _bf16_cache.get(key)
+    if hit is None:
+        _bf16_cache.clear()
+        hit = t.to(device=device, dtype=torch.bfloat16).contiguous()
+        _bf16_cache[key] = hit
+    return hit
+
+
+@dataclass(frozen=True)
+class IndexedCorpus:
+    """A corpus with its premise embeddings (common.py:329-338)."""
+
+    corpus: Corpus
+    embeddings: torch.Tensor
+
+    def __post_init__(self):
+        assert self.embeddings.device == torch.device("cpu")
+        assert len(self.embeddings) == len(self.corpus)
+
+
+def format_augmented_state(s: str, premises: List[Premise], max_len: Optional[int] = None, p_drop: float = 0.0) -> str:
+    """Byte-budgeted concatenation of retrieved premises in front of a state (common.py:357-378);
+    the caller-side consumer of ``retrieve`` (prover/tactic_generator.py:293-295)."""
+    import random
+
+    budget = (max_len if max_len is not None else 9999999999999999999999) - len(s.encode("utf-8"))
+    aug, used = "", 0
+    for p in premises:
+        if random.random() < p_drop:
+            continue
+        piece = f"{p.serialize()}\n\n"
+        n = len(piece.encode("utf-8"))
+        if used + n > budget:
+            continue
+        used += n
+        aug = piece + aug
+    return aug + s
+
+
+def zip_strict(*args):
+    """common.py:428-431."""
+    assert len(args) > 1 and all(len(args[0]) == len(a) for a in args[1:])
+    return zip(*args)

@@ -1,0 +1,745 @@
+// ByT5 / T5 encoder forward + masked mean-pool + L2 normalise on gfx950.
+//
+// Replaces (reference lean-dojo/ReProver) retrieval/model.py:92-114 `_encode` and the HuggingFace
+// T5Stack.forward it calls (transformers models/t5/modeling_t5.py:663-750, blocks :435-509,
+// attention :281-369, RMSNorm :50-72, gated-GELU FFN :97-123).  Exact math: SURVEY.md App. A.
+//
+// Data layout in HBM for a pass over T packed tokens (Tp = T rounded up to 128):
+//   x    f32  [Tp, D]        residual stream (kept fp32; HF-bf16 keeps it bf16)
+//   h    bf16 [Tp, D]        RMSNorm output = GEMM A operand
+//   qkv  bf16 [Tp, 3*H*64]   fused projection output, [q | k | v], head-major inside each
+//   att  bf16 [Tp, H*64]     attention output
+//   ff   bf16 [Tp, F]        gelu_new(wi_0 h) * (wi_1 h)
+// Sequences are packed back to back (varlen): no padded token is ever computed except the
+// <128 rows that round the last GEMM tile.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "rp_gemm.h"
+
+namespace rp {
+
+thread_local std::string g_last_error;
+
+// ------------------------------------------------------------------------------------------
+// options
+// ------------------------------------------------------------------------------------------
+static int g_gemm_group_m = 8;
+
+// ------------------------------------------------------------------------------------------
+// weight packing (create time only)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float load_as_f32(const void* p, size_t i);
+template <>
+__device__ __forceinline__ float load_as_f32<float>(const void* p, size_t i) {
+  return reinterpret_cast<const float*>(p)[i];
+}
+template <>
+__device__ __forceinline__ float load_as_f32<bf16_t>(const void* p, size_t i) {
+  return bf2f(reinterpret_cast<const bf16_t*>(p)[i]);
+}
+
+enum PackMode { PACK_CONCAT3 = 0, PACK_GEGLU = 1, PACK_COPY = 2 };
+
+// dst bf16 [rows_dst, cols]; source row mapping by mode:
+//   CONCAT3: rows [0,n) from s0, [n,2n) from s1, [2n,3n) from s2      (fused q|k|v)
+//   GEGLU  : 64-row blocks: 32 rows of s0 (gate, wi_0) then 32 rows of s1 (up, wi_1)
+//   COPY   : row r from s0
+template <typename T>
+__global__ void pack_rows_kernel(bf16_t* dst, const void* s0, const void* s1, const void* s2,
+                                 int rows_dst, int cols, int n, int mode) {
+  const int r = blockIdx.x;
+  const void* src;
+  int sr;
+  if (mode == PACK_CONCAT3) {
+    src = (r < n) ? s0 : (r < 2 * n ? s1 : s2);
+    sr = r % n;
+  } else if (mode == PACK_GEGLU) {
+    src = ((r >> 5) & 1) ? s1 : s0;
+    sr = (r >> 6) * 32 + (r & 31);
+  } else {
+    src = s0;
+    sr = r;
+  }
+  for (int c = threadIdx.x; c < cols; c += blockDim.x)
+    dst[(size_t)r * cols + c] = f2bf(load_as_f32<T>(src, (size_t)sr * cols + c));
+}
+
+template <typename T>
+__global__ void to_f32_kernel(float* dst, const void* src, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = load_as_f32<T>(src, i);
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: byte-token embedding gather  x[t] = embed[ids[t]]   (HF:678); the table (vocab x D fp32,
+//   2.3 MB for ByT5-small) is L2-resident.
+//   rows >= T (tile padding) get token 0 so every workspace row stays finite.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ ids,
+                                                    const float* __restrict__ table,
+                                                    float* __restrict__ x, int T, int Tp, int D,
+                                                    int vocab) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= Tp) return;
+  int id = (row < T) ? ids[row] : 0;
+  id = min(max(id, 0), vocab - 1);
+  const float4* src = reinterpret_cast<const float4*>(table + (size_t)id * D);
+  float4* dst = reinterpret_cast<float4*>(x + (size_t)row * D);
+  for (int c = lane; c < (D >> 2); c += 64) dst[c] = src[c];
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: T5 RMSNorm  h = w * x * rsqrt(mean(x^2) + eps)  (HF:59-72), fp32 in, bf16 out.
+//   One wave per row; the row (<= 8 float4 per lane, D <= 2048) stays in registers between the
+//   reduction and the scaled store, so x is read exactly once.
+// ------------------------------------------------------------------------------------------
+constexpr int RMS_MAX_V4 = 8;
+
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x,
+                                                      const float* __restrict__ w,
+                                                      bf16_t* __restrict__ h, int rows, int D,
+                                                      float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4* src = reinterpret_cast<const float4*>(x + (size_t)row * D);
+  const int nv = D >> 2;
+  float4 v[RMS_MAX_V4];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < RMS_MAX_V4; ++i) {
+    int c = lane + 64 * i;
+    if (c < nv) {
+      v[i] = src[c];
+      ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
+  }
+  ss = wave_sum(ss);
+  const float rs = rsqrtf(ss / (float)D + eps);
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  uint2* dst = reinterpret_cast<uint2*>(h + (size_t)row * D);
+#pragma unroll
+  for (int i = 0; i < RMS_MAX_V4; ++i) {
+    int c = lane + 64 * i;
+    if (c < nv) {
+      float4 g = w4[c];
+      uint2 o;
+      o.x = pack_bf2(v[i].x * rs * g.x, v[i].y * rs * g.y);
+      o.y = pack_bf2(v[i].z * rs * g.z, v[i].w * rs * g.w);
+      dst[c] = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3/K6/K7/K8: GEMM epilogues
+// ------------------------------------------------------------------------------------------
+struct EpiStoreBf16 {  // out[row, col] = bf16(acc)
+  bf16_t* out;
+  int ldo, n_valid;
+  __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int m_base, int n_base, int lane) {
+    const int hi = lane >> 5, cl = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n_base + j * 32 + cl;
+        if (col < n_valid) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m_base + i * 32 + mfma32_row(r, hi);
+            out[(size_t)row * ldo + col] = f2bf(acc[i][j][r]);
+          }
+        }
+      }
+  }
+};
+
+struct EpiResidF32 {  // x[row, col] += acc   (residual stream, fp32)
+  float* x;
+  int ldx, n_valid;
+  __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int m_base, int n_base, int lane) {
+    const int hi = lane >> 5, cl = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n_base + j * 32 + cl;
+        if (col < n_valid) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m_base + i * 32 + mfma32_row(r, hi);
+            float* p = x + (size_t)row * ldx + col;
+            *p = *p + acc[i][j][r];
+          }
+        }
+      }
+  }
+};
+
+struct EpiGegluBf16 {  // W rows interleaved 32 gate / 32 up: frag j=0 gate, j=1 up
+  bf16_t* out;         // [M, n_valid/2]
+  int ldo, n_valid;    // n_valid counts interleaved columns (= 2 * d_ff)
+  __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int m_base, int n_base, int lane) {
+    const int hi = lane >> 5, cl = lane & 31;
+    if (n_base >= n_valid) return;
+    const int col = (n_base >> 1) + cl;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m_base + i * 32 + mfma32_row(r, hi);
+        out[(size_t)row * ldo + col] = f2bf(gelu_new(acc[i][0][r]) * acc[i][1][r]);
+      }
+  }
+};
+
+template <class Epi>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmOperand A, GemmOperand W, int K, int tiles_m,
+                                                   int tiles_n, int group_m, Epi epi) {
+  __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS_BYTES];
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  int tm, tn;
+  tile_coords(logical, tiles_m, tiles_n, group_m, tm, tn);
+  gemm_tile(A, W, K, tm, tn, epi, smem);
+}
+
+template <class Epi>
+static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, int ldw, int n_rows_w,
+                            int K, Epi epi, hipStream_t stream) {
+  RP_REQUIRE(M % GEMM_BM == 0 && K % GEMM_BK == 0, "gemm: M=%d must be a multiple of 128, K=%d of 32", M, K);
+  const int tiles_m = M / GEMM_BM, tiles_n = (n_rows_w + GEMM_BN - 1) / GEMM_BN;
+  GemmOperand a{A, lda, M}, w{W, ldw, n_rows_w};
+  hipLaunchKernelGGL((gemm_kernel<Epi>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, a, w, K, tiles_m,
+                     tiles_n, g_gemm_group_m, epi);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K4+K5: T5 self-attention, flash-style, varlen.
+//   scores = q·k (NO 1/sqrt(d) scaling, HF:197) + bias[h, clamp(j-i, -128, 128)]; keys >= len are
+//   excluded (HF uses finfo.min via where(mask, bias, min): identical result whenever a row has
+//   at least one real key, which every real query row does); fp32 online softmax; o = p·v.
+//   The additive bias depends only on j-i and saturates at |j-i| >= max_distance, so it is a
+//   [H, 2*max_distance+1] table (built on the host from relative_attention_bias.weight with HF's
+//   bucket function) instead of HF's dense [1,H,L,L] tensor.
+//
+//   Workgroup = (128 queries of one sequence, one head); wave w owns queries 32w..32w+31.
+//   S^T = K·Q^T is computed so that each lane holds, for ONE query (lane & 31), 16 keys per 32-key
+//   block: the softmax row reductions are in-lane plus one exchange with lane^32.  O^T = V^T·P^T
+//   reuses those registers directly as the MFMA B operand (the k-slot -> key permutation implied
+//   by the accumulator layout is applied to V^T when its A fragment is read from LDS).
+// ------------------------------------------------------------------------------------------
+constexpr int ATT_Q = 128, ATT_KV = 64;
+constexpr int ATT_KS_STRIDE = 144;  // bytes per staged K row: 64 bf16 + 16 B pad
+constexpr int ATT_VT_STRIDE = 136;  // bytes per staged V^T row: 64 keys bf16 + 8 B pad
+constexpr int ATT_KS_BYTES = ATT_KV * ATT_KS_STRIDE;  // 9216
+constexpr int ATT_VT_BYTES = 64 * ATT_VT_STRIDE;      // 8704
+constexpr int ATT_TAB_MAX = 1024;                     // max table entries (2*max_distance+1)
+
+__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv,
+                                                        const int32_t* __restrict__ cu,
+                                                        const float* __restrict__ bias_tab,
+                                                        bf16_t* __restrict__ out, int H, int maxd,
+                                                        int rows_total) {
+  __shared__ __attribute__((aligned(16))) char smem[ATT_KS_BYTES + ATT_VT_BYTES + ATT_TAB_MAX * 4];
+  char* Ks = smem;
+  char* Vt = smem + ATT_KS_BYTES;
+  float* tab = reinterpret_cast<float*>(smem + ATT_KS_BYTES + ATT_VT_BYTES);
+
+  const int b = blockIdx.y, h = blockIdx.z;
+  const int s0 = cu[b];
+  const int len = cu[b + 1] - s0;
+  const int q0 = blockIdx.x * ATT_Q;
+  if (q0 >= len) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, cl = lane & 31;
+  const int inner = H * 64, ld = 3 * inner;
+  const int ntab = 2 * maxd + 1;
+  for (int i = tid; i < ntab; i += 256) tab[i] = bias_tab[h * ntab + i];
+
+  const int qi = q0 + wave * 32 + cl;  // this lane's query (position inside the sequence)
+  bf16x8 qf[4];
+  {
+    const bf16_t* qp = qkv + (size_t)(s0 + min(qi, len - 1)) * ld + h * 64 + hi * 8;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const bf16x8*>(qp + c * 16);
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int n_tiles = (len + ATT_KV - 1) / ATT_KV;
+  // staging: 64 keys x 8 chunks(16 B) = 512 chunks, two per thread
+  uint4 rk[2], rv[2];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c2 = tid + 256 * i;
+      const int key = c2 >> 3, dch = c2 & 7;
+      const int krow = s0 + min(kt * ATT_KV + key, len - 1);
+      const bf16_t* p = qkv + (size_t)krow * ld + inner + h * 64 + dch * 8;
+      rk[i] = *reinterpret_cast<const uint4*>(p);
+      rv[i] = *reinterpret_cast<const uint4*>(p + inner);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c2 = tid + 256 * i;
+      const int key = c2 >> 3, dch = c2 & 7;
+      *reinterpret_cast<uint4*>(Ks + key * ATT_KS_STRIDE + dch * 16) = rk[i];
+      const uint32_t w[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bf16_t val = (bf16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+        *reinterpret_cast<bf16_t*>(Vt + (dch * 8 + e) * ATT_VT_STRIDE + key * 2) = val;
+      }
+    }
+  };
+
+  load_tile(0);
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    __syncthreads();  // previous tile fully consumed (and tab written, first iteration)
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < n_tiles) load_tile(kt + 1);  // in flight during the MFMAs below
+
+    const int k0 = kt * ATT_KV;
+    // ---- S^T = K Q^T : s[kb][r] = score(key k0 + 32 kb + mfma32_row(r,hi), query qi)
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+      const char* kp = Ks + (kb * 32 + cl) * ATT_KS_STRIDE + hi * 16;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + c * 32);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], s[kb], 0, 0, 0);
+      }
+    }
+    // ---- relative-position bias + key-padding mask
+    const int w_qmin = q0 + wave * 32, w_qmax = w_qmin + 31;
+    const bool full = (k0 + ATT_KV <= len);
+    if (k0 - w_qmax >= maxd && full) {  // whole tile saturated on the right
+      const float bb = tab[2 * maxd];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] += bb;
+    } else if (k0 + ATT_KV - 1 - w_qmin <= -maxd && full) {  // saturated on the left
+      const float bb = tab[0];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] += bb;
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = k0 + kb * 32 + mfma32_row(r, hi);
+          const int rel = min(max(j - qi, -maxd), maxd) + maxd;
+          s[kb][r] = (j < len) ? s[kb][r] + tab[rel] : -INFINITY;
+        }
+    }
+    // ---- online softmax (per query = per lane pair {lane, lane^32})
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);  // m_run = -inf on the first tile -> 0
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __expf(s[kb][r] - m_new);
+        s[kb][r] = p;
+        psum += p;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    // ---- O^T += V^T P^T over four 16-key slabs
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const int kb = sl >> 1, sub = sl & 1;
+      bf16x8 pf;
+      {
+        uint32_t pw[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pw[e] = pack_bf2(s[kb][8 * sub + 2 * e], s[kb][8 * sub + 2 * e + 1]);
+        uint4 t = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+        pf = *reinterpret_cast<bf16x8*>(&t);
+      }
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const char* vp = Vt + (d * 32 + cl) * ATT_VT_STRIDE + (16 * sl + 4 * hi) * 2;
+        uint2 lo = *reinterpret_cast<const uint2*>(vp);
+        uint2 up = *reinterpret_cast<const uint2*>(vp + 16);
+        uint4 t = make_uint4(lo.x, lo.y, up.x, up.y);
+        bf16x8 vf = *reinterpret_cast<bf16x8*>(&t);
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+      }
+    }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_tot;
+  if (qi < len) {
+    bf16_t* op = out + (size_t)(s0 + qi) * inner + h * 64;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 v;
+        v.x = pack_bf2(o[d][4 * g] * inv, o[d][4 * g + 1] * inv);
+        v.y = pack_bf2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(op + d * 32 + 8 * g + 4 * hi) = v;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2(final)+K9+K10: final RMSNorm, masked mean over the sequence's tokens, L2 normalise.
+//   mean_t(w * x_t * rs_t) = w * mean_t(x_t * rs_t); e / max(||e||, 1e-12)  (model.py:108-114)
+//   One workgroup per sequence; wave w takes tokens w, w+4, ...; per-lane partial column sums
+//   live in registers, combined through LDS at the end.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x,
+                                                   const float* __restrict__ w,
+                                                   const int32_t* __restrict__ cu,
+                                                   void* __restrict__ out, int out_bf16, int D,
+                                                   float eps) {
+  __shared__ float red[4][RMS_MAX_V4 * 64 * 4];
+  __shared__ float nrm[4];
+  const int b = blockIdx.x;
+  const int s0 = cu[b], len = cu[b + 1] - s0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = D >> 2;
+  float4 acc[RMS_MAX_V4];
+#pragma unroll
+  for (int i = 0; i < RMS_MAX_V4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = wave; t < len; t += 4) {
+    const float4* src = reinterpret_cast<const float4*>(x + (size_t)(s0 + t) * D);
+    float4 v[RMS_MAX_V4];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < RMS_MAX_V4; ++i) {
+      int c = lane + 64 * i;
+      if (c < nv) {
+        v[i] = src[c];
+        ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+      }
+    }
+    ss = wave_sum(ss);
+    const float rs = rsqrtf(ss / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < RMS_MAX_V4; ++i) {
+      int c = lane + 64 * i;
+      if (c < nv) {
+        acc[i].x += v[i].x * rs;
+        acc[i].y += v[i].y * rs;
+        acc[i].z += v[i].z * rs;
+        acc[i].w += v[i].w * rs;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RMS_MAX_V4; ++i) {
+    int c = lane + 64 * i;
+    if (c < nv) *reinterpret_cast<float4*>(&red[wave][c * 4]) = acc[i];
+  }
+  __syncthreads();
+  // every thread finalises columns tid, tid+256, ...
+  const float inv_len = 1.f / (float)len;
+  float part = 0.f;
+  float vals[8];
+  int cnt = 0;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float e = (red[0][c] + red[1][c] + red[2][c] + red[3][c]) * inv_len * w[c];
+    vals[cnt++] = e;
+    part += e * e;
+  }
+  part = wave_sum(part);
+  if (lane == 0) nrm[wave] = part;
+  __syncthreads();
+  const float norm = sqrtf(nrm[0] + nrm[1] + nrm[2] + nrm[3]);
+  const float sc = 1.f / fmaxf(norm, 1e-12f);
+  cnt = 0;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    const float e = vals[cnt++] * sc;
+    if (out_bf16)
+      reinterpret_cast<bf16_t*>(out)[(size_t)b * D + c] = f2bf(e);
+    else
+      reinterpret_cast<float*>(out)[(size_t)b * D + c] = e;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct LayerPacked {
+  float* ln_attn;
+  float* ln_ff;
+  bf16_t* wqkv;  // [3*inner, D]
+  bf16_t* wo;    // [D, inner]
+  bf16_t* wi;    // [2F, D] gate/up interleaved by 32
+  bf16_t* wo2;   // [D, F]
+};
+
+}  // namespace rp
+
+struct RpEncoder {
+  RpT5Config cfg;
+  int inner;
+  int maxd;
+  float* embed;        // [V, D] f32
+  float* final_ln;     // [D]
+  float* bias_tab;     // [H, 2*maxd+1]
+  std::vector<rp::LayerPacked> layers;
+  std::vector<void*> allocs;
+};
+
+using namespace rp;
+
+extern "C" int32_t rp_abi_version(void) { return 1; }
+extern "C" const char* rp_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
+  if (!strcmp(name, "gemm_group_m")) {
+    RP_REQUIRE(value >= 1 && value <= 64, "gemm_group_m out of range");
+    g_gemm_group_m = value;
+    return RP_OK;
+  }
+  return fail(RP_E_INVALID, "unknown option %s", name);
+}
+
+// modeling_t5.py:216-262, bidirectional branch; float32 arithmetic as torch evaluates it.
+extern "C" int32_t rp_relative_position_bucket(int32_t rel, int32_t num_buckets, int32_t max_distance) {
+  int nb = num_buckets / 2;
+  int bucket = (rel > 0) ? nb : 0;
+  int n = rel < 0 ? -rel : rel;
+  int max_exact = nb / 2;
+  if (n < max_exact) return bucket + n;
+  float ratio = (float)n / (float)max_exact;
+  float t = logf(ratio) / (float)log((double)max_distance / (double)max_exact) * (float)(nb - max_exact);
+  int large = max_exact + (int)t;  // truncation toward zero, as .to(torch.long)
+  if (large > nb - 1) large = nb - 1;
+  return bucket + large;
+}
+
+template <typename T>
+static RpStatus pack_all(RpEncoder* e, const RpT5Weights* w) {
+  const RpT5Config& c = e->cfg;
+  const int D = c.d_model, F = c.d_ff, inner = e->inner;
+  auto alloc = [&](size_t bytes, void** p) -> RpStatus {
+    RP_HIP(hipMalloc(p, bytes));
+    e->allocs.push_back(*p);
+    return RP_OK;
+  };
+  RpStatus st;
+  if ((st = alloc((size_t)c.vocab_size * D * 4, (void**)&e->embed))) return st;
+  hipLaunchKernelGGL((to_f32_kernel<T>), dim3((c.vocab_size * D + 255) / 256), dim3(256), 0, 0, e->embed,
+                     w->embed, c.vocab_size * D);
+  if ((st = alloc((size_t)D * 4, (void**)&e->final_ln))) return st;
+  hipLaunchKernelGGL((to_f32_kernel<T>), dim3((D + 255) / 256), dim3(256), 0, 0, e->final_ln, w->final_ln, D);
+  e->layers.resize(c.num_layers);
+  for (int i = 0; i < c.num_layers; ++i) {
+    const RpT5LayerWeights& s = w->layers[i];
+    LayerPacked& L = e->layers[i];
+    if ((st = alloc((size_t)D * 4, (void**)&L.ln_attn))) return st;
+    if ((st = alloc((size_t)D * 4, (void**)&L.ln_ff))) return st;
+    if ((st = alloc((size_t)3 * inner * D * 2, (void**)&L.wqkv))) return st;
+    if ((st = alloc((size_t)D * inner * 2, (void**)&L.wo))) return st;
+    if ((st = alloc((size_t)2 * F * D * 2, (void**)&L.wi))) return st;
+    if ((st = alloc((size_t)D * F * 2, (void**)&L.wo2))) return st;
+    hipLaunchKernelGGL((to_f32_kernel<T>), dim3((D + 255) / 256), dim3(256), 0, 0, L.ln_attn, s.ln_attn, D);
+    hipLaunchKernelGGL((to_f32_kernel<T>), dim3((D + 255) / 256), dim3(256), 0, 0, L.ln_ff, s.ln_ff, D);
+    hipLaunchKernelGGL((pack_rows_kernel<T>), dim3(3 * inner), dim3(256), 0, 0, L.wqkv, s.q, s.k, s.v, 3 * inner,
+                       D, inner, (int)PACK_CONCAT3);
+    hipLaunchKernelGGL((pack_rows_kernel<T>), dim3(D), dim3(256), 0, 0, L.wo, s.o, nullptr, nullptr, D, inner, 0,
+                       (int)PACK_COPY);
+    hipLaunchKernelGGL((pack_rows_kernel<T>), dim3(2 * F), dim3(256), 0, 0, L.wi, s.wi_0, s.wi_1, nullptr, 2 * F,
+                       D, 0, (int)PACK_GEGLU);
+    hipLaunchKernelGGL((pack_rows_kernel<T>), dim3(D), dim3(256), 0, 0, L.wo2, s.wo, nullptr, nullptr, D, F, 0,
+                       (int)PACK_COPY);
+    RP_CHECK_LAUNCH();
+  }
+  // relative-position bias -> [H, 2*maxd+1] table (host; the raw table is tiny)
+  const int nbk = c.rel_num_buckets, H = c.num_heads, maxd = e->maxd, ntab = 2 * maxd + 1;
+  std::vector<float> raw((size_t)nbk * H);
+  {
+    float* tmp;
+    RP_HIP(hipMalloc((void**)&tmp, raw.size() * 4));
+    hipLaunchKernelGGL((to_f32_kernel<T>), dim3((nbk * H + 255) / 256), dim3(256), 0, 0, tmp, w->rel_bias, nbk * H);
+    RP_HIP(hipMemcpy(raw.data(), tmp, raw.size() * 4, hipMemcpyDeviceToHost));
+    RP_HIP(hipFree(tmp));
+  }
+  std::vector<float> tab((size_t)H * ntab);
+  for (int d = -maxd; d <= maxd; ++d) {
+    const int bk = rp_relative_position_bucket(d, nbk, c.rel_max_distance);
+    for (int h = 0; h < H; ++h) tab[(size_t)h * ntab + d + maxd] = raw[(size_t)bk * H + h];
+  }
+  if ((st = alloc(tab.size() * 4, (void**)&e->bias_tab))) return st;
+  RP_HIP(hipMemcpy(e->bias_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  RP_HIP(hipDeviceSynchronize());
+  return RP_OK;
+}
+
+extern "C" RpStatus rp_encoder_create(const RpT5Config* cfg, const RpT5Weights* weights, int32_t weight_dtype,
+                                      RpEncoder** out) {
+  RP_REQUIRE(cfg && weights && out, "null argument");
+  if (cfg->d_kv != 64) return fail(RP_E_UNSUPPORTED, "d_kv=%d: kernels implement d_kv=64", cfg->d_kv);
+  if (cfg->d_model % 32 || cfg->d_model > RMS_MAX_V4 * 256 || cfg->d_ff % 32)
+    return fail(RP_E_UNSUPPORTED, "d_model=%d (multiple of 32, <= %d) / d_ff=%d (multiple of 32) unsupported",
+                cfg->d_model, RMS_MAX_V4 * 256, cfg->d_ff);
+  if (2 * cfg->rel_max_distance + 1 > ATT_TAB_MAX)
+    return fail(RP_E_UNSUPPORTED, "relative_attention_max_distance=%d too large", cfg->rel_max_distance);
+  RP_REQUIRE(weight_dtype == RP_DT_F32 || weight_dtype == RP_DT_BF16, "weight_dtype");
+  RpEncoder* e = new RpEncoder();
+  e->cfg = *cfg;
+  e->inner = cfg->num_heads * cfg->d_kv;
+  e->maxd = cfg->rel_max_distance;
+  RpStatus st = (weight_dtype == RP_DT_F32) ? pack_all<float>(e, weights) : pack_all<bf16_t>(e, weights);
+  if (st != RP_OK) {
+    rp_encoder_destroy(e);
+    return st;
+  }
+  *out = e;
+  return RP_OK;
+}
+
+extern "C" void rp_encoder_destroy(RpEncoder* e) {
+  if (!e) return;
+  for (void* p : e->allocs) (void)hipFree(p);
+  delete e;
+}
+
+namespace {
+struct Workspace {
+  float* x;
+  bf16_t *h, *qkv, *att, *ff;
+  size_t bytes;
+};
+Workspace carve(const RpEncoder* e, int T, char* base) {
+  const size_t Tp = align_up((size_t)T, 128);
+  const size_t D = e->cfg.d_model, F = e->cfg.d_ff, inner = e->inner;
+  Workspace w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  w.x = (float*)take(Tp * D * 4);
+  w.h = (bf16_t*)take(Tp * D * 2);
+  w.qkv = (bf16_t*)take(Tp * 3 * inner * 2);
+  w.att = (bf16_t*)take(Tp * inner * 2);
+  w.ff = (bf16_t*)take(Tp * F * 2);
+  w.bytes = off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t rp_encoder_workspace_bytes(const RpEncoder* enc, int32_t total_tokens, int32_t batch) {
+  (void)batch;
+  if (!enc || total_tokens <= 0) return 0;
+  return carve(enc, total_tokens, nullptr).bytes;
+}
+
+extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int32_t* cu_seqlens, int32_t batch,
+                                     int32_t T, int32_t max_len, void* out, int32_t out_dtype, void* workspace,
+                                     size_t workspace_bytes, void* stream_) {
+  RP_REQUIRE(e && ids && cu_seqlens && out, "null argument");
+  RP_REQUIRE(batch > 0 && T > 0 && max_len > 0 && max_len <= T, "batch=%d total_tokens=%d max_len=%d", batch, T,
+             max_len);
+  RP_REQUIRE(out_dtype == RP_DT_F32 || out_dtype == RP_DT_BF16, "out_dtype");
+  hipStream_t stream = (hipStream_t)stream_;
+  Workspace w = carve(e, T, (char*)workspace);
+  if (!workspace || workspace_bytes < w.bytes)
+    return fail(RP_E_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, w.bytes);
+  const RpT5Config& c = e->cfg;
+  const int D = c.d_model, F = c.d_ff, inner = e->inner, H = c.num_heads;
+  const int Tp = (int)align_up((size_t)T, 128);
+  RpStatus st;
+
+  hipLaunchKernelGGL(embed_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.x, T, Tp, D,
+                     c.vocab_size);
+  RP_CHECK_LAUNCH();
+  const dim3 att_grid((max_len + ATT_Q - 1) / ATT_Q, batch, H);
+  for (int i = 0; i < c.num_layers; ++i) {
+    const LayerPacked& L = e->layers[i];
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, w.x, L.ln_attn, w.h, Tp, D,
+                       c.layer_norm_eps);
+    if ((st = launch_gemm(w.h, D, Tp, L.wqkv, D, 3 * inner, D, EpiStoreBf16{w.qkv, 3 * inner, 3 * inner}, stream)))
+      return st;
+    hipLaunchKernelGGL(attention_kernel, att_grid, dim3(256), 0, stream, w.qkv, cu_seqlens, e->bias_tab, w.att, H,
+                       e->maxd, Tp);
+    if ((st = launch_gemm(w.att, inner, Tp, L.wo, inner, D, inner, EpiResidF32{w.x, D, D}, stream))) return st;
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, w.x, L.ln_ff, w.h, Tp, D,
+                       c.layer_norm_eps);
+    if ((st = launch_gemm(w.h, D, Tp, L.wi, D, 2 * F, D, EpiGegluBf16{w.ff, F, 2 * F}, stream))) return st;
+    if ((st = launch_gemm(w.ff, F, Tp, L.wo2, F, D, F, EpiResidF32{w.x, D, D}, stream))) return st;
+  }
+  hipLaunchKernelGGL(pool_kernel, dim3(batch), dim3(256), 0, stream, w.x, e->final_ln, cu_seqlens, out,
+                     out_dtype == RP_DT_BF16 ? 1 : 0, D, c.layer_norm_eps);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel-level test entry points
+// ------------------------------------------------------------------------------------------
+extern "C" RpStatus rp_dbg_gemm(const void* A, const void* W, void* out, int32_t M, int32_t N, int32_t K,
+                                int32_t n_valid, int32_t epilogue, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const bf16_t* a = (const bf16_t*)A;
+  const bf16_t* w = (const bf16_t*)W;
+  switch (epilogue) {
+    case RP_EPI_STORE_BF16:
+      return launch_gemm(a, K, M, w, K, N, K, EpiStoreBf16{(bf16_t*)out, n_valid, n_valid}, stream);
+    case RP_EPI_RESID_F32:
+      return launch_gemm(a, K, M, w, K, N, K, EpiResidF32{(float*)out, n_valid, n_valid}, stream);
+    case RP_EPI_GEGLU_BF16:
+      return launch_gemm(a, K, M, w, K, N, K, EpiGegluBf16{(bf16_t*)out, n_valid / 2, n_valid}, stream);
+  }
+  return fail(RP_E_INVALID, "unknown epilogue %d", epilogue);
+}
+
+extern "C" RpStatus rp_dbg_rmsnorm(const float* x, const float* w, void* out_bf16, int32_t rows, int32_t D,
+                                   float eps, void* stream_) {
+  RP_REQUIRE(D % 4 == 0 && D <= RMS_MAX_V4 * 256, "D=%d", D);
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream_, x, w,
+                     (bf16_t*)out_bf16, rows, D, eps);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" RpStatus rp_dbg_attention(const void* qkv, const int32_t* cu, const float* bias_tab, void* out,
+                                     int32_t batch, int32_t max_len, int32_t H, int32_t rows_total, void* stream_) {
+  const int maxd = 128;
+  const dim3 grid((max_len + ATT_Q - 1) / ATT_Q, batch, H);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)qkv, cu, bias_tab,
+                     (bf16_t*)out, H, maxd, rows_total);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}

@@ -1,0 +1,460 @@
+// Similarity scan + accessibility mask + exact top-k on gfx950.
+//
+// Replaces (reference lean-dojo/ReProver) common.py:299-326 Corpus.get_nearest_premises:
+//   similarities = Q @ E.T (:307); argsort(descending).tolist() (:308); per-query Python walk over
+//   the sorted ids keeping premises in get_accessible_premises(path, pos) (:312-322, :280-289).
+//
+// Design (HBM-bound scan: E is N x D bf16, read once):
+//   * scan kernel = the bf16 MFMA GEMM core (rp_gemm.h) with A = Q (queries, L2-resident) and
+//     W = E (premises, streamed); the epilogue turns each fp32 score into a 64-bit sortable key
+//     (ordered(score) << 32 | ~id) after applying the accessibility predicate, so "masked top-k"
+//     is exact: the mask is applied BEFORE selection, ties break toward the lower id.
+//   * the B x N score matrix is never materialised.  Pass 1 scans every `stride`-th premise tile
+//     and writes its keys densely; a radix-select finds each query's k best of that sample,
+//     whose k-th key is a valid lower bound for the global k-th key.  Pass 2 scans the remaining
+//     tiles and appends only keys above the bound to a per-query candidate list (expected size
+//     ~ k * stride).  A final radix-select + bitonic sort over <= cap candidates yields the
+//     sorted top-k.  Small shards (N <= 16384) and RP_TOPK_DENSE take the single dense pass.
+#include "rp_gemm.h"
+
+namespace rp {
+
+constexpr int SIM_DENSE_MAX_N = 16384;
+constexpr int SIM_STRIDE = 16;
+constexpr int SIM_CAND_CAP = 8192;
+constexpr int SIM_MAX_K = 1024;
+
+__device__ __forceinline__ uint64_t make_key(float score, int32_t id) {
+  return ((uint64_t)f2ord(score) << 32) | (uint32_t)(~(uint32_t)id);
+}
+
+struct EpiSim {
+  // premise side (NULL file_of => no accessibility mask)
+  const int32_t* file_of;
+  const int64_t* end_key;
+  int N;
+  // query side
+  const uint32_t* bits_t;  // [F, bits_words]
+  int bits_words;
+  const int32_t* own_file;
+  const int64_t* q_key;
+  int B;
+  int id_offset;
+  // output
+  int filter;          // 0: dense write, 1: append keys > thr
+  uint64_t* dense;     // [B, dense_ld]
+  size_t dense_ld;
+  int slot_shift;      // slot = premise_row + slot_shift (set per workgroup)
+  const uint64_t* thr; // [B]
+  uint64_t* cand;      // [B, cap]
+  int cap;
+  int32_t* count;      // [B]
+  char* smem;          // GEMM LDS, free once the main loop is done
+
+  __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int m_base, int n_base, int lane) {
+    const int hi = lane >> 5, cl = lane & 31;
+    const int tile_q0 = m_base & ~127;
+    // stage the 128 queries' own_file / q_key / threshold
+    int32_t* s_own = reinterpret_cast<int32_t*>(smem);
+    int64_t* s_qk = reinterpret_cast<int64_t*>(smem + 512);
+    uint64_t* s_thr = reinterpret_cast<uint64_t*>(smem + 512 + 1024);
+    if (threadIdx.x < 128) {
+      const int q = tile_q0 + threadIdx.x;
+      const bool ok = q < B;
+      s_own[threadIdx.x] = (ok && file_of) ? own_file[q] : -1;
+      s_qk[threadIdx.x] = (ok && file_of) ? q_key[q] : 0;
+      s_thr[threadIdx.x] = (ok && filter) ? thr[q] : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int p = n_base + j * 32 + cl;
+      const bool pvalid = p < N;
+      int32_t f = -2;
+      int64_t ek = 0;
+      uint32_t w[2] = {0xffffffffu, 0xffffffffu};
+      if (file_of) {
+        w[0] = w[1] = 0;
+        if (pvalid) {
+          f = file_of[p];
+          ek = end_key[p];
+          const int wi = m_base >> 5;
+          if (wi < bits_words) w[0] = bits_t[(size_t)f * bits_words + wi];
+          if (wi + 1 < bits_words) w[1] = bits_t[(size_t)f * bits_words + wi + 1];
+        }
+      }
+      const int32_t id = p + id_offset;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = mfma32_row(r, hi);
+          const int ql = (m_base - tile_q0) + i * 32 + rr;  // query index inside the tile
+          const int q = tile_q0 + ql;
+          bool ok = pvalid && (q < B);
+          if (file_of) {
+            const bool imported = (w[i] >> rr) & 1u;
+            const bool own = (f == s_own[ql]) && (ek <= s_qk[ql]);
+            ok = ok && (imported || own);
+          }
+          const uint64_t key = ok ? make_key(acc[i][j][r], id) : 0ull;
+          if (!filter) {
+            if (q < B && (p + slot_shift) < (int)dense_ld) dense[(size_t)q * dense_ld + p + slot_shift] = key;
+          } else if (key > s_thr[ql]) {  // s_thr >= 0; masked keys are 0 and never pass
+            const int pos = atomicAdd(&count[q], 1);
+            if (pos < cap) cand[(size_t)q * cap + pos] = key;
+          }
+        }
+    }
+  }
+};
+
+// pass 0 (dense): premise tile = ord * stride.   pass 1 (filter): all tiles with pt % stride != 0.
+__global__ __launch_bounds__(256) void sim_scan_kernel(GemmOperand Qop, GemmOperand Eop, int K, int tiles_q,
+                                                       int stride, EpiSim epi) {
+  __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS_BYTES];
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = logical % tiles_q;
+  const int ord = logical / tiles_q;
+  int pt;
+  if (!epi.filter) {
+    pt = ord * stride;
+    epi.slot_shift = ord * GEMM_BN - pt * GEMM_BN;
+  } else {
+    pt = ord + ord / (stride - 1) + 1;
+    epi.slot_shift = 0;
+  }
+  epi.smem = smem;
+  gemm_tile(Qop, Eop, K, qt, pt, epi, smem);
+}
+
+// ------------------------------------------------------------------------------------------
+// exact top-k of one query's key list: MSB radix select (8-bit digits) + bitonic sort.
+//   keys are distinct (ids differ) except for 0 = "not a candidate".
+// ------------------------------------------------------------------------------------------
+struct SelectArgs {
+  const uint64_t* keys;   // [B, ld]
+  size_t ld;
+  const int32_t* counts;  // per-query list length (NULL: n_fixed); > cap => overflow
+  int n_fixed;
+  int cap;
+  int k;
+  // mode A outputs (sample stage): top keys into out_keys[q, 0..kk), out_cnt[q] = kk, thr[q]
+  uint64_t* out_keys;
+  size_t out_ld;
+  int32_t* out_cnt;
+  uint64_t* out_thr;
+  // mode B outputs (final)
+  float* out_scores;   // [B, k]
+  int32_t* out_ids;    // [B, k]
+  int32_t* out_count;  // [B]
+};
+
+__global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
+  __shared__ int hist[256];
+  __shared__ uint64_t sel[SIM_MAX_K];
+  __shared__ int s_digit, s_need, s_cnt, s_done;
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  int n = a.counts ? a.counts[q] : a.n_fixed;
+  const bool overflow = a.counts && n > a.cap;
+  if (n > a.cap && a.counts) n = a.cap;
+  const uint64_t* src = a.keys + (size_t)q * a.ld;
+
+  // number of real candidates
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  {
+    int c = 0;
+    for (int i = tid; i < n; i += 256) c += (src[i] != 0ull);
+    c = (int)wave_sum((float)c);  // exact: c <= 2^24 per wave
+    if (lane == 0) atomicAdd(&s_cnt, c);
+  }
+  __syncthreads();
+  const int nvalid = s_cnt;
+  const int kk = min(a.k, nvalid);
+  __syncthreads();
+
+  uint64_t T = ~0ull;  // keys >= T are selected
+  if (kk > 0) {
+    uint64_t prefix = 0;
+    int need = kk;
+    bool done = false;
+    for (int shift = 56; shift >= 0 && !done; shift -= 8) {
+      hist[tid] = 0;
+      __syncthreads();
+      for (int i = tid; i < n; i += 256) {
+        const uint64_t key = src[i];
+        const bool in = (shift == 56) ? true : ((key >> (shift + 8)) == prefix);
+        if (in) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
+      }
+      __syncthreads();
+      if (tid < 64) {  // wave 0: lane l owns digits 255-4l .. 252-4l (descending)
+        const int d0 = 255 - 4 * lane;
+        const int h0 = hist[d0], h1 = hist[d0 - 1], h2 = hist[d0 - 2], h3 = hist[d0 - 3];
+        const int mine = h0 + h1 + h2 + h3;
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          int t = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += t;
+        }
+        const int excl = incl - mine;
+        if (excl < need && incl >= need) {  // the crossing happens in this lane's 4 digits
+          int cum = excl, d = d0, hsel = h0;
+          const int hs[4] = {h0, h1, h2, h3};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (cum + hs[t] >= need) {
+              d = d0 - t;
+              hsel = hs[t];
+              break;
+            }
+            cum += hs[t];
+          }
+          s_digit = d;
+          s_need = need - cum;          // how many to take inside the chosen bucket
+          s_done = (hsel == need - cum);  // whole bucket taken: no need to refine further
+        }
+      }
+      __syncthreads();
+      prefix = (prefix << 8) | (uint64_t)s_digit;
+      need = s_need;
+      done = s_done || shift == 0;
+      if (done) T = prefix << shift;
+      __syncthreads();
+    }
+  }
+
+  // collect the kk selected keys, pad to a power of two, sort descending
+  int P = 1;
+  while (P < kk) P <<= 1;
+  for (int i = tid; i < P; i += 256) sel[i] = 0ull;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  if (kk > 0) {
+    for (int i = tid; i < n; i += 256) {
+      const uint64_t key = src[i];
+      if (key >= T && key != 0ull) {
+        const int pos = atomicAdd(&s_cnt, 1);
+        if (pos < SIM_MAX_K) sel[pos] = key;
+      }
+    }
+  }
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int strd = size >> 1; strd > 0; strd >>= 1) {
+      for (int i = tid; i < (P >> 1); i += 256) {
+        const int lo = ((i / strd) * strd * 2) + (i % strd);
+        const int hi2 = lo + strd;
+        const bool desc = ((lo & size) == 0);
+        const uint64_t x = sel[lo], y = sel[hi2];
+        if ((x < y) == desc) {
+          sel[lo] = y;
+          sel[hi2] = x;
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  if (a.out_keys) {
+    for (int i = tid; i < kk; i += 256) a.out_keys[(size_t)q * a.out_ld + i] = sel[i];
+    if (tid == 0) {
+      a.out_cnt[q] = kk;
+      a.out_thr[q] = (kk == a.k) ? sel[kk - 1] : 0ull;
+    }
+  }
+  if (a.out_scores) {
+    for (int i = tid; i < a.k; i += 256) {
+      const bool v = i < kk;
+      const uint64_t key = v ? sel[i] : 0ull;
+      a.out_scores[(size_t)q * a.k + i] = v ? ord2f((uint32_t)(key >> 32)) : -INFINITY;
+      a.out_ids[(size_t)q * a.k + i] = v ? (int32_t)(~(uint32_t)key) : -1;
+    }
+    if (tid == 0) a.out_count[q] = overflow ? -1 : kk;
+  }
+}
+
+// (scores, ids, counts)[R, B, k] -> keys[B, R*k]
+__global__ void merge_keys_kernel(const float* scores, const int32_t* ids, const int32_t* counts, int R, int B,
+                                  int k, uint64_t* keys) {
+  const int q = blockIdx.x;
+  for (int t = threadIdx.x; t < R * k; t += blockDim.x) {
+    const int r = t / k, i = t % k;
+    const size_t src = ((size_t)r * B + q) * k + i;
+    const int c = counts[(size_t)r * B + q];
+    keys[(size_t)q * R * k + t] = (i < c) ? make_key(scores[src], ids[src]) : 0ull;
+  }
+}
+
+struct SimPlan {
+  bool dense_only;
+  int tiles_q, tiles_p, sample_tiles, filter_tiles;
+  size_t dense_ld;
+  size_t off_dense, off_cand, off_count, off_thr, bytes;
+};
+
+static SimPlan plan_sim(int B, int N, int k, int flags) {
+  SimPlan p;
+  p.tiles_q = (B + GEMM_BM - 1) / GEMM_BM;
+  p.tiles_p = (N + GEMM_BN - 1) / GEMM_BN;
+  p.dense_only = (flags & RP_TOPK_DENSE) || N <= SIM_DENSE_MAX_N || p.tiles_p < 2 * SIM_STRIDE;
+  p.sample_tiles = p.dense_only ? p.tiles_p : (p.tiles_p + SIM_STRIDE - 1) / SIM_STRIDE;
+  p.filter_tiles = p.tiles_p - p.sample_tiles;
+  p.dense_ld = (size_t)p.sample_tiles * GEMM_BN;
+  size_t off = 0;
+  p.off_dense = off;
+  off += align_up((size_t)B * p.dense_ld * 8, 256);
+  p.off_cand = off;
+  off += align_up((size_t)B * (SIM_CAND_CAP + k) * 8, 256);
+  p.off_count = off;
+  off += align_up((size_t)B * 4, 256);
+  p.off_thr = off;
+  off += align_up((size_t)B * 8, 256);
+  p.bytes = off;
+  return p;
+}
+
+}  // namespace rp
+
+using namespace rp;
+
+extern "C" size_t rp_sim_topk_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t k, int32_t flags) {
+  (void)D;
+  if (B <= 0 || N <= 0 || k <= 0) return 0;
+  return plan_sim(B, N, k, flags).bytes;
+}
+
+extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t N, int32_t D,
+                                const int32_t* file_of, const int64_t* end_key, const uint32_t* file_bits_t,
+                                int32_t F, const int32_t* own_file, const int64_t* q_key, int32_t id_offset,
+                                int32_t k, int32_t flags, float* out_scores, int32_t* out_ids, int32_t* out_count,
+                                void* workspace, size_t workspace_bytes, void* stream_) {
+  RP_REQUIRE(Q && E && out_scores && out_ids && out_count, "null argument");
+  RP_REQUIRE(B > 0 && N > 0 && D > 0 && D % GEMM_BK == 0, "B=%d N=%d D=%d (D must be a multiple of 32)", B, N, D);
+  RP_REQUIRE(k > 0 && k <= SIM_MAX_K, "k=%d out of range (1..%d)", k, SIM_MAX_K);
+  if (file_of) RP_REQUIRE(end_key && file_bits_t && own_file && q_key && F > 0, "mask arrays incomplete");
+  hipStream_t stream = (hipStream_t)stream_;
+  const SimPlan p = plan_sim(B, N, k, flags);
+  if (!workspace || workspace_bytes < p.bytes)
+    return fail(RP_E_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, p.bytes);
+  char* ws = (char*)workspace;
+  uint64_t* dense = (uint64_t*)(ws + p.off_dense);
+  uint64_t* cand = (uint64_t*)(ws + p.off_cand);
+  int32_t* count = (int32_t*)(ws + p.off_count);
+  uint64_t* thr = (uint64_t*)(ws + p.off_thr);
+  const int cap = SIM_CAND_CAP + k;
+
+  GemmOperand qop{(const bf16_t*)Q, D, B}, eop{(const bf16_t*)E, D, N};
+  EpiSim epi;
+  epi.file_of = file_of;
+  epi.end_key = end_key;
+  epi.N = N;
+  epi.bits_t = file_bits_t;
+  epi.bits_words = (B + 31) / 32;
+  epi.own_file = own_file;
+  epi.q_key = q_key;
+  epi.B = B;
+  epi.id_offset = id_offset;
+  epi.filter = 0;
+  epi.dense = dense;
+  epi.dense_ld = p.dense_ld;
+  epi.slot_shift = 0;
+  epi.thr = thr;
+  epi.cand = cand;
+  epi.cap = cap;
+  epi.count = count;
+  epi.smem = nullptr;
+
+  // pass 0: dense keys of the sampled (or all) premise tiles
+  const int stride0 = p.dense_only ? 1 : SIM_STRIDE;
+  hipLaunchKernelGGL(sim_scan_kernel, dim3(p.tiles_q * p.sample_tiles), dim3(256), 0, stream, qop, eop, D,
+                     p.tiles_q, stride0, epi);
+  RP_CHECK_LAUNCH();
+  SelectArgs sa;
+  sa.keys = dense;
+  sa.ld = p.dense_ld;
+  sa.counts = nullptr;
+  sa.n_fixed = (int)p.dense_ld;
+  sa.cap = (int)p.dense_ld;
+  sa.k = k;
+  if (p.dense_only) {
+    sa.out_keys = nullptr;
+    sa.out_ld = 0;
+    sa.out_cnt = nullptr;
+    sa.out_thr = nullptr;
+    sa.out_scores = out_scores;
+    sa.out_ids = out_ids;
+    sa.out_count = out_count;
+    hipLaunchKernelGGL(select_kernel, dim3(B), dim3(256), 0, stream, sa);
+    RP_CHECK_LAUNCH();
+    return RP_OK;
+  }
+  sa.out_keys = cand;
+  sa.out_ld = cap;
+  sa.out_cnt = count;
+  sa.out_thr = thr;
+  sa.out_scores = nullptr;
+  sa.out_ids = nullptr;
+  sa.out_count = nullptr;
+  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(256), 0, stream, sa);
+  RP_CHECK_LAUNCH();
+  // pass 1: remaining tiles, keep only keys above each query's bound
+  epi.filter = 1;
+  hipLaunchKernelGGL(sim_scan_kernel, dim3(p.tiles_q * p.filter_tiles), dim3(256), 0, stream, qop, eop, D,
+                     p.tiles_q, SIM_STRIDE, epi);
+  RP_CHECK_LAUNCH();
+  SelectArgs sb;
+  sb.keys = cand;
+  sb.ld = cap;
+  sb.counts = count;
+  sb.n_fixed = 0;
+  sb.cap = cap;
+  sb.k = k;
+  sb.out_keys = nullptr;
+  sb.out_ld = 0;
+  sb.out_cnt = nullptr;
+  sb.out_thr = nullptr;
+  sb.out_scores = out_scores;
+  sb.out_ids = out_ids;
+  sb.out_count = out_count;
+  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(256), 0, stream, sb);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" size_t rp_topk_merge_workspace_bytes(int32_t R, int32_t B, int32_t k) {
+  if (R <= 0 || B <= 0 || k <= 0) return 0;
+  return align_up((size_t)R * B * k * 8, 256);
+}
+
+extern "C" RpStatus rp_topk_merge(const float* scores, const int32_t* ids, const int32_t* counts, int32_t R,
+                                  int32_t B, int32_t k, float* out_scores, int32_t* out_ids, int32_t* out_count,
+                                  void* workspace, size_t workspace_bytes, void* stream_) {
+  RP_REQUIRE(scores && ids && counts && out_scores && out_ids && out_count, "null argument");
+  RP_REQUIRE(R > 0 && B > 0 && k > 0 && k <= SIM_MAX_K, "R=%d B=%d k=%d", R, B, k);
+  const size_t need = rp_topk_merge_workspace_bytes(R, B, k);
+  if (!workspace || workspace_bytes < need)
+    return fail(RP_E_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, need);
+  hipStream_t stream = (hipStream_t)stream_;
+  uint64_t* keys = (uint64_t*)workspace;
+  hipLaunchKernelGGL(merge_keys_kernel, dim3(B), dim3(256), 0, stream, scores, ids, counts, R, B, k, keys);
+  RP_CHECK_LAUNCH();
+  SelectArgs sa;
+  sa.keys = keys;
+  sa.ld = (size_t)R * k;
+  sa.counts = nullptr;
+  sa.n_fixed = R * k;
+  sa.cap = R * k;
+  sa.k = k;
+  sa.out_keys = nullptr;
+  sa.out_ld = 0;
+  sa.out_cnt = nullptr;
+  sa.out_thr = nullptr;
+  sa.out_scores = out_scores;
+  sa.out_ids = out_ids;
+  sa.out_count = out_count;
+  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(256), 0, stream, sa);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}

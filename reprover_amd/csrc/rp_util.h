@@ -1,0 +1,99 @@
+// Shared host/device helpers for libreprover_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+
+#include "../../include/reprover_hip.h"
+
+namespace rp {
+
+// ---- error plumbing --------------------------------------------------------------------------
+extern thread_local std::string g_last_error;
+
+inline RpStatus fail(RpStatus code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+inline RpStatus fail(RpStatus code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define RP_HIP(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess)                                                                         \
+      return rp::fail(RP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                      __LINE__);                                                                  \
+  } while (0)
+
+#define RP_CHECK_LAUNCH() RP_HIP(hipGetLastError())
+
+#define RP_REQUIRE(cond, ...)                                                                     \
+  do {                                                                                            \
+    if (!(cond)) return rp::fail(RP_E_INVALID, __VA_ARGS__);                                      \
+  } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- device types ----------------------------------------------------------------------------
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA A/B operand: 8 bf16 = 4 VGPRs
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, as torch's float -> bfloat16 conversion
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// gelu_new (tanh form), transformers/activations.py NewGELUActivation
+__device__ __forceinline__ float gelu_new(float u) {
+  const float c = 0.7978845608028654f;  // sqrt(2/pi)
+  float t = tanhf(c * (u + 0.044715f * u * u * u));
+  return 0.5f * u * (1.0f + t);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// monotone float <-> uint32 map (larger float = larger uint)
+__host__ __device__ __forceinline__ uint32_t f2ord(float f) {
+#ifdef __HIP_DEVICE_COMPILE__
+  uint32_t u = __float_as_uint(f);
+#else
+  uint32_t u;
+  memcpy(&u, &f, 4);
+#endif
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float ord2f(uint32_t o) {
+  uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+#ifdef __HIP_DEVICE_COMPILE__
+  return __uint_as_float(u);
+#else
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+#endif
+}
+
+}  // namespace rp

@@ -1,0 +1,195 @@
+"""HipT5Encoder: the ByT5/T5 text encoder of the retrieval path, running on libreprover_hip.
+
+Stands in for ``AutoModelForTextEncoding.from_pretrained(...)`` → ``T5EncoderModel``
+(retrieval/model.py:45) *together with* the masked mean-pool + L2 normalise of
+``PremiseRetriever._encode`` (model.py:92-114): one call = ``rp_encode_varlen``.
+PyTorch tensors are containers only (device memory + stream).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from types import SimpleNamespace
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_LAYER_KEYS = {
+    "ln_attn": "layer.0.layer_norm.weight",
+    "q": "layer.0.SelfAttention.q.weight",
+    "k": "layer.0.SelfAttention.k.weight",
+    "v": "layer.0.SelfAttention.v.weight",
+    "o": "layer.0.SelfAttention.o.weight",
+    "ln_ff": "layer.1.layer_norm.weight",
+    "wi_0": "layer.1.DenseReluDense.wi_0.weight",
+    "wi_1": "layer.1.DenseReluDense.wi_1.weight",
+    "wo": "layer.1.DenseReluDense.wo.weight",
+}
+
+
+def _require_gpu(device) -> torch.device:
+    device = torch.device(device)
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise _lib.HipLibraryError(
+            "the MI355X retrieval engine needs a HIP device; there is no CPU path "
+            f"(requested device={device}, torch.cuda.is_available()={torch.cuda.is_available()})"
+        )
+    return device
+
+
+class HipT5Encoder:
+    """T5 encoder weights resident on one GPU + the packed varlen forward."""
+
+    def __init__(self, cfg: Dict, state_dict: Dict[str, torch.Tensor], device, dtype: torch.dtype = torch.bfloat16,
+                 max_tokens_per_pass: int = 1 << 18):
+        if cfg.get("feed_forward_proj", "gated-gelu") != "gated-gelu":
+            raise _lib.HipLibraryError(f"feed_forward_proj={cfg.get('feed_forward_proj')!r} is not implemented")
+        self.device = _require_gpu(device)
+        assert dtype in (torch.bfloat16, torch.float32)
+        self.dtype = dtype  # dtype of the embeddings handed back (compute is bf16 MFMA / fp32 accumulate)
+        self.cfg = dict(cfg)
+        self.config = SimpleNamespace(hidden_size=cfg["d_model"], **cfg)
+        self.max_tokens_per_pass = int(max_tokens_per_pass)
+        self._state_dict_cpu = None
+        lib = _lib.load()
+        c = _lib.RpT5Config(
+            cfg["vocab_size"], cfg["d_model"], cfg["d_kv"], cfg["num_heads"], cfg["d_ff"], cfg["num_layers"],
+            cfg.get("relative_attention_num_buckets", 32), cfg.get("relative_attention_max_distance", 128),
+            float(cfg.get("layer_norm_epsilon", 1e-6)),
+        )
+        with torch.cuda.device(self.device):
+            keep = []
+
+            def dev(name: str) -> int:
+                t = state_dict[name].detach().to(device=self.device, dtype=torch.float32).contiguous()
+                keep.append(t)
+                return t.data_ptr()
+
+            emb = "shared.weight" if "shared.weight" in state_dict else "encoder.embed_tokens.weight"
+            layers = (_lib.RpT5LayerWeights * cfg["num_layers"])()
+            for i in range(cfg["num_layers"]):
+                for fld, key in _LAYER_KEYS.items():
+                    setattr(layers[i], fld, dev(f"encoder.block.{i}.{key}"))
+            w = _lib.RpT5Weights(
+                dev(emb),
+                dev("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"),
+                dev("encoder.final_layer_norm.weight"),
+                layers,
+            )
+            handle = C.c_void_p()
+            torch.cuda.synchronize(self.device)
+            _lib.check(lib.rp_encoder_create(C.byref(c), C.byref(w), _lib.RP_DT_F32, C.byref(handle)),
+                       "rp_encoder_create")
+            del keep
+        self._handle = handle
+        self._lib = lib
+        self._ws: Optional[torch.Tensor] = None
+
+    # -- construction helpers ---------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, path: str, device, dtype: torch.dtype = torch.bfloat16) -> "HipT5Encoder":
+        """Load a HuggingFace T5/ByT5 checkpoint directory (config.json + model.safetensors or
+        pytorch_model.bin; key names SURVEY.md App. B.5; decoder.* keys are ignored)."""
+        if not os.path.isdir(path):
+            raise FileExistsError(f"Checkpoint {path} does not exist.")  # common.py:409-410's convention
+        with open(os.path.join(path, "config.json")) as fh:
+            hf = json.load(fh)
+        cfg = dict(
+            vocab_size=hf["vocab_size"], d_model=hf["d_model"], d_kv=hf["d_kv"], num_heads=hf["num_heads"],
+            d_ff=hf["d_ff"], num_layers=hf["num_layers"],
+            relative_attention_num_buckets=hf.get("relative_attention_num_buckets", 32),
+            relative_attention_max_distance=hf.get("relative_attention_max_distance", 128),
+            layer_norm_epsilon=hf.get("layer_norm_epsilon", 1e-6),
+            feed_forward_proj=hf.get("feed_forward_proj", "relu"),
+        )
+        st = os.path.join(path, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+        sd = {k: v for k, v in sd.items() if not k.startswith("decoder.") and not k.startswith("lm_head")}
+        return cls(cfg, sd, device, dtype)
+
+    def save_pretrained(self, path: str) -> None:
+        raise NotImplementedError("saving checkpoints is outside the retrieval hot path")
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            try:
+                self._lib.rp_encoder_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    # -- forward ----------------------------------------------------------------------------------
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def encode_packed_device(self, ids: torch.Tensor, cu: torch.Tensor, batch: int, total: int, max_len: int,
+                             out: torch.Tensor) -> None:
+        """One ``rp_encode_varlen`` launch sequence; everything already on the device.
+        ``out`` = [batch, d_model] rows (may be a slice of a larger matrix), dtype f32 or bf16."""
+        assert ids.dtype == torch.int32 and cu.dtype == torch.int32
+        assert out.is_contiguous() and out.shape == (batch, self.cfg["d_model"])
+        nbytes = self._lib.rp_encoder_workspace_bytes(self._handle, total, batch)
+        ws = self._workspace(nbytes)
+        out_dt = _lib.RP_DT_BF16 if out.dtype == torch.bfloat16 else _lib.RP_DT_F32
+        with torch.cuda.device(self.device):
+            _lib.check(
+                self._lib.rp_encode_varlen(self._handle, _lib.ptr(ids), _lib.ptr(cu), batch, total, max_len,
+                                           out.data_ptr(), out_dt, _lib.ptr(ws), ws.numel(),
+                                           _lib.current_stream()),
+                "rp_encode_varlen",
+            )
+
+    def encode_packed(self, ids: np.ndarray, cu: np.ndarray, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Encode sequences given as packed host ids (int32 [T]) + cu_seqlens (int32 [B+1]);
+        splits into passes of at most ``max_tokens_per_pass`` tokens.  Returns [B, d_model]."""
+        B = len(cu) - 1
+        D = self.cfg["d_model"]
+        if out is None:
+            out = torch.empty((B, D), dtype=self.dtype, device=self.device)
+        lens = np.diff(cu)
+        assert B > 0 and lens.min() > 0, "every sequence needs at least the EOS token"
+        b0 = 0
+        while b0 < B:
+            b1 = int(np.searchsorted(cu, cu[b0] + self.max_tokens_per_pass, side="right")) - 1
+            b1 = min(max(b1, b0 + 1), B)
+            t0, t1 = int(cu[b0]), int(cu[b1])
+            ids_d = torch.from_numpy(np.ascontiguousarray(ids[t0:t1])).pin_memory().to(self.device, non_blocking=True)
+            cu_d = torch.from_numpy((cu[b0 : b1 + 1] - cu[b0]).astype(np.int32)).pin_memory().to(
+                self.device, non_blocking=True)
+            self.encode_packed_device(ids_d, cu_d, b1 - b0, t1 - t0, int(lens[b0:b1].max()), out[b0:b1])
+            b0 = b1
+        return out
+
+    def encode_padded(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        """Drop-in for ``_encode(input_ids, attention_mask)`` with right-padded [B, L] inputs."""
+        input_ids = input_ids.to(self.device)
+        attention_mask = attention_mask.to(self.device)
+        m = attention_mask.bool()
+        if input_ids.shape[1] > 1 and bool((m[:, 1:] & ~m[:, :-1]).any()):
+            raise ValueError("attention_mask must be right-padded (1s then 0s), as the tokenizer produces")
+        lens = m.sum(dim=1)
+        if bool((lens == 0).any()):
+            raise ValueError("empty sequence in batch")
+        cu = torch.zeros(input_ids.shape[0] + 1, dtype=torch.int32, device=self.device)
+        cu[1:] = torch.cumsum(lens, 0)
+        ids = input_ids[m].to(torch.int32).contiguous()
+        lens_h = lens.cpu()
+        B, T = input_ids.shape[0], int(lens_h.sum())
+        out = torch.empty((B, self.cfg["d_model"]), dtype=self.dtype, device=self.device)
+        if T <= self.max_tokens_per_pass:
+            self.encode_packed_device(ids, cu, B, T, int(lens_h.max()), out)
+            return out
+        return self.encode_packed(ids.cpu().numpy(), cu.cpu().numpy(), out)

@@ -1,0 +1,185 @@
+"""PremiseRetriever on MI355X: drop-in for the inference surface of the reference's
+``retrieval/model.py::PremiseRetriever`` (lean-dojo/ReProver).
+
+Same names, argument meaning and error behaviour as the reference for:
+``load_hf`` (model.py:52-66), ``load_corpus`` (:68-85), ``embedding_size`` (:87-90), ``_encode``
+(:92-114), ``reindex_corpus`` (:183-210), ``retrieve`` (:338-375) and the predict hooks' bodies
+(:274-336).  The training half (``forward``, ``training_step``, optimizers) is out of scope.
+
+What is different underneath: the encoder forward, pooling, similarity, masking and top-k all
+run in hand-written HIP kernels behind the C ABI of libreprover_hip.so; premises are encoded as
+packed variable-length sequences (no padding, no dense [B,H,L,L] mask), the corpus matrix stays
+resident in HBM in bf16, and nothing falls back to the CPU.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from ..common import Context, Corpus, IndexedCorpus, Pos, Premise, zip_strict
+from ..encoder import HipT5Encoder
+from ..tokenizer import ByT5Tokenizer
+
+
+class PremiseRetriever:
+    def __init__(
+        self,
+        model_name: Union[str, HipT5Encoder],
+        lr: float = 0.0,
+        warmup_steps: int = 0,
+        max_seq_len: int = 2048,
+        num_retrieved: int = 100,
+        device: Union[str, torch.device] = "cuda",
+        dtype: torch.dtype = torch.bfloat16,
+    ) -> None:
+        self.lr = lr
+        self.warmup_steps = warmup_steps
+        self.num_retrieved = num_retrieved
+        self.max_seq_len = max_seq_len
+        self.tokenizer = ByT5Tokenizer()
+        if isinstance(model_name, HipT5Encoder):
+            self.encoder = model_name
+        else:
+            self.encoder = HipT5Encoder.from_pretrained(model_name, device, dtype)
+        self.corpus: Optional[Corpus] = None
+        self.corpus_embeddings: Optional[torch.Tensor] = None
+        self.embeddings_staled = True
+        self.predict_step_outputs: List[Dict[str, Any]] = []
+
+    # -- construction (model.py:52-66) --------------------------------------------------------------
+    @classmethod
+    def load_hf(cls, ckpt_path: str, max_seq_len: int, device, dtype=None) -> "PremiseRetriever":
+        """``dtype`` None → bf16, the reference's own choice on a capable GPU (model.py:59-64)."""
+        return cls(ckpt_path, 0.0, 0, max_seq_len, 100, device=device, dtype=dtype or torch.bfloat16)
+
+    @classmethod
+    def from_state_dict(cls, cfg: Dict, state_dict: Dict[str, torch.Tensor], max_seq_len: int, device,
+                        dtype: torch.dtype = torch.bfloat16) -> "PremiseRetriever":
+        """Build from an in-memory HF-keyed state dict (synthetic weights; no checkpoint on disk)."""
+        return cls(HipT5Encoder(cfg, state_dict, device, dtype), 0.0, 0, max_seq_len, 100)
+
+    @property
+    def device(self) -> torch.device:
+        return self.encoder.device
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.encoder.dtype
+
+    def eval(self) -> "PremiseRetriever":
+        return self
+
+    # -- corpus (model.py:68-85) --------------------------------------------------------------------
+    def load_corpus(self, path_or_corpus: Union[str, Corpus]) -> None:
+        """Associate the retriever with a corpus: a ``Corpus``, a ``corpus.jsonl`` (embeddings
+        stale) or a pickled ``IndexedCorpus`` with pre-computed embeddings."""
+        if isinstance(path_or_corpus, Corpus):
+            self.corpus = path_or_corpus
+            self.corpus_embeddings = None
+            self.embeddings_staled = True
+            return
+        path = path_or_corpus
+        if path.endswith(".jsonl"):
+            self.corpus = Corpus(path)
+            self.corpus_embeddings = None
+            self.embeddings_staled = True
+        else:
+            with open(path, "rb") as fh:
+                indexed_corpus = pickle.load(fh)
+            self.corpus = indexed_corpus.corpus
+            self.corpus_embeddings = indexed_corpus.embeddings
+            self.embeddings_staled = False
+
+    @property
+    def embedding_size(self) -> int:
+        return self.encoder.config.hidden_size
+
+    # -- encode (model.py:92-114) -------------------------------------------------------------------
+    def _encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        """Unit-norm feature vectors [B, D] for right-padded token batches."""
+        return self.encoder.encode_padded(input_ids, attention_mask)
+
+    def encode_texts(self, texts: List[str], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Tokenise + encode without materialising padding (the packed form the engine consumes)."""
+        ids, cu = self.tokenizer.packed(texts, self.max_seq_len)
+        return self.encoder.encode_packed(ids, cu, out)
+
+    # -- index (model.py:183-210) -------------------------------------------------------------------
+    @torch.no_grad()
+    def reindex_corpus(self, batch_size: int) -> None:
+        """Re-encode every premise of the corpus if the embeddings are stale.
+
+        The reference walks the corpus ``batch_size`` premises at a time, padding each batch to its
+        longest member.  Encoding a premise does not depend on its batch, so
+        here ``batch_size`` only bounds the host-side serialise/tokenise step; the GPU receives
+        packed chunks sized by tokens.  Row i of ``corpus_embeddings`` is premise i, as in the
+        reference."""
+        if not self.embeddings_staled:
+            return
+        N = len(self.corpus.all_premises)
+        self.corpus_embeddings = torch.zeros(N, self.embedding_size, dtype=self.encoder.dtype, device=self.device)
+        step = max(int(batch_size), 4096)
+        for i in range(0, N, step):
+            chunk = self.corpus.all_premises[i : i + step]
+            self.encode_texts([p.serialize() for p in chunk], out=self.corpus_embeddings[i : i + len(chunk)])
+        self.embeddings_staled = False
+
+    # -- prediction (model.py:274-336) --------------------------------------------------------------
+    def on_predict_start(self, corpus: Corpus, eval_batch_size: int) -> None:
+        self.corpus = corpus
+        self.corpus_embeddings = None
+        self.embeddings_staled = True
+        self.reindex_corpus(eval_batch_size)
+        self.predict_step_outputs = []
+
+    def predict_step(self, batch: Dict[str, Any], _=None) -> None:
+        context_emb = self._encode(batch["context_ids"], batch["context_mask"])
+        assert not self.embeddings_staled
+        retrieved_premises, scores = self.corpus.get_nearest_premises(
+            self.corpus_embeddings, batch["context"], context_emb, self.num_retrieved
+        )
+        for url, commit, file_path, full_name, start, tactic_idx, ctx, pos_premises, premises, s in zip_strict(
+            batch["url"], batch["commit"], batch["file_path"], batch["full_name"], batch["start"],
+            batch["tactic_idx"], batch["context"], batch["all_pos_premises"], retrieved_premises, scores,
+        ):
+            self.predict_step_outputs.append(
+                {
+                    "url": url,
+                    "commit": commit,
+                    "file_path": file_path,
+                    "full_name": full_name,
+                    "start": start,
+                    "tactic_idx": tactic_idx,
+                    "context": ctx,
+                    "all_pos_premises": pos_premises,
+                    "retrieved_premises": premises,
+                    "scores": s,
+                }
+            )
+
+    def on_predict_epoch_end(self, log_dir: Optional[str]) -> None:
+        if log_dir is not None:
+            path = os.path.join(log_dir, "predictions.pickle")
+            with open(path, "wb") as oup:
+                pickle.dump(self.predict_step_outputs, oup)
+        self.predict_step_outputs.clear()
+
+    # -- single query (model.py:338-375) ------------------------------------------------------------
+    @torch.no_grad()
+    def retrieve(
+        self, state: str, file_name: str, theorem_full_name: str, theorem_pos: Pos, k: int
+    ) -> Tuple[List[Premise], List[float]]:
+        """Retrieve ``k`` premises from the corpus using ``state`` as the query."""
+        self.reindex_corpus(batch_size=32)
+        ctx = Context(file_name, theorem_full_name, theorem_pos, state)
+        context_emb = self.encode_texts([ctx.serialize()])
+        if self.corpus_embeddings.device != context_emb.device or self.corpus_embeddings.dtype != torch.bfloat16:
+            # a pickled index arrives as fp32 on the CPU (index.py:37-40): move + cast once
+            self.corpus_embeddings = self.corpus_embeddings.to(device=context_emb.device, dtype=torch.bfloat16)
+        retrieved_premises, scores = self.corpus.get_nearest_premises(self.corpus_embeddings, [ctx], context_emb, k)
+        assert len(retrieved_premises) == len(scores) == 1
+        return retrieved_premises[0], scores[0]

@@ -1,0 +1,220 @@
+"""Deterministic synthetic inputs: encoder weights, premise/state texts, corpus files.
+
+There is no network in the build or GPU environments, so neither the pretrained
+``kaiyuy/leandojo-lean4-retriever-byt5-small`` checkpoint nor the LeanDojo benchmark can be
+fetched.  Tests, ``bench.py`` and the golden-vector generator all draw from the generators here
+(seed 3407 = the reference's ``seed_everything``, retrieval/confs/cli_lean4_random.yaml:1), which
+are bit-reproducible from raw Philox counters so that the authoring container and the GPU box
+build identical weights without shipping a 0.9 GB checkpoint.
+"""
+from __future__ import annotations
+
+import json
+import zlib
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+SEED = 3407
+
+CONFIGS: Dict[str, Dict] = {
+    # google/byt5-small encoder
+    "byt5-small": dict(vocab_size=384, d_model=1472, d_kv=64, num_heads=6, d_ff=3584, num_layers=12),
+    # google/byt5-base encoder
+    "byt5-base": dict(vocab_size=384, d_model=1536, d_kv=64, num_heads=12, d_ff=3968, num_layers=18),
+    # small shapes for fast parity tests; keeps d_kv = 64 like both real models
+    "tiny": dict(vocab_size=384, d_model=128, d_kv=64, num_heads=2, d_ff=256, num_layers=2),
+}
+for _c in CONFIGS.values():
+    _c.update(
+        relative_attention_num_buckets=32,
+        relative_attention_max_distance=128,
+        layer_norm_epsilon=1e-6,
+        feed_forward_proj="gated-gelu",
+    )
+
+
+def t5_config(name: str) -> Dict:
+    return dict(CONFIGS[name])
+
+
+def _philox_normal(name: str, n: int, seed: int) -> np.ndarray:
+    """n standard normals from raw Philox-4x64 output (stable by specification) via Box-Muller
+    in float64; the stream is keyed by (seed, crc32(name)) so tensors are independent."""
+    key = (int(seed) << 32) ^ zlib.crc32(name.encode())
+    raw = np.random.Philox(key=key).random_raw(2 * ((n + 1) // 2))
+    u = (raw >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    u1, u2 = u[0::2], u[1::2]
+    r = np.sqrt(-2.0 * np.log1p(-u1))  # u1 in [0,1) -> log argument in (0,1]
+    z = np.concatenate([r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)])
+    return z[:n]
+
+
+def _philox_uniform(name: str, n: int, seed: int) -> np.ndarray:
+    key = (int(seed) << 32) ^ zlib.crc32(name.encode())
+    raw = np.random.Philox(key=key).random_raw(n)
+    return (raw >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+def synth_state_dict(cfg: Dict, seed: int = SEED) -> Dict[str, torch.Tensor]:
+    """HF-keyed fp32 encoder state dict (key names: SURVEY.md App. B.5).
+
+    Scales follow HF's T5 init (modeling_t5.py:563-616) except that q and the relative-position
+    table are made stronger so that attention is sharp and the position bias matters, which is
+    what a trained retriever looks like and what makes the parity tests discriminating:
+    q ~ N(0, (0.5·D^-½)²) → logits std ≈ 4; bias table ~ N(0, 1).
+    """
+    D, dk, H, F, V = cfg["d_model"], cfg["d_kv"], cfg["num_heads"], cfg["d_ff"], cfg["vocab_size"]
+    inner = H * dk
+    sd: Dict[str, torch.Tensor] = {}
+
+    def normal(name, shape, std):
+        n = int(np.prod(shape))
+        sd[name] = torch.from_numpy((_philox_normal(name, n, seed) * std).astype(np.float32).reshape(shape))
+
+    def ln(name):
+        sd[name] = torch.from_numpy((0.5 + _philox_uniform(name, D, seed)).astype(np.float32))
+
+    normal("shared.weight", (V, D), 1.0)
+    sd["encoder.embed_tokens.weight"] = sd["shared.weight"]
+    normal(
+        "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight",
+        (cfg["relative_attention_num_buckets"], H),
+        1.0,
+    )
+    for i in range(cfg["num_layers"]):
+        p = f"encoder.block.{i}.layer."
+        ln(p + "0.layer_norm.weight")
+        normal(p + "0.SelfAttention.q.weight", (inner, D), 0.5 * D**-0.5)
+        normal(p + "0.SelfAttention.k.weight", (inner, D), D**-0.5)
+        normal(p + "0.SelfAttention.v.weight", (inner, D), D**-0.5)
+        normal(p + "0.SelfAttention.o.weight", (D, inner), inner**-0.5)
+        ln(p + "1.layer_norm.weight")
+        normal(p + "1.DenseReluDense.wi_0.weight", (F, D), D**-0.5)
+        normal(p + "1.DenseReluDense.wi_1.weight", (F, D), D**-0.5)
+        normal(p + "1.DenseReluDense.wo.weight", (D, F), F**-0.5)
+    ln("encoder.final_layer_norm.weight")
+    return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# Texts
+# ----------------------------------------------------------------------------------------------
+_SYMS = ["ℕ", "⊢", "→", "∀"]  # 3-byte UTF-8 symbols (SURVEY.md §8d byte-value mix)
+
+
+def synth_text(rng: np.random.Generator, n_bytes: int) -> str:
+    """A string of exactly ``n_bytes`` UTF-8 bytes: ≈90 % printable ASCII, ≈10 % of the bytes
+    belong to 3-byte math symbols.  No '<' so no tokenizer special can appear by accident."""
+    out: List[str] = []
+    left = n_bytes
+    while left > 0:
+        if left >= 3 and rng.random() < 0.035:
+            out.append(_SYMS[int(rng.integers(4))])
+            left -= 3
+        else:
+            c = int(rng.integers(32, 127))
+            if c == 60:  # '<'
+                c = 32
+            out.append(chr(c))
+            left -= 1
+    return "".join(out)
+
+
+def synth_lengths(rng: np.random.Generator, n: int, kind: str = "mix", lo: int = 8, hi: int = 2048) -> np.ndarray:
+    """Token lengths incl. EOS.  'mix' = clip(round(LogNormal(ln 180, 0.9)), lo, hi) (the
+    mathlib-like mix of SURVEY.md §8d); an integer string = fixed tier."""
+    if kind == "mix":
+        return np.clip(np.rint(rng.lognormal(np.log(180.0), 0.9, size=n)), lo, hi).astype(np.int64)
+    return np.full(n, int(kind), dtype=np.int64)
+
+
+def synth_token_batch(
+    rng: np.random.Generator, lengths: Sequence[int]
+) -> Tuple[np.ndarray, np.ndarray]:
+    """Packed ByT5 ids for sequences of the given lengths (each ends in EOS = 1) without going
+    through strings: ids uniform over printable-ASCII byte ids.  Returns (ids int32 [T],
+    cu_seqlens int32 [B+1])."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    cu = np.zeros(len(lengths) + 1, dtype=np.int32)
+    cu[1:] = np.cumsum(lengths)
+    ids = rng.integers(32 + 3, 127 + 3, size=int(cu[-1]), dtype=np.int32)
+    ids[cu[1:] - 1] = 1
+    return ids, cu
+
+
+# ----------------------------------------------------------------------------------------------
+# Corpus (corpus.jsonl of SURVEY.md App. B.1)
+# ----------------------------------------------------------------------------------------------
+def synth_corpus_records(
+    n_files: int,
+    n_premises: int,
+    seed: int = SEED,
+    code_bytes: Tuple[int, int] = (24, 120),
+    max_imports: int = 3,
+    with_edge_cases: bool = True,
+) -> List[dict]:
+    """File records in topological order.  Premises get dotted names, code that mentions the
+    name (so ``serialize`` has something to mark), increasing positions inside a file with some
+    nested (non-monotone ``end``) declarations, and — when ``with_edge_cases`` — the records
+    ``File.from_data`` must drop (null / ``user__.n`` / ``[mutual]`` names, empty code) plus
+    duplicate ``full_name``s inside a file."""
+    rng = np.random.default_rng(seed)
+    weights = rng.lognormal(0.0, 0.8, size=n_files)
+    counts = np.floor(weights / weights.sum() * n_premises).astype(int)
+    counts[: n_premises - counts.sum()] += 1
+    files = []
+    for f in range(n_files):
+        path = f"Synth/Dir{f % 7}/File{f}.lean"
+        n_imp = int(rng.integers(0, max_imports + 1)) if f > 0 else 0
+        imports = sorted({int(x) for x in rng.integers(max(0, f - 40), f, size=n_imp)}) if f > 0 else []
+        prem = []
+        line = 1
+        for j in range(int(counts[f])):
+            ns = ["Nat", "List", "Set", "Finset", "Real"][int(rng.integers(5))]
+            short = f"lemma_{f}_{j}"
+            full = f"{ns}.{short}" if rng.random() < 0.8 else short
+            nbytes = int(rng.integers(code_bytes[0], code_bytes[1]))
+            style = rng.random()
+            if style < 0.5:
+                head = f"theorem {short} "
+            elif style < 0.7:
+                head = f"theorem _root_.{full} "
+            elif style < 0.85:
+                head = f"lemma «{short}» "
+            else:
+                head = "instance : Inhabited Foo "
+            body = synth_text(rng, max(4, nbytes - len(head.encode())))
+            start = [line, int(rng.integers(0, 4))]
+            span = int(rng.integers(1, 6))
+            end = [line + span, int(rng.integers(0, 40))]
+            # sometimes nest the next declaration inside this one (end not monotone in order)
+            line += span + 1 if rng.random() < 0.85 else 1
+            prem.append({"full_name": full, "code": head + ": " + body, "start": start, "end": end, "kind": "theorem"})
+        if with_edge_cases and f % 9 == 3:
+            prem.insert(0, {"full_name": None, "code": "x", "start": [1, 0], "end": [1, 1], "kind": "x"})
+            prem.append({"full_name": "user__.n.1", "code": "y", "start": [line, 0], "end": [line, 1], "kind": "x"})
+            prem.append({"full_name": "[mutual.a, mutual.b]", "code": "z", "start": [line, 0], "end": [line, 1], "kind": "x"})
+            prem.append({"full_name": f"Empty.code_{f}", "code": "", "start": [line, 0], "end": [line, 1], "kind": "x"})
+        if with_edge_cases and f % 11 == 5 and len(prem) >= 2 and prem[0]["full_name"] is not None:
+            dup = dict(prem[0])
+            dup["start"], dup["end"] = [line + 1, 0], [line + 2, 0]
+            dup["code"] = dup["code"] + " -- again"
+            prem.append(dup)
+        files.append({"path": path, "imports": [files[i]["path"] for i in imports], "premises": prem})
+    return files
+
+
+def write_corpus_jsonl(path: str, records: Sequence[dict]) -> None:
+    with open(path, "w") as fh:
+        for rec in records:
+            fh.write(json.dumps(rec, ensure_ascii=False) + "\n")
+
+
+def synth_state(rng: np.random.Generator, n_bytes: int) -> str:
+    """A proof-state-like string containing the mandatory '⊢' (common.py:46-52)."""
+    n_bytes = max(n_bytes, 8)
+    head = synth_text(rng, (n_bytes - 4) // 2)
+    tail = synth_text(rng, n_bytes - 4 - len(head.encode()))
+    return head + " ⊢" + tail  # ' ' + 3-byte turnstile = 4 bytes

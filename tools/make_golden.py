@@ -1,0 +1,382 @@
+"""Generate tests/golden/* by running the REFERENCE itself (lean-dojo/ReProver, imported from
+/root/reference through tools/ref_harness.py) and HuggingFace transformers on CPU.
+
+Authoring container only.  Only the resulting small data files are committed; no reference
+source travels.  Usage:  python tools/make_golden.py [g1 g2 g3 g4 g5 g6 g7]   (default: all)
+
+Every fixture records the inputs and the reference's outputs; while generating, the oracle
+(oracle/) is checked against the reference so a drifting restatement fails here first.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_harness as H  # noqa: E402
+
+common, rm = H.install()
+from transformers import ByT5Tokenizer  # noqa: E402
+from transformers.models.t5.modeling_t5 import T5Attention  # noqa: E402
+
+from oracle import common_ref, t5_ref  # noqa: E402
+from reprover_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def hf_cfg(cfg):
+    return dict(
+        vocab_size=cfg["vocab_size"],
+        d_model=cfg["d_model"],
+        d_kv=cfg["d_kv"],
+        d_ff=cfg["d_ff"],
+        num_layers=cfg["num_layers"],
+        num_decoder_layers=1,
+        num_heads=cfg["num_heads"],
+        feed_forward_proj="gated-gelu",
+        tie_word_embeddings=False,
+    )
+
+
+# ----------------------------------------------------------------------------------------------
+def g1_tokenizer():
+    tok = ByT5Tokenizer()
+    rng = np.random.default_rng(1)
+    texts = [
+        "abc",
+        "",
+        " ",
+        "theorem foo (n : ℕ) : n + 0 = n := by simp",
+        "ℕ ⊢ «x» → ∀ y, y ≤ x",
+        "a\n\nb  c\t\td",
+        "a </s> b",
+        "x<pad>y",
+        "<unk>",
+        "<extra_id_0> z <extra_id_124>",
+        "<extra_id_125> not special",
+        "tail eos </s>",
+        "</s>",
+        "<a>Nat.add_comm</a> : ∀ (n m : ℕ), n + m = m + n",
+        "ℕℕℕℕℕℕ",  # multi-byte char split by truncation at max_length 16/8
+        "x" * 15,
+        "x" * 16,
+        "x" * 17,
+        synth.synth_text(rng, 1023),
+        synth.synth_text(rng, 1024),
+        synth.synth_text(rng, 2047),
+        synth.synth_text(rng, 2048),
+        synth.synth_text(rng, 3000),
+        "𝔸𝔹ℂ 😀 日本語",
+    ]
+    cases = []
+    for ml in (8, 16, 1024, 2048):
+        enc = tok(texts, padding="longest", max_length=ml, truncation=True, return_tensors="np")
+        ids, mask = enc["input_ids"], enc["attention_mask"]
+        o_ids, o_mask = t5_ref.byt5_batch(texts, ml)
+        assert np.array_equal(ids, o_ids) and np.array_equal(mask, o_mask), f"oracle tokenizer drift @ {ml}"
+        rows = [ids[i, : int(mask[i].sum())].tolist() for i in range(len(texts))]
+        cases.append({"max_length": ml, "padded_len": int(ids.shape[1]), "ids": rows})
+    json.dump({"texts": texts, "cases": cases}, open(os.path.join(OUT, "g1_tokenizer.json"), "w"), ensure_ascii=False)
+    print("g1 ok:", len(texts), "texts x", len(cases), "max_lengths")
+
+
+# ----------------------------------------------------------------------------------------------
+def g2_serialize():
+    P = H.Pos
+    recs = [
+        ("A.lean", "Nat.add_comm", "theorem Nat.add_comm (n m : ℕ) : n + m = m + n := sorry"),
+        ("A.lean", "Nat.add_comm", "theorem add_comm (n m : ℕ) : n + m = m + n"),
+        ("A.lean", "Nat.add_comm", "theorem _root_.Nat.add_comm : True"),
+        ("A.lean", "Foo.bar.baz", "lemma baz : 1 = 1\nlemma bar.baz' : 2 = 2"),
+        ("A.lean", "Foo.bar.baz", "lemma «baz» : 1 = 1"),
+        ("A.lean", "Foo.bar.baz", "lemma «bar.baz» «baz» : 1 = 1"),
+        ("A.lean", "Foo.bar.baz", "no match here"),
+        ("A.lean", "Foo.bar.baz", "baz at start is not preceded by whitespace"),
+        ("A.lean", "a.b", "theorem aXb : True  -- '.' is a regex wildcard in the reference"),
+        ("A.lean", "List.map", "def map (f : α → β) : List α → List β\n  | [] => []\n  | a::as => f a :: map f as"),
+        ("A.lean", "instInhabitedNat", "instance : Inhabited ℕ := ⟨0⟩"),
+        ("A.lean", "Set.mem_def", "theorem\tmem_def {a : α} {s : Set α} : a ∈ s ↔ s a"),
+        ("A.lean", "x", "def x := x + x"),
+        ("A.lean", "Real.sqrt", "noncomputable def Real.sqrt (x : ℝ) : ℝ := NNReal.sqrt (Real.toNNReal x)"),
+        ("A.lean", "Nat.succ_le", "theorem succ_le {n m : ℕ} : succ n ≤ m ↔ n < m  -- succ_le succ_le"),
+        ("A.lean", "Foo.Bar", "structure Bar where\n  x : ℕ\n\n«Foo.Bar» Bar"),
+    ]
+    cases = []
+    for path, name, code in recs:
+        ref = common.Premise(path, name, P(1, 0), P(2, 0), code).serialize()
+        mine = common_ref.PremiseRef(path, name, common_ref.Pos(1, 0), common_ref.Pos(2, 0), code).serialize()
+        assert ref == mine, (name, code, ref, mine)
+        cases.append({"path": path, "full_name": name, "code": code, "serialized": ref})
+    # File.from_data filters + a full synthetic corpus' serialisations
+    files = synth.synth_corpus_records(12, 150, seed=7)
+    kept = []
+    for fd in files:
+        f = common.File.from_data(fd)
+        mine = common_ref.premises_of_file(fd)
+        assert [p.full_name for p in f.premises] == [p.full_name for p in mine]
+        assert [p.serialize() for p in f.premises] == [p.serialize() for p in mine]
+        kept.append({"path": fd["path"], "names": [p.full_name for p in f.premises],
+                     "serialized": [p.serialize() for p in f.premises]})
+    json.dump({"cases": cases, "corpus_seed": 7, "corpus_files": 12, "corpus_premises": 150, "kept": kept},
+              open(os.path.join(OUT, "g2_serialize.json"), "w"), ensure_ascii=False)
+    print("g2 ok:", len(cases), "premises;", sum(len(k["names"]) for k in kept), "kept of synthetic corpus")
+
+
+# ----------------------------------------------------------------------------------------------
+def g3_buckets():
+    d = torch.arange(-2200, 2201, dtype=torch.long)
+    b = T5Attention._relative_position_bucket(d, bidirectional=True, num_buckets=32, max_distance=128).numpy()
+    mine = t5_ref.relative_position_bucket(d.numpy(), 32, 128)
+    assert np.array_equal(b, mine)
+    np.savez_compressed(os.path.join(OUT, "g3_buckets.npz"), rel=d.numpy().astype(np.int32), bucket=b.astype(np.int8))
+    print("g3 ok: buckets for", len(d), "offsets; distinct", len(np.unique(b)))
+
+
+# ----------------------------------------------------------------------------------------------
+def _texts_with_lengths(rng, lens):
+    return [synth.synth_text(rng, int(n) - 1) for n in lens]  # +EOS = n tokens
+
+
+def _ref_encode(model, texts, max_len, bs):
+    """The reference's own tokenise → _encode, in corpus-order batches (model.py:197-208)."""
+    outs = []
+    for i in range(0, len(texts), bs):
+        t = model.tokenizer(texts[i : i + bs], padding="longest", max_length=max_len, truncation=True,
+                            return_tensors="pt")
+        with torch.no_grad():
+            outs.append(model._encode(t.input_ids, t.attention_mask))
+    return torch.cat(outs)
+
+
+def g4_tiny():
+    cfg = synth.t5_config("tiny")
+    sd = synth.synth_state_dict(cfg)
+    model = H.offline_retriever(rm, hf_cfg(cfg), sd, max_seq_len=512)
+    assert model.encoder.dtype == torch.float32
+    rng = np.random.default_rng(4)
+    lens = [2, 3, 9, 31, 32, 33, 64, 65, 100, 127, 128, 129, 200, 257, 300, 512]
+    texts = _texts_with_lengths(rng, lens)
+    texts[3] = "n : ℕ ⊢ n + 0 = n"
+    t = model.tokenizer(texts, padding="longest", max_length=512, truncation=True, return_tensors="pt")
+    with torch.no_grad():
+        hidden = model.encoder(input_ids=t.input_ids, attention_mask=t.attention_mask).last_hidden_state
+        emb = model._encode(t.input_ids, t.attention_mask)
+    o_hidden = t5_ref.encoder_forward(cfg, sd, t.input_ids.numpy(), t.attention_mask.numpy())
+    o_emb = t5_ref.encode(cfg, sd, t.input_ids.numpy(), t.attention_mask.numpy())
+    m = t.attention_mask.bool()
+    dh = (hidden - o_hidden)[m].abs().max().item()
+    de = (emb - o_emb).abs().max().item()
+    print(f"g4: oracle vs HF  max|Δhidden| = {dh:.2e}  max|Δemb| = {de:.2e}")
+    assert dh < 5e-5 and de < 1e-6
+    # padding invariance: each text alone == inside the batch
+    solo = _ref_encode(model, texts, 512, 1)
+    print(f"g4: batch vs solo max|Δemb| = {(solo - emb).abs().max().item():.2e}")
+    np.savez_compressed(
+        os.path.join(OUT, "g4_tiny.npz"),
+        texts=np.array(texts, dtype=object),
+        input_ids=t.input_ids.numpy().astype(np.int32),
+        attention_mask=t.attention_mask.numpy().astype(np.int8),
+        hidden_last_rows=hidden[torch.arange(len(texts)), t.attention_mask.sum(1) - 1].numpy(),
+        hidden_first_rows=hidden[:, 0].numpy(),
+        emb=emb.numpy(),
+        seed=np.int64(synth.SEED),
+    )
+    print("g4 ok")
+
+
+def g5_small():
+    cfg = synth.t5_config("byt5-small")
+    t0 = time.time()
+    sd = synth.synth_state_dict(cfg)
+    print(f"g5: weights generated in {time.time() - t0:.1f}s")
+    model = H.offline_retriever(rm, hf_cfg(cfg), sd, max_seq_len=2048)
+    n_par = sum(p.numel() for p in model.encoder.parameters())
+    print("g5: encoder params", n_par)
+    rng = np.random.default_rng(5)
+    lens = [8, 17, 33, 64, 100, 128, 180, 256, 300, 400, 512, 700, 1024, 1500, 2048, 2600]
+    texts = _texts_with_lengths(rng, lens)
+    texts[4] = "α : Type u_1\ninst✝ : LinearOrder α\na b : α\nh : a ≤ b\n⊢ max a b = b" + synth.synth_text(rng, 20)
+    t0 = time.time()
+    emb = _ref_encode(model, texts, 2048, 4)
+    print(f"g5: HF fp32 encode of {sum(min(l, 2048) for l in lens)} tokens in {time.time() - t0:.1f}s")
+    t0 = time.time()
+    o_emb = t5_ref.encode_texts(cfg, sd, texts, 2048, 4)
+    de = (emb - o_emb).abs().max().item()
+    print(f"g5: oracle vs HF max|Δemb| = {de:.2e}  ({time.time() - t0:.1f}s)")
+    assert de < 2e-5
+    # the reference's GPU numerics (bf16 everywhere) for the tolerance envelope
+    t0 = time.time()
+    model_bf = model.to(torch.bfloat16)
+    emb_bf = _ref_encode(model_bf, texts, 2048, 4).float()
+    print(f"g5: HF bf16 vs fp32 max|Δemb| = {(emb_bf - emb).abs().max().item():.2e}; "
+          f"min cos = {torch.nn.functional.cosine_similarity(emb_bf, emb).min().item():.5f} ({time.time() - t0:.1f}s)")
+    np.savez_compressed(
+        os.path.join(OUT, "g5_byt5_small.npz"),
+        texts=np.array(texts, dtype=object),
+        emb=emb.numpy(),
+        emb_hf_bf16=emb_bf.numpy().astype(np.float16),
+        seed=np.int64(synth.SEED),
+    )
+    print("g5 ok")
+
+
+# ----------------------------------------------------------------------------------------------
+def _ref_nearest_indexes(corpus, E, ctxs, Q, k):
+    """Reference get_nearest_premises → (indexes, scores); Premise objects are mapped back to
+    their position in all_premises by object identity."""
+    where = {id(p): i for i, p in enumerate(corpus.all_premises)}
+    prem, scores = corpus.get_nearest_premises(E, ctxs, Q, k)
+    return [[where[id(p)] for p in row] for row in prem], scores
+
+
+def g6_nearest():
+    files = synth.synth_corpus_records(40, 1000, seed=6)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "corpus.jsonl")
+        synth.write_corpus_jsonl(path, files)
+        corpus = common.Corpus(path)
+        ocorpus = common_ref.CorpusRef(path)
+    N = len(corpus)
+    assert N == len(ocorpus)
+    rng = np.random.default_rng(66)
+    D = 64
+    E = rng.standard_normal((N, D)).astype(np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    B = 24
+    Q = rng.standard_normal((B, D)).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    # query positions: late files so that plenty is accessible, plus a few early/edge ones
+    qfiles = list(rng.integers(25, 40, size=B - 4)) + [39, 30, 1, 0]
+    ctxs, octxs, qmeta = [], [], []
+    for j, f in enumerate(qfiles):
+        fpath = files[int(f)]["path"]
+        prem = corpus.get_premises(fpath)
+        if prem and j % 3 != 0:
+            anchor = prem[int(rng.integers(len(prem)))]
+            pos = (anchor.end.line_nb, anchor.end.column_nb + int(rng.integers(0, 2)))
+        else:
+            pos = (int(rng.integers(1, 400)), int(rng.integers(0, 50)))
+        ctxs.append(common.Context(fpath, f"thm{j}", H.Pos(*pos), f"x{j} ⊢ y"))
+        octxs.append(common_ref.ContextRef(fpath, f"thm{j}", common_ref.Pos(*pos), f"x{j} ⊢ y"))
+        qmeta.append({"path": fpath, "pos": list(pos)})
+    # accessibility: reference set-form vs oracle, and index-form
+    acc = np.zeros((B, N), dtype=bool)
+    for j, c in enumerate(ctxs):
+        s = corpus.get_accessible_premises(c.path, c.theorem_pos)
+        row = np.array([p in s for p in corpus.all_premises])
+        keys = ocorpus.accessible_keys(c.path, octxs[j].theorem_pos)
+        orow = np.array([(p.path, p.full_name) in keys for p in ocorpus.all_premises])
+        assert np.array_equal(row, orow)
+        acc[j] = row
+    out = {"acc_counts": acc.sum(1).tolist()}
+    results = {}
+    Et, Qt = torch.from_numpy(E), torch.from_numpy(Q)
+    for k in (1, 10, 100):
+        ok = [j for j in range(B) if acc[j].sum() >= k]
+        idx, sc = _ref_nearest_indexes(corpus, Et, [ctxs[j] for j in ok], Qt[ok], k)
+        oidx, osc = ocorpus.get_nearest_premises(E, [octxs[j] for j in ok], Q[ok], k)
+        assert idx == oidx, f"oracle nearest drift at k={k}"
+        assert np.allclose(np.array(sc), np.array(osc), atol=1e-6)
+        results[str(k)] = {"queries": ok, "ids": idx, "scores": sc}
+    # the ValueError case: a query with < k accessible premises (common.py:323-324)
+    bad = [j for j in range(B) if acc[j].sum() < 100]
+    assert bad, "need at least one query with <100 accessible premises"
+    try:
+        corpus.get_nearest_premises(Et, [ctxs[bad[0]]], Qt[bad[:1]], 100)
+        raise AssertionError("reference did not raise")
+    except ValueError:
+        pass
+    try:
+        ocorpus.get_nearest_premises(E, [octxs[bad[0]]], Q[bad[:1]], 100)
+        raise AssertionError("oracle did not raise")
+    except ValueError:
+        pass
+    out.update({"corpus_seed": 6, "n_files": 40, "n_premises": 1000, "N": N, "D": D, "emb_seed": 66,
+                "queries": qmeta, "results": results, "value_error_query": bad[0]})
+    json.dump(out, open(os.path.join(OUT, "g6_nearest.json"), "w"))
+    np.savez_compressed(os.path.join(OUT, "g6_nearest.npz"), E=E, Q=Q, acc=np.packbits(acc, axis=1))
+    print("g6 ok: N =", N, "accessible counts min/max", acc.sum(1).min(), acc.sum(1).max())
+
+
+# ----------------------------------------------------------------------------------------------
+def g7_predict():
+    """BASELINE config 1: 1k synthetic premises, 128 states, top-10 through the reference's
+    reindex_corpus + predict_step logic (Lightning is stubbed; the hooks' bodies are the
+    reference's)."""
+    cfg = synth.t5_config("byt5-small")
+    sd = synth.synth_state_dict(cfg)
+    model = H.offline_retriever(rm, hf_cfg(cfg), sd, max_seq_len=1024)
+    files = synth.synth_corpus_records(60, 1000, seed=71, code_bytes=(24, 96))
+    td = tempfile.mkdtemp()
+    path = os.path.join(td, "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    model.load_corpus(path)
+    N = len(model.corpus)
+    t0 = time.time()
+    model.reindex_corpus(batch_size=64)
+    print(f"g7: reference reindex_corpus of {N} premises took {time.time() - t0:.1f}s")
+    E = model.corpus_embeddings
+    rng = np.random.default_rng(72)
+    B = 128
+    ctxs, qmeta = [], []
+    for j in range(B):
+        while True:  # the reference raises ValueError when < k premises are accessible
+            f = int(rng.integers(30, 60))
+            pos = (int(rng.integers(1, 300)), int(rng.integers(0, 40)))
+            if len(model.corpus.get_accessible_premises(files[f]["path"], H.Pos(*pos))) >= 12:
+                break
+        state = synth.synth_state(rng, int(rng.integers(40, 200)))
+        ctxs.append(common.Context(files[f]["path"], f"thm{j}", H.Pos(*pos), state))
+        qmeta.append({"path": files[f]["path"], "pos": list(pos), "state": state})
+    where = {id(p): i for i, p in enumerate(model.corpus.all_premises)}
+    ids_all, sc_all = [], []
+    t0 = time.time()
+    for i in range(0, B, 64):  # eval_batch_size 64 (retrieval/confs/*.yaml)
+        batch = ctxs[i : i + 64]
+        tok = model.tokenizer([c.serialize() for c in batch], padding="longest", max_length=1024,
+                              truncation=True, return_tensors="pt")  # datamodule.py:130-144
+        model.predict_step_outputs = []
+        b = {"context": batch, "context_ids": tok.input_ids, "context_mask": tok.attention_mask}
+        for key in ("url", "commit", "file_path", "full_name", "start", "tactic_idx", "all_pos_premises"):
+            b[key] = [None] * len(batch)
+        with torch.no_grad():
+            model.predict_step(b, 0)  # model.py:281-327
+        for rec in model.predict_step_outputs:
+            ids_all.append([where[id(p)] for p in rec["retrieved_premises"]])
+            sc_all.append(rec["scores"])
+    print(f"g7: reference predict of {B} states took {time.time() - t0:.1f}s")
+    # single-query retrieve() (model.py:338-375) on the first 4 states
+    single = []
+    for j in range(4):
+        c = ctxs[j]
+        prem, sc = model.retrieve(c.state, c.path, c.theorem_full_name, c.theorem_pos, 10)
+        single.append({"ids": [where[id(p)] for p in prem], "scores": sc})
+        assert single[-1]["ids"] == ids_all[j]
+    probe = np.random.default_rng(73).standard_normal((E.shape[1], 4)).astype(np.float32)
+    json.dump({"corpus_seed": 71, "n_files": 60, "n_premises": 1000, "code_bytes": [24, 96], "N": N,
+               "queries": qmeta, "k": 10, "ids": ids_all, "scores": sc_all, "retrieve": single,
+               "max_seq_len": 1024, "batch_size": 64},
+              open(os.path.join(OUT, "g7_predict.json"), "w"), ensure_ascii=False)
+    np.savez_compressed(os.path.join(OUT, "g7_predict.npz"), E_probe=(E @ torch.from_numpy(probe)).numpy(),
+                        probe_seed=np.int64(73), E_head=E[:16].numpy())
+    print("g7 ok")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    torch.manual_seed(0)
+    for name in which:
+        {"g1": g1_tokenizer, "g2": g2_serialize, "g3": g3_buckets, "g4": g4_tiny, "g5": g5_small,
+         "g6": g6_nearest, "g7": g7_predict}[name]()
