@@ -1,0 +1,343 @@
+"""Benchmark of the retrieval hot path on MI355X (driver contract: see the task statement).
+
+One *step* = one pass of the hot path over one batch of synthetic input, BASELINE.json configs[1]:
+encode B = 256 proof states with the ByT5-small encoder (random-init weights of that
+architecture) and retrieve the top-100 accessible premises for each from a resident
+130,000-premise bf16 index (similarity GEMM + accessibility mask + exact top-k).  Inputs (token
+ids, masks, the index) are resident in HBM when the timed region starts.
+
+N > 1 GPUs (one process per GPU, torch.distributed over RCCL): the index is row-sharded N ways;
+every rank encodes its own 256 states (weak scaling), query embeddings are all-gathered, each
+rank scans its shard for all N*256 queries, the per-shard top-k lists are all-gathered and each
+rank merges the lists of its own queries.  value = (N*256 queries) / max-over-ranks step time.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from reprover_amd import _lib, build, synth  # noqa: E402
+from reprover_amd.common import Context, Corpus, Pos  # noqa: E402
+from reprover_amd.encoder import HipT5Encoder  # noqa: E402
+
+N_PREMISES, N_FILES, B_STATES, TOP_K = 130_000, 5_000, 256, 100
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0  # HBM3E spec
+
+
+def fast_corpus_records(n_files: int, n_premises: int, seed: int):
+    """corpus.jsonl records with a dense-ish import DAG (transitive closure of a typical late file
+    covers a large fraction of earlier files, like mathlib) and trivial code strings."""
+    rng = np.random.default_rng(seed)
+    w = rng.lognormal(0.0, 0.8, size=n_files)
+    counts = np.floor(w / w.sum() * n_premises).astype(int)
+    counts[: n_premises - counts.sum()] += 1
+    files = []
+    for f in range(n_files):
+        n_imp = int(rng.integers(1, 5)) if f else 0
+        imps = sorted({int(x) for x in rng.integers(max(0, f - 300), f, size=n_imp)}) if f else []
+        prem, line = [], 1
+        for j in range(int(counts[f])):
+            prem.append({"full_name": f"F{f}.t{j}", "code": f"theorem t{j} : True", "start": [line, 0],
+                         "end": [line + 1, 10]})
+            line += 2
+        files.append({"path": f"M/F{f}.lean", "imports": [files[i]["path"] for i in imps], "premises": prem})
+    return files
+
+
+def random_init_state_dict(cfg, device, seed):
+    """Random-init ByT5-small encoder weights (HF init scales), generated on the device."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    D, dk, H, F, V = cfg["d_model"], cfg["d_kv"], cfg["num_heads"], cfg["d_ff"], cfg["vocab_size"]
+    inner = H * dk
+
+    def n(shape, std):
+        return torch.randn(shape, generator=g, device=device) * std
+
+    sd = {"shared.weight": n((V, D), 1.0),
+          "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight": n((32, H), 1.0),
+          "encoder.final_layer_norm.weight": 0.5 + torch.rand(D, generator=g, device=device)}
+    for i in range(cfg["num_layers"]):
+        p = f"encoder.block.{i}.layer."
+        sd[p + "0.layer_norm.weight"] = 0.5 + torch.rand(D, generator=g, device=device)
+        sd[p + "0.SelfAttention.q.weight"] = n((inner, D), 0.5 * D ** -0.5)
+        sd[p + "0.SelfAttention.k.weight"] = n((inner, D), D ** -0.5)
+        sd[p + "0.SelfAttention.v.weight"] = n((inner, D), D ** -0.5)
+        sd[p + "0.SelfAttention.o.weight"] = n((D, inner), inner ** -0.5)
+        sd[p + "1.layer_norm.weight"] = 0.5 + torch.rand(D, generator=g, device=device)
+        sd[p + "1.DenseReluDense.wi_0.weight"] = n((F, D), D ** -0.5)
+        sd[p + "1.DenseReluDense.wi_1.weight"] = n((F, D), D ** -0.5)
+        sd[p + "1.DenseReluDense.wo.weight"] = n((D, F), F ** -0.5)
+    return sd
+
+
+def cpu_baseline(cfg, sd_dev, corpus_path, E_dev, state_texts, state_ctx, n_sample=16):
+    """The reference's CPU path as restated by the oracle (kind 'port'), timed on this host:
+    pad-to-longest batch encode (fp32) + Q@E.T + full argsort + per-query Python accessibility walk
+    (common.py:299-326) over the full 130k x 1472 fp32 matrix, on a sample of `n_sample` states."""
+    from oracle import common_ref, t5_ref
+
+    sd = {k: v.float().cpu() for k, v in sd_dev.items()}
+    E = E_dev.float().cpu().numpy()
+    ref_corpus = common_ref.CorpusRef(corpus_path)
+    texts = state_texts[:n_sample]
+    ctxs = [common_ref.ContextRef(c.path, c.theorem_full_name, common_ref.Pos(*c.theorem_pos), c.state)
+            for c in state_ctx[:n_sample]]
+    t0 = time.perf_counter()
+    q = t5_ref.encode_texts(cfg, sd, texts, 2048).numpy()
+    t1 = time.perf_counter()
+    ref_corpus.get_nearest_premises(E, ctxs, q, TOP_K)
+    t2 = time.perf_counter()
+    enc_s, ret_s = t1 - t0, t2 - t1
+    return {
+        "value": n_sample / (enc_s + ret_s),
+        "unit": "queries/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{n_sample} of the step's 256 states: oracle fp32 encode {enc_s:.2f}s + "
+                  f"get_nearest_premises on the full 130k x 1472 fp32 index {ret_s:.2f}s",
+        "encode_qps": n_sample / enc_s,
+        "retrieve_only_qps": n_sample / ret_s,
+        "cpu_model": _cpu_model(),
+    }
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--premise-sample", type=int, default=4096, help="premises in the encode-throughput leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+    build.build()
+    lib = _lib.load()
+
+    cfg = synth.t5_config("byt5-small")
+    D = cfg["d_model"]
+    sd = random_init_state_dict(cfg, dev, seed=synth.SEED)
+    enc = HipT5Encoder(cfg, sd, dev, torch.bfloat16)
+
+    # ---- corpus: 130k premises in 5k files, identical on every rank; this rank's row shard ------
+    tmp = tempfile.mkdtemp()
+    corpus_path = os.path.join(tmp, "corpus.jsonl")
+    synth.write_corpus_jsonl(corpus_path, fast_corpus_records(N_FILES, N_PREMISES, synth.SEED))
+    corpus = Corpus(corpus_path)
+    N = len(corpus)
+    bounds = np.linspace(0, N, world + 1).astype(int)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    g = torch.Generator(device=dev)
+    g.manual_seed(synth.SEED + 1)
+    E_full = torch.nn.functional.normalize(torch.randn(N, D, generator=g, device=dev), dim=1).to(torch.bfloat16)
+    E = E_full[lo:hi].contiguous()
+    file_of = torch.from_numpy(corpus.file_of[lo:hi].copy()).to(dev)
+    end_key = torch.from_numpy(corpus.end_key[lo:hi].copy()).to(dev)
+
+    # ---- states: 256 per rank, byte lengths from the log-normal mix, files from the later half ---
+    BQ = B_STATES * world
+    all_ctx, all_txt = [], []
+    for r in range(world):
+        rng = np.random.default_rng(synth.SEED + 100 + r)
+        lens = synth.synth_lengths(rng, B_STATES, "mix", lo=16, hi=2048)
+        for j in range(B_STATES):
+            f = int(rng.integers(N_FILES // 2, N_FILES))
+            txt = synth.synth_state(rng, int(lens[j]) - 1)
+            all_txt.append(txt)
+            all_ctx.append(Context(f"M/F{f}.lean", f"thm{r}_{j}", Pos(int(rng.integers(1, 60)), 0), txt))
+    from reprover_amd import tokenizer
+
+    my_txt = all_txt[rank * B_STATES : (rank + 1) * B_STATES]
+    ids_np, cu_np = tokenizer.encode_packed(my_txt, 2048)
+    T, max_len = int(cu_np[-1]), int(np.diff(cu_np).max())
+    ids_d, cu_d = torch.from_numpy(ids_np).to(dev), torch.from_numpy(cu_np).to(dev)
+    bits_t, own, qk = corpus.query_masks(all_ctx)
+    bits_d = torch.from_numpy(bits_t.view(np.int32)).to(dev)
+    own_d, qk_d = torch.from_numpy(own).to(dev), torch.from_numpy(qk).to(dev)
+    n_acc = np.array([int(corpus.accessible_mask(c.path, c.theorem_pos).sum()) for c in all_ctx[:8]])
+
+    q_loc = torch.empty((B_STATES, D), dtype=torch.bfloat16, device=dev)
+    q_all = torch.empty((BQ, D), dtype=torch.bfloat16, device=dev) if world > 1 else q_loc
+    out_s = torch.empty((BQ, TOP_K), dtype=torch.float32, device=dev)
+    out_i = torch.empty((BQ, TOP_K), dtype=torch.int32, device=dev)
+    out_c = torch.empty((BQ,), dtype=torch.int32, device=dev)
+    ws_bytes = lib.rp_sim_topk_workspace_bytes(BQ, hi - lo, D, TOP_K, 0)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    if world > 1:
+        g_s = torch.empty((world, BQ, TOP_K), dtype=torch.float32, device=dev)
+        g_i = torch.empty((world, BQ, TOP_K), dtype=torch.int32, device=dev)
+        g_c = torch.empty((world, BQ), dtype=torch.int32, device=dev)
+        mws_bytes = lib.rp_topk_merge_workspace_bytes(world, B_STATES, TOP_K)
+        mws = torch.empty(mws_bytes, dtype=torch.uint8, device=dev)
+        f_s = torch.empty((B_STATES, TOP_K), dtype=torch.float32, device=dev)
+        f_i = torch.empty((B_STATES, TOP_K), dtype=torch.int32, device=dev)
+        f_c = torch.empty((B_STATES,), dtype=torch.int32, device=dev)
+
+    def scan():
+        _lib.check(lib.rp_sim_topk(q_all.data_ptr(), E.data_ptr(), BQ, hi - lo, D, file_of.data_ptr(),
+                                   end_key.data_ptr(), bits_d.data_ptr(), corpus.num_files, own_d.data_ptr(),
+                                   qk_d.data_ptr(), lo, TOP_K, 0, out_s.data_ptr(), out_i.data_ptr(),
+                                   out_c.data_ptr(), ws.data_ptr(), ws_bytes, _lib.current_stream()), "rp_sim_topk")
+
+    def step():
+        enc.encode_packed_device(ids_d, cu_d, B_STATES, T, max_len, q_loc)
+        if world > 1:
+            dist.all_gather_into_tensor(q_all, q_loc)
+        scan()
+        if world > 1:
+            dist.all_gather_into_tensor(g_s, out_s)
+            dist.all_gather_into_tensor(g_i, out_i)
+            dist.all_gather_into_tensor(g_c, out_c)
+            sl = slice(rank * B_STATES, (rank + 1) * B_STATES)
+            ms_, mi_, mc_ = g_s[:, sl].contiguous(), g_i[:, sl].contiguous(), g_c[:, sl].contiguous()
+            _lib.check(lib.rp_topk_merge(ms_.data_ptr(), mi_.data_ptr(), mc_.data_ptr(), world, B_STATES, TOP_K,
+                                         f_s.data_ptr(), f_i.data_ptr(), f_c.data_ptr(), mws.data_ptr(), mws_bytes,
+                                         _lib.current_stream()), "rp_topk_merge")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    counts_ok = bool((out_c.cpu() == TOP_K).all())
+    ms_per_step = dt / args.steps * 1e3
+    qps = BQ * args.steps / dt
+
+    # ---- per-kernel roofline figures from the HIP-event records of the timed region --------------
+    Tp = (T + 127) // 128 * 128
+    F_ = cfg["d_ff"]
+    wi_ms, wi_n = prof["gemm_wi"]
+    wi_flops = 2.0 * Tp * D * 2 * F_
+    wi_tf = wi_flops * wi_n / (wi_ms * 1e-3) / 1e12 if wi_ms > 0 else 0.0
+    scan_ms, scan_n = prof["scan"]
+    n_loc = hi - lo
+    scan_bytes = n_loc * D * 2 + n_loc * 12 + BQ * D * 2 + BQ * 12 + BQ * TOP_K * 8
+    scan_gbs = scan_bytes * args.steps / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    tot_gemm_ms = sum(prof[k][0] for k in ("gemm_qkv", "gemm_o", "gemm_wi", "gemm_wo"))
+    lin_flops = 2.0 * Tp * (D * 3 * enc.cfg["num_heads"] * 64 + enc.cfg["num_heads"] * 64 * D + D * 2 * F_ + F_ * D)
+    all_gemm_tf = lin_flops * cfg["num_layers"] * args.steps / (tot_gemm_ms * 1e-3) / 1e12 if tot_gemm_ms else 0.0
+
+    # ---- scan-only QPS and premise-encode throughput (reported beside the headline value) --------
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        scan()
+    torch.cuda.synchronize()
+    scan_only_qps = BQ * 20 / (time.perf_counter() - t0)
+    rngp = np.random.default_rng(synth.SEED + 7)
+    plens = synth.synth_lengths(rngp, args.premise_sample, "mix", lo=8, hi=2048)
+    pids, pcu = synth.synth_token_batch(rngp, plens)
+    pout = torch.empty((args.premise_sample, D), dtype=torch.bfloat16, device=dev)
+    enc.encode_packed(pids, pcu, pout)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    enc.encode_packed(pids, pcu, pout)
+    torch.cuda.synchronize()
+    pdt = time.perf_counter() - t0
+    prem_per_s = args.premise_sample / pdt
+    if world > 1:
+        agg = torch.tensor([prem_per_s, scan_only_qps], dtype=torch.float64, device=dev)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)  # re-index shards by rank: throughputs add
+        prem_per_s = float(agg[0].item())
+        scan_only_qps = float(agg[1].item()) / world  # every rank scanned all queries on its shard
+
+    result = {
+        "metric": "retrieve QPS@top-100 (state encode + masked similarity top-k), ByT5-small, 130k-premise corpus",
+        "value": qps,
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {
+            "workload": "configs[1]: ByT5-small encode+retrieve, 130k premises, batch=256 states/GPU, top-100, bf16",
+            "n_premises": N, "n_files": N_FILES, "states_per_gpu": B_STATES, "k": TOP_K,
+            "state_tokens_per_gpu": T, "state_len_mix": "clip(round(LogNormal(ln 180, 0.9)), 16, 2048) bytes",
+            "index": "row-sharded %d-way, bf16 unit-norm random rows" % world,
+            "weights": "random-init ByT5-small (d_model 1472, 12 layers, 6 heads, d_ff 3584)",
+            "accessible_premises_first_queries": n_acc.tolist(), "all_counts_eq_k": counts_ok,
+        },
+        "premises_per_s": prem_per_s,
+        "premise_tokens_per_s": float(pcu[-1]) / pdt * (world if world > 1 else 1),
+        "premise_len_mix": "clip(round(LogNormal(ln 180, 0.9)), 8, 2048) tokens, %d premises/GPU" % args.premise_sample,
+        "scan_only_qps": scan_only_qps,
+        "roofline": {
+            "kernel": "gemm_kernel<EpiGegluBf16> (FFN wi_0|wi_1 GEMM + gated-GELU epilogue; 58% of encoder FLOPs)",
+            "bound": "mfma", "achieved": wi_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": wi_tf / PEAK_BF16_TFLOPS, "traffic": None,
+            "flops_per_launch": wi_flops, "avg_launch_ms": wi_ms / max(wi_n, 1), "launches": wi_n,
+        },
+        "roofline_scan": {
+            "kernel": "sim_scan_kernel (both passes of one rp_sim_topk)", "bound": "hbm", "achieved": scan_gbs,
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": scan_gbs / PEAK_HBM_GBS, "traffic": None,
+            "bytes_per_step": scan_bytes, "ms_per_step": scan_ms / args.steps,
+        },
+        "all_encoder_gemms_tflops": all_gemm_tf,
+        "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg, sd, corpus_path, E_full, all_txt, all_ctx)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -161,6 +161,18 @@ RpStatus rp_topk_merge(const float* scores, const int32_t* ids, const int32_t* c
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline
+ * object).  While enabled, every kernel launch of the engine is bracketed by an event pair.
+ * ------------------------------------------------------------------------------------------- */
+enum {
+  RP_K_EMBED = 0, RP_K_RMSNORM = 1, RP_K_GEMM_QKV = 2, RP_K_ATTENTION = 3, RP_K_GEMM_O = 4,
+  RP_K_GEMM_WI = 5, RP_K_GEMM_WO = 6, RP_K_POOL = 7, RP_K_SCAN = 8, RP_K_SELECT = 9, RP_K_COUNT = 10
+};
+RpStatus rp_profile_enable(int32_t on);   /* on != 0: start collecting (clears previous records) */
+/* Synchronises the recorded events; total_ms = sum of launch durations, launches = their number. */
+RpStatus rp_profile_read(int32_t kernel_class, double* total_ms, int64_t* launches);
+
+/* ---------------------------------------------------------------------------------------------
  * Kernel-level entry points used by the parity tests (tests/test_kernels_gpu.py) to check each
  * HIP kernel against the oracle in isolation.  Same conventions as above.
  * ------------------------------------------------------------------------------------------- */

@@ -19,6 +19,8 @@ RP_DT_F32, RP_DT_BF16 = 0, 1
 RP_TOPK_AUTO, RP_TOPK_DENSE = 0, 1
 RP_EPI_STORE_BF16, RP_EPI_RESID_F32, RP_EPI_GEGLU_BF16 = 0, 1, 2
 ABI_VERSION = 1
+KERNEL_CLASSES = ["embed", "rmsnorm", "gemm_qkv", "attention", "gemm_o", "gemm_wi", "gemm_wo", "pool", "scan",
+                  "select"]
 
 
 class RpT5Config(C.Structure):
@@ -88,6 +90,8 @@ SIGNATURES = {
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
     ),
     "rp_set_option": (C.c_int32, [C.c_char_p, C.c_int32]),
+    "rp_profile_enable": (C.c_int32, [C.c_int32]),
+    "rp_profile_read": (C.c_int32, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -133,3 +137,18 @@ def current_stream() -> int:
     import torch
 
     return torch.cuda.current_stream().cuda_stream
+
+
+def profile_enable(on: bool) -> None:
+    check(load().rp_profile_enable(1 if on else 0), "rp_profile_enable")
+
+
+def profile_read() -> dict:
+    """{kernel class: (total_ms, launches)} of the launches recorded since profile_enable(True)."""
+    lib = load()
+    out = {}
+    for i, name in enumerate(KERNEL_CLASSES):
+        ms, n = C.c_double(), C.c_int64()
+        check(lib.rp_profile_read(i, C.byref(ms), C.byref(n)), "rp_profile_read")
+        out[name] = (ms.value, n.value)
+    return out

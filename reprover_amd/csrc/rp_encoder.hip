@@ -29,6 +29,38 @@ thread_local std::string g_last_error;
 static int g_gemm_group_m = 8;
 
 // ------------------------------------------------------------------------------------------
+// per-kernel event timing
+// ------------------------------------------------------------------------------------------
+struct ProfRec {
+  int cls;
+  hipEvent_t a, b;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+
+static hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) {
+    hipEvent_t e = g_prof_pool.back();
+    g_prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void prof_begin(hipStream_t stream, int kernel_class) {
+  if (!g_prof_on) return;
+  ProfRec r{kernel_class, prof_event(), prof_event()};
+  (void)hipEventRecord(r.a, stream);
+  g_prof_recs.push_back(r);
+}
+void prof_end(hipStream_t stream) {
+  if (!g_prof_on) return;
+  (void)hipEventRecord(g_prof_recs.back().b, stream);
+}
+
+// ------------------------------------------------------------------------------------------
 // weight packing (create time only)
 // ------------------------------------------------------------------------------------------
 template <typename T>
@@ -211,10 +243,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmOperand A, GemmOperand W,
 
 template <class Epi>
 static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, int ldw, int n_rows_w,
-                            int K, Epi epi, hipStream_t stream) {
+                            int K, Epi epi, hipStream_t stream, int prof_class) {
   RP_REQUIRE(M % GEMM_BM == 0 && K % GEMM_BK == 0, "gemm: M=%d must be a multiple of 128, K=%d of 32", M, K);
   const int tiles_m = M / GEMM_BM, tiles_n = (n_rows_w + GEMM_BN - 1) / GEMM_BN;
   GemmOperand a{A, lda, M}, w{W, ldw, n_rows_w};
+  ProfScope ps(stream, prof_class);
   hipLaunchKernelGGL((gemm_kernel<Epi>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, a, w, K, tiles_m,
                      tiles_n, g_gemm_group_m, epi);
   RP_CHECK_LAUNCH();
@@ -533,6 +566,33 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   return fail(RP_E_INVALID, "unknown option %s", name);
 }
 
+extern "C" RpStatus rp_profile_enable(int32_t on) {
+  for (auto& r : g_prof_recs) {
+    g_prof_pool.push_back(r.a);
+    g_prof_pool.push_back(r.b);
+  }
+  g_prof_recs.clear();
+  g_prof_on = on != 0;
+  return RP_OK;
+}
+
+extern "C" RpStatus rp_profile_read(int32_t kernel_class, double* total_ms, int64_t* launches) {
+  RP_REQUIRE(total_ms && launches && kernel_class >= 0 && kernel_class < RP_K_COUNT, "bad argument");
+  double tot = 0;
+  int64_t n = 0;
+  for (auto& r : g_prof_recs) {
+    if (r.cls != kernel_class) continue;
+    RP_HIP(hipEventSynchronize(r.b));
+    float ms = 0;
+    RP_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    tot += ms;
+    ++n;
+  }
+  *total_ms = tot;
+  *launches = n;
+  return RP_OK;
+}
+
 // modeling_t5.py:216-262, bidirectional branch; float32 arithmetic as torch evaluates it.
 extern "C" int32_t rp_relative_position_bucket(int32_t rel, int32_t num_buckets, int32_t max_distance) {
   int nb = num_buckets / 2;
@@ -682,26 +742,45 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
   const int Tp = (int)align_up((size_t)T, 128);
   RpStatus st;
 
-  hipLaunchKernelGGL(embed_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.x, T, Tp, D,
-                     c.vocab_size);
+  {
+    ProfScope ps(stream, RP_K_EMBED);
+    hipLaunchKernelGGL(embed_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.x, T, Tp, D,
+                       c.vocab_size);
+  }
   RP_CHECK_LAUNCH();
   const dim3 att_grid((max_len + ATT_Q - 1) / ATT_Q, batch, H);
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerPacked& L = e->layers[i];
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, w.x, L.ln_attn, w.h, Tp, D,
-                       c.layer_norm_eps);
-    if ((st = launch_gemm(w.h, D, Tp, L.wqkv, D, 3 * inner, D, EpiStoreBf16{w.qkv, 3 * inner, 3 * inner}, stream)))
+    {
+      ProfScope ps(stream, RP_K_RMSNORM);
+      hipLaunchKernelGGL(rmsnorm_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, w.x, L.ln_attn, w.h, Tp, D,
+                         c.layer_norm_eps);
+    }
+    if ((st = launch_gemm(w.h, D, Tp, L.wqkv, D, 3 * inner, D, EpiStoreBf16{w.qkv, 3 * inner, 3 * inner}, stream,
+                          RP_K_GEMM_QKV)))
       return st;
-    hipLaunchKernelGGL(attention_kernel, att_grid, dim3(256), 0, stream, w.qkv, cu_seqlens, e->bias_tab, w.att, H,
-                       e->maxd, Tp);
-    if ((st = launch_gemm(w.att, inner, Tp, L.wo, inner, D, inner, EpiResidF32{w.x, D, D}, stream))) return st;
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, w.x, L.ln_ff, w.h, Tp, D,
-                       c.layer_norm_eps);
-    if ((st = launch_gemm(w.h, D, Tp, L.wi, D, 2 * F, D, EpiGegluBf16{w.ff, F, 2 * F}, stream))) return st;
-    if ((st = launch_gemm(w.ff, F, Tp, L.wo2, F, D, F, EpiResidF32{w.x, D, D}, stream))) return st;
+    {
+      ProfScope ps(stream, RP_K_ATTENTION);
+      hipLaunchKernelGGL(attention_kernel, att_grid, dim3(256), 0, stream, w.qkv, cu_seqlens, e->bias_tab, w.att, H,
+                         e->maxd, Tp);
+    }
+    if ((st = launch_gemm(w.att, inner, Tp, L.wo, inner, D, inner, EpiResidF32{w.x, D, D}, stream, RP_K_GEMM_O)))
+      return st;
+    {
+      ProfScope ps(stream, RP_K_RMSNORM);
+      hipLaunchKernelGGL(rmsnorm_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, w.x, L.ln_ff, w.h, Tp, D,
+                         c.layer_norm_eps);
+    }
+    if ((st = launch_gemm(w.h, D, Tp, L.wi, D, 2 * F, D, EpiGegluBf16{w.ff, F, 2 * F}, stream, RP_K_GEMM_WI)))
+      return st;
+    if ((st = launch_gemm(w.ff, F, Tp, L.wo2, F, D, F, EpiResidF32{w.x, D, D}, stream, RP_K_GEMM_WO)))
+      return st;
   }
-  hipLaunchKernelGGL(pool_kernel, dim3(batch), dim3(256), 0, stream, w.x, e->final_ln, cu_seqlens, out,
-                     out_dtype == RP_DT_BF16 ? 1 : 0, D, c.layer_norm_eps);
+  {
+    ProfScope ps(stream, RP_K_POOL);
+    hipLaunchKernelGGL(pool_kernel, dim3(batch), dim3(256), 0, stream, w.x, e->final_ln, cu_seqlens, out,
+                       out_dtype == RP_DT_BF16 ? 1 : 0, D, c.layer_norm_eps);
+  }
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
@@ -716,11 +795,11 @@ extern "C" RpStatus rp_dbg_gemm(const void* A, const void* W, void* out, int32_t
   const bf16_t* w = (const bf16_t*)W;
   switch (epilogue) {
     case RP_EPI_STORE_BF16:
-      return launch_gemm(a, K, M, w, K, N, K, EpiStoreBf16{(bf16_t*)out, n_valid, n_valid}, stream);
+      return launch_gemm(a, K, M, w, K, N, K, EpiStoreBf16{(bf16_t*)out, n_valid, n_valid}, stream, RP_K_GEMM_QKV);
     case RP_EPI_RESID_F32:
-      return launch_gemm(a, K, M, w, K, N, K, EpiResidF32{(float*)out, n_valid, n_valid}, stream);
+      return launch_gemm(a, K, M, w, K, N, K, EpiResidF32{(float*)out, n_valid, n_valid}, stream, RP_K_GEMM_O);
     case RP_EPI_GEGLU_BF16:
-      return launch_gemm(a, K, M, w, K, N, K, EpiGegluBf16{(bf16_t*)out, n_valid / 2, n_valid}, stream);
+      return launch_gemm(a, K, M, w, K, N, K, EpiGegluBf16{(bf16_t*)out, n_valid / 2, n_valid}, stream, RP_K_GEMM_WI);
   }
   return fail(RP_E_INVALID, "unknown epilogue %d", epilogue);
 }

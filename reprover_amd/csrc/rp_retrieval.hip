@@ -287,6 +287,11 @@ __global__ void merge_keys_kernel(const float* scores, const int32_t* ids, const
   }
 }
 
+static void launch_select(const SelectArgs& a, int B, hipStream_t stream) {
+  ProfScope ps(stream, RP_K_SELECT);
+  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(256), 0, stream, a);
+}
+
 struct SimPlan {
   bool dense_only;
   int tiles_q, tiles_p, sample_tiles, filter_tiles;
@@ -368,8 +373,10 @@ extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t
 
   // pass 0: dense keys of the sampled (or all) premise tiles
   const int stride0 = p.dense_only ? 1 : SIM_STRIDE;
+  prof_begin(stream, RP_K_SCAN);
   hipLaunchKernelGGL(sim_scan_kernel, dim3(p.tiles_q * p.sample_tiles), dim3(256), 0, stream, qop, eop, D,
                      p.tiles_q, stride0, epi);
+  prof_end(stream);
   RP_CHECK_LAUNCH();
   SelectArgs sa;
   sa.keys = dense;
@@ -386,7 +393,7 @@ extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t
     sa.out_scores = out_scores;
     sa.out_ids = out_ids;
     sa.out_count = out_count;
-    hipLaunchKernelGGL(select_kernel, dim3(B), dim3(256), 0, stream, sa);
+    launch_select(sa, B, stream);
     RP_CHECK_LAUNCH();
     return RP_OK;
   }
@@ -397,12 +404,14 @@ extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t
   sa.out_scores = nullptr;
   sa.out_ids = nullptr;
   sa.out_count = nullptr;
-  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(256), 0, stream, sa);
+  launch_select(sa, B, stream);
   RP_CHECK_LAUNCH();
   // pass 1: remaining tiles, keep only keys above each query's bound
   epi.filter = 1;
+  prof_begin(stream, RP_K_SCAN);
   hipLaunchKernelGGL(sim_scan_kernel, dim3(p.tiles_q * p.filter_tiles), dim3(256), 0, stream, qop, eop, D,
                      p.tiles_q, SIM_STRIDE, epi);
+  prof_end(stream);
   RP_CHECK_LAUNCH();
   SelectArgs sb;
   sb.keys = cand;
@@ -418,7 +427,7 @@ extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t
   sb.out_scores = out_scores;
   sb.out_ids = out_ids;
   sb.out_count = out_count;
-  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(256), 0, stream, sb);
+  launch_select(sb, B, stream);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
@@ -454,7 +463,7 @@ extern "C" RpStatus rp_topk_merge(const float* scores, const int32_t* ids, const
   sa.out_scores = out_scores;
   sa.out_ids = out_ids;
   sa.out_count = out_count;
-  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(256), 0, stream, sa);
+  launch_select(sa, B, stream);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

@@ -40,6 +40,15 @@ inline RpStatus fail(RpStatus code, const char* fmt, ...) {
     if (!(cond)) return rp::fail(RP_E_INVALID, __VA_ARGS__);                                      \
   } while (0)
 
+// ---- optional per-kernel event timing (rp_profile_*) ------------------------------------------
+void prof_begin(hipStream_t stream, int kernel_class);
+void prof_end(hipStream_t stream);
+struct ProfScope {
+  hipStream_t s;
+  ProfScope(hipStream_t stream, int kernel_class) : s(stream) { prof_begin(stream, kernel_class); }
+  ~ProfScope() { prof_end(s); }
+};
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- device types ----------------------------------------------------------------------------

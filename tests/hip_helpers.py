@@ -1,0 +1,142 @@
+"""Thin callers of the C ABI used by the GPU parity tests (raw pointers in, torch tensors as
+containers) + comparison helpers."""
+import numpy as np
+import torch
+
+from reprover_amd import _lib
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def gemm(A, W, n_valid, epilogue, out):
+    lib = _lib.load()
+    M, K = A.shape
+    N = W.shape[0]
+    _lib.check(lib.rp_dbg_gemm(_lib.ptr(A), _lib.ptr(W), _lib.ptr(out), M, N, K, n_valid, epilogue,
+                               _lib.current_stream()), "rp_dbg_gemm")
+    torch.cuda.synchronize()
+    return out
+
+
+def rmsnorm(x, w, eps=1e-6):
+    lib = _lib.load()
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.rp_dbg_rmsnorm(_lib.ptr(x), _lib.ptr(w), _lib.ptr(out), x.shape[0], x.shape[1], eps,
+                                  _lib.current_stream()), "rp_dbg_rmsnorm")
+    torch.cuda.synchronize()
+    return out
+
+
+def attention(qkv, cu, tab, H):
+    lib = _lib.load()
+    T = qkv.shape[0]
+    out = torch.zeros((T, H * 64), dtype=torch.bfloat16, device=qkv.device)
+    lens = (cu[1:] - cu[:-1]).cpu()
+    _lib.check(lib.rp_dbg_attention(_lib.ptr(qkv), _lib.ptr(cu), _lib.ptr(tab), _lib.ptr(out), len(lens),
+                                    int(lens.max()), H, T, _lib.current_stream()), "rp_dbg_attention")
+    torch.cuda.synchronize()
+    return out
+
+
+def sim_topk(Q, E, k, masks=None, id_offset=0, flags=0):
+    """masks = (file_of i32 [N], end_key i64 [N], bits_t u32-as-i32 [F, W], own i32 [B], qk i64 [B]) device tensors."""
+    lib = _lib.load()
+    B, D = Q.shape
+    N = E.shape[0]
+    out_s = torch.empty((B, k), dtype=torch.float32, device=Q.device)
+    out_i = torch.empty((B, k), dtype=torch.int32, device=Q.device)
+    out_c = torch.empty((B,), dtype=torch.int32, device=Q.device)
+    nbytes = lib.rp_sim_topk_workspace_bytes(B, N, D, k, flags)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=Q.device)
+    if masks is None:
+        f = ek = bt = own = qk = None
+        F = 0
+    else:
+        f, ek, bt, own, qk = masks
+        F = bt.shape[0]
+    _lib.check(lib.rp_sim_topk(_lib.ptr(Q), _lib.ptr(E), B, N, D, _lib.ptr(f), _lib.ptr(ek), _lib.ptr(bt), F,
+                               _lib.ptr(own), _lib.ptr(qk), id_offset, k, flags, _lib.ptr(out_s), _lib.ptr(out_i),
+                               _lib.ptr(out_c), _lib.ptr(ws), nbytes, _lib.current_stream()), "rp_sim_topk")
+    torch.cuda.synchronize()
+    return out_i, out_s, out_c
+
+
+def topk_merge(scores, ids, counts):
+    lib = _lib.load()
+    R, B, k = scores.shape
+    out_s = torch.empty((B, k), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((B, k), dtype=torch.int32, device=scores.device)
+    out_c = torch.empty((B,), dtype=torch.int32, device=scores.device)
+    nbytes = lib.rp_topk_merge_workspace_bytes(R, B, k)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=scores.device)
+    _lib.check(lib.rp_topk_merge(_lib.ptr(scores), _lib.ptr(ids), _lib.ptr(counts), R, B, k, _lib.ptr(out_s),
+                                 _lib.ptr(out_i), _lib.ptr(out_c), _lib.ptr(ws), nbytes, _lib.current_stream()),
+               "rp_topk_merge")
+    torch.cuda.synchronize()
+    return out_i, out_s, out_c
+
+
+def synth_masks(rng, N, B, F, density=0.3):
+    """Random accessibility operands + the boolean [B, N] predicate they encode."""
+    cuts = np.sort(rng.choice(np.arange(1, N), size=F - 1, replace=False)) if F > 1 else np.array([], dtype=int)
+    file_of = np.zeros(N, dtype=np.int32)
+    file_of[cuts] = 1
+    file_of = np.cumsum(file_of).astype(np.int32)
+    end_key = rng.integers(0, 1 << 30, size=N).astype(np.int64)
+    own = rng.integers(0, F, size=B).astype(np.int32)
+    qk = rng.integers(0, 1 << 30, size=B).astype(np.int64)
+    imp = rng.random((B, F)) < density
+    imp[np.arange(B), own] = False
+    words = (B + 31) // 32
+    padded = np.zeros((F, words * 32), dtype=np.uint8)
+    padded[:, :B] = imp.T
+    bits_t = np.packbits(padded, axis=1, bitorder="little").view(np.uint32).reshape(F, words)
+    acc = imp[:, file_of] | ((file_of[None, :] == own[:, None]) & (end_key[None, :] <= qk[:, None]))
+    return (file_of, end_key, bits_t, own, qk), acc
+
+
+def masks_to_device(m, device):
+    f, ek, bt, own, qk = m
+    return (torch.from_numpy(f).to(device), torch.from_numpy(ek).to(device),
+            torch.from_numpy(bt.view(np.int32)).to(device), torch.from_numpy(own).to(device),
+            torch.from_numpy(qk).to(device))
+
+
+def check_topk_against_scores(ids, scores, counts, S, acc, k, tol):
+    """Size-independent properties of an exact masked top-k, given the full fp32 score matrix S
+    [B, N] (numpy) and the accessibility predicate acc [B, N]:
+    sortedness, accessibility, no duplicates, count = min(k, #accessible), reported score = S at the
+    reported id (within tol), and r-th reported score within tol of the true r-th best."""
+    B = S.shape[0]
+    masked = np.where(acc, S, -np.inf)
+    want_sorted = -np.sort(-masked, axis=1)[:, :k]
+    n_acc = acc.sum(1)
+    assert np.array_equal(counts, np.minimum(k, n_acc)), (counts[:8], n_acc[:8])
+    for j in range(B):
+        c = int(counts[j])
+        row_i, row_s = ids[j, :c], scores[j, :c]
+        assert np.all(np.diff(row_s) <= 0), f"row {j} not sorted"
+        assert len(set(row_i.tolist())) == c, f"row {j} has duplicate ids"
+        assert acc[j, row_i].all(), f"row {j} returned an inaccessible premise"
+        assert np.abs(S[j, row_i] - row_s).max(initial=0) <= tol, f"row {j} score mismatch"
+        assert np.abs(want_sorted[j, :c] - row_s).max(initial=0) <= tol, f"row {j} not the top-k"
+        assert np.all(ids[j, c:] == -1) and np.all(np.isneginf(scores[j, c:]))
+        ties = np.flatnonzero(np.diff(row_s) == 0)  # equal scores must come lower-id first
+        assert np.all(row_i[ties] < row_i[ties + 1]), f"row {j} tie order"
+
+
+def gap_rule_ids(ours_ids, gold_ids, gold_scores, tol):
+    """ids must agree at every rank whose golden score is separated from both neighbours by more
+    than 2*tol.  Returns (#checked, #mismatched)."""
+    checked = bad = 0
+    for o, g, s in zip(ours_ids, gold_ids, gold_scores):
+        s = np.asarray(s, dtype=np.float64)
+        for r in range(len(g)):
+            left = s[r - 1] - s[r] if r > 0 else np.inf
+            right = s[r] - s[r + 1] if r + 1 < len(g) else 0.0  # the (k+1)-th is unknown: skip the last rank
+            if left > 2 * tol and right > 2 * tol:
+                checked += 1
+                bad += int(o[r] != g[r])
+    return checked, bad

@@ -1,0 +1,162 @@
+"""Host-side logic of the product package, checked on the CPU against the golden vectors and
+the oracle: tokenizer, serialisation, corpus arrays / accessibility masks, the C-ABI surface.
+No kernel is launched here."""
+import ctypes
+import json
+import os
+import re
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import common_ref
+from reprover_amd import _lib, synth, tokenizer
+from reprover_amd.common import Context, Corpus, File, Pos, Premise, format_augmented_state
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_tokenizer_matches_hf_golden(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "g1_tokenizer.json")))
+    tok = tokenizer.ByT5Tokenizer()
+    for case in g["cases"]:
+        enc = tok(g["texts"], padding="longest", max_length=case["max_length"], truncation=True, return_tensors="pt")
+        assert enc.input_ids.dtype == torch.int64 and enc.input_ids.shape[1] == case["padded_len"]
+        ids, cu = tok.packed(g["texts"], case["max_length"])
+        assert ids.dtype == np.int32 and cu[0] == 0 and cu[-1] == len(ids)
+        for i, row in enumerate(case["ids"]):
+            n = int(enc.attention_mask[i].sum())
+            assert enc.input_ids[i, :n].tolist() == row
+            assert int(enc.input_ids[i, n:].abs().sum()) == 0
+            assert ids[cu[i] : cu[i + 1]].tolist() == row
+
+
+def test_premise_serialize_and_file_filters(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "g2_serialize.json")))
+    for c in g["cases"]:
+        assert Premise(c["path"], c["full_name"], Pos(1, 0), Pos(2, 0), c["code"]).serialize() == c["serialized"]
+    files = synth.synth_corpus_records(g["corpus_files"], g["corpus_premises"], seed=g["corpus_seed"])
+    for fd, kept in zip(files, g["kept"]):
+        f = File.from_data(fd)
+        assert [p.full_name for p in f.premises] == kept["names"]
+        assert [p.serialize() for p in f.premises] == kept["serialized"]
+
+
+def test_pos_and_context_invariants():
+    assert Pos(3, 4) < Pos(3, 5) < Pos(4, 0) and list(Pos(7, 9)) == [7, 9]
+    assert Pos(3, 4).key() < Pos(3, 5).key() < Pos(4, 0).key()
+    with pytest.raises(AssertionError):
+        Context("A.lean", "t", Pos(1, 1), "no turnstile")
+    with pytest.raises(AssertionError):
+        Premise("A.lean", "x", Pos(2, 0), Pos(1, 0), "code")
+    a = Context("A.lean", "t", Pos(1, 1), "x ⊢ y")
+    b = Context("A.lean", "t", Pos(9, 9), "x ⊢ y")
+    assert a == b and hash(a) == hash(b)  # theorem_pos is compare=False (common.py:40)
+
+
+@pytest.fixture(scope="module")
+def g6(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "g6_nearest.json")))
+    z = np.load(os.path.join(golden_dir, "g6_nearest.npz"))
+    files = synth.synth_corpus_records(g["n_files"], g["n_premises"], seed=g["corpus_seed"])
+    path = os.path.join(tempfile.mkdtemp(), "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    return g, z, path
+
+
+def test_corpus_arrays_reproduce_reference_accessibility(g6):
+    g, z, path = g6
+    corpus = Corpus(path)
+    ref = common_ref.CorpusRef(path)
+    assert len(corpus) == g["N"] == len(ref)
+    assert [p.full_name for p in corpus.all_premises] == [p.full_name for p in ref.all_premises]
+    acc = np.unpackbits(z["acc"], axis=1)[:, : g["N"]].astype(bool)
+    ctxs = [Context(q["path"], f"thm{j}", Pos(*q["pos"]), f"x{j} ⊢ y") for j, q in enumerate(g["queries"])]
+    for j, c in enumerate(ctxs):
+        assert np.array_equal(corpus.accessible_mask(c.path, c.theorem_pos), acc[j]), j
+        s = corpus.get_accessible_premises(c.path, c.theorem_pos)
+        assert np.array_equal(np.array([p in s for p in corpus.all_premises]), acc[j])
+        assert sorted(corpus.get_dependencies(c.path)) == sorted(ref.reach[c.path])
+    # the operands handed to rp_sim_topk encode exactly the same predicate
+    bits_t, own, qk = corpus.query_masks(ctxs)
+    B, N = len(ctxs), g["N"]
+    assert bits_t.dtype == np.uint32 and bits_t.shape == (corpus.num_files, (B + 31) // 32)
+    j = np.arange(B)
+    imported = (bits_t[corpus.file_of][:, j >> 5] >> (j & 31).astype(np.uint32)) & 1  # [N, B]
+    own_ok = (corpus.file_of[:, None] == own[None, :]) & (corpus.end_key[:, None] <= qk[None, :])
+    assert np.array_equal((imported.astype(bool) | own_ok).T, acc)
+    with pytest.raises(KeyError):
+        corpus.query_masks([Context("Not/In/Corpus.lean", "t", Pos(1, 1), "⊢")])
+
+
+def test_duplicate_names_follow_set_semantics():
+    recs = [
+        {"path": "A.lean", "imports": [], "premises": [
+            {"full_name": "foo", "code": "def foo := 1", "start": [1, 0], "end": [2, 0]},
+            {"full_name": "bar", "code": "def bar := 1", "start": [3, 0], "end": [4, 0]},
+            {"full_name": "foo", "code": "def foo := 2", "start": [9, 0], "end": [10, 0]},
+        ]},
+    ]
+    path = os.path.join(tempfile.mkdtemp(), "c.jsonl")
+    synth.write_corpus_jsonl(path, recs)
+    c, ref = Corpus(path), common_ref.CorpusRef(path)
+    for pos in [(1, 5), (2, 0), (5, 0), (20, 0)]:
+        keys = ref.accessible_keys("A.lean", common_ref.Pos(*pos))
+        want = np.array([(p.path, p.full_name) in keys for p in ref.all_premises])
+        assert np.array_equal(c.accessible_mask("A.lean", Pos(*pos)), want), pos
+    # position (5,0): first foo and bar ended; the later duplicate of foo counts as accessible too
+    assert c.accessible_mask("A.lean", Pos(5, 0)).tolist() == [True, True, True]
+    assert c.get_accessible_premise_indexes("A.lean", Pos(5, 0)) == [0, 1]  # index form differs (common.py:291-297)
+
+
+def test_format_augmented_state_matches_oracle():
+    prem = [Premise("A.lean", f"n{i}", Pos(1, 0), Pos(2, 0), f"theorem n{i} : {'x' * (5 * i)}") for i in range(6)]
+    s = "h : p ⊢ q"
+    for budget in (None, 10, 40, 80, 200):
+        want = common_ref.format_augmented_state(s, [p.serialize() for p in prem], budget)
+        assert format_augmented_state(s, prem, budget) == want
+
+
+def test_c_abi_loads_and_exports_every_declared_symbol(hip_lib):
+    header = open(os.path.join(ROOT, "include", "reprover_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(rp_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} is declared in include/reprover_hip.h but not exported"
+    assert hip_lib.rp_abi_version() == _lib.ABI_VERSION
+    assert hip_lib.rp_set_option(b"no_such_option", 1) != 0
+    assert b"no_such_option" in hip_lib.rp_last_error()
+    assert hip_lib.rp_sim_topk_workspace_bytes(256, 130000, 1472, 100, 0) > 0
+    assert hip_lib.rp_topk_merge_workspace_bytes(8, 256, 100) >= 8 * 256 * 100 * 8
+
+
+def test_bucket_function_matches_hf(hip_lib, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g3_buckets.npz"))
+    mine = np.array([hip_lib.rp_relative_position_bucket(int(r), 32, 128) for r in g["rel"]])
+    assert np.array_equal(mine, g["bucket"])
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_path_fails_loudly_without_a_gpu(tiny_weights):
+    from reprover_amd.encoder import HipT5Encoder
+    from reprover_amd.retrieval.model import PremiseRetriever
+
+    cfg, sd = tiny_weights
+    with pytest.raises(_lib.HipLibraryError):
+        HipT5Encoder(cfg, sd, "cpu")
+    with pytest.raises(_lib.HipLibraryError):
+        PremiseRetriever.from_state_dict(cfg, sd, 512, "cuda")
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "reprover_amd")
+    for dirpath, _, names in os.walk(pkg):
+        for n in names:
+            if n.endswith(".py"):
+                src = open(os.path.join(dirpath, n)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, n)

@@ -1,0 +1,203 @@
+"""Each HIP kernel against a plain fp32 restatement of the same op, through the C ABI."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import hip_helpers as hh
+from oracle import common_ref
+from reprover_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_bf16(gen, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=gen, device="cuda") * scale).to(torch.bfloat16)
+
+
+@pytest.fixture(scope="module")
+def gen():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3407)
+    return g
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 96), (384, 1472, 1472), (128, 200, 384)])
+def test_gemm_store_bf16(gen, M, N, K):
+    A, W = _rand_bf16(gen, M, K), _rand_bf16(gen, N, K)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    hh.gemm(A, W, N, _lib.RP_EPI_STORE_BF16, out)
+    ref = A.float() @ W.float().T
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 2 ** -8 * ref.abs().max().item() + 1e-3, err  # one bf16 rounding of the result
+
+
+def test_gemm_detects_transposes_with_structured_operands(gen):
+    # A = row index pattern, W = column index pattern: any row/col swap changes the answer
+    M, N, K = 128, 256, 64
+    A = torch.zeros(M, K, device="cuda")
+    A[:, 0] = torch.arange(M, device="cuda") % 7
+    A[:, 1] = 1.0
+    W = torch.zeros(N, K, device="cuda")
+    W[:, 0] = 1.0
+    W[:, 1] = (torch.arange(N, device="cuda") % 5) * 8.0
+    out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    hh.gemm(A.to(torch.bfloat16), W.to(torch.bfloat16), N, _lib.RP_EPI_STORE_BF16, out)
+    assert torch.equal(out.float(), A @ W.T)
+
+
+def test_gemm_residual_f32(gen):
+    M, N, K = 256, 1472, 384
+    A, W = _rand_bf16(gen, M, K), _rand_bf16(gen, N, K, scale=K ** -0.5)
+    x = torch.randn(M, N, generator=gen, device="cuda")
+    ref = x + A.float() @ W.float().T
+    hh.gemm(A, W, N, _lib.RP_EPI_RESID_F32, x)
+    assert (x - ref).abs().max().item() < 2e-4
+
+
+def test_gemm_geglu(gen):
+    M, F, K = 128, 256, 128
+    A = _rand_bf16(gen, M, K)
+    w0, w1 = _rand_bf16(gen, F, K, scale=K ** -0.5), _rand_bf16(gen, F, K, scale=K ** -0.5)
+    W = torch.empty(2 * F, K, dtype=torch.bfloat16, device="cuda")  # 32 gate rows / 32 up rows interleaved
+    Wv = W.view(F // 32, 2, 32, K)
+    Wv[:, 0] = w0.view(F // 32, 32, K)
+    Wv[:, 1] = w1.view(F // 32, 32, K)
+    out = torch.empty((M, F), dtype=torch.bfloat16, device="cuda")
+    hh.gemm(A, W, 2 * F, _lib.RP_EPI_GEGLU_BF16, out)
+    g = A.float() @ w0.float().T
+    u = A.float() @ w1.float().T
+    ref = 0.5 * g * (1 + torch.tanh(math.sqrt(2 / math.pi) * (g + 0.044715 * g ** 3))) * u
+    assert (out.float() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("D", [128, 1472, 1536])
+def test_rmsnorm(gen, D):
+    x = torch.randn(260, D, generator=gen, device="cuda") * 3
+    w = torch.rand(D, generator=gen, device="cuda") + 0.5
+    out = hh.rmsnorm(x, w)
+    ref = w * x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6)
+    assert (out.float() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-4
+
+
+def _attention_ref(qkv, cu, tab, H):
+    T = qkv.shape[0]
+    inner = H * 64
+    out = torch.zeros(T, inner, device=qkv.device)
+    q, k, v = qkv[:, :inner].float(), qkv[:, inner : 2 * inner].float(), qkv[:, 2 * inner :].float()
+    cu = cu.tolist()
+    for b in range(len(cu) - 1):
+        s0, s1 = cu[b], cu[b + 1]
+        L = s1 - s0
+        pos = torch.arange(L, device=qkv.device)
+        rel = (pos[None, :] - pos[:, None]).clamp(-128, 128) + 128
+        for h in range(H):
+            sl = slice(h * 64, (h + 1) * 64)
+            s = q[s0:s1, sl] @ k[s0:s1, sl].T + tab[h][rel]  # no 1/sqrt(d) scaling in T5
+            out[s0:s1, sl] = torch.softmax(s, dim=-1) @ v[s0:s1, sl]
+    return out
+
+
+@pytest.mark.parametrize("lens", [[1, 5, 64, 65, 127, 128, 129, 200, 300], [700], [2048, 33]])
+def test_attention(gen, lens):
+    H = 2
+    T = sum(lens)
+    Tp = (T + 127) // 128 * 128
+    qkv = _rand_bf16(gen, Tp, 3 * H * 64)
+    qkv[:, : H * 64] *= 0.5  # logits std ~ 4: sharp but finite softmax
+    tab = torch.randn(H, 257, generator=gen, device="cuda")
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device="cuda")
+    out = hh.attention(qkv, cu, tab, H)
+    ref = _attention_ref(qkv[:T], cu, tab, H)
+    err = (out[:T].float() - ref).abs().max().item()
+    assert err < 3e-2, err  # p and the output pass through bf16
+    assert torch.count_nonzero(out[T:]) == 0, "rows past the last sequence must not be written"
+
+
+def test_attention_online_softmax_rescale_is_exercised(gen):
+    """Force the running-max to jump at a late key tile (cdna guide rule 26): one key far into the
+    sequence dominates one query row."""
+    H, L = 1, 320
+    qkv = _rand_bf16(gen, 384, 3 * 64, scale=0.3)
+    qkv[7, :64] = 2.0  # query 7
+    qkv[300, 64:128] = 2.0  # key 300 aligned with it: logit 256 vs O(1) elsewhere
+    tab = torch.zeros(H, 257, device="cuda")
+    cu = torch.tensor([0, L], dtype=torch.int32, device="cuda")
+    out = hh.attention(qkv, cu, tab, H)
+    ref = _attention_ref(qkv[:L], cu, tab, H)
+    assert (out[:L].float() - ref).abs().max().item() < 3e-2
+    assert (out[7].float() - qkv[300, 128:192].float()).abs().max().item() < 1e-2  # row 7 == v[300]
+
+
+def _scores(Q, E):
+    return (Q.double() @ E.double().T).float().cpu().numpy()  # exact products, fp64 accumulate
+
+
+@pytest.mark.parametrize("B,N,D,k,masked", [
+    (1, 1000, 64, 10, True), (37, 5000, 128, 100, True), (256, 20000, 1472, 100, True),
+    (130, 40000, 256, 100, True), (64, 70000, 128, 7, False), (3, 300, 32, 100, True)])
+def test_sim_topk(gen, B, N, D, k, masked):
+    rng = np.random.default_rng(B * 7 + N)
+    E = torch.nn.functional.normalize(torch.randn(N, D, generator=gen, device="cuda"), dim=1).to(torch.bfloat16)
+    Q = torch.nn.functional.normalize(torch.randn(B, D, generator=gen, device="cuda"), dim=1).to(torch.bfloat16)
+    if masked:
+        m, acc = hh.synth_masks(rng, N, B, F=max(2, N // 25))
+        dm = hh.masks_to_device(m, Q.device)
+    else:
+        dm, acc = None, np.ones((B, N), dtype=bool)
+    S = _scores(Q, E)
+    ids, sc, cnt = hh.sim_topk(Q, E, k, dm)
+    hh.check_topk_against_scores(ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy(), S, acc, k, tol=5e-6)
+    # the dense single-pass path must give bit-identical answers
+    ids2, sc2, cnt2 = hh.sim_topk(Q, E, k, dm, flags=_lib.RP_TOPK_DENSE)
+    assert torch.equal(ids, ids2) and torch.equal(sc, sc2) and torch.equal(cnt, cnt2)
+
+
+def test_sim_topk_exact_ties_and_order(gen):
+    """Small-integer embeddings: every dot product is exact, many scores tie exactly, so ids must
+    equal the oracle's (score desc, id asc) order bit for bit."""
+    rng = np.random.default_rng(5)
+    B, N, D, k = 40, 30000, 64, 100
+    E = torch.from_numpy(rng.integers(-2, 3, size=(N, D)).astype(np.float32)).cuda().to(torch.bfloat16)
+    Q = torch.from_numpy(rng.integers(-2, 3, size=(B, D)).astype(np.float32)).cuda().to(torch.bfloat16)
+    m, acc = hh.synth_masks(rng, N, B, F=500)
+    S = (Q.float() @ E.float().T).cpu().numpy()
+    want_i, want_s = common_ref.masked_topk(S, acc, k)
+    for flags in (_lib.RP_TOPK_AUTO, _lib.RP_TOPK_DENSE):
+        ids, sc, cnt = hh.sim_topk(Q, E, k, hh.masks_to_device(m, Q.device), flags=flags)
+        assert np.array_equal(ids.cpu().numpy(), want_i)
+        assert np.array_equal(sc.cpu().numpy(), want_s)
+        assert (cnt == k).all()
+
+
+def test_sim_topk_fewer_than_k_accessible(gen):
+    rng = np.random.default_rng(9)
+    B, N, D, k = 8, 20000, 64, 100
+    E, Q = _rand_bf16(gen, N, D), _rand_bf16(gen, B, D)
+    m, acc = hh.synth_masks(rng, N, B, F=400, density=0.004)  # ~ a few dozen accessible each
+    S = _scores(Q, E)
+    ids, sc, cnt = hh.sim_topk(Q, E, k, hh.masks_to_device(m, Q.device))
+    assert (acc.sum(1) < k).any()
+    hh.check_topk_against_scores(ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy(), S, acc, k, tol=1e-4)
+
+
+def test_shard_merge_equals_single_shot(gen):
+    """Row-sharded corpus (north_star: 8 shards): per-shard masked top-k with id_offset, then
+    rp_topk_merge, must equal the single-GPU answer exactly on ids and scores."""
+    rng = np.random.default_rng(11)
+    B, N, D, k, R = 64, 50000, 128, 100, 8
+    E = torch.nn.functional.normalize(torch.randn(N, D, generator=gen, device="cuda"), dim=1).to(torch.bfloat16)
+    Q = torch.nn.functional.normalize(torch.randn(B, D, generator=gen, device="cuda"), dim=1).to(torch.bfloat16)
+    m, acc = hh.synth_masks(rng, N, B, F=900)
+    f, ek, bt, own, qk = hh.masks_to_device(m, Q.device)
+    ids, sc, cnt = hh.sim_topk(Q, E, k, (f, ek, bt, own, qk))
+    bounds = np.linspace(0, N, R + 1).astype(int)
+    parts = [hh.sim_topk(Q, E[lo:hi].contiguous(), k, (f[lo:hi].contiguous(), ek[lo:hi].contiguous(), bt, own, qk),
+                         id_offset=int(lo)) for lo, hi in zip(bounds[:-1], bounds[1:])]
+    g_i = torch.stack([p[0] for p in parts])
+    g_s = torch.stack([p[1] for p in parts])
+    g_c = torch.stack([p[2] for p in parts])
+    mi, ms, mc = hh.topk_merge(g_s, g_i, g_c)
+    assert torch.equal(mi, ids) and torch.equal(ms, sc) and torch.equal(mc, cnt)

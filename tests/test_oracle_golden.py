@@ -1,0 +1,109 @@
+"""The oracle (oracle/) against the golden vectors produced by the reference + HuggingFace
+(tools/make_golden.py).  CPU only.  If these fail the oracle has drifted from the reference and
+no GPU parity claim means anything."""
+import json
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import common_ref, t5_ref
+from reprover_amd import synth
+
+
+def test_g1_tokenizer(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "g1_tokenizer.json")))
+    for case in g["cases"]:
+        ids, mask = t5_ref.byt5_batch(g["texts"], case["max_length"])
+        assert ids.shape[1] == case["padded_len"]
+        for i, row in enumerate(case["ids"]):
+            n = int(mask[i].sum())
+            assert ids[i, :n].tolist() == row
+            assert not ids[i, n:].any() and not mask[i, n:].any()
+
+
+def test_g2_serialize_and_file_filters(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "g2_serialize.json")))
+    P = common_ref.Pos
+    for c in g["cases"]:
+        p = common_ref.PremiseRef(c["path"], c["full_name"], P(1, 0), P(2, 0), c["code"])
+        assert p.serialize() == c["serialized"]
+    files = synth.synth_corpus_records(g["corpus_files"], g["corpus_premises"], seed=g["corpus_seed"])
+    for fd, kept in zip(files, g["kept"]):
+        prem = common_ref.premises_of_file(fd)
+        assert [p.full_name for p in prem] == kept["names"]
+        assert [p.serialize() for p in prem] == kept["serialized"]
+
+
+def test_g3_buckets(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g3_buckets.npz"))
+    assert np.array_equal(t5_ref.relative_position_bucket(g["rel"], 32, 128), g["bucket"])
+
+
+def test_g4_tiny_encoder(golden_dir, tiny_weights):
+    cfg, sd = tiny_weights
+    g = np.load(os.path.join(golden_dir, "g4_tiny.npz"), allow_pickle=True)
+    ids, mask = g["input_ids"].astype(np.int64), g["attention_mask"].astype(np.int64)
+    o_ids, o_mask = t5_ref.byt5_batch(list(g["texts"]), 512)
+    assert np.array_equal(ids, o_ids) and np.array_equal(mask, o_mask)
+    hidden = t5_ref.encoder_forward(cfg, sd, ids, mask)
+    last = hidden[torch.arange(len(ids)), torch.from_numpy(mask.sum(1) - 1)]
+    assert (last - torch.from_numpy(g["hidden_last_rows"])).abs().max() < 5e-5
+    assert (hidden[:, 0] - torch.from_numpy(g["hidden_first_rows"])).abs().max() < 5e-5
+    emb = t5_ref.encode(cfg, sd, ids, mask)
+    assert (emb - torch.from_numpy(g["emb"])).abs().max() < 1e-5  # stated CPU-restatement tolerance
+
+
+def test_g5_byt5_small(golden_dir, small_weights):
+    cfg, sd = small_weights
+    g = np.load(os.path.join(golden_dir, "g5_byt5_small.npz"), allow_pickle=True)
+    texts = list(g["texts"])
+    sub = [0, 3, 6, 9, 12]  # a few rows keep the CPU suite short; all rows are checked on the GPU
+    emb = t5_ref.encode_texts(cfg, sd, [texts[i] for i in sub], 2048, 1)
+    assert (emb - torch.from_numpy(g["emb"][sub])).abs().max() < 1e-5
+
+
+def _g6_setup(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "g6_nearest.json")))
+    z = np.load(os.path.join(golden_dir, "g6_nearest.npz"))
+    files = synth.synth_corpus_records(g["n_files"], g["n_premises"], seed=g["corpus_seed"])
+    td = tempfile.mkdtemp()
+    path = os.path.join(td, "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    return g, z, path
+
+
+def test_g6_nearest_premises(golden_dir):
+    g, z, path = _g6_setup(golden_dir)
+    corpus = common_ref.CorpusRef(path)
+    assert len(corpus) == g["N"]
+    E, Q = z["E"], z["Q"]
+    acc = np.unpackbits(z["acc"], axis=1)[:, : g["N"]].astype(bool)
+    ctxs = [
+        common_ref.ContextRef(q["path"], f"thm{j}", common_ref.Pos(*q["pos"]), f"x{j} ⊢ y")
+        for j, q in enumerate(g["queries"])
+    ]
+    for j, c in enumerate(ctxs):
+        keys = corpus.accessible_keys(c.path, c.theorem_pos)
+        row = np.array([(p.path, p.full_name) in keys for p in corpus.all_premises])
+        assert np.array_equal(row, acc[j])
+    for k, res in g["results"].items():
+        qs = res["queries"]
+        idx, sc = corpus.get_nearest_premises(E, [ctxs[j] for j in qs], Q[qs], int(k))
+        assert idx == res["ids"]
+        assert np.allclose(np.array(sc), np.array(res["scores"]), atol=1e-6)
+        # array form used to check kernels
+        ids2, sc2 = common_ref.masked_topk(Q[qs] @ E.T, acc[qs], int(k))
+        assert ids2.tolist() == res["ids"]
+    bad = g["value_error_query"]
+    with pytest.raises(ValueError):
+        corpus.get_nearest_premises(E, [ctxs[bad]], Q[[bad]], 100)
+
+
+def test_format_augmented_state():
+    s = "a ⊢ b"
+    out = common_ref.format_augmented_state(s, ["p1", "p22", "p333"], max_len=len(s.encode()) + 9)
+    # p1\n\n = 4 bytes, p22\n\n = 5 bytes fit (9); p333 does not; later premises go in front
+    assert out == "p22\n\np1\n\n" + s

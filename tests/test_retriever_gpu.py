@@ -1,0 +1,171 @@
+"""End-to-end parity of the drop-in classes on the GPU: Corpus.get_nearest_premises (G6),
+reindex_corpus + predict_step + retrieve on BASELINE config 1 (G7: 1k premises, 128 states,
+top-10, ByT5-small), and size-independent properties at BASELINE config 2 size (130k premises,
+B=256, k=100)."""
+import json
+import os
+import pickle
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+import hip_helpers as hh
+from oracle import common_ref
+from reprover_amd import _lib, synth
+from reprover_amd.common import Context, Corpus, IndexedCorpus, Pos
+from reprover_amd.retrieval.model import PremiseRetriever
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16_round(a: np.ndarray) -> np.ndarray:
+    return torch.from_numpy(a).to(torch.bfloat16).float().numpy()
+
+
+def test_g6_get_nearest_premises(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "g6_nearest.json")))
+    z = np.load(os.path.join(golden_dir, "g6_nearest.npz"))
+    files = synth.synth_corpus_records(g["n_files"], g["n_premises"], seed=g["corpus_seed"])
+    path = os.path.join(tempfile.mkdtemp(), "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    corpus, ref = Corpus(path), common_ref.CorpusRef(path)
+    E, Q = torch.from_numpy(z["E"]).cuda(), torch.from_numpy(z["Q"]).cuda()
+    Eb, Qb = _bf16_round(z["E"]), _bf16_round(z["Q"])  # what the kernel sees
+    ctxs = [Context(q["path"], f"thm{j}", Pos(*q["pos"]), f"x{j} ⊢ y") for j, q in enumerate(g["queries"])]
+    rctx = [common_ref.ContextRef(q["path"], f"thm{j}", common_ref.Pos(*q["pos"]), f"x{j} ⊢ y")
+            for j, q in enumerate(g["queries"])]
+    where = {id(p): i for i, p in enumerate(corpus.all_premises)}
+    for k, res in g["results"].items():
+        qs = res["queries"]
+        prem, scores = corpus.get_nearest_premises(E, [ctxs[j] for j in qs], Q[qs], int(k))
+        ids = [[where[id(p)] for p in row] for row in prem]
+        assert all(isinstance(s, float) for row in scores for s in row)
+        # (a) exact against the oracle evaluated on the same bf16-rounded operands
+        oid, osc = ref.get_nearest_premises(Eb, [rctx[j] for j in qs], Qb[qs], int(k))
+        checked, bad = hh.gap_rule_ids(ids, oid, osc, tol=1e-6)
+        assert bad == 0 and (checked > 0 or int(k) == 1)
+        assert np.abs(np.array(scores) - np.array(osc)).max() < 1e-5
+        # (b) against the reference's fp32 golden output, within the stated bf16 tolerance
+        checked, bad = hh.gap_rule_ids(ids, res["ids"], res["scores"], tol=1e-2)
+        assert bad == 0
+        assert np.abs(np.array(scores) - np.array(res["scores"])).max() < 1e-2
+    with pytest.raises(ValueError):  # common.py:323-324
+        bad_q = g["value_error_query"]
+        corpus.get_nearest_premises(E, [ctxs[bad_q]], Q[[bad_q]], 100)
+
+
+@pytest.fixture(scope="module")
+def g7(golden_dir, small_weights):
+    g = json.load(open(os.path.join(golden_dir, "g7_predict.json")))
+    z = np.load(os.path.join(golden_dir, "g7_predict.npz"))
+    files = synth.synth_corpus_records(g["n_files"], g["n_premises"], seed=g["corpus_seed"],
+                                       code_bytes=tuple(g["code_bytes"]))
+    path = os.path.join(tempfile.mkdtemp(), "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    cfg, sd = small_weights
+    model = PremiseRetriever.from_state_dict(cfg, sd, g["max_seq_len"], "cuda:0")  # bf16, the GPU default
+    model.load_corpus(path)
+    assert model.embeddings_staled
+    model.reindex_corpus(batch_size=g["batch_size"])
+    assert not model.embeddings_staled
+    return g, z, model, path
+
+
+def test_g7_reindex_corpus(g7):
+    g, z, model, _ = g7
+    E = model.corpus_embeddings
+    assert E.shape == (g["N"], 1472) and E.dtype == torch.bfloat16 and E.is_cuda
+    Ef = E.float().cpu()
+    assert torch.allclose(Ef.norm(dim=1), torch.ones(g["N"]), atol=1e-2)
+    cos = torch.nn.functional.cosine_similarity(Ef[:16], torch.from_numpy(z["E_head"]), dim=1)
+    assert cos.min().item() >= 0.999
+    probe = torch.from_numpy(np.random.default_rng(int(z["probe_seed"])).standard_normal((1472, 4)).astype(np.float32))
+    err = (Ef @ probe - torch.from_numpy(z["E_probe"])).abs().max().item()
+    print(f"g7: max|E·probe - golden| = {err:.3e} (|probe column| ~ {probe.norm(dim=0).mean().item():.1f})")
+    assert err < 0.25  # = 1e-2-scale embedding error times |probe| ~ 38, a loose all-rows checksum
+
+
+def test_g7_predict_and_retrieve(g7):
+    g, z, model, _ = g7
+    k = g["k"]
+    model.num_retrieved = k
+    ctxs = [Context(q["path"], f"thm{j}", Pos(*q["pos"]), q["state"]) for j, q in enumerate(g["queries"])]
+    where = {id(p): i for i, p in enumerate(model.corpus.all_premises)}
+    model.predict_step_outputs = []
+    for i in range(0, len(ctxs), g["batch_size"]):
+        batch = ctxs[i : i + g["batch_size"]]
+        tok = model.tokenizer([c.serialize() for c in batch], padding="longest", max_length=g["max_seq_len"],
+                              truncation=True, return_tensors="pt")
+        b = {"context": batch, "context_ids": tok.input_ids.cuda(), "context_mask": tok.attention_mask.cuda()}
+        for key in ("url", "commit", "file_path", "full_name", "start", "tactic_idx", "all_pos_premises"):
+            b[key] = [None] * len(batch)
+        model.predict_step(b, 0)
+    recs = model.predict_step_outputs
+    assert len(recs) == len(ctxs) and set(recs[0]) == {
+        "url", "commit", "file_path", "full_name", "start", "tactic_idx", "context", "all_pos_premises",
+        "retrieved_premises", "scores"}
+    ids = [[where[id(p)] for p in r["retrieved_premises"]] for r in recs]
+    scores = np.array([r["scores"] for r in recs])
+    gold_s = np.array(g["scores"])
+    checked, bad = hh.gap_rule_ids(ids, g["ids"], g["scores"], tol=1e-2)
+    overlap = np.mean([len(set(a) & set(b)) / k for a, b in zip(ids, g["ids"])])
+    top1 = np.mean([a[0] == b[0] for a, b in zip(ids, g["ids"])])
+    print(f"g7: max|Δscore| {np.abs(scores - gold_s).max():.3e}; top-{k} overlap {overlap:.3f}; top-1 agreement "
+          f"{top1:.3f}; gap-rule ranks checked {checked}, mismatched {bad}")
+    assert np.abs(scores - gold_s).max() < 1e-2
+    assert bad == 0
+    assert overlap >= 0.9
+    # single-query path (model.py:338-375)
+    for j, single in enumerate(g["retrieve"]):
+        c = ctxs[j]
+        prem, sc = model.retrieve(c.state, c.path, c.theorem_full_name, c.theorem_pos, k)
+        assert [where[id(p)] for p in prem] == ids[j]
+        assert np.abs(np.array(sc) - np.array(single["scores"])).max() < 1e-2
+    # predictions.pickle round trip (model.py:329-336)
+    d = tempfile.mkdtemp()
+    model.on_predict_epoch_end(d)
+    back = pickle.load(open(os.path.join(d, "predictions.pickle"), "rb"))
+    assert len(back) == len(ctxs) and back[3]["retrieved_premises"][0].full_name == \
+        model.corpus.all_premises[ids[3][0]].full_name
+
+
+def test_indexed_corpus_pickle_roundtrip(g7):
+    g, z, model, _ = g7
+    path = os.path.join(tempfile.mkdtemp(), "indexed.pickle")
+    with open(path, "wb") as fh:  # what retrieval/index.py writes (index.py:37-40)
+        pickle.dump(IndexedCorpus(model.corpus, model.corpus_embeddings.to(torch.float32).cpu()), fh)
+    m2 = PremiseRetriever(model.encoder, max_seq_len=g["max_seq_len"])
+    m2.load_corpus(path)
+    assert not m2.embeddings_staled and m2.corpus_embeddings.device.type == "cpu"
+    q = g["queries"][0]
+    a = m2.retrieve(q["state"], q["path"], "thm0", Pos(*q["pos"]), 10)
+    b = model.retrieve(q["state"], q["path"], "thm0", Pos(*q["pos"]), 10)
+    assert [p.full_name for p in a[0]] == [p.full_name for p in b[0]] and a[1] == b[1]
+    assert m2.corpus_embeddings.is_cuda and m2.corpus_embeddings.dtype == torch.bfloat16  # moved + cast once
+
+
+def test_full_size_properties_130k_b256_k100():
+    """BASELINE config 2 shape: N=130,000 premises, D=1472, B=256 states, k=100."""
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3407)
+    rng = np.random.default_rng(3407)
+    N, D, B, k, F = 130_000, 1472, 256, 100, 5000
+    E = torch.nn.functional.normalize(torch.randn(N, D, generator=gen, device="cuda"), dim=1).to(torch.bfloat16)
+    Q = torch.nn.functional.normalize(torch.randn(B, D, generator=gen, device="cuda"), dim=1).to(torch.bfloat16)
+    m, acc = hh.synth_masks(rng, N, B, F)
+    dm = hh.masks_to_device(m, Q.device)
+    ids, sc, cnt = hh.sim_topk(Q, E, k, dm)
+    S = (Q.float() @ E.float().T).cpu().numpy()  # plain torch fp32 reference of the similarity GEMM
+    hh.check_topk_against_scores(ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy(), S, acc, k, tol=2e-5)
+    ids2, sc2, cnt2 = hh.sim_topk(Q, E, k, dm, flags=_lib.RP_TOPK_DENSE)
+    assert torch.equal(ids, ids2) and torch.equal(sc, sc2) and torch.equal(cnt, cnt2)
+    # 8-way row shard + merge == single shot (north_star's multi-GPU layout, on one GPU)
+    f, ek, bt, own, qk = dm
+    bounds = np.linspace(0, N, 9).astype(int)
+    parts = [hh.sim_topk(Q, E[lo:hi].contiguous(), k, (f[lo:hi].contiguous(), ek[lo:hi].contiguous(), bt, own, qk),
+                         id_offset=int(lo)) for lo, hi in zip(bounds[:-1], bounds[1:])]
+    mi, ms, mc = hh.topk_merge(torch.stack([p[1] for p in parts]), torch.stack([p[0] for p in parts]),
+                               torch.stack([p[2] for p in parts]))
+    assert torch.equal(mi, ids) and torch.equal(ms, sc) and torch.equal(mc, cnt)

@@ -341,6 +341,7 @@ def g7_predict():
         ctxs.append(common.Context(files[f]["path"], f"thm{j}", H.Pos(*pos), state))
         qmeta.append({"path": files[f]["path"], "pos": list(pos), "state": state})
     where = {id(p): i for i, p in enumerate(model.corpus.all_premises)}
+    model.num_retrieved = 10  # BASELINE config 1: top-10 (the hook reads self.num_retrieved, model.py:288)
     ids_all, sc_all = [], []
     t0 = time.time()
     for i in range(0, B, 64):  # eval_batch_size 64 (retrieval/confs/*.yaml)
