@@ -102,6 +102,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # The engine shares torch's HIP runtime instance (device pointers and streams cross the ABI),
+    # so torch's bundled libamdhip64 must be the one already loaded when the library is dlopen'ed.
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise HipLibraryError(
             f"{LIB_PATH} is missing: build it with `python -m reprover_amd.build` "

@@ -4,7 +4,7 @@
 // T5Stack.forward it calls (transformers models/t5/modeling_t5.py:663-750, blocks :435-509,
 // attention :281-369, RMSNorm :50-72, gated-GELU FFN :97-123).  Exact math: SURVEY.md App. A.
 //
-// Data layout in HBM for a pass over T packed tokens (Tp = T rounded up to 128):
+// Data layout in HBM for a pass over T packed tokens (Tp = T rounded up to 256):
 //   x    f32  [Tp, D]        residual stream (kept fp32; HF-bf16 keeps it bf16)
 //   h    bf16 [Tp, D]        RMSNorm output = GEMM A operand
 //   qkv  bf16 [Tp, 3*H*64]   fused projection output, [q | k | v], head-major inside each
@@ -27,6 +27,7 @@ thread_local std::string g_last_error;
 // options
 // ------------------------------------------------------------------------------------------
 static int g_gemm_group_m = 8;
+static int g_gemm_variant = 8;  // tile/pipeline configuration, see launch_gemm()
 
 // ------------------------------------------------------------------------------------------
 // per-kernel event timing
@@ -174,12 +175,13 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 struct EpiStoreBf16 {  // out[row, col] = bf16(acc)
   bf16_t* out;
   int ldo, n_valid;
-  __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int m_base, int n_base, int lane) {
+  template <int FM, int FN>
+  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane) {
     const int hi = lane >> 5, cl = lane & 31;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < FN; ++j) {
         const int col = n_base + j * 32 + cl;
         if (col < n_valid) {
 #pragma unroll
@@ -195,12 +197,13 @@ struct EpiStoreBf16 {  // out[row, col] = bf16(acc)
 struct EpiResidF32 {  // x[row, col] += acc   (residual stream, fp32)
   float* x;
   int ldx, n_valid;
-  __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int m_base, int n_base, int lane) {
+  template <int FM, int FN>
+  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane) {
     const int hi = lane >> 5, cl = lane & 31;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < FN; ++j) {
         const int col = n_base + j * 32 + cl;
         if (col < n_valid) {
 #pragma unroll
@@ -214,44 +217,108 @@ struct EpiResidF32 {  // x[row, col] += acc   (residual stream, fp32)
   }
 };
 
-struct EpiGegluBf16 {  // W rows interleaved 32 gate / 32 up: frag j=0 gate, j=1 up
+struct EpiGegluBf16 {  // W rows interleaved 32 gate / 32 up: even fragments gate, odd fragments up
   bf16_t* out;         // [M, n_valid/2]
   int ldo, n_valid;    // n_valid counts interleaved columns (= 2 * d_ff)
-  __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int m_base, int n_base, int lane) {
+  template <int FM, int FN>
+  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane) {
+    static_assert(FN % 2 == 0, "gate/up pairs");
     const int hi = lane >> 5, cl = lane & 31;
-    if (n_base >= n_valid) return;
-    const int col = (n_base >> 1) + cl;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < FN; j += 2) {
+      if (n_base + j * 32 >= n_valid) continue;
+      const int col = ((n_base + j * 32) >> 1) + cl;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m_base + i * 32 + mfma32_row(r, hi);
-        out[(size_t)row * ldo + col] = f2bf(gelu_new(acc[i][0][r]) * acc[i][1][r]);
-      }
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m_base + i * 32 + mfma32_row(r, hi);
+          out[(size_t)row * ldo + col] = f2bf(gelu_new(acc[i][j][r]) * acc[i][j + 1][r]);
+        }
+    }
   }
 };
 
-template <class Epi>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmOperand A, GemmOperand W, int K, int tiles_m,
-                                                   int tiles_n, int group_m, Epi epi) {
-  __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS_BYTES];
+template <class C, class Epi>
+__global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOperand W, int K, int tiles_m,
+                                                          int tiles_n, int group_m, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   int tm, tn;
   tile_coords(logical, tiles_m, tiles_n, group_m, tm, tn);
-  gemm_tile(A, W, K, tm, tn, epi, smem);
+  gemm_tile<C>(A, W, K, tm, tn, epi, smem);
 }
+
+template <class C, class Epi, int EXP>
+__global__ __launch_bounds__(C::THREADS) void gemm_pp_kernel(GemmOperand A, GemmOperand W, int K, int tiles_m,
+                                                             int tiles_n, int group_m, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  int tm, tn;
+  tile_coords(logical, tiles_m, tiles_n, group_m, tm, tn);
+  gemm_tile_pingpong<C, EXP>(A, W, K, tm, tn, epi, smem);
+}
+
+template <class C, class Epi, int PP>
+struct KernelSel {
+  static auto get() { return gemm_pp_kernel<C, Epi, PP - 1>; }
+};
+template <class C, class Epi>
+struct KernelSel<C, Epi, 0> {
+  static auto get() { return gemm_kernel<C, Epi>; }
+};
+
+template <class C, class Epi, int PINGPONG = 0>
+static RpStatus launch_gemm_cfg(GemmOperand a, GemmOperand w, int K, Epi epi, hipStream_t stream,
+                                int prof_class) {
+  auto kern = KernelSel<C, Epi, PINGPONG>::get();
+  static bool attr_done = false;
+  if (!attr_done) {
+    RP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    attr_done = true;
+  }
+  RP_REQUIRE(K % C::BK == 0 && a.rows % C::BM == 0, "gemm: K=%d must be a multiple of %d, M=%d of %d", K, C::BK,
+             a.rows, C::BM);
+  const int tiles_m = a.rows / C::BM, tiles_n = (w.rows + C::BN - 1) / C::BN;
+  const int group_m = max(1, g_gemm_group_m * 128 / C::BM);
+  ProfScope ps(stream, prof_class);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(C::THREADS), C::LDS_BYTES, stream, a, w, K, tiles_m,
+                     tiles_n, group_m, epi);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+// rows of the activation workspace are padded to this so every variant tiles M exactly
+constexpr int GEMM_M_ALIGN = 256;
 
 template <class Epi>
 static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, int ldw, int n_rows_w,
                             int K, Epi epi, hipStream_t stream, int prof_class) {
-  RP_REQUIRE(M % GEMM_BM == 0 && K % GEMM_BK == 0, "gemm: M=%d must be a multiple of 128, K=%d of 32", M, K);
-  const int tiles_m = M / GEMM_BM, tiles_n = (n_rows_w + GEMM_BN - 1) / GEMM_BN;
   GemmOperand a{A, lda, M}, w{W, ldw, n_rows_w};
-  ProfScope ps(stream, prof_class);
-  hipLaunchKernelGGL((gemm_kernel<Epi>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, a, w, K, tiles_m,
-                     tiles_n, g_gemm_group_m, epi);
-  RP_CHECK_LAUNCH();
-  return RP_OK;
+  int v = g_gemm_variant;
+  const bool k64 = (K % 64 == 0), m256 = (M % 256 == 0);
+  if ((v == 1 || v == 2 || v == 6 || v == 7) && !k64) v = 0;
+  if (v >= 5 && !m256) v = 0;
+  switch (v) {
+    case 1: return launch_gemm_cfg<GemmCfg<128, 128, 64, 2, 2, 2>>(a, w, K, epi, stream, prof_class);
+    case 2: return launch_gemm_cfg<GemmCfg<128, 128, 64, 2, 2, 3>>(a, w, K, epi, stream, prof_class);
+    case 3: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 4>>(a, w, K, epi, stream, prof_class);
+    case 4: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 2>>(a, w, K, epi, stream, prof_class);
+    case 5: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>>(a, w, K, epi, stream, prof_class);
+    case 6: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 4, 2>>(a, w, K, epi, stream, prof_class);
+    case 7: return launch_gemm_cfg<GemmCfg<256, 128, 64, 4, 2, 2>>(a, w, K, epi, stream, prof_class);
+    case 8: return launch_gemm_cfg<GemmCfg<256, 128, 32, 4, 2, 3>>(a, w, K, epi, stream, prof_class);
+    case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 3>>(a, w, K, epi, stream, prof_class);
+    case 10: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 1>(a, w, K, epi, stream, prof_class);
+    case 11: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 2>(a, w, K, epi, stream, prof_class);
+    case 12: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 3>(a, w, K, epi, stream, prof_class);
+    case 13: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 4>(a, w, K, epi, stream, prof_class);
+    case 14: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 5>(a, w, K, epi, stream, prof_class);
+    case 15: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 6>(a, w, K, epi, stream, prof_class);
+    case 16: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 7>(a, w, K, epi, stream, prof_class);
+    case 17: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 8>(a, w, K, epi, stream, prof_class);
+    default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(a, w, K, epi, stream, prof_class);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -563,6 +630,11 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     g_gemm_group_m = value;
     return RP_OK;
   }
+  if (!strcmp(name, "gemm_variant")) {
+    RP_REQUIRE(value >= 0 && value <= 17, "gemm_variant out of range");
+    g_gemm_variant = value;
+    return RP_OK;
+  }
   return fail(RP_E_INVALID, "unknown option %s", name);
 }
 
@@ -701,7 +773,7 @@ struct Workspace {
   size_t bytes;
 };
 Workspace carve(const RpEncoder* e, int T, char* base) {
-  const size_t Tp = align_up((size_t)T, 128);
+  const size_t Tp = align_up((size_t)T, GEMM_M_ALIGN);
   const size_t D = e->cfg.d_model, F = e->cfg.d_ff, inner = e->inner;
   Workspace w;
   size_t off = 0;
@@ -739,7 +811,7 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
     return fail(RP_E_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, w.bytes);
   const RpT5Config& c = e->cfg;
   const int D = c.d_model, F = c.d_ff, inner = e->inner, H = c.num_heads;
-  const int Tp = (int)align_up((size_t)T, 128);
+  const int Tp = (int)align_up((size_t)T, GEMM_M_ALIGN);
   RpStatus st;
 
   {

@@ -1,14 +1,17 @@
 // bf16 MFMA GEMM core for gfx950:  C[M,N] = A[M,K] · W[N,K]^T   (both operands K-contiguous,
 // i.e. activations row-major and nn.Linear weights as stored), fp32 accumulate.
 //
-// Workgroup = 256 threads = 4 waves (2 x 2), tile 128 x 128 x 32; each wave owns a 64 x 64
-// sub-tile as 2 x 2 v_mfma_f32_32x32x16_bf16 accumulators (64 fp32 VGPRs).  A and W tiles are
-// staged through LDS (2 stages x (8 KB + 8 KB)); fragments are read with ds_read_b128 from an
-// XOR-swizzled image (16-B chunk index ^= (row >> 2) & 3) that is conflict-free for the
-// 16-lane groups ds_read_b128 is serviced in.  Staging variant 0 goes global -> VGPR -> LDS
-// (prefetch of tile t+1 issued before the MFMAs of tile t); variant 1 uses the gfx950 LDS-DMA
-// (global_load_lds_dwordx4) with the swizzle applied to the per-lane SOURCE address, LDS image
-// linear per wave.
+// Workgroup = WM x WN waves over a BM x BN x BK block tile; each wave owns an (FM*32) x (FN*32)
+// sub-tile as FM x FN v_mfma_f32_32x32x16_bf16 accumulators (16 fp32 registers each).
+//
+// Staging: A and W tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round
+// trip, 1 KiB per wave-instruction) into an NSTAGE-deep ring; tile t+NSTAGE-1 is issued while
+// tile t is consumed, with a COUNTED s_waitcnt vmcnt(...) and a raw s_barrier per K-step so the
+// DMAs stay in flight across barriers (cdna_hip_programming.md §5 "Pipelining across barriers").
+// The LDS image is lane-linear per DMA instruction, so the bank-conflict swizzle is applied to the
+// per-lane SOURCE address and again on the ds_read_b128 fragment reads (rule 21): 16-B slot index
+// ^= f(row), with f chosen per BK so that the 16-lane groups ds_read_b128 is serviced in hit 16
+// distinct slots of the 256-B bank row (conflict-free).
 //
 // The epilogue is a functor so the same core serves the encoder GEMMs (bf16 store, fp32
 // residual add, gated-GELU) and the similarity scan (accessibility mask + top-k filter).
@@ -17,17 +20,29 @@
 
 namespace rp {
 
-constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32;
-constexpr int GEMM_STAGE_BYTES = (GEMM_BM + GEMM_BN) * GEMM_BK * 2;  // 16 KB
-constexpr int GEMM_LDS_BYTES = 2 * GEMM_STAGE_BYTES;                  // 32 KB
-
 // C/D layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 __device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-// byte offset of 16-B chunk `kc` (0..3) of row `row` inside a [rows][32] bf16 tile image
-__device__ __forceinline__ int tile_off(int row, int kc) {
-  return row * 64 + ((kc ^ ((row >> 2) & 3)) << 4);
-}
+// Tile configuration: block tile BM x BN x BK, WM x WN waves, NSTAGE-deep LDS ring.
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSTAGE_>
+struct GemmCfg {
+  static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_;
+  static constexpr int NWAVES = WM * WN, THREADS = NWAVES * 64;
+  static constexpr int FM = BM / WM / 32, FN = BN / WN / 32;  // 32x32 accumulator fragments per wave
+  static constexpr int ROW_BYTES = BK * 2;
+  static constexpr int SLOTS = ROW_BYTES / 16;           // 16-B chunks per row: 4 (BK=32) / 8 (BK=64)
+  static constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES;
+  static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+  static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
+  static constexpr int ROWS_PER_DMA = 1024 / ROW_BYTES;  // rows covered by one wave-instruction
+  static constexpr int A_DMA = BM / ROWS_PER_DMA / NWAVES, W_DMA = BN / ROWS_PER_DMA / NWAVES;  // per wave
+  static_assert(BM % (ROWS_PER_DMA * NWAVES) == 0 && BN % (ROWS_PER_DMA * NWAVES) == 0, "DMA split");
+  static_assert(BK == 32 || BK == 64, "BK");
+  // physical 16-B slot of logical chunk kc in row `row`: conflict-free for the 16-lane groups of
+  // ds_read_b128 when 32 consecutive rows read the same logical chunk
+  __device__ static __forceinline__ int swz(int row) { return (BK == 32) ? ((row >> 2) & 3) : ((row >> 1) & 7); }
+  __device__ static __forceinline__ int off(int row, int kc) { return row * ROW_BYTES + ((kc ^ swz(row)) << 4); }
+};
 
 struct GemmOperand {
   const bf16_t* ptr;  // [rows, ld] row-major, K-contiguous
@@ -35,107 +50,247 @@ struct GemmOperand {
   int rows;           // rows that may be read; tile rows beyond are clamped to rows-1
 };
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // acc[mfrag][nfrag]; wave covers rows m_base + mfrag*32 + mfma32_row(r, hi), cols n_base + nfrag*32 + (lane&31)
-template <class Epilogue>
-__device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand W, int K,
-                                          int tile_m, int tile_n, Epilogue& epi, char* smem) {
+template <class C, class Epilogue>
+__device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand W, int K, int tile_m,
+                                          int tile_n, Epilogue& epi, char* smem) {
+  constexpr int BK = C::BK, NSTAGE = C::NSTAGE, FM = C::FM, FN = C::FN;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wave_row = wave >> 1, wave_col = wave & 1;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_row = wave / C::WN, wave_col = wave % C::WN;
   const int hi = lane >> 5;
 
-  f32x16 acc[2][2];
+  f32x16 acc[FM][FN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging assignment: chunk c = tid + 256*i -> row c>>2, k-chunk c&3
-  const bf16_t* a_src[2];
-  const bf16_t* w_src[2];
-  int st_off[2];
+  // ---- LDS-DMA assignment: instruction d of this wave fills rows [(wave*DPW + d) * RPD, +RPD) of an
+  // operand image; lane l lands at byte (l * 16) of that 1-KiB piece = (row l / SLOTS, slot l % SLOTS),
+  // and therefore fetches logical chunk (slot ^ swz(row)) of that row.
+  const bf16_t* a_src[C::A_DMA];
+  const bf16_t* w_src[C::W_DMA];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int c = tid + 256 * i;
-    int row = c >> 2, kc = c & 3;
-    int ar = min(tile_m * GEMM_BM + row, A.rows - 1);
-    int wr = min(tile_n * GEMM_BN + row, W.rows - 1);
-    a_src[i] = A.ptr + (size_t)ar * A.ld + kc * 8;
-    w_src[i] = W.ptr + (size_t)wr * W.ld + kc * 8;
-    st_off[i] = tile_off(row, kc);
+  for (int d = 0; d < C::A_DMA; ++d) {
+    const int row = (wave * C::A_DMA + d) * C::ROWS_PER_DMA + lane / C::SLOTS;
+    const int kc = (lane % C::SLOTS) ^ C::swz(row);
+    a_src[d] = A.ptr + (size_t)min(tile_m * C::BM + row, A.rows - 1) * A.ld + kc * 8;
   }
-  // fragment read offsets (within a tile image)
-  int a_off[2][2], b_off[2][2];  // [frag][ksub]
 #pragma unroll
-  for (int f = 0; f < 2; ++f)
+  for (int d = 0; d < C::W_DMA; ++d) {
+    const int row = (wave * C::W_DMA + d) * C::ROWS_PER_DMA + lane / C::SLOTS;
+    const int kc = (lane % C::SLOTS) ^ C::swz(row);
+    w_src[d] = W.ptr + (size_t)min(tile_n * C::BN + row, W.rows - 1) * W.ld + kc * 8;
+  }
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * C::STAGE_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      a_off[f][ks] = tile_off(wave_row * 64 + f * 32 + (lane & 31), ks * 2 + hi);
-      b_off[f][ks] = tile_off(wave_col * 64 + f * 32 + (lane & 31), ks * 2 + hi);
-    }
+    for (int d = 0; d < C::A_DMA; ++d)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + (size_t)kt * BK),
+                                       (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int d = 0; d < C::W_DMA; ++d)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[d] + (size_t)kt * BK),
+                                       (lds_ptr_t)(base + C::A_BYTES + (wave * C::W_DMA + d) * 1024), 16, 0, 0);
+  };
+  constexpr int DMA_PER_STAGE = C::A_DMA + C::W_DMA;  // per wave
 
-  const int nk = K / GEMM_BK;
-  uint4 ra[2], rb[2];
+  // fragment read offsets (within an operand image)
+  int a_off[FM][BK / 16], b_off[FN][BK / 16];  // [frag][k16 step]
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    ra[i] = *reinterpret_cast<const uint4*>(a_src[i]);
-    rb[i] = *reinterpret_cast<const uint4*>(w_src[i]);
-  }
+  for (int ks = 0; ks < BK / 16; ++ks) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    *reinterpret_cast<uint4*>(smem + st_off[i]) = ra[i];
-    *reinterpret_cast<uint4*>(smem + GEMM_BM * 64 + st_off[i]) = rb[i];
+    for (int f = 0; f < FM; ++f) a_off[f][ks] = C::off(wave_row * (FM * 32) + f * 32 + (lane & 31), ks * 2 + hi);
+#pragma unroll
+    for (int f = 0; f < FN; ++f) b_off[f][ks] = C::off(wave_col * (FN * 32) + f * 32 + (lane & 31), ks * 2 + hi);
   }
-  __syncthreads();
 
-  int cur = 0;
+  const int nk = K / BK;
+  // prologue: NSTAGE-1 tiles in flight
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) stage(s, s);
+
+  int buf = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1 < nk);
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ra[i] = *reinterpret_cast<const uint4*>(a_src[i] + (size_t)(kt + 1) * GEMM_BK);
-        rb[i] = *reinterpret_cast<const uint4*>(w_src[i] + (size_t)(kt + 1) * GEMM_BK);
-      }
+    // tile kt has landed once at most (NSTAGE-2) younger tiles' DMAs of this wave remain in flight
+    if (kt + NSTAGE - 2 < nk)
+      wait_vmcnt<(NSTAGE - 2) * DMA_PER_STAGE>();
+    else
+      wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // every wave's share of tile kt is in LDS; tile kt-1 fully consumed
+    if (kt + NSTAGE - 1 < nk) {
+      int nb = buf + NSTAGE - 1;
+      if (nb >= NSTAGE) nb -= NSTAGE;
+      stage(kt + NSTAGE - 1, nb);
     }
-    const char* sa = smem + cur * GEMM_STAGE_BYTES;
-    const char* sb = sa + GEMM_BM * 64;
+    const char* sa = smem + buf * C::STAGE_BYTES;
+    const char* sb = sa + C::A_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[2], bfr[2];
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 af[FM], bfr[FN];
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        af[f] = *reinterpret_cast<const bf16x8*>(sa + a_off[f][ks]);
-        bfr[f] = *reinterpret_cast<const bf16x8*>(sb + b_off[f][ks]);
-      }
+      for (int f = 0; f < FM; ++f) af[f] = *reinterpret_cast<const bf16x8*>(sa + a_off[f][ks]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int f = 0; f < FN; ++f) bfr[f] = *reinterpret_cast<const bf16x8*>(sb + b_off[f][ks]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if (more) {
-      char* da = smem + (cur ^ 1) * GEMM_STAGE_BYTES;
+    if (++buf == NSTAGE) buf = 0;
+  }
+  __syncthreads();  // all waves done with LDS before an epilogue reuses it
+
+  epi.template run<FM, FN>(acc, tile_m * C::BM + wave_row * (FM * 32), tile_n * C::BN + wave_col * (FN * 32), lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ping-pong schedule for the 8-wave 256 x 256 x 32 tile (one workgroup per CU, two waves per SIMD).
+//
+// The waves form two groups (waves 0-3 = upper 128 rows, waves 4-7 = lower 128 rows; each group has
+// one wave on every SIMD).  Every K-tile is split into a LOAD part (issue the LDS-DMA of tile kt+3,
+// read this wave's 12 operand fragments of tile kt with ds_read_b128) and a COMPUTE part (16 MFMAs),
+// separated by workgroup barriers, and group 1 runs ONE barrier behind group 0.  So in every
+// barrier interval one wave of each SIMD is inside its MFMA cluster (at raised priority) while its
+// partner fetches: the matrix pipe sees back-to-back MFMAs and the LDS/DMA traffic hides beneath.
+//   interval 2kt   : group0 LOAD(kt)      group1 COMPUTE(kt-1)
+//   interval 2kt+1 : group0 COMPUTE(kt)   group1 LOAD(kt)
+// LDS ring of 4 stages (4 x 32 KiB): tile kt+3 overwrites the stage of tile kt-1, whose last reader
+// (group1, interval 2kt-1) has drained its ds_reads (lgkmcnt(0)) before the barrier that precedes the
+// first overwrite (group0, interval 2kt).  Tile kt+1 is complete in LDS before interval 2kt+2: every
+// wave ends LOAD(kt) with a counted vmcnt that leaves only tiles kt+2, kt+3 in flight.
+// ------------------------------------------------------------------------------------------------
+template <class C, int EXP, class Epilogue>
+__device__ __forceinline__ void gemm_tile_pingpong(const GemmOperand A, const GemmOperand W, int K, int tile_m,
+                                                   int tile_n, Epilogue& epi, char* smem) {
+  static_assert(C::NWAVES == 8 && C::WM == 2 && C::NSTAGE == 4 && C::BK == 32, "ping-pong geometry");
+  constexpr int BK = C::BK, FM = C::FM, FN = C::FN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_row = wave / C::WN, wave_col = wave % C::WN;
+  const int grp = (EXP == 2) ? (wave & 1) : (EXP == 5 ? 0 : wave_row);  // 0: leads, 1: one barrier behind
+  const int hi = lane >> 5;
+
+  f32x16 acc[FM][FN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        *reinterpret_cast<uint4*>(da + st_off[i]) = ra[i];
-        *reinterpret_cast<uint4*>(da + GEMM_BM * 64 + st_off[i]) = rb[i];
-      }
-    }
-    __syncthreads();
-    cur ^= 1;
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const bf16_t* a_src[C::A_DMA];
+  const bf16_t* w_src[C::W_DMA];
+#pragma unroll
+  for (int d = 0; d < C::A_DMA; ++d) {
+    const int row = (wave * C::A_DMA + d) * C::ROWS_PER_DMA + lane / C::SLOTS;
+    const int kc = (lane % C::SLOTS) ^ C::swz(row);
+    a_src[d] = A.ptr + (size_t)min(tile_m * C::BM + row, A.rows - 1) * A.ld + kc * 8;
+  }
+#pragma unroll
+  for (int d = 0; d < C::W_DMA; ++d) {
+    const int row = (wave * C::W_DMA + d) * C::ROWS_PER_DMA + lane / C::SLOTS;
+    const int kc = (lane % C::SLOTS) ^ C::swz(row);
+    w_src[d] = W.ptr + (size_t)min(tile_n * C::BN + row, W.rows - 1) * W.ld + kc * 8;
+  }
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * C::STAGE_BYTES;
+#pragma unroll
+    for (int d = 0; d < C::A_DMA; ++d)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + (size_t)kt * BK),
+                                       (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int d = 0; d < C::W_DMA; ++d)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[d] + (size_t)kt * BK),
+                                       (lds_ptr_t)(base + C::A_BYTES + (wave * C::W_DMA + d) * 1024), 16, 0, 0);
+  };
+  constexpr int DPS = C::A_DMA + C::W_DMA;  // DMA instructions per stage per wave
+
+  int a_off[FM][2], b_off[FN][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int f = 0; f < FM; ++f) a_off[f][ks] = C::off(wave_row * (FM * 32) + f * 32 + (lane & 31), ks * 2 + hi);
+#pragma unroll
+    for (int f = 0; f < FN; ++f) b_off[f][ks] = C::off(wave_col * (FN * 32) + f * 32 + (lane & 31), ks * 2 + hi);
   }
 
-  epi(acc, tile_m * GEMM_BM + wave_row * 64, tile_n * GEMM_BN + wave_col * 64, lane);
+  const int nk = K / BK;
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+    if (s < nk) stage(s, s);
+  if (nk >= 3)
+    wait_vmcnt<2 * DPS>();  // tile 0 landed; tiles 1, 2 may still fly
+  else
+    wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one interval behind
+
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // ---------------- LOAD part
+    if (EXP != 3 && EXP != 4)
+      if (kt + 3 < nk) stage(EXP == 7 ? 0 : kt + 3, (buf + 3) & 3);
+    const char* sa = smem + buf * C::STAGE_BYTES;
+    const char* sb = sa + C::A_BYTES;
+    bf16x8 af[FM][2], bfr[FN][2];
+    if ((EXP != 3 && EXP != 6) || kt == 0) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int f = 0; f < FN; ++f) bfr[f][ks] = *reinterpret_cast<const bf16x8*>(sb + b_off[f][ks]);
+#pragma unroll
+        for (int f = 0; f < FM; ++f) af[f][ks] = *reinterpret_cast<const bf16x8*>(sa + a_off[f][ks]);
+      }
+    }
+    if (kt + 3 < nk)
+      wait_vmcnt<2 * DPS>();  // tile kt+1 complete (this wave's share); kt+2, kt+3 in flight
+    else
+      wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers, stage kt released
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- COMPUTE part
+    if (EXP != 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ks], bfr[j][ks], acc[i][j], 0, 0, 0);
+    if (EXP != 1) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    buf = (buf + 1) & 3;
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // group 0 waits out group 1's last COMPUTE
+  __syncthreads();
+
+  epi.template run<FM, FN>(acc, tile_m * C::BM + wave_row * (FM * 32), tile_n * C::BN + wave_col * (FN * 32), lane);
 }
 
 // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (observed, speed only), so consecutive
 // "logical" ids are handed out per XCD: logical = (b % 8) * ceil-chunk + b / 8 (bijective form),
 // then logical ids walk the tile grid in column-groups of GROUP_M row-tiles so that the
-// 32 workgroups resident on one XCD share a few A row-panels and W column-panels in its L2.
+// workgroups resident on one XCD share a few A row-panels and W column-panels in its L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7;
   const int xcd = bid & 7, idx = bid >> 3;

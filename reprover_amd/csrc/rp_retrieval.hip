@@ -23,6 +23,9 @@ constexpr int SIM_DENSE_MAX_N = 16384;
 constexpr int SIM_STRIDE = 16;
 constexpr int SIM_CAND_CAP = 8192;
 constexpr int SIM_MAX_K = 1024;
+typedef GemmCfg<128, 128, 64, 2, 2, 2> SimCfg64;  // D % 64 == 0: 64 KiB LDS ring per workgroup
+typedef GemmCfg<128, 128, 32, 2, 2, 3> SimCfg32;  // otherwise (D % 32 == 0): 48 KiB
+constexpr int GEMM_BM = 128, GEMM_BN = 128;
 
 __device__ __forceinline__ uint64_t make_key(float score, int32_t id) {
   return ((uint64_t)f2ord(score) << 32) | (uint32_t)(~(uint32_t)id);
@@ -51,7 +54,9 @@ struct EpiSim {
   int32_t* count;      // [B]
   char* smem;          // GEMM LDS, free once the main loop is done
 
-  __device__ __forceinline__ void operator()(f32x16 (&acc)[2][2], int m_base, int n_base, int lane) {
+  template <int FM, int FN>
+  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane) {
+    static_assert(FM == 2 && FN == 2, "scan epilogue is written for 64x64 wave tiles of a 128x128 block");
     const int hi = lane >> 5, cl = lane & 31;
     const int tile_q0 = m_base & ~127;
     // stage the 128 queries' own_file / q_key / threshold
@@ -110,9 +115,10 @@ struct EpiSim {
 };
 
 // pass 0 (dense): premise tile = ord * stride.   pass 1 (filter): all tiles with pt % stride != 0.
+template <class C>
 __global__ __launch_bounds__(256) void sim_scan_kernel(GemmOperand Qop, GemmOperand Eop, int K, int tiles_q,
                                                        int stride, EpiSim epi) {
-  __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int qt = logical % tiles_q;
   const int ord = logical / tiles_q;
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256) void sim_scan_kernel(GemmOperand Qop, GemmOper
     epi.slot_shift = 0;
   }
   epi.smem = smem;
-  gemm_tile(Qop, Eop, K, qt, pt, epi, smem);
+  gemm_tile<C>(Qop, Eop, K, qt, pt, epi, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -336,7 +342,7 @@ extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t
                                 int32_t k, int32_t flags, float* out_scores, int32_t* out_ids, int32_t* out_count,
                                 void* workspace, size_t workspace_bytes, void* stream_) {
   RP_REQUIRE(Q && E && out_scores && out_ids && out_count, "null argument");
-  RP_REQUIRE(B > 0 && N > 0 && D > 0 && D % GEMM_BK == 0, "B=%d N=%d D=%d (D must be a multiple of 32)", B, N, D);
+  RP_REQUIRE(B > 0 && N > 0 && D > 0 && D % 32 == 0, "B=%d N=%d D=%d (D must be a multiple of 32)", B, N, D);
   RP_REQUIRE(k > 0 && k <= SIM_MAX_K, "k=%d out of range (1..%d)", k, SIM_MAX_K);
   if (file_of) RP_REQUIRE(end_key && file_bits_t && own_file && q_key && F > 0, "mask arrays incomplete");
   hipStream_t stream = (hipStream_t)stream_;
@@ -374,8 +380,12 @@ extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t
   // pass 0: dense keys of the sampled (or all) premise tiles
   const int stride0 = p.dense_only ? 1 : SIM_STRIDE;
   prof_begin(stream, RP_K_SCAN);
-  hipLaunchKernelGGL(sim_scan_kernel, dim3(p.tiles_q * p.sample_tiles), dim3(256), 0, stream, qop, eop, D,
-                     p.tiles_q, stride0, epi);
+  if (D % 64 == 0)
+    hipLaunchKernelGGL((sim_scan_kernel<SimCfg64>), dim3(p.tiles_q * p.sample_tiles), dim3(256), 0, stream, qop,
+                       eop, D, p.tiles_q, stride0, epi);
+  else
+    hipLaunchKernelGGL((sim_scan_kernel<SimCfg32>), dim3(p.tiles_q * p.sample_tiles), dim3(256), 0, stream, qop,
+                       eop, D, p.tiles_q, stride0, epi);
   prof_end(stream);
   RP_CHECK_LAUNCH();
   SelectArgs sa;
@@ -409,8 +419,12 @@ extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t
   // pass 1: remaining tiles, keep only keys above each query's bound
   epi.filter = 1;
   prof_begin(stream, RP_K_SCAN);
-  hipLaunchKernelGGL(sim_scan_kernel, dim3(p.tiles_q * p.filter_tiles), dim3(256), 0, stream, qop, eop, D,
-                     p.tiles_q, SIM_STRIDE, epi);
+  if (D % 64 == 0)
+    hipLaunchKernelGGL((sim_scan_kernel<SimCfg64>), dim3(p.tiles_q * p.filter_tiles), dim3(256), 0, stream, qop,
+                       eop, D, p.tiles_q, SIM_STRIDE, epi);
+  else
+    hipLaunchKernelGGL((sim_scan_kernel<SimCfg32>), dim3(p.tiles_q * p.filter_tiles), dim3(256), 0, stream, qop,
+                       eop, D, p.tiles_q, SIM_STRIDE, epi);
   prof_end(stream);
   RP_CHECK_LAUNCH();
   SelectArgs sb;

