@@ -44,6 +44,9 @@ class Pos(tuple):
     def __new__(cls, line_nb: int, column_nb: int):
         return super().__new__(cls, (int(line_nb), int(column_nb)))
 
+    def __getnewargs__(self):  # picklable (an IndexedCorpus pickle holds every premise's positions)
+        return (self[0], self[1])
+
     @property
     def line_nb(self) -> int:
         return self[0]
@@ -227,6 +230,11 @@ class Corpus:
                 i += 1
         self._file_start[F] = i
         self._dev: Dict[str, torch.Tensor] = {}
+
+    def __getstate__(self):  # pickled inside IndexedCorpus: never carry device tensors along
+        state = dict(self.__dict__)
+        state["_dev"] = {}
+        return state
 
     # -- reference interface --------------------------------------------------------------------
     def _get_file(self, path: str) -> File:

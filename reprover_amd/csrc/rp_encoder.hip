@@ -27,7 +27,7 @@ thread_local std::string g_last_error;
 // options
 // ------------------------------------------------------------------------------------------
 static int g_gemm_group_m = 8;
-static int g_gemm_variant = 8;  // tile/pipeline configuration, see launch_gemm()
+static int g_gemm_variant = 6;  // tile/pipeline configuration, see launch_gemm()
 
 // ------------------------------------------------------------------------------------------
 // per-kernel event timing
@@ -172,81 +172,102 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // K3/K6/K7/K8: GEMM epilogues
 // ------------------------------------------------------------------------------------------
-struct EpiStoreBf16 {  // out[row, col] = bf16(acc)
+// The encoder GEMMs are issued "transposed": the weight matrix is the MFMA row operand (rows of the
+// accumulator tile = output features) and the activations the column operand (cols = tokens).  With
+// the 32x32 C/D layout a lane then owns ONE token (col = lane & 31) and, per 4-register group, FOUR
+// CONSECUTIVE output features (row = 8g + 4hi + 0..3) — so every epilogue moves 8 B (bf16x4) or 16 B
+// (fp32x4) per lane per access instead of 2-4 B, a quarter of the store instructions.
+//   acc[i][j][4g + e]  <->  feature m_base + 32 i + 8 g + 4 hi + e,  token n_base + 32 j + (lane & 31)
+struct EpiStoreBf16 {  // out[token, feature] = bf16(acc)
   bf16_t* out;
-  int ldo, n_valid;
+  int ldo, n_valid;  // n_valid = number of real output features
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane) {
     const int hi = lane >> 5, cl = lane & 31;
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int j = 0; j < FN; ++j) {
+      bf16_t* row = out + (size_t)(n_base + j * 32 + cl) * ldo;
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int col = n_base + j * 32 + cl;
-        if (col < n_valid) {
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = m_base + i * 32 + mfma32_row(r, hi);
-            out[(size_t)row * ldo + col] = f2bf(acc[i][j][r]);
+        for (int g = 0; g < 4; ++g) {
+          const int f = m_base + i * 32 + 8 * g + 4 * hi;
+          if (f < n_valid) {  // n_valid is a multiple of 4
+            uint2 v;
+            v.x = pack_bf2(acc[i][j][4 * g], acc[i][j][4 * g + 1]);
+            v.y = pack_bf2(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            *reinterpret_cast<uint2*>(row + f) = v;
           }
         }
-      }
+    }
   }
 };
 
-struct EpiResidF32 {  // x[row, col] += acc   (residual stream, fp32)
+struct EpiResidF32 {  // x[token, feature] += acc   (residual stream, fp32)
   float* x;
   int ldx, n_valid;
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane) {
     const int hi = lane >> 5, cl = lane & 31;
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int col = n_base + j * 32 + cl;
-        if (col < n_valid) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = m_base + i * 32 + mfma32_row(r, hi);
-            float* p = x + (size_t)row * ldx + col;
-            *p = *p + acc[i][j][r];
-          }
-        }
-      }
-  }
-};
-
-struct EpiGegluBf16 {  // W rows interleaved 32 gate / 32 up: even fragments gate, odd fragments up
-  bf16_t* out;         // [M, n_valid/2]
-  int ldo, n_valid;    // n_valid counts interleaved columns (= 2 * d_ff)
-  template <int FM, int FN>
-  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane) {
-    static_assert(FN % 2 == 0, "gate/up pairs");
-    const int hi = lane >> 5, cl = lane & 31;
-#pragma unroll
-    for (int j = 0; j < FN; j += 2) {
-      if (n_base + j * 32 >= n_valid) continue;
-      const int col = ((n_base + j * 32) >> 1) + cl;
+    for (int j = 0; j < FN; ++j) {
+      float* row = x + (size_t)(n_base + j * 32 + cl) * ldx;
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m_base + i * 32 + mfma32_row(r, hi);
-          out[(size_t)row * ldo + col] = f2bf(gelu_new(acc[i][j][r]) * acc[i][j + 1][r]);
+        for (int g = 0; g < 4; ++g) {
+          const int f = m_base + i * 32 + 8 * g + 4 * hi;
+          if (f < n_valid) {
+            float4* p = reinterpret_cast<float4*>(row + f);
+            float4 v = *p;
+            v.x += acc[i][j][4 * g];
+            v.y += acc[i][j][4 * g + 1];
+            v.z += acc[i][j][4 * g + 2];
+            v.w += acc[i][j][4 * g + 3];
+            *p = v;
+          }
         }
     }
   }
 };
 
-template <class C, class Epi>
+struct EpiGegluBf16 {  // W rows interleaved 32 gate / 32 up: even row-fragments gate, odd up
+  bf16_t* out;         // [tokens, n_valid/2]
+  int ldo, n_valid;    // n_valid counts interleaved rows (= 2 * d_ff)
+  template <int FM, int FN>
+  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane) {
+    static_assert(FM % 2 == 0, "gate/up pairs");
+    const int hi = lane >> 5, cl = lane & 31;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      bf16_t* row = out + (size_t)(n_base + j * 32 + cl) * ldo;
+#pragma unroll
+      for (int i = 0; i < FM; i += 2) {
+        if (m_base + i * 32 >= n_valid) continue;
+        const int f0 = ((m_base + i * 32) >> 1) + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float y[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = gelu_new(acc[i][j][4 * g + e]) * acc[i + 1][j][4 * g + e];
+          uint2 v;
+          v.x = pack_bf2(y[0], y[1]);
+          v.y = pack_bf2(y[2], y[3]);
+          *reinterpret_cast<uint2*>(row + f0 + 8 * g) = v;
+        }
+      }
+    }
+  }
+};
+
+template <class C, class Epi, int EXP = 0>
 __global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOperand W, int K, int tiles_m,
                                                           int tiles_n, int group_m, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   int tm, tn;
-  tile_coords(logical, tiles_m, tiles_n, group_m, tm, tn);
-  gemm_tile<C>(A, W, K, tm, tn, epi, smem);
+  tile_coords(logical, tiles_n, tiles_m, group_m, tn, tm);  // token tiles grouped, feature tiles inside
+  gemm_tile<C, Epi, EXP>(A, W, K, tm, tn, epi, smem);
 }
 
 template <class C, class Epi, int EXP>
@@ -255,7 +276,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_pp_kernel(GemmOperand A, Gemm
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   int tm, tn;
-  tile_coords(logical, tiles_m, tiles_n, group_m, tm, tn);
+  tile_coords(logical, tiles_n, tiles_m, group_m, tn, tm);  // token tiles grouped, feature tiles inside
   gemm_tile_pingpong<C, EXP>(A, W, K, tm, tn, epi, smem);
 }
 
@@ -268,8 +289,10 @@ struct KernelSel<C, Epi, 0> {
   static auto get() { return gemm_kernel<C, Epi>; }
 };
 
+// `w` = weight matrix [n_rows_w, K] (row operand: tile rows = output features, clamped at the edge),
+// `a` = activations [M, K] (column operand: tile cols = tokens, M a multiple of the token tile).
 template <class C, class Epi, int PINGPONG = 0>
-static RpStatus launch_gemm_cfg(GemmOperand a, GemmOperand w, int K, Epi epi, hipStream_t stream,
+static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hipStream_t stream,
                                 int prof_class) {
   auto kern = KernelSel<C, Epi, PINGPONG>::get();
   static bool attr_done = false;
@@ -277,18 +300,19 @@ static RpStatus launch_gemm_cfg(GemmOperand a, GemmOperand w, int K, Epi epi, hi
     RP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     attr_done = true;
   }
-  RP_REQUIRE(K % C::BK == 0 && a.rows % C::BM == 0, "gemm: K=%d must be a multiple of %d, M=%d of %d", K, C::BK,
-             a.rows, C::BM);
-  const int tiles_m = a.rows / C::BM, tiles_n = (w.rows + C::BN - 1) / C::BN;
-  const int group_m = max(1, g_gemm_group_m * 128 / C::BM);
+  RP_REQUIRE(K % C::BK == 0 && a.rows % C::BN == 0, "gemm: K=%d must be a multiple of %d, M=%d of %d", K, C::BK,
+             a.rows, C::BN);
+  const int tiles_f = (w.rows + C::BM - 1) / C::BM, tiles_t = a.rows / C::BN;
+  // tile order: feature tiles fastest inside groups of `group` token tiles (shared activation panels)
+  const int group = max(1, g_gemm_group_m * 128 / C::BN);
   ProfScope ps(stream, prof_class);
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(C::THREADS), C::LDS_BYTES, stream, a, w, K, tiles_m,
-                     tiles_n, group_m, epi);
+  hipLaunchKernelGGL(kern, dim3(tiles_f * tiles_t), dim3(C::THREADS), C::LDS_BYTES, stream, w, a, K, tiles_f,
+                     tiles_t, group, epi);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
 
-// rows of the activation workspace are padded to this so every variant tiles M exactly
+// rows of the activation workspace are padded to this so every variant tiles the tokens exactly
 constexpr int GEMM_M_ALIGN = 256;
 
 template <class Epi>
@@ -299,25 +323,20 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
   const bool k64 = (K % 64 == 0), m256 = (M % 256 == 0);
   if ((v == 1 || v == 2 || v == 6 || v == 7) && !k64) v = 0;
   if (v >= 5 && !m256) v = 0;
+  // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages>
   switch (v) {
-    case 1: return launch_gemm_cfg<GemmCfg<128, 128, 64, 2, 2, 2>>(a, w, K, epi, stream, prof_class);
-    case 2: return launch_gemm_cfg<GemmCfg<128, 128, 64, 2, 2, 3>>(a, w, K, epi, stream, prof_class);
-    case 3: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 4>>(a, w, K, epi, stream, prof_class);
-    case 4: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 2>>(a, w, K, epi, stream, prof_class);
-    case 5: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>>(a, w, K, epi, stream, prof_class);
-    case 6: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 4, 2>>(a, w, K, epi, stream, prof_class);
-    case 7: return launch_gemm_cfg<GemmCfg<256, 128, 64, 4, 2, 2>>(a, w, K, epi, stream, prof_class);
-    case 8: return launch_gemm_cfg<GemmCfg<256, 128, 32, 4, 2, 3>>(a, w, K, epi, stream, prof_class);
-    case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 3>>(a, w, K, epi, stream, prof_class);
-    case 10: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 1>(a, w, K, epi, stream, prof_class);
-    case 11: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 2>(a, w, K, epi, stream, prof_class);
-    case 12: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 3>(a, w, K, epi, stream, prof_class);
-    case 13: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 4>(a, w, K, epi, stream, prof_class);
-    case 14: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 5>(a, w, K, epi, stream, prof_class);
-    case 15: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 6>(a, w, K, epi, stream, prof_class);
-    case 16: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 7>(a, w, K, epi, stream, prof_class);
-    case 17: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 8>(a, w, K, epi, stream, prof_class);
-    default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(a, w, K, epi, stream, prof_class);
+    case 1: return launch_gemm_cfg<GemmCfg<128, 128, 64, 2, 2, 2>>(w, a, K, epi, stream, prof_class);
+    case 2: return launch_gemm_cfg<GemmCfg<128, 128, 64, 2, 2, 3>>(w, a, K, epi, stream, prof_class);
+    case 3: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 4>>(w, a, K, epi, stream, prof_class);
+    case 4: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 2>>(w, a, K, epi, stream, prof_class);
+    case 5: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 4>>(w, a, K, epi, stream, prof_class);
+    case 6: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2>>(w, a, K, epi, stream, prof_class);
+    case 7: return launch_gemm_cfg<GemmCfg<128, 256, 64, 2, 4, 2>>(w, a, K, epi, stream, prof_class);
+    case 8: return launch_gemm_cfg<GemmCfg<128, 256, 32, 2, 4, 3>>(w, a, K, epi, stream, prof_class);
+    case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
+    case 10: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 1>(w, a, K, epi, stream, prof_class);
+    case 11: return launch_gemm_cfg<GemmCfg<256, 128, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
+    default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class);
   }
 }
 
@@ -631,7 +650,7 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     return RP_OK;
   }
   if (!strcmp(name, "gemm_variant")) {
-    RP_REQUIRE(value >= 0 && value <= 17, "gemm_variant out of range");
+    RP_REQUIRE(value >= 0 && value <= 11, "gemm_variant out of range");
     g_gemm_variant = value;
     return RP_OK;
   }

@@ -59,7 +59,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // acc[mfrag][nfrag]; wave covers rows m_base + mfrag*32 + mfma32_row(r, hi), cols n_base + nfrag*32 + (lane&31)
-template <class C, class Epilogue>
+template <class C, class Epilogue, int EXP = 0>
 __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand W, int K, int tile_m,
                                           int tile_n, Epilogue& epi, char* smem) {
   constexpr int BK = C::BK, NSTAGE = C::NSTAGE, FM = C::FM, FN = C::FN;
@@ -138,6 +138,10 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
     }
     const char* sa = smem + buf * C::STAGE_BYTES;
     const char* sb = sa + C::A_BYTES;
+    if (EXP == 8 && kt > 0) {  // experiment: DMA + barriers only
+      if (++buf == NSTAGE) buf = 0;
+      continue;
+    }
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 af[FM], bfr[FN];
@@ -249,7 +253,7 @@ __device__ __forceinline__ void gemm_tile_pingpong(const GemmOperand A, const Ge
     const char* sa = smem + buf * C::STAGE_BYTES;
     const char* sb = sa + C::A_BYTES;
     bf16x8 af[FM][2], bfr[FN][2];
-    if ((EXP != 3 && EXP != 6) || kt == 0) {
+    if ((EXP != 3 && EXP != 6 && EXP != 8) || kt == 0) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -268,13 +272,15 @@ __device__ __forceinline__ void gemm_tile_pingpong(const GemmOperand A, const Ge
     __builtin_amdgcn_sched_barrier(0);
     // ---------------- COMPUTE part
     if (EXP != 1) __builtin_amdgcn_s_setprio(1);
+    if (EXP != 8 || kt == 0) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ks], bfr[j][ks], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ks], bfr[j][ks], acc[i][j], 0, 0, 0);
+    }
     if (EXP != 1) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();

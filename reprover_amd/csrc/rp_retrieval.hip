@@ -23,9 +23,12 @@ constexpr int SIM_DENSE_MAX_N = 16384;
 constexpr int SIM_STRIDE = 16;
 constexpr int SIM_CAND_CAP = 8192;
 constexpr int SIM_MAX_K = 1024;
-typedef GemmCfg<128, 128, 64, 2, 2, 2> SimCfg64;  // D % 64 == 0: 64 KiB LDS ring per workgroup
-typedef GemmCfg<128, 128, 32, 2, 2, 3> SimCfg32;  // otherwise (D % 32 == 0): 48 KiB
-constexpr int GEMM_BM = 128, GEMM_BN = 128;
+// scan tile configurations: BM queries x 128 premises (premise tiles are always 128 rows so that the
+// sampled-tile bookkeeping is independent of the query tile)
+typedef GemmCfg<256, 128, 32, 4, 2, 3> SimCfgQ256;  // B > 128: 8 waves, one workgroup sees up to 256 queries
+typedef GemmCfg<128, 128, 64, 2, 2, 2> SimCfgQ128;  // B <= 128, D % 64 == 0
+typedef GemmCfg<128, 128, 32, 2, 2, 3> SimCfgQ128K32;  // B <= 128, D % 32 == 0
+constexpr int GEMM_BN = 128;
 
 __device__ __forceinline__ uint64_t make_key(float score, int32_t id) {
   return ((uint64_t)f2ord(score) << 32) | (uint32_t)(~(uint32_t)id);
@@ -53,84 +56,115 @@ struct EpiSim {
   int cap;
   int32_t* count;      // [B]
   char* smem;          // GEMM LDS, free once the main loop is done
+  int tile_q0;         // first query of this workgroup's tile (set per workgroup)
+  int bm;              // queries per workgroup tile
+
+  // Accessibility predicate + key of one score.  imported/own exactly as common.py:280-289.
+  __device__ __forceinline__ bool accessible(uint32_t word, int bit, int32_t f, int64_t ek, int32_t own,
+                                             int64_t qk) const {
+    return ((word >> bit) & 1u) || (f == own && ek <= qk);
+  }
 
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane) {
-    static_assert(FM == 2 && FN == 2, "scan epilogue is written for 64x64 wave tiles of a 128x128 block");
     const int hi = lane >> 5, cl = lane & 31;
-    const int tile_q0 = m_base & ~127;
-    // stage the 128 queries' own_file / q_key / threshold
-    int32_t* s_own = reinterpret_cast<int32_t*>(smem);
-    int64_t* s_qk = reinterpret_cast<int64_t*>(smem + 512);
-    uint64_t* s_thr = reinterpret_cast<uint64_t*>(smem + 512 + 1024);
-    if (threadIdx.x < 128) {
-      const int q = tile_q0 + threadIdx.x;
+    // stage the tile's queries: own_file / q_key / threshold key / float lower bound of the threshold
+    int32_t* s_own = reinterpret_cast<int32_t*>(smem);                  // [bm]
+    float* s_tau = reinterpret_cast<float*>(smem + 1024);               // [bm]
+    int64_t* s_qk = reinterpret_cast<int64_t*>(smem + 2048);            // [bm]
+    uint64_t* s_thr = reinterpret_cast<uint64_t*>(smem + 2048 + 2048);  // [bm]
+    for (int t = threadIdx.x; t < bm; t += blockDim.x) {
+      const int q = tile_q0 + t;
       const bool ok = q < B;
-      s_own[threadIdx.x] = (ok && file_of) ? own_file[q] : -1;
-      s_qk[threadIdx.x] = (ok && file_of) ? q_key[q] : 0;
-      s_thr[threadIdx.x] = (ok && filter) ? thr[q] : 0;
+      s_own[t] = (ok && file_of) ? own_file[q] : -1;
+      s_qk[t] = (ok && file_of) ? q_key[q] : 0;
+      const uint64_t th = (ok && filter) ? thr[q] : 0ull;
+      s_thr[t] = th;
+      // keys > th have ordered(score) >= th.hi, i.e. score >= ord2f(th.hi): a cheap float pre-test
+      s_tau[t] = (ok && filter && th) ? ord2f((uint32_t)(th >> 32)) : -INFINITY;
     }
     __syncthreads();
+    const int ql0 = m_base - tile_q0;  // this wave's first query inside the tile
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < FN; ++j) {
       const int p = n_base + j * 32 + cl;
       const bool pvalid = p < N;
       int32_t f = -2;
       int64_t ek = 0;
-      uint32_t w[2] = {0xffffffffu, 0xffffffffu};
+      uint32_t w[FM];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) w[i] = 0xffffffffu;
       if (file_of) {
-        w[0] = w[1] = 0;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) w[i] = 0;
         if (pvalid) {
           f = file_of[p];
           ek = end_key[p];
           const int wi = m_base >> 5;
-          if (wi < bits_words) w[0] = bits_t[(size_t)f * bits_words + wi];
-          if (wi + 1 < bits_words) w[1] = bits_t[(size_t)f * bits_words + wi + 1];
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+            if (wi + i < bits_words) w[i] = bits_t[(size_t)f * bits_words + wi + i];
         }
       }
       const int32_t id = p + id_offset;
+      if (!filter) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rr = mfma32_row(r, hi);
-          const int ql = (m_base - tile_q0) + i * 32 + rr;  // query index inside the tile
-          const int q = tile_q0 + ql;
-          bool ok = pvalid && (q < B);
-          if (file_of) {
-            const bool imported = (w[i] >> rr) & 1u;
-            const bool own = (f == s_own[ql]) && (ek <= s_qk[ql]);
-            ok = ok && (imported || own);
-          }
-          const uint64_t key = ok ? make_key(acc[i][j][r], id) : 0ull;
-          if (!filter) {
+          for (int r = 0; r < 16; ++r) {
+            const int rr = mfma32_row(r, hi);
+            const int ql = ql0 + i * 32 + rr;
+            const int q = tile_q0 + ql;
+            bool ok = pvalid && (q < B);
+            if (file_of) ok = ok && accessible(w[i], rr, f, ek, s_own[ql], s_qk[ql]);
+            const uint64_t key = ok ? make_key(acc[i][j][r], id) : 0ull;
             if (q < B && (p + slot_shift) < (int)dense_ld) dense[(size_t)q * dense_ld + p + slot_shift] = key;
-          } else if (key > s_thr[ql]) {  // s_thr >= 0; masked keys are 0 and never pass
-            const int pos = atomicAdd(&count[q], 1);
-            if (pos < cap) cand[(size_t)q * cap + pos] = key;
           }
-        }
+      } else {
+        // Almost every score is below its query's bound: test that first (one LDS read + one compare),
+        // and only survivors pay for the accessibility predicate, the 64-bit key and the atomic.
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rr = mfma32_row(r, hi);
+            const int ql = ql0 + i * 32 + rr;
+            const float sc = acc[i][j][r];
+            if (sc >= s_tau[ql]) {
+              const int q = tile_q0 + ql;
+              bool ok = pvalid && (q < B);
+              if (file_of) ok = ok && accessible(w[i], rr, f, ek, s_own[ql], s_qk[ql]);
+              const uint64_t key = ok ? make_key(sc, id) : 0ull;
+              if (key > s_thr[ql]) {
+                const int pos = atomicAdd(&count[q], 1);
+                if (pos < cap) cand[(size_t)q * cap + pos] = key;
+              }
+            }
+          }
+      }
     }
   }
 };
 
 // pass 0 (dense): premise tile = ord * stride.   pass 1 (filter): all tiles with pt % stride != 0.
 template <class C>
-__global__ __launch_bounds__(256) void sim_scan_kernel(GemmOperand Qop, GemmOperand Eop, int K, int tiles_q,
-                                                       int stride, EpiSim epi) {
-  __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
+__global__ __launch_bounds__(C::THREADS) void sim_scan_kernel(GemmOperand Qop, GemmOperand Eop, int K, int tiles_q,
+                                                              int stride, EpiSim epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int qt = logical % tiles_q;
   const int ord = logical / tiles_q;
   int pt;
   if (!epi.filter) {
     pt = ord * stride;
-    epi.slot_shift = ord * GEMM_BN - pt * GEMM_BN;
+    epi.slot_shift = ord * C::BN - pt * C::BN;
   } else {
     pt = ord + ord / (stride - 1) + 1;
     epi.slot_shift = 0;
   }
   epi.smem = smem;
+  epi.tile_q0 = qt * C::BM;
+  epi.bm = C::BM;
   gemm_tile<C>(Qop, Eop, K, qt, pt, epi, smem);
 }
 
@@ -300,14 +334,15 @@ static void launch_select(const SelectArgs& a, int B, hipStream_t stream) {
 
 struct SimPlan {
   bool dense_only;
-  int tiles_q, tiles_p, sample_tiles, filter_tiles;
+  int bm, tiles_q, tiles_p, sample_tiles, filter_tiles;
   size_t dense_ld;
   size_t off_dense, off_cand, off_count, off_thr, bytes;
 };
 
 static SimPlan plan_sim(int B, int N, int k, int flags) {
   SimPlan p;
-  p.tiles_q = (B + GEMM_BM - 1) / GEMM_BM;
+  p.bm = (B > 128) ? 256 : 128;
+  p.tiles_q = (B + p.bm - 1) / p.bm;
   p.tiles_p = (N + GEMM_BN - 1) / GEMM_BN;
   p.dense_only = (flags & RP_TOPK_DENSE) || N <= SIM_DENSE_MAX_N || p.tiles_p < 2 * SIM_STRIDE;
   p.sample_tiles = p.dense_only ? p.tiles_p : (p.tiles_p + SIM_STRIDE - 1) / SIM_STRIDE;
@@ -324,6 +359,30 @@ static SimPlan plan_sim(int B, int N, int k, int flags) {
   off += align_up((size_t)B * 8, 256);
   p.bytes = off;
   return p;
+}
+
+template <class C>
+static RpStatus launch_scan_cfg(GemmOperand q, GemmOperand e, int D, int tiles_q, int n_ptiles, int stride,
+                                const EpiSim& epi, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    RP_HIP(hipFuncSetAttribute((const void*)sim_scan_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               C::LDS_BYTES));
+    attr_done = true;
+  }
+  ProfScope ps(stream, RP_K_SCAN);
+  hipLaunchKernelGGL((sim_scan_kernel<C>), dim3(tiles_q * n_ptiles), dim3(C::THREADS), C::LDS_BYTES, stream, q, e,
+                     D, tiles_q, stride, epi);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+static RpStatus launch_scan(const SimPlan& p, GemmOperand q, GemmOperand e, int D, int n_ptiles, int stride,
+                            const EpiSim& epi, hipStream_t stream) {
+  if (n_ptiles <= 0) return RP_OK;
+  if (p.bm == 256) return launch_scan_cfg<SimCfgQ256>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
+  if (D % 64 == 0) return launch_scan_cfg<SimCfgQ128>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
+  return launch_scan_cfg<SimCfgQ128K32>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
 }
 
 }  // namespace rp
@@ -376,18 +435,13 @@ extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t
   epi.cap = cap;
   epi.count = count;
   epi.smem = nullptr;
+  epi.tile_q0 = 0;
+  epi.bm = p.bm;
 
   // pass 0: dense keys of the sampled (or all) premise tiles
   const int stride0 = p.dense_only ? 1 : SIM_STRIDE;
-  prof_begin(stream, RP_K_SCAN);
-  if (D % 64 == 0)
-    hipLaunchKernelGGL((sim_scan_kernel<SimCfg64>), dim3(p.tiles_q * p.sample_tiles), dim3(256), 0, stream, qop,
-                       eop, D, p.tiles_q, stride0, epi);
-  else
-    hipLaunchKernelGGL((sim_scan_kernel<SimCfg32>), dim3(p.tiles_q * p.sample_tiles), dim3(256), 0, stream, qop,
-                       eop, D, p.tiles_q, stride0, epi);
-  prof_end(stream);
-  RP_CHECK_LAUNCH();
+  RpStatus st;
+  if ((st = launch_scan(p, qop, eop, D, p.sample_tiles, stride0, epi, stream))) return st;
   SelectArgs sa;
   sa.keys = dense;
   sa.ld = p.dense_ld;
@@ -418,15 +472,7 @@ extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t
   RP_CHECK_LAUNCH();
   // pass 1: remaining tiles, keep only keys above each query's bound
   epi.filter = 1;
-  prof_begin(stream, RP_K_SCAN);
-  if (D % 64 == 0)
-    hipLaunchKernelGGL((sim_scan_kernel<SimCfg64>), dim3(p.tiles_q * p.filter_tiles), dim3(256), 0, stream, qop,
-                       eop, D, p.tiles_q, SIM_STRIDE, epi);
-  else
-    hipLaunchKernelGGL((sim_scan_kernel<SimCfg32>), dim3(p.tiles_q * p.filter_tiles), dim3(256), 0, stream, qop,
-                       eop, D, p.tiles_q, SIM_STRIDE, epi);
-  prof_end(stream);
-  RP_CHECK_LAUNCH();
+  if ((st = launch_scan(p, qop, eop, D, p.filter_tiles, SIM_STRIDE, epi, stream))) return st;
   SelectArgs sb;
   sb.keys = cand;
   sb.ld = cap;

@@ -1,0 +1,165 @@
+"""Multi-GPU retrieval: the premise-embedding matrix row-sharded over the GPUs of one node.
+
+The reference has no multi-GPU retrieval at all (every Lightning rank / Ray actor re-indexes and
+holds the full corpus: retrieval/model.py:274-279, prover/proof_search.py:438-447).  Here, one
+process per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI):
+
+  * re-index: premises are independent, so rank r encodes only rows [lo_r, hi_r) — no exchange at
+    all.  Bounds are chosen on the cumulative serialized byte length so every rank encodes about the
+    same number of tokens (encode cost ~ tokens), while shards stay contiguous row ranges and global
+    premise ids stay ``lo_r + local row``.
+  * retrieve: every rank scans its shard for ALL queries of the step with the accessibility mask
+    applied before selection (``rp_sim_topk`` with ``id_offset = lo_r``), then ONE all-gather of the
+    per-rank ``[B, k]`` (score, id) lists + counts (B*k*8 bytes per rank: latency-bound) and a k-way
+    merge (``rp_topk_merge``).  Masked top-k is a decomposable reduction, so the result is exactly
+    the single-GPU result.
+
+The collective plumbing is backend-agnostic; the two compute steps are injectable so that the
+world_size-2 ``gloo`` tests on CPU can drive the same code with the oracle as the checker.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .common import Context, Corpus, _workspace, as_bf16_matrix
+
+TopK = Tuple[torch.Tensor, torch.Tensor, torch.Tensor]  # ids int32 [B,k], scores f32 [B,k], counts int32 [B]
+
+
+def shard_bounds(weights: Sequence[int], world: int) -> np.ndarray:
+    """Contiguous row ranges with (nearly) equal total weight: int64 [world+1], bounds[0] = 0,
+    bounds[world] = N.  ``weights[i]`` = token count (serialized byte length + 1) of premise i."""
+    w = np.asarray(weights, dtype=np.int64)
+    cum = np.concatenate([[0], np.cumsum(w)])
+    targets = cum[-1] * np.arange(1, world) / world
+    inner = np.searchsorted(cum, targets, side="left")
+    b = np.concatenate([[0], inner, [len(w)]]).astype(np.int64)
+    return np.maximum.accumulate(b)
+
+
+def premise_token_counts(corpus: Corpus, max_seq_len: int) -> np.ndarray:
+    return np.fromiter(
+        (min(len(p.serialize().encode("utf-8")) + 1, max_seq_len) for p in corpus.all_premises),
+        dtype=np.int64,
+        count=len(corpus),
+    )
+
+
+class IndexShard:
+    """Rows [lo, hi) of the corpus embedding matrix on this rank, with the matching slices of the
+    per-premise accessibility arrays."""
+
+    def __init__(self, corpus: Corpus, bounds: np.ndarray, rank: int, device: torch.device):
+        self.corpus = corpus
+        self.bounds = np.asarray(bounds, dtype=np.int64)
+        self.rank = rank
+        self.lo, self.hi = int(bounds[rank]), int(bounds[rank + 1])
+        self.device = device
+        self.embeddings: Optional[torch.Tensor] = None  # [hi-lo, D] on `device`
+        self.file_of = torch.from_numpy(corpus.file_of[self.lo : self.hi].copy()).to(device)
+        self.end_key = torch.from_numpy(corpus.end_key[self.lo : self.hi].copy()).to(device)
+
+    def __len__(self) -> int:
+        return self.hi - self.lo
+
+
+def reindex_shard(retriever, shard: IndexShard) -> None:
+    """This rank's part of ``reindex_corpus`` (retrieval/model.py:183-210): encode premises
+    [lo, hi) into ``shard.embeddings``.  No communication."""
+    prem = retriever.corpus.all_premises[shard.lo : shard.hi]
+    out = torch.zeros(len(prem), retriever.embedding_size, dtype=retriever.encoder.dtype, device=retriever.device)
+    step = 4096
+    for i in range(0, len(prem), step):
+        chunk = prem[i : i + step]
+        retriever.encode_texts([p.serialize() for p in chunk], out=out[i : i + len(chunk)])
+    shard.embeddings = out
+
+
+def hip_local_topk(shard: IndexShard, batch_context: Sequence[Context], query_emb: torch.Tensor, k: int) -> TopK:
+    """Masked top-k of all queries against this rank's rows (global ids), on the GPU."""
+    lib = _lib.load()
+    dev = query_emb.device
+    E = as_bf16_matrix(shard.embeddings, dev)
+    Q = as_bf16_matrix(query_emb, dev)
+    B, D = Q.shape
+    bits_t, own, qk = shard.corpus.query_masks(batch_context)
+    d_bits = torch.from_numpy(bits_t.view(np.int32)).to(dev)
+    d_own, d_qk = torch.from_numpy(own).to(dev), torch.from_numpy(qk).to(dev)
+    out_s = torch.empty((B, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((B, k), dtype=torch.int32, device=dev)
+    out_c = torch.empty((B,), dtype=torch.int32, device=dev)
+    nbytes = lib.rp_sim_topk_workspace_bytes(B, len(shard), D, k, 0)
+    ws = _workspace(dev, nbytes)
+    _lib.check(
+        lib.rp_sim_topk(
+            _lib.ptr(Q), _lib.ptr(E), B, len(shard), D, _lib.ptr(shard.file_of), _lib.ptr(shard.end_key),
+            _lib.ptr(d_bits), shard.corpus.num_files, _lib.ptr(d_own), _lib.ptr(d_qk), shard.lo, k, 0,
+            _lib.ptr(out_s), _lib.ptr(out_i), _lib.ptr(out_c), _lib.ptr(ws), nbytes, _lib.current_stream(),
+        ),
+        "rp_sim_topk",
+    )
+    return out_i, out_s, out_c
+
+
+def hip_merge(ids: torch.Tensor, scores: torch.Tensor, counts: torch.Tensor) -> TopK:
+    """Merge [R, B, k] per-rank lists into the global top-k on the GPU (rp_topk_merge)."""
+    lib = _lib.load()
+    R, B, k = scores.shape
+    dev = scores.device
+    out_s = torch.empty((B, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((B, k), dtype=torch.int32, device=dev)
+    out_c = torch.empty((B,), dtype=torch.int32, device=dev)
+    nbytes = lib.rp_topk_merge_workspace_bytes(R, B, k)
+    ws = _workspace(dev, nbytes)
+    _lib.check(
+        lib.rp_topk_merge(_lib.ptr(scores.contiguous()), _lib.ptr(ids.contiguous()), _lib.ptr(counts.contiguous()),
+                          R, B, k, _lib.ptr(out_s), _lib.ptr(out_i), _lib.ptr(out_c), _lib.ptr(ws), nbytes,
+                          _lib.current_stream()),
+        "rp_topk_merge",
+    )
+    return out_i, out_s, out_c
+
+
+def all_gather_stack(t: torch.Tensor, group=None) -> torch.Tensor:
+    """[world, *t.shape]: one all-gather (RCCL ncclAllGather on GPUs; gloo on CPU)."""
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    else:
+        dist.all_gather(list(out.unbind(0)), t.contiguous(), group=group)
+    return out
+
+
+def sharded_nearest_premise_ids(
+    shard: IndexShard,
+    batch_context: Sequence[Context],
+    query_emb: torch.Tensor,
+    k: int,
+    group=None,
+    local_topk: Callable[..., TopK] = hip_local_topk,
+    merge: Callable[..., TopK] = hip_merge,
+) -> TopK:
+    """Global masked top-k for a batch of queries that every rank holds (e.g. after an all-gather of
+    the per-rank query embeddings).  Returns identical tensors on every rank."""
+    ids, scores, counts = local_topk(shard, batch_context, query_emb, k)
+    g_ids = all_gather_stack(ids, group)
+    g_scores = all_gather_stack(scores, group)
+    g_counts = all_gather_stack(counts, group)
+    return merge(g_ids, g_scores, g_counts)
+
+
+def sharded_get_nearest_premises(shard: IndexShard, batch_context: List[Context], query_emb: torch.Tensor, k: int,
+                                 group=None, **kw):
+    """Sharded drop-in for ``Corpus.get_nearest_premises`` (common.py:299-326): same return value and
+    the same ``ValueError`` when a query has fewer than ``k`` accessible premises in the whole corpus."""
+    ids, scores, counts = sharded_nearest_premise_ids(shard, batch_context, query_emb, k, group, **kw)
+    if bool((counts.cpu() < k).any()):
+        raise ValueError
+    prem = shard.corpus.all_premises
+    return [[prem[i] for i in row] for row in ids.cpu().tolist()], scores.cpu().tolist()

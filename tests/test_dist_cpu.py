@@ -1,0 +1,122 @@
+"""The N > 1 path on CPU: world_size 2, gloo.  The collective plumbing of reprover_amd.dist (shard
+bounds, id offsets, all-gather of the per-rank top-k lists, merge) is the product code; the two
+compute steps are injected from the oracle here because the HIP kernels need a GPU (their sharded
+parity is checked on the GPU in tests/test_kernels_gpu.py::test_shard_merge_equals_single_shot)."""
+import json
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import common_ref
+from reprover_amd import synth
+from reprover_amd.common import Context, Corpus, Pos
+from reprover_amd.dist import IndexShard, shard_bounds, sharded_get_nearest_premises, sharded_nearest_premise_ids
+
+
+def test_shard_bounds_balance_tokens():
+    rng = np.random.default_rng(0)
+    w = rng.integers(8, 2048, size=10_000)
+    for world in (1, 2, 3, 8):
+        b = shard_bounds(w, world)
+        assert b[0] == 0 and b[-1] == len(w) and np.all(np.diff(b) >= 0) and len(b) == world + 1
+        loads = np.array([w[b[r] : b[r + 1]].sum() for r in range(world)])
+        assert loads.max() - loads.min() <= 2 * 2048
+    assert shard_bounds([5], 4).tolist()[-1] == 1
+
+
+def _oracle_local_topk(shard, batch_context, query_emb, k):
+    """Oracle stand-in for rp_sim_topk on this rank's rows (ids are global)."""
+    E = shard.embeddings.numpy()
+    S = query_emb.numpy() @ E.T
+    acc = np.stack([shard.corpus.accessible_mask(c.path, c.theorem_pos)[shard.lo : shard.hi] for c in batch_context])
+    B = len(batch_context)
+    ids = np.full((B, k), -1, dtype=np.int32)
+    sc = np.full((B, k), -np.inf, dtype=np.float32)
+    cnt = np.zeros(B, dtype=np.int32)
+    for j in range(B):
+        n = int(min(k, acc[j].sum()))
+        if n:
+            li, ls = common_ref.masked_topk(S[j : j + 1], acc[j : j + 1], n)
+            ids[j, :n] = li[0] + shard.lo
+            sc[j, :n] = ls[0]
+        cnt[j] = n
+    return torch.from_numpy(ids), torch.from_numpy(sc), torch.from_numpy(cnt)
+
+
+def _oracle_merge(g_ids, g_scores, g_counts):
+    R, B, k = g_scores.shape
+    ids = np.full((B, k), -1, dtype=np.int32)
+    sc = np.full((B, k), -np.inf, dtype=np.float32)
+    cnt = np.zeros(B, dtype=np.int32)
+    for j in range(B):
+        cand = [(-float(g_scores[r, j, i]), int(g_ids[r, j, i])) for r in range(R) for i in range(int(g_counts[r, j]))]
+        cand.sort()
+        n = min(k, len(cand))
+        ids[j, :n] = [c[1] for c in cand[:n]]
+        sc[j, :n] = [-c[0] for c in cand[:n]]
+        cnt[j] = n
+    return torch.from_numpy(ids), torch.from_numpy(sc), torch.from_numpy(cnt)
+
+
+def _worker(rank, world, port, corpus_path, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        corpus = Corpus(corpus_path)
+        N, D, B, k = len(corpus), 48, 12, 20
+        rng = np.random.default_rng(123)  # same on every rank
+        E = rng.standard_normal((N, D)).astype(np.float32)
+        Q = rng.standard_normal((B, D)).astype(np.float32)
+        files = [json.loads(l) for l in open(corpus_path)]
+        ctxs = [Context(files[int(f)]["path"], f"t{j}", Pos(int(rng.integers(1, 300)), 0), "a ⊢ b")
+                for j, f in enumerate(rng.integers(20, len(files), size=B))]
+        weights = [len(p.code) for p in corpus.all_premises]
+        shard = IndexShard(corpus, shard_bounds(weights, world), rank, torch.device("cpu"))
+        shard.embeddings = torch.from_numpy(E[shard.lo : shard.hi].copy())
+        ids, scores, counts = sharded_nearest_premise_ids(shard, ctxs, torch.from_numpy(Q), k, None,
+                                                          local_topk=_oracle_local_topk, merge=_oracle_merge)
+        # single-process answer
+        acc = np.stack([corpus.accessible_mask(c.path, c.theorem_pos) for c in ctxs])
+        S = Q @ E.T
+        for j in range(B):
+            n = int(min(k, acc[j].sum()))
+            assert counts[j] == n
+            if n:
+                wi, ws = common_ref.masked_topk(S[j : j + 1], acc[j : j + 1], n)
+                assert ids[j, :n].tolist() == wi[0].tolist()
+                assert np.allclose(scores[j, :n].numpy(), ws[0])
+        # the drop-in wrapper raises ValueError exactly when the reference would
+        short = [j for j in range(B) if acc[j].sum() < k]
+        ok = [j for j in range(B) if acc[j].sum() >= k]
+        if ok:
+            prem, sc = sharded_get_nearest_premises(shard, [ctxs[j] for j in ok], torch.from_numpy(Q[ok]), k, None,
+                                                    local_topk=_oracle_local_topk, merge=_oracle_merge)
+            assert len(prem) == len(ok) and all(len(r) == k for r in prem)
+            assert prem[0][0] is corpus.all_premises[int(ids[ok[0], 0])]
+        raised = False
+        try:
+            sharded_get_nearest_premises(shard, ctxs, torch.from_numpy(Q), k, None,
+                                         local_topk=_oracle_local_topk, merge=_oracle_merge)
+        except ValueError:
+            raised = True
+        assert raised == bool(short)
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write(f"{shard.lo} {shard.hi}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_retrieval_world2_gloo():
+    files = synth.synth_corpus_records(40, 600, seed=21, max_imports=6)
+    d = tempfile.mkdtemp()
+    path = os.path.join(d, "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    port = 29500 + os.getpid() % 2000
+    mp.start_processes(_worker, args=(2, port, path, d), nprocs=2, join=True, start_method="spawn")
+    spans = [tuple(map(int, open(os.path.join(d, f"ok{r}")).read().split())) for r in range(2)]
+    assert spans[0][0] == 0 and spans[0][1] == spans[1][0] and spans[1][1] > spans[1][0]

@@ -9,45 +9,56 @@ variants = [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3,4").split(",")]
 groups = [int(v) for v in os.environ.get("GROUPS", "8").split(",")]
 dev = torch.device("cuda")
 g = torch.Generator(device=dev); g.manual_seed(0)
+only = os.environ.get('ONLY')
 shapes = [("wi  geglu", 7168, 1472, _lib.RP_EPI_GEGLU_BF16), ("wo  resid", 1472, 3584, _lib.RP_EPI_RESID_F32),
           ("qkv store", 1152, 1472, _lib.RP_EPI_STORE_BF16), ("o   resid", 1472, 384, _lib.RP_EPI_RESID_F32)]
-only = os.environ.get('ONLY')
+ROUNDS = int(os.environ.get("ROUNDS", "3"))
 for name, N, K, epi in shapes:
     if only and not name.startswith(only):
         continue
     A = (torch.randn(M, K, generator=g, device=dev)).to(torch.bfloat16)
     W = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.bfloat16)
     ref = A[:256].float() @ W.float().T
-    for v in variants:
-        for gm in groups:
-            _lib.check(lib.rp_set_option(b"gemm_variant", v), "opt")
-            _lib.check(lib.rp_set_option(b"gemm_group_m", gm), "opt")
-            if epi == _lib.RP_EPI_RESID_F32:
-                out = torch.zeros(M, N, device=dev)
-            elif epi == _lib.RP_EPI_GEGLU_BF16:
-                out = torch.empty(M, N // 2, dtype=torch.bfloat16, device=dev)
-            else:
-                out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-            def run():
-                _lib.check(lib.rp_dbg_gemm(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, N, epi,
-                                           _lib.current_stream()), "gemm")
-            run(); torch.cuda.synchronize()
-            if epi == _lib.RP_EPI_RESID_F32:
-                err = (out[:256] - ref).abs().max().item()
-            elif epi == _lib.RP_EPI_STORE_BF16:
-                err = (out[:256].float() - ref).abs().max().item()
-            else:
-                r = ref.view(256, N // 64, 2, 32)
-                gg, uu = r[:, :, 0].reshape(256, -1), r[:, :, 1].reshape(256, -1)
-                want = 0.5 * gg * (1 + torch.tanh(0.7978845608 * (gg + 0.044715 * gg ** 3))) * uu
-                err = (out[:256].float() - want).abs().max().item()
-            if epi == _lib.RP_EPI_RESID_F32:
-                out.zero_()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            iters = 5
-            e0.record()
-            for _ in range(iters):
-                run()
-            e1.record(); torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / iters
-            print(f"{name} M={M} N={N} K={K} variant={v} group_m={gm}: {ms:8.3f} ms  {2.0*M*N*K/ms/1e9:8.1f} TF  maxerr {err:.3e}", flush=True)
+    if epi == _lib.RP_EPI_RESID_F32:
+        out = torch.zeros(M, N, device=dev)
+    elif epi == _lib.RP_EPI_GEGLU_BF16:
+        out = torch.empty(M, N // 2, dtype=torch.bfloat16, device=dev)
+    else:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+
+    def run():
+        _lib.check(lib.rp_dbg_gemm(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, N, epi,
+                                   _lib.current_stream()), "gemm")
+    times = {}
+    errs = {}
+    for rnd in range(ROUNDS + 1):  # round 0 = correctness + warm-up; then interleaved timing rounds
+        for v in variants:
+            for gm in groups:
+                _lib.check(lib.rp_set_option(b"gemm_variant", v), "opt")
+                _lib.check(lib.rp_set_option(b"gemm_group_m", gm), "opt")
+                if rnd == 0:
+                    if epi == _lib.RP_EPI_RESID_F32:
+                        out.zero_()
+                    run(); torch.cuda.synchronize()
+                    if epi == _lib.RP_EPI_RESID_F32:
+                        err = (out[:256] - ref).abs().max().item()
+                    elif epi == _lib.RP_EPI_STORE_BF16:
+                        err = (out[:256].float() - ref).abs().max().item()
+                    else:
+                        r = ref.view(256, N // 64, 2, 32)
+                        gg, uu = r[:, :, 0].reshape(256, -1), r[:, :, 1].reshape(256, -1)
+                        want = 0.5 * gg * (1 + torch.tanh(0.7978845608 * (gg + 0.044715 * gg ** 3))) * uu
+                        err = (out[:256].float() - want).abs().max().item()
+                    errs[(v, gm)] = err
+                    continue
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                iters = 5
+                e0.record()
+                for _ in range(iters):
+                    run()
+                e1.record(); torch.cuda.synchronize()
+                times.setdefault((v, gm), []).append(e0.elapsed_time(e1) / iters)
+    for (v, gm), ts in times.items():
+        best, med = min(ts), sorted(ts)[len(ts) // 2]
+        print(f"{name} M={M} N={N} K={K} variant={v:2d} group_m={gm}: best {best:7.3f} ms {2.0*M*N*K/best/1e9:7.1f} TF | "
+              f"median {med:7.3f} ms {2.0*M*N*K/med/1e9:7.1f} TF  maxerr {errs[(v, gm)]:.3e}", flush=True)

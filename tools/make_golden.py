@@ -365,10 +365,33 @@ def g7_predict():
         prem, sc = model.retrieve(c.state, c.path, c.theorem_full_name, c.theorem_pos, 10)
         single.append({"ids": [where[id(p)] for p in prem], "scores": sc})
         assert single[-1]["ids"] == ids_all[j]
+    # The reference's own GPU numerics (model.py:59-64: everything bf16) on the same inputs: how far
+    # HuggingFace-bf16 lands from its fp32 self, measured at the golden ids (the tolerance envelope).
+    t0 = time.time()
+    E32 = E.clone()
+    model_bf = model.to(torch.bfloat16)
+    model_bf.embeddings_staled = True
+    model_bf.reindex_corpus(batch_size=64)
+    Ebf = model_bf.corpus_embeddings.float()
+    hf_bf16_scores = []
+    for i in range(0, B, 64):
+        batch = ctxs[i : i + 64]
+        tok = model_bf.tokenizer([c.serialize() for c in batch], padding="longest", max_length=1024,
+                                 truncation=True, return_tensors="pt")
+        with torch.no_grad():
+            qbf = model_bf._encode(tok.input_ids, tok.attention_mask).float()
+        for j in range(len(batch)):
+            hf_bf16_scores.append((Ebf[ids_all[i + j]] @ qbf[j]).tolist())
+    d_hf = np.abs(np.array(hf_bf16_scores) - np.array(sc_all))
+    cos_hf = torch.nn.functional.cosine_similarity(Ebf, E32, dim=1)
+    print(f"g7: HF-bf16 vs fp32: max|Δscore| at golden ids {d_hf.max():.3e}, mean {d_hf.mean():.3e}; "
+          f"min embedding cosine {cos_hf.min().item():.5f} ({time.time() - t0:.0f}s)")
+    E = E32
     probe = np.random.default_rng(73).standard_normal((E.shape[1], 4)).astype(np.float32)
     json.dump({"corpus_seed": 71, "n_files": 60, "n_premises": 1000, "code_bytes": [24, 96], "N": N,
                "queries": qmeta, "k": 10, "ids": ids_all, "scores": sc_all, "retrieve": single,
-               "max_seq_len": 1024, "batch_size": 64},
+               "max_seq_len": 1024, "batch_size": 64, "hf_bf16_scores_at_gold_ids": hf_bf16_scores,
+               "hf_bf16_min_embedding_cosine": float(cos_hf.min())},
               open(os.path.join(OUT, "g7_predict.json"), "w"), ensure_ascii=False)
     np.savez_compressed(os.path.join(OUT, "g7_predict.npz"), E_probe=(E @ torch.from_numpy(probe)).numpy(),
                         probe_seed=np.int64(73), E_head=E[:16].numpy())
