@@ -26,6 +26,7 @@ thread_local std::string g_last_error;
 // ------------------------------------------------------------------------------------------
 // options
 // ------------------------------------------------------------------------------------------
+extern int g_scan_cfg;
 static int g_gemm_group_m = 8;
 static int g_gemm_variant = 6;  // tile/pipeline configuration, see launch_gemm()
 
@@ -288,6 +289,14 @@ template <class C, class Epi>
 struct KernelSel<C, Epi, 0> {
   static auto get() { return gemm_kernel<C, Epi>; }
 };
+template <class C, class Epi>
+struct KernelSel<C, Epi, -8> {
+  static auto get() { return gemm_kernel<C, Epi, 8>; }
+};
+template <class C, class Epi>
+struct KernelSel<C, Epi, -9> {
+  static auto get() { return gemm_kernel<C, Epi, 9>; }
+};
 
 // `w` = weight matrix [n_rows_w, K] (row operand: tile rows = output features, clamped at the edge),
 // `a` = activations [M, K] (column operand: tile cols = tokens, M a multiple of the token tile).
@@ -336,6 +345,10 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
     case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
     case 10: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 1>(w, a, K, epi, stream, prof_class);
     case 11: return launch_gemm_cfg<GemmCfg<256, 128, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
+    case 12: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2>, Epi, -8>(w, a, K, epi, stream, prof_class);
+    case 13: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2>, Epi, -9>(w, a, K, epi, stream, prof_class);
+    case 14: return launch_gemm_cfg<GemmCfg<256, 128, 32, 4, 2, 3>, Epi, -8>(w, a, K, epi, stream, prof_class);
+    case 15: return launch_gemm_cfg<GemmCfg<256, 128, 32, 4, 2, 3>, Epi, -9>(w, a, K, epi, stream, prof_class);
     default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class);
   }
 }
@@ -650,8 +663,13 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     return RP_OK;
   }
   if (!strcmp(name, "gemm_variant")) {
-    RP_REQUIRE(value >= 0 && value <= 11, "gemm_variant out of range");
+    RP_REQUIRE(value >= 0 && value <= 15, "gemm_variant out of range");
     g_gemm_variant = value;
+    return RP_OK;
+  }
+  if (!strcmp(name, "scan_cfg")) {
+    RP_REQUIRE(value >= 0 && value <= 2, "scan_cfg out of range");
+    g_scan_cfg = value;
     return RP_OK;
   }
   return fail(RP_E_INVALID, "unknown option %s", name);

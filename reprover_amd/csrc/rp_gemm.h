@@ -59,9 +59,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // acc[mfrag][nfrag]; wave covers rows m_base + mfrag*32 + mfma32_row(r, hi), cols n_base + nfrag*32 + (lane&31)
+// k_rot rotates the order in which the K-tiles are visited (tile kt of the loop reads K-slice
+// (kt + k_rot) mod nk): workgroups that share one operand (the scan's query block) then touch
+// different cache lines at any moment instead of hammering the same L2 channel in lockstep.
 template <class C, class Epilogue, int EXP = 0>
 __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand W, int K, int tile_m,
-                                          int tile_n, Epilogue& epi, char* smem) {
+                                          int tile_n, Epilogue& epi, char* smem, int k_rot = 0) {
   constexpr int BK = C::BK, NSTAGE = C::NSTAGE, FM = C::FM, FN = C::FN;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -94,15 +97,27 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
     const int kc = (lane % C::SLOTS) ^ C::swz(row);
     w_src[d] = W.ptr + (size_t)min(tile_n * C::BN + row, W.rows - 1) * W.ld + kc * 8;
   }
-  auto stage = [&](int kt, int buf) {
-    char* base = smem + buf * C::STAGE_BYTES;
+  const int nk = K / BK;
+  if (EXP == 9) {  // experiment: same bytes, but every DMA instruction reads one contiguous 1 KiB
 #pragma unroll
     for (int d = 0; d < C::A_DMA; ++d)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + (size_t)kt * BK),
+      a_src[d] = A.ptr + ((size_t)(tile_m % 8) * C::BM * (K / BK) * BK) + (size_t)(wave * C::A_DMA + d) * 512 + lane * 8;
+#pragma unroll
+    for (int d = 0; d < C::W_DMA; ++d)
+      w_src[d] = W.ptr + ((size_t)(tile_n % 8) * C::BN * (K / BK) * BK) + (size_t)(wave * C::W_DMA + d) * 512 + lane * 8;
+  }
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * C::STAGE_BYTES;
+    int ke = kt + k_rot;
+    if (ke >= nk) ke -= nk;
+    if (EXP == 9) ke = ke * (C::BM > C::BN ? C::BM : C::BN);  // next contiguous chunk
+#pragma unroll
+    for (int d = 0; d < C::A_DMA; ++d)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + (size_t)ke * BK),
                                        (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024), 16, 0, 0);
 #pragma unroll
     for (int d = 0; d < C::W_DMA; ++d)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[d] + (size_t)kt * BK),
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[d] + (size_t)ke * BK),
                                        (lds_ptr_t)(base + C::A_BYTES + (wave * C::W_DMA + d) * 1024), 16, 0, 0);
   };
   constexpr int DMA_PER_STAGE = C::A_DMA + C::W_DMA;  // per wave
@@ -117,7 +132,6 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
     for (int f = 0; f < FN; ++f) b_off[f][ks] = C::off(wave_col * (FN * 32) + f * 32 + (lane & 31), ks * 2 + hi);
   }
 
-  const int nk = K / BK;
   // prologue: NSTAGE-1 tiles in flight
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
@@ -138,7 +152,7 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
     }
     const char* sa = smem + buf * C::STAGE_BYTES;
     const char* sb = sa + C::A_BYTES;
-    if (EXP == 8 && kt > 0) {  // experiment: DMA + barriers only
+    if ((EXP == 8 || EXP == 9) && kt > 0) {  // experiment: DMA + barriers only
       if (++buf == NSTAGE) buf = 0;
       continue;
     }

@@ -23,12 +23,16 @@ constexpr int SIM_DENSE_MAX_N = 16384;
 constexpr int SIM_STRIDE = 16;
 constexpr int SIM_CAND_CAP = 8192;
 constexpr int SIM_MAX_K = 1024;
+constexpr int SIM_COUNT_STRIDE = 32;  // one candidate counter per 128-B line: contended atomics of different
+                                      // queries must not serialise in the same L2 line
 // scan tile configurations: BM queries x 128 premises (premise tiles are always 128 rows so that the
 // sampled-tile bookkeeping is independent of the query tile)
 typedef GemmCfg<256, 128, 32, 4, 2, 3> SimCfgQ256;  // B > 128: 8 waves, one workgroup sees up to 256 queries
+typedef GemmCfg<256, 128, 64, 4, 2, 2> SimCfgQ256K64;  // same, 128-B rows per K-step (full cache lines of E)
 typedef GemmCfg<128, 128, 64, 2, 2, 2> SimCfgQ128;  // B <= 128, D % 64 == 0
 typedef GemmCfg<128, 128, 32, 2, 2, 3> SimCfgQ128K32;  // B <= 128, D % 32 == 0
 constexpr int GEMM_BN = 128;
+int g_scan_cfg = 0;  // 0: auto; 1: force 128-query tiles; 2: 256-query tiles with BK=64
 
 __device__ __forceinline__ uint64_t make_key(float score, int32_t id) {
   return ((uint64_t)f2ord(score) << 32) | (uint32_t)(~(uint32_t)id);
@@ -136,7 +140,7 @@ struct EpiSim {
               if (file_of) ok = ok && accessible(w[i], rr, f, ek, s_own[ql], s_qk[ql]);
               const uint64_t key = ok ? make_key(sc, id) : 0ull;
               if (key > s_thr[ql]) {
-                const int pos = atomicAdd(&count[q], 1);
+                const int pos = atomicAdd(&count[(size_t)q * SIM_COUNT_STRIDE], 1);
                 if (pos < cap) cand[(size_t)q * cap + pos] = key;
               }
             }
@@ -175,7 +179,8 @@ __global__ __launch_bounds__(C::THREADS) void sim_scan_kernel(GemmOperand Qop, G
 struct SelectArgs {
   const uint64_t* keys;   // [B, ld]
   size_t ld;
-  const int32_t* counts;  // per-query list length (NULL: n_fixed); > cap => overflow
+  const int32_t* counts;  // per-query list length at counts[q * count_stride] (NULL: n_fixed); > cap => overflow
+  int count_stride;
   int n_fixed;
   int cap;
   int k;
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   __shared__ uint64_t sel[SIM_MAX_K];
   __shared__ int s_digit, s_need, s_cnt, s_done;
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  int n = a.counts ? a.counts[q] : a.n_fixed;
+  int n = a.counts ? a.counts[(size_t)q * a.count_stride] : a.n_fixed;
   const bool overflow = a.counts && n > a.cap;
   if (n > a.cap && a.counts) n = a.cap;
   const uint64_t* src = a.keys + (size_t)q * a.ld;
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   if (a.out_keys) {
     for (int i = tid; i < kk; i += 256) a.out_keys[(size_t)q * a.out_ld + i] = sel[i];
     if (tid == 0) {
-      a.out_cnt[q] = kk;
+      a.out_cnt[(size_t)q * SIM_COUNT_STRIDE] = kk;
       a.out_thr[q] = (kk == a.k) ? sel[kk - 1] : 0ull;
     }
   }
@@ -341,7 +346,7 @@ struct SimPlan {
 
 static SimPlan plan_sim(int B, int N, int k, int flags) {
   SimPlan p;
-  p.bm = (B > 128) ? 256 : 128;
+  p.bm = (B > 128 && g_scan_cfg != 1) ? 256 : 128;
   p.tiles_q = (B + p.bm - 1) / p.bm;
   p.tiles_p = (N + GEMM_BN - 1) / GEMM_BN;
   p.dense_only = (flags & RP_TOPK_DENSE) || N <= SIM_DENSE_MAX_N || p.tiles_p < 2 * SIM_STRIDE;
@@ -354,7 +359,7 @@ static SimPlan plan_sim(int B, int N, int k, int flags) {
   p.off_cand = off;
   off += align_up((size_t)B * (SIM_CAND_CAP + k) * 8, 256);
   p.off_count = off;
-  off += align_up((size_t)B * 4, 256);
+  off += align_up((size_t)B * 4 * SIM_COUNT_STRIDE, 256);
   p.off_thr = off;
   off += align_up((size_t)B * 8, 256);
   p.bytes = off;
@@ -380,6 +385,8 @@ static RpStatus launch_scan_cfg(GemmOperand q, GemmOperand e, int D, int tiles_q
 static RpStatus launch_scan(const SimPlan& p, GemmOperand q, GemmOperand e, int D, int n_ptiles, int stride,
                             const EpiSim& epi, hipStream_t stream) {
   if (n_ptiles <= 0) return RP_OK;
+  if (p.bm == 256 && g_scan_cfg == 2 && D % 64 == 0)
+    return launch_scan_cfg<SimCfgQ256K64>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
   if (p.bm == 256) return launch_scan_cfg<SimCfgQ256>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
   if (D % 64 == 0) return launch_scan_cfg<SimCfgQ128>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
   return launch_scan_cfg<SimCfgQ128K32>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
@@ -446,6 +453,7 @@ extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t
   sa.keys = dense;
   sa.ld = p.dense_ld;
   sa.counts = nullptr;
+  sa.count_stride = 1;
   sa.n_fixed = (int)p.dense_ld;
   sa.cap = (int)p.dense_ld;
   sa.k = k;
@@ -477,6 +485,7 @@ extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t
   sb.keys = cand;
   sb.ld = cap;
   sb.counts = count;
+  sb.count_stride = SIM_COUNT_STRIDE;
   sb.n_fixed = 0;
   sb.cap = cap;
   sb.k = k;
@@ -513,6 +522,7 @@ extern "C" RpStatus rp_topk_merge(const float* scores, const int32_t* ids, const
   sa.keys = keys;
   sa.ld = (size_t)R * k;
   sa.counts = nullptr;
+  sa.count_stride = 1;
   sa.n_fixed = R * k;
   sa.cap = R * k;
   sa.k = k;

@@ -1,0 +1,44 @@
+#!/bin/bash
+# rocprofv3 evidence for the bench command: kernel-trace + stats (one run), then PMC passes
+# (separate runs, --kernel-trace only, as the guide prescribes).  Summaries -> gpurun_out/prof_*/
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
+R=${ROUND:-r01}
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$R -o bench --output-format csv -- \
+  python bench.py --steps 3 --warmup 1 --no-cpu-baseline --premise-sample 1024 > gpurun_out/prof_$R.log 2>&1
+tail -1 gpurun_out/prof_$R.log | cut -c1-400
+python - <<PY
+import csv, collections, glob
+f = glob.glob("gpurun_out/prof_$R/*kernel_stats.csv")
+print(f)
+rows = list(csv.DictReader(open(f[0])))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+out = ["kernel,calls,total_ms,avg_us,pct"]
+for r in rows[:25]:
+    out.append(f'"{r["Name"][:110]}",{r["Calls"]},{float(r["TotalDurationNs"])/1e6:.3f},{float(r["AverageNs"])/1e3:.1f},{100*float(r["TotalDurationNs"])/tot:.2f}')
+open("gpurun_out/prof_${R}_kernel_stats_top.csv","w").write("\n".join(out)+"\n")
+print("\n".join(out[:16]))
+PY
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
+  tag=$(echo $grp | cut -d' ' -f1)
+  rocprofv3 --kernel-trace --pmc $grp -d gpurun_out/pmc_${R}_$tag -o bench --output-format csv -- \
+    python bench.py --steps 2 --warmup 1 --no-cpu-baseline --premise-sample 512 > gpurun_out/pmc_${R}_$tag.log 2>&1
+done
+python - <<PY
+import csv, collections, glob
+res = collections.defaultdict(dict)
+for f in glob.glob("gpurun_out/pmc_${R}_*/*counter_collection.csv"):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"]
+        if "rp::" not in k: continue
+        key = (k[:90], row["Counter_Name"])
+        agg[key][0] += float(row["Counter_Value"]); agg[key][1] += 1
+    for (k, c), (v, n) in agg.items():
+        res[k][c] = (v / n, n)
+lines = ["kernel,counter,avg_per_launch,launches"]
+for k, d in sorted(res.items()):
+    for c, (v, n) in sorted(d.items()):
+        lines.append(f'"{k}",{c},{v:.1f},{n}')
+open("gpurun_out/pmc_${R}_summary.csv", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines[:60]))
+PY
