@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--premise-sample", type=int, default=4096, help="premises in the encode-throughput leg")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the premise-encode and scan-only legs (used under rocprofv3 so that every launch of "
+                         "the dominant kernel has the step's shape and the stats average is comparable)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -270,26 +273,30 @@ def main():
 
     # ---- scan-only QPS and premise-encode throughput (reported beside the headline value) --------
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(20):
-        scan()
-    torch.cuda.synchronize()
-    scan_only_qps = BQ * 20 / (time.perf_counter() - t0)
-    rngp = np.random.default_rng(synth.SEED + 7)
-    plens = synth.synth_lengths(rngp, args.premise_sample, "mix", lo=8, hi=2048)
-    pids, pcu = synth.synth_token_batch(rngp, plens)
-    pout = torch.empty((args.premise_sample, D), dtype=torch.bfloat16, device=dev)
-    enc.encode_packed(pids, pcu, pout)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    enc.encode_packed(pids, pcu, pout)
-    torch.cuda.synchronize()
-    pdt = time.perf_counter() - t0
-    prem_per_s = args.premise_sample / pdt
-    if world > 1:
+    scan_only_qps = prem_per_s = prem_tok_per_s = None
+    if not args.headline_only:
+        t0 = time.perf_counter()
+        for _ in range(20):
+            scan()
+        torch.cuda.synchronize()
+        scan_only_qps = BQ * 20 / (time.perf_counter() - t0)
+        rngp = np.random.default_rng(synth.SEED + 7)
+        plens = synth.synth_lengths(rngp, args.premise_sample, "mix", lo=8, hi=2048)
+        pids, pcu = synth.synth_token_batch(rngp, plens)
+        pout = torch.empty((args.premise_sample, D), dtype=torch.bfloat16, device=dev)
+        enc.encode_packed(pids, pcu, pout)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        enc.encode_packed(pids, pcu, pout)
+        torch.cuda.synchronize()
+        pdt = time.perf_counter() - t0
+        prem_per_s = args.premise_sample / pdt
+        prem_tok_per_s = float(pcu[-1]) / pdt
+    if world > 1 and not args.headline_only:
         agg = torch.tensor([prem_per_s, scan_only_qps], dtype=torch.float64, device=dev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)  # re-index shards by rank: throughputs add
         prem_per_s = float(agg[0].item())
+        prem_tok_per_s *= world
         scan_only_qps = float(agg[1].item()) / world  # every rank scanned all queries on its shard
 
     result = {
@@ -314,7 +321,7 @@ def main():
             "accessible_premises_first_queries": n_acc.tolist(), "all_counts_eq_k": counts_ok,
         },
         "premises_per_s": prem_per_s,
-        "premise_tokens_per_s": float(pcu[-1]) / pdt * (world if world > 1 else 1),
+        "premise_tokens_per_s": prem_tok_per_s,
         "premise_len_mix": "clip(round(LogNormal(ln 180, 0.9)), 8, 2048) tokens, %d premises/GPU" % args.premise_sample,
         "scan_only_qps": scan_only_qps,
         "roofline": {
@@ -331,6 +338,12 @@ def main():
         "all_encoder_gemms_tflops": all_gemm_tf,
         "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
     }
+    traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(traffic_file):  # HBM-side bytes per launch from the rocprofv3 PMC passes of this command
+        tj = json.load(open(traffic_file))
+        result["roofline"]["traffic"] = tj.get("gemm_wi_bytes_per_launch")
+        result["roofline"]["traffic_source"] = tj.get("source")
+        result["roofline_scan"]["traffic"] = tj.get("scan_bytes_per_step")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, sd, corpus_path, E_full, all_txt, all_ctx)
     if rank == 0:

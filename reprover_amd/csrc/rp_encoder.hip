@@ -28,7 +28,8 @@ thread_local std::string g_last_error;
 // ------------------------------------------------------------------------------------------
 extern int g_scan_cfg;
 static int g_gemm_group_m = 8;
-static int g_gemm_variant = 6;  // tile/pipeline configuration, see launch_gemm()
+static int g_gemm_variant = 6;
+static int g_attn_variant = 1;  // 0: register-staged kernel, 1: LDS-DMA + transpose-read kernel  // tile/pipeline configuration, see launch_gemm()
 
 // ------------------------------------------------------------------------------------------
 // per-kernel event timing
@@ -551,6 +552,212 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// attention, second generation: same math and work split as attention_kernel, but
+//   * K and V tiles go HBM -> LDS by LDS-DMA into a 2-stage ring (tile t+1 in flight under the
+//     MFMAs/softmax of tile t, one barrier per tile, no VGPR staging, no ds_write at all);
+//   * V stays row-major in LDS ([d-half][key][32 d], 64-B rows) and its MFMA A fragments
+//     (V^T: 4 consecutive keys for one d per lane) are produced by the gfx950 transpose read
+//     ds_read_b64_tr_b16: within each 16-lane group, lane i supplies the address of
+//     V[k0 + i/4][d0 + 4 (i%4) .. +3] and lane l receives V[k0 .. k0+3][d0 + l]  (mapping measured
+//     with tools/probes/tr_probe.hip); 4 rows x 64 B = one 256-B bank row: conflict-free;
+//   * K is staged with the GEMM's XOR swizzle (slot ^= (row >> 1) & 7 on the DMA source address);
+//   * waves whose 32 queries lie past the sequence end only help with the DMA.
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short v4s16;
+constexpr int AT2_K_BYTES = 64 * 128, AT2_V_BYTES = 64 * 128, AT2_STAGE = AT2_K_BYTES + AT2_V_BYTES;
+
+__global__ __launch_bounds__(256) void attention2_kernel(const bf16_t* __restrict__ qkv,
+                                                         const int32_t* __restrict__ cu,
+                                                         const float* __restrict__ bias_tab,
+                                                         bf16_t* __restrict__ out, int H, int maxd,
+                                                         int rows_total) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * AT2_STAGE + ATT_TAB_MAX * 4];
+  float* tab = reinterpret_cast<float*>(smem + 2 * AT2_STAGE);
+
+  const int b = blockIdx.y, h = blockIdx.z;
+  const int s0 = cu[b];
+  const int len = cu[b + 1] - s0;
+  const int q0 = blockIdx.x * ATT_Q;
+  if (q0 >= len) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, cl = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int inner = H * 64, ld = 3 * inner;
+  const int ntab = 2 * maxd + 1;
+  for (int i = tid; i < ntab; i += 256) tab[i] = bias_tab[h * ntab + i];
+
+  const int wq0 = q0 + wave * 32;
+  const bool active = wq0 < len;  // wave-uniform
+  const int qi = wq0 + cl;
+  bf16x8 qf[4];
+  {
+    const bf16_t* qp = qkv + (size_t)(s0 + min(qi, len - 1)) * ld + h * 64 + hi * 8;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const bf16x8*>(qp + c * 16);
+  }
+
+  // DMA pieces of this wave: K pieces {2w, 2w+1} (8 keys x 128 B each), V pieces {2w, 2w+1}
+  // (d-half p >> 2, 16 keys x 64 B each); LDS destinations are lane-linear.
+  const bf16_t* kv_base = qkv + (size_t)s0 * ld + inner + h * 64;
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * AT2_STAGE;
+    const int k0 = kt * ATT_KV;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int p = wave * 2 + e;
+      {
+        const int key = 8 * p + (lane >> 3);
+        const int kc = (lane & 7) ^ ((key >> 1) & 7);
+        const bf16_t* src = kv_base + (size_t)min(k0 + key, len - 1) * ld + kc * 8;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + p * 1024), 16, 0, 0);
+      }
+      {
+        const int key = 16 * (p & 3) + (lane >> 2);
+        const bf16_t* src = kv_base + (size_t)min(k0 + key, len - 1) * ld + inner + (p >> 2) * 32 + (lane & 3) * 8;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + AT2_K_BYTES + p * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  // fragment offsets
+  int k_off[2][4];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int key = kb * 32 + cl;
+      k_off[kb][c] = key * 128 + (((c * 2 + hi) ^ ((key >> 1) & 7)) << 4);
+    }
+  // V^T fragment, first transpose-read of slab 0 / d-half 0: row 4 hi + (lane&15)/4, 4 d's at 4 (lane&3) + 16 ((lane>>4)&1)
+  const int v_off0 = AT2_K_BYTES + (4 * hi + ((lane & 15) >> 2)) * 64 + (4 * (lane & 3) + 16 * ((lane >> 4) & 1)) * 2;
+
+  f32x16 o[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int n_tiles = (len + ATT_KV - 1) / ATT_KV;
+  stage(0, 0);
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // tile kt complete in LDS; tile kt-1's buffer free (and tab written)
+    if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
+    if (!active) continue;
+    const char* sb = smem + (kt & 1) * AT2_STAGE;
+    const int k0 = kt * ATT_KV;
+    // ---- S^T = K Q^T
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bf16x8 kf = *reinterpret_cast<const bf16x8*>(sb + k_off[kb][c]);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], s[kb], 0, 0, 0);
+      }
+    }
+    // ---- relative-position bias + key-padding mask, per 32-key block.  Four cases, wave-uniform:
+    //   saturated right / left (one constant), interior (|j-i| <= maxd everywhere and all keys real:
+    //   the table index is base + compile-time offset, no clamp, no mask), general.
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int c0 = k0 + kb * 32;
+      const bool all_real = (c0 + 32 <= len);
+      if (c0 - (wq0 + 31) >= maxd && all_real) {
+        const float bb = tab[2 * maxd];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] += bb;
+      } else if (c0 + 31 - wq0 <= -maxd && all_real) {
+        const float bb = tab[0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] += bb;
+      } else if (c0 + 31 - wq0 <= maxd && c0 - (wq0 + 31) >= -maxd && all_real) {
+        const float* tp = tab + (c0 - qi + maxd + 4 * hi);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] += tp[(r & 3) + 8 * (r >> 2)];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = c0 + mfma32_row(r, hi);
+          const int rel = min(max(j - qi, -maxd), maxd) + maxd;
+          s[kb][r] = (j < len) ? s[kb][r] + tab[rel] : -INFINITY;
+        }
+      }
+    }
+    // ---- online softmax in the exp2 domain: p = 2^((s - m) * log2 e)
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float LOG2E = 1.4426950408889634f;
+    const float mneg = -m_new * LOG2E;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], LOG2E, mneg));
+        s[kb][r] = p;
+        psum += p;
+      }
+    if (__any(m_new != m_run)) {  // rescale only when some row's running max moved (exact: alpha = 1 otherwise)
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);  // m_run = -inf first -> 0
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
+    l_run += psum;
+    m_run = m_new;
+    // ---- O^T += V^T P^T over four 16-key slabs
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const int kb = sl >> 1, sub = sl & 1;
+      bf16x8 pf;
+      {
+        uint32_t pw[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pw[e] = pack_bf2(s[kb][8 * sub + 2 * e], s[kb][8 * sub + 2 * e + 1]);
+        uint4 t = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+        pf = *reinterpret_cast<bf16x8*>(&t);
+      }
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const char* vp = sb + v_off0 + d * 4096 + sl * 16 * 64;
+        v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(vp));
+        v4s16 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(vp + 8 * 64));
+        bf16x8 vf;
+        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+        vf[4] = up[0]; vf[5] = up[1]; vf[6] = up[2]; vf[7] = up[3];
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+      }
+    }
+  }
+
+  if (active && qi < len) {
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    bf16_t* op = out + (size_t)(s0 + qi) * inner + h * 64;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 v;
+        v.x = pack_bf2(o[d][4 * g] * inv, o[d][4 * g + 1] * inv);
+        v.y = pack_bf2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(op + d * 32 + 8 * g + 4 * hi) = v;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K2(final)+K9+K10: final RMSNorm, masked mean over the sequence's tokens, L2 normalise.
 //   mean_t(w * x_t * rs_t) = w * mean_t(x_t * rs_t); e / max(||e||, 1e-12)  (model.py:108-114)
 //   One workgroup per sequence; wave w takes tokens w, w+4, ...; per-lane partial column sums
@@ -665,6 +872,11 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   if (!strcmp(name, "gemm_variant")) {
     RP_REQUIRE(value >= 0 && value <= 15, "gemm_variant out of range");
     g_gemm_variant = value;
+    return RP_OK;
+  }
+  if (!strcmp(name, "attn_variant")) {
+    RP_REQUIRE(value >= 0 && value <= 1, "attn_variant out of range");
+    g_attn_variant = value;
     return RP_OK;
   }
   if (!strcmp(name, "scan_cfg")) {
@@ -870,8 +1082,8 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
       return st;
     {
       ProfScope ps(stream, RP_K_ATTENTION);
-      hipLaunchKernelGGL(attention_kernel, att_grid, dim3(256), 0, stream, w.qkv, cu_seqlens, e->bias_tab, w.att, H,
-                         e->maxd, Tp);
+      hipLaunchKernelGGL(g_attn_variant ? attention2_kernel : attention_kernel, att_grid, dim3(256), 0, stream, w.qkv,
+                         cu_seqlens, e->bias_tab, w.att, H, e->maxd, Tp);
     }
     if ((st = launch_gemm(w.att, inner, Tp, L.wo, inner, D, inner, EpiResidF32{w.x, D, D}, stream, RP_K_GEMM_O)))
       return st;
@@ -926,8 +1138,8 @@ extern "C" RpStatus rp_dbg_attention(const void* qkv, const int32_t* cu, const f
                                      int32_t batch, int32_t max_len, int32_t H, int32_t rows_total, void* stream_) {
   const int maxd = 128;
   const dim3 grid((max_len + ATT_Q - 1) / ATT_Q, batch, H);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)qkv, cu, bias_tab,
-                     (bf16_t*)out, H, maxd, rows_total);
+  hipLaunchKernelGGL(g_attn_variant ? attention2_kernel : attention_kernel, grid, dim3(256), 0, (hipStream_t)stream_,
+                     (const bf16_t*)qkv, cu, bias_tab, (bf16_t*)out, H, maxd, rows_total);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

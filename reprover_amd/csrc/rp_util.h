@@ -59,16 +59,20 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even, as torch's float -> bfloat16 conversion
+// float -> bfloat16, round-to-nearest-even (as torch's conversion).  Going through the native
+// __bf16 type lets hipcc emit the gfx950 hardware conversion (v_cvt_pk_bf16_f32) instead of the
+// five-instruction integer sequence.
 __device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, h);
 }
 
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+  typedef __attribute__((ext_vector_type(2))) float f2_t;
+  f2_t v = {lo, hi};
+  bf2_t h = __builtin_convertvector(v, bf2_t);
+  return __builtin_bit_cast(uint32_t, h);
 }
 
 // gelu_new (tanh form), transformers/activations.py NewGELUActivation

@@ -4,7 +4,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 R=${ROUND:-r01}
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$R -o bench --output-format csv -- \
-  python bench.py --steps 3 --warmup 1 --no-cpu-baseline --premise-sample 1024 > gpurun_out/prof_$R.log 2>&1
+  python bench.py --steps 5 --warmup 2 --no-cpu-baseline --headline-only > gpurun_out/prof_$R.log 2>&1
 tail -1 gpurun_out/prof_$R.log | cut -c1-400
 python - <<PY
 import csv, collections, glob
@@ -21,7 +21,7 @@ PY
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
   tag=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $grp -d gpurun_out/pmc_${R}_$tag -o bench --output-format csv -- \
-    python bench.py --steps 2 --warmup 1 --no-cpu-baseline --premise-sample 512 > gpurun_out/pmc_${R}_$tag.log 2>&1
+    python bench.py --steps 2 --warmup 1 --no-cpu-baseline --headline-only > gpurun_out/pmc_${R}_$tag.log 2>&1
 done
 python - <<PY
 import csv, collections, glob
