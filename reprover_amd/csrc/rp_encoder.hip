@@ -262,46 +262,38 @@ struct EpiGegluBf16 {  // W rows interleaved 32 gate / 32 up: even row-fragments
   }
 };
 
-template <class C, class Epi, int EXP = 0>
+template <class C, class Epi>
 __global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOperand W, int K, int tiles_m,
                                                           int tiles_n, int group_m, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   int tm, tn;
   tile_coords(logical, tiles_n, tiles_m, group_m, tn, tm);  // token tiles grouped, feature tiles inside
-  gemm_tile<C, Epi, EXP>(A, W, K, tm, tn, epi, smem);
+  gemm_tile<C>(A, W, K, tm, tn, epi, smem);
 }
 
-template <class C, class Epi, int EXP>
+template <class C, class Epi>
 __global__ __launch_bounds__(C::THREADS) void gemm_pp_kernel(GemmOperand A, GemmOperand W, int K, int tiles_m,
                                                              int tiles_n, int group_m, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   int tm, tn;
-  tile_coords(logical, tiles_n, tiles_m, group_m, tn, tm);  // token tiles grouped, feature tiles inside
-  gemm_tile_pingpong<C, EXP>(A, W, K, tm, tn, epi, smem);
+  tile_coords(logical, tiles_n, tiles_m, group_m, tn, tm);
+  gemm_tile_pingpong<C>(A, W, K, tm, tn, epi, smem);
 }
 
-template <class C, class Epi, int PP>
+template <class C, class Epi, bool PP>
 struct KernelSel {
-  static auto get() { return gemm_pp_kernel<C, Epi, PP - 1>; }
-};
-template <class C, class Epi>
-struct KernelSel<C, Epi, 0> {
   static auto get() { return gemm_kernel<C, Epi>; }
 };
 template <class C, class Epi>
-struct KernelSel<C, Epi, -8> {
-  static auto get() { return gemm_kernel<C, Epi, 8>; }
-};
-template <class C, class Epi>
-struct KernelSel<C, Epi, -9> {
-  static auto get() { return gemm_kernel<C, Epi, 9>; }
+struct KernelSel<C, Epi, true> {
+  static auto get() { return gemm_pp_kernel<C, Epi>; }
 };
 
 // `w` = weight matrix [n_rows_w, K] (row operand: tile rows = output features, clamped at the edge),
 // `a` = activations [M, K] (column operand: tile cols = tokens, M a multiple of the token tile).
-template <class C, class Epi, int PINGPONG = 0>
+template <class C, class Epi, bool PINGPONG = false>
 static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hipStream_t stream,
                                 int prof_class) {
   auto kern = KernelSel<C, Epi, PINGPONG>::get();
@@ -331,25 +323,16 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
   GemmOperand a{A, lda, M}, w{W, ldw, n_rows_w};
   int v = g_gemm_variant;
   const bool k64 = (K % 64 == 0), m256 = (M % 256 == 0);
-  if ((v == 1 || v == 2 || v == 6 || v == 7) && !k64) v = 0;
+  if ((v == 1 || v == 6) && !k64) v = (v == 6 && m256) ? 9 : 0;
   if (v >= 5 && !m256) v = 0;
-  // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages>
+  // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages>; measured on
+  // MI355X at M = 65536 (tools/gemm_bench.py): 6 is the best all-rounder, 11 is 2-3 % ahead on FFN-in.
   switch (v) {
     case 1: return launch_gemm_cfg<GemmCfg<128, 128, 64, 2, 2, 2>>(w, a, K, epi, stream, prof_class);
-    case 2: return launch_gemm_cfg<GemmCfg<128, 128, 64, 2, 2, 3>>(w, a, K, epi, stream, prof_class);
-    case 3: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 4>>(w, a, K, epi, stream, prof_class);
-    case 4: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 2>>(w, a, K, epi, stream, prof_class);
-    case 5: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 4>>(w, a, K, epi, stream, prof_class);
     case 6: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2>>(w, a, K, epi, stream, prof_class);
-    case 7: return launch_gemm_cfg<GemmCfg<128, 256, 64, 2, 4, 2>>(w, a, K, epi, stream, prof_class);
-    case 8: return launch_gemm_cfg<GemmCfg<128, 256, 32, 2, 4, 3>>(w, a, K, epi, stream, prof_class);
     case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
-    case 10: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, 1>(w, a, K, epi, stream, prof_class);
+    case 10: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, true>(w, a, K, epi, stream, prof_class);
     case 11: return launch_gemm_cfg<GemmCfg<256, 128, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
-    case 12: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2>, Epi, -8>(w, a, K, epi, stream, prof_class);
-    case 13: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2>, Epi, -9>(w, a, K, epi, stream, prof_class);
-    case 14: return launch_gemm_cfg<GemmCfg<256, 128, 32, 4, 2, 3>, Epi, -8>(w, a, K, epi, stream, prof_class);
-    case 15: return launch_gemm_cfg<GemmCfg<256, 128, 32, 4, 2, 3>, Epi, -9>(w, a, K, epi, stream, prof_class);
     default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class);
   }
 }
@@ -760,32 +743,38 @@ __global__ __launch_bounds__(256) void attention2_kernel(const bf16_t* __restric
 // ------------------------------------------------------------------------------------------
 // K2(final)+K9+K10: final RMSNorm, masked mean over the sequence's tokens, L2 normalise.
 //   mean_t(w * x_t * rs_t) = w * mean_t(x_t * rs_t); e / max(||e||, 1e-12)  (model.py:108-114)
-//   One workgroup per sequence; wave w takes tokens w, w+4, ...; per-lane partial column sums
-//   live in registers, combined through LDS at the end.
+//   Two deterministic passes (no atomics, so results are bit-reproducible whatever the batch):
+//   pool_partial_kernel: one workgroup per 128-token chunk of a sequence; wave w takes tokens
+//     w, w+4, ...; per-lane partial column sums of x_t * rs_t in registers, combined through LDS,
+//     written to partial[chunk_base(b) + c][D]   (chunk_base(b) = cu[b] / 128 + b);
+//   pool_finish_kernel: one workgroup per sequence sums its chunks in order, applies w / len and
+//     the L2 normalisation.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x,
-                                                   const float* __restrict__ w,
-                                                   const int32_t* __restrict__ cu,
-                                                   void* __restrict__ out, int out_bf16, int D,
-                                                   float eps) {
+constexpr int POOL_CHUNK = 128;
+
+__global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restrict__ x,
+                                                           const int32_t* __restrict__ cu,
+                                                           float* __restrict__ partial, int D, float eps) {
   __shared__ float red[4][RMS_MAX_V4 * 64 * 4];
-  __shared__ float nrm[4];
-  const int b = blockIdx.x;
+  const int b = blockIdx.y, c = blockIdx.x;
   const int s0 = cu[b], len = cu[b + 1] - s0;
+  const int t0 = c * POOL_CHUNK;
+  if (t0 >= len) return;
+  const int t1 = min(len, t0 + POOL_CHUNK);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = D >> 2;
   float4 acc[RMS_MAX_V4];
 #pragma unroll
   for (int i = 0; i < RMS_MAX_V4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int t = wave; t < len; t += 4) {
+  for (int t = t0 + wave; t < t1; t += 4) {
     const float4* src = reinterpret_cast<const float4*>(x + (size_t)(s0 + t) * D);
     float4 v[RMS_MAX_V4];
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < RMS_MAX_V4; ++i) {
-      int c = lane + 64 * i;
-      if (c < nv) {
-        v[i] = src[c];
+      int col = lane + 64 * i;
+      if (col < nv) {
+        v[i] = src[col];
         ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
       }
     }
@@ -793,8 +782,8 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x,
     const float rs = rsqrtf(ss / (float)D + eps);
 #pragma unroll
     for (int i = 0; i < RMS_MAX_V4; ++i) {
-      int c = lane + 64 * i;
-      if (c < nv) {
+      int col = lane + 64 * i;
+      if (col < nv) {
         acc[i].x += v[i].x * rs;
         acc[i].y += v[i].y * rs;
         acc[i].z += v[i].z * rs;
@@ -804,32 +793,47 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x,
   }
 #pragma unroll
   for (int i = 0; i < RMS_MAX_V4; ++i) {
-    int c = lane + 64 * i;
-    if (c < nv) *reinterpret_cast<float4*>(&red[wave][c * 4]) = acc[i];
+    int col = lane + 64 * i;
+    if (col < nv) *reinterpret_cast<float4*>(&red[wave][col * 4]) = acc[i];
   }
   __syncthreads();
-  // every thread finalises columns tid, tid+256, ...
+  float* dst = partial + (size_t)(s0 / POOL_CHUNK + b + c) * D;
+  for (int col = threadIdx.x; col < D; col += 256) dst[col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+}
+
+__global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restrict__ partial,
+                                                          const float* __restrict__ w,
+                                                          const int32_t* __restrict__ cu,
+                                                          void* __restrict__ out, int out_bf16, int D) {
+  __shared__ float nrm[4];
+  const int b = blockIdx.x;
+  const int s0 = cu[b], len = cu[b + 1] - s0;
+  const int nchunk = (len + POOL_CHUNK - 1) / POOL_CHUNK;
+  const float* src = partial + (size_t)(s0 / POOL_CHUNK + b) * D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float inv_len = 1.f / (float)len;
-  float part = 0.f;
   float vals[8];
+  float part = 0.f;
   int cnt = 0;
-  for (int c = threadIdx.x; c < D; c += 256) {
-    float e = (red[0][c] + red[1][c] + red[2][c] + red[3][c]) * inv_len * w[c];
+  for (int col = threadIdx.x; col < D; col += 256) {
+    float sum = 0.f;
+    for (int c = 0; c < nchunk; ++c) sum += src[(size_t)c * D + col];
+    const float e = sum * inv_len * w[col];
     vals[cnt++] = e;
     part += e * e;
   }
   part = wave_sum(part);
   if (lane == 0) nrm[wave] = part;
   __syncthreads();
-  const float norm = sqrtf(nrm[0] + nrm[1] + nrm[2] + nrm[3]);
+  const float norm = sqrtf((nrm[0] + nrm[1]) + (nrm[2] + nrm[3]));
   const float sc = 1.f / fmaxf(norm, 1e-12f);
   cnt = 0;
-  for (int c = threadIdx.x; c < D; c += 256) {
+  for (int col = threadIdx.x; col < D; col += 256) {
     const float e = vals[cnt++] * sc;
     if (out_bf16)
-      reinterpret_cast<bf16_t*>(out)[(size_t)b * D + c] = f2bf(e);
+      reinterpret_cast<bf16_t*>(out)[(size_t)b * D + col] = f2bf(e);
     else
-      reinterpret_cast<float*>(out)[(size_t)b * D + c] = e;
+      reinterpret_cast<float*>(out)[(size_t)b * D + col] = e;
   }
 }
 
@@ -870,7 +874,7 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     return RP_OK;
   }
   if (!strcmp(name, "gemm_variant")) {
-    RP_REQUIRE(value >= 0 && value <= 15, "gemm_variant out of range");
+    RP_REQUIRE(value >= 0 && value <= 11, "gemm_variant out of range");
     g_gemm_variant = value;
     return RP_OK;
   }
@@ -1019,9 +1023,10 @@ namespace {
 struct Workspace {
   float* x;
   bf16_t *h, *qkv, *att, *ff;
+  float* pool;  // [Tp / 128 + batch, D] partial column sums of the pooling pass
   size_t bytes;
 };
-Workspace carve(const RpEncoder* e, int T, char* base) {
+Workspace carve(const RpEncoder* e, int T, int batch, char* base) {
   const size_t Tp = align_up((size_t)T, GEMM_M_ALIGN);
   const size_t D = e->cfg.d_model, F = e->cfg.d_ff, inner = e->inner;
   Workspace w;
@@ -1036,15 +1041,15 @@ Workspace carve(const RpEncoder* e, int T, char* base) {
   w.qkv = (bf16_t*)take(Tp * 3 * inner * 2);
   w.att = (bf16_t*)take(Tp * inner * 2);
   w.ff = (bf16_t*)take(Tp * F * 2);
+  w.pool = (float*)take((Tp / POOL_CHUNK + (size_t)batch + 1) * D * 4);
   w.bytes = off;
   return w;
 }
 }  // namespace
 
 extern "C" size_t rp_encoder_workspace_bytes(const RpEncoder* enc, int32_t total_tokens, int32_t batch) {
-  (void)batch;
-  if (!enc || total_tokens <= 0) return 0;
-  return carve(enc, total_tokens, nullptr).bytes;
+  if (!enc || total_tokens <= 0 || batch <= 0) return 0;
+  return carve(enc, total_tokens, batch, nullptr).bytes;
 }
 
 extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int32_t* cu_seqlens, int32_t batch,
@@ -1055,7 +1060,7 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
              max_len);
   RP_REQUIRE(out_dtype == RP_DT_F32 || out_dtype == RP_DT_BF16, "out_dtype");
   hipStream_t stream = (hipStream_t)stream_;
-  Workspace w = carve(e, T, (char*)workspace);
+  Workspace w = carve(e, T, batch, (char*)workspace);
   if (!workspace || workspace_bytes < w.bytes)
     return fail(RP_E_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, w.bytes);
   const RpT5Config& c = e->cfg;
@@ -1099,8 +1104,10 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
   }
   {
     ProfScope ps(stream, RP_K_POOL);
-    hipLaunchKernelGGL(pool_kernel, dim3(batch), dim3(256), 0, stream, w.x, e->final_ln, cu_seqlens, out,
-                       out_dtype == RP_DT_BF16 ? 1 : 0, D, c.layer_norm_eps);
+    hipLaunchKernelGGL(pool_partial_kernel, dim3((max_len + POOL_CHUNK - 1) / POOL_CHUNK, batch), dim3(256), 0, stream,
+                       w.x, cu_seqlens, w.pool, D, c.layer_norm_eps);
+    hipLaunchKernelGGL(pool_finish_kernel, dim3(batch), dim3(256), 0, stream, w.pool, e->final_ln, cu_seqlens, out,
+                       out_dtype == RP_DT_BF16 ? 1 : 0, D);
   }
   RP_CHECK_LAUNCH();
   return RP_OK;

@@ -59,12 +59,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // acc[mfrag][nfrag]; wave covers rows m_base + mfrag*32 + mfma32_row(r, hi), cols n_base + nfrag*32 + (lane&31)
-// k_rot rotates the order in which the K-tiles are visited (tile kt of the loop reads K-slice
-// (kt + k_rot) mod nk): workgroups that share one operand (the scan's query block) then touch
-// different cache lines at any moment instead of hammering the same L2 channel in lockstep.
-template <class C, class Epilogue, int EXP = 0>
+template <class C, class Epilogue>
 __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand W, int K, int tile_m,
-                                          int tile_n, Epilogue& epi, char* smem, int k_rot = 0) {
+                                          int tile_n, Epilogue& epi, char* smem) {
   constexpr int BK = C::BK, NSTAGE = C::NSTAGE, FM = C::FM, FN = C::FN;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -98,19 +95,9 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
     w_src[d] = W.ptr + (size_t)min(tile_n * C::BN + row, W.rows - 1) * W.ld + kc * 8;
   }
   const int nk = K / BK;
-  if (EXP == 9) {  // experiment: same bytes, but every DMA instruction reads one contiguous 1 KiB
-#pragma unroll
-    for (int d = 0; d < C::A_DMA; ++d)
-      a_src[d] = A.ptr + ((size_t)(tile_m % 8) * C::BM * (K / BK) * BK) + (size_t)(wave * C::A_DMA + d) * 512 + lane * 8;
-#pragma unroll
-    for (int d = 0; d < C::W_DMA; ++d)
-      w_src[d] = W.ptr + ((size_t)(tile_n % 8) * C::BN * (K / BK) * BK) + (size_t)(wave * C::W_DMA + d) * 512 + lane * 8;
-  }
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * C::STAGE_BYTES;
-    int ke = kt + k_rot;
-    if (ke >= nk) ke -= nk;
-    if (EXP == 9) ke = ke * (C::BM > C::BN ? C::BM : C::BN);  // next contiguous chunk
+    const int ke = kt;
 #pragma unroll
     for (int d = 0; d < C::A_DMA; ++d)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + (size_t)ke * BK),
@@ -152,10 +139,6 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
     }
     const char* sa = smem + buf * C::STAGE_BYTES;
     const char* sb = sa + C::A_BYTES;
-    if ((EXP == 8 || EXP == 9) && kt > 0) {  // experiment: DMA + barriers only
-      if (++buf == NSTAGE) buf = 0;
-      continue;
-    }
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 af[FM], bfr[FN];
@@ -192,7 +175,7 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
 // first overwrite (group0, interval 2kt).  Tile kt+1 is complete in LDS before interval 2kt+2: every
 // wave ends LOAD(kt) with a counted vmcnt that leaves only tiles kt+2, kt+3 in flight.
 // ------------------------------------------------------------------------------------------------
-template <class C, int EXP, class Epilogue>
+template <class C, class Epilogue>
 __device__ __forceinline__ void gemm_tile_pingpong(const GemmOperand A, const GemmOperand W, int K, int tile_m,
                                                    int tile_n, Epilogue& epi, char* smem) {
   static_assert(C::NWAVES == 8 && C::WM == 2 && C::NSTAGE == 4 && C::BK == 32, "ping-pong geometry");
@@ -201,7 +184,7 @@ __device__ __forceinline__ void gemm_tile_pingpong(const GemmOperand A, const Ge
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_row = wave / C::WN, wave_col = wave % C::WN;
-  const int grp = (EXP == 2) ? (wave & 1) : (EXP == 5 ? 0 : wave_row);  // 0: leads, 1: one barrier behind
+  const int grp = wave_row;  // 0: leads, 1: one barrier behind
   const int hi = lane >> 5;
 
   f32x16 acc[FM][FN];
@@ -228,13 +211,14 @@ __device__ __forceinline__ void gemm_tile_pingpong(const GemmOperand A, const Ge
   }
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * C::STAGE_BYTES;
+    const size_t kstep = (size_t)kt * BK;
 #pragma unroll
     for (int d = 0; d < C::A_DMA; ++d)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + (size_t)kt * BK),
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + kstep),
                                        (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024), 16, 0, 0);
 #pragma unroll
     for (int d = 0; d < C::W_DMA; ++d)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[d] + (size_t)kt * BK),
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[d] + kstep),
                                        (lds_ptr_t)(base + C::A_BYTES + (wave * C::W_DMA + d) * 1024), 16, 0, 0);
   };
   constexpr int DPS = C::A_DMA + C::W_DMA;  // DMA instructions per stage per wave
@@ -262,19 +246,16 @@ __device__ __forceinline__ void gemm_tile_pingpong(const GemmOperand A, const Ge
   int buf = 0;
   for (int kt = 0; kt < nk; ++kt) {
     // ---------------- LOAD part
-    if (EXP != 3 && EXP != 4)
-      if (kt + 3 < nk) stage(EXP == 7 ? 0 : kt + 3, (buf + 3) & 3);
+    if (kt + 3 < nk) stage(kt + 3, (buf + 3) & 3);
     const char* sa = smem + buf * C::STAGE_BYTES;
     const char* sb = sa + C::A_BYTES;
     bf16x8 af[FM][2], bfr[FN][2];
-    if ((EXP != 3 && EXP != 6 && EXP != 8) || kt == 0) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int f = 0; f < FN; ++f) bfr[f][ks] = *reinterpret_cast<const bf16x8*>(sb + b_off[f][ks]);
+      for (int f = 0; f < FN; ++f) bfr[f][ks] = *reinterpret_cast<const bf16x8*>(sb + b_off[f][ks]);
 #pragma unroll
-        for (int f = 0; f < FM; ++f) af[f][ks] = *reinterpret_cast<const bf16x8*>(sa + a_off[f][ks]);
-      }
+      for (int f = 0; f < FM; ++f) af[f][ks] = *reinterpret_cast<const bf16x8*>(sa + a_off[f][ks]);
     }
     if (kt + 3 < nk)
       wait_vmcnt<2 * DPS>();  // tile kt+1 complete (this wave's share); kt+2, kt+3 in flight
@@ -285,17 +266,15 @@ __device__ __forceinline__ void gemm_tile_pingpong(const GemmOperand A, const Ge
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ---------------- COMPUTE part
-    if (EXP != 1) __builtin_amdgcn_s_setprio(1);
-    if (EXP != 8 || kt == 0) {
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
-          for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ks], bfr[j][ks], acc[i][j], 0, 0, 0);
-    }
-    if (EXP != 1) __builtin_amdgcn_s_setprio(0);
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ks], bfr[j][ks], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);

@@ -42,3 +42,32 @@ for k, d in sorted(res.items()):
 open("gpurun_out/pmc_${R}_summary.csv", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[:60]))
 PY
+# ---- copy the judged summaries into profiles/ (tracked) -----------------------------------------
+mkdir -p gpurun_out/profiles_$R
+cp gpurun_out/prof_${R}_kernel_stats_top.csv gpurun_out/profiles_$R/${R}_bench_kernel_stats.csv
+cp gpurun_out/pmc_${R}_summary.csv gpurun_out/profiles_$R/${R}_bench_pmc_summary.csv
+grep "^{\"metric\"" gpurun_out/prof_$R.log | tail -1 > gpurun_out/profiles_$R/${R}_bench_under_rocprof.json
+R=$R python - <<'PY'
+import csv, json, os
+R = os.environ["R"]
+rows = list(csv.DictReader(open(f"gpurun_out/pmc_{R}_summary.csv")))
+def get(kfrag, counter):
+    for r in rows:
+        if kfrag in r["kernel"] and r["counter"] == counter:
+            return float(r["avg_per_launch"])
+    return None
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB per launch) of 'python bench.py "
+                 "--headline-only'; read bytes = 2 x FETCH_SIZE x 1024 (gfx950 wide-read correction, "
+                 "MI355X_MICROARCH.md HBM section), write bytes = WRITE_SIZE x 1024; Infinity-Cache hits are included",
+       "round": R}
+f, w = get("EpiGegluBf16", "FETCH_SIZE"), get("EpiGegluBf16", "WRITE_SIZE")
+if f is not None and w is not None:
+    out["gemm_wi_bytes_per_launch"] = 2 * f * 1024 + w * 1024
+    out["gemm_wi_fetch_kib"], out["gemm_wi_write_kib"] = f, w
+fs, ws = get("sim_scan_kernel", "FETCH_SIZE"), get("sim_scan_kernel", "WRITE_SIZE")
+if fs is not None and ws is not None:
+    out["scan_bytes_per_step"] = 2 * (2 * fs * 1024 + ws * 1024)  # two launches (sample + filter pass) per step
+    out["scan_fetch_kib_per_launch"], out["scan_write_kib_per_launch"] = fs, ws
+json.dump(out, open(f"gpurun_out/profiles_{R}/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(out)[:700])
+PY
