@@ -442,6 +442,18 @@ class IndexedCorpus:
         assert len(self.embeddings) == len(self.corpus)
 
 
+def get_all_pos_premises(annot_tac, corpus: Corpus) -> List[Premise]:
+    """Premises used by an annotated tactic: each provenance ``{def_path, def_pos}`` is resolved with
+    ``corpus.locate_premise``; unresolvable ones are skipped (common.py:341-354)."""
+    _, provenances = annot_tac
+    found = set()
+    for prov in provenances:
+        p = corpus.locate_premise(prov["def_path"], Pos(*prov["def_pos"]))
+        if p is not None:
+            found.add(p)
+    return list(found)
+
+
 def format_augmented_state(s: str, premises: List[Premise], max_len: Optional[int] = None, p_drop: float = 0.0) -> str:
     """Byte-budgeted concatenation of retrieved premises in front of a state (common.py:357-378);
     the caller-side consumer of ``retrieve`` (prover/tactic_generator.py:293-295)."""

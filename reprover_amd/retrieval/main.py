@@ -1,0 +1,90 @@
+"""``predict`` / ``validate`` driver of the retriever — stands in for the reference's
+``python retrieval/main.py {predict,validate} --config …`` (retrieval/main.py:12-21, a LightningCLI)
+for the inference subcommands.  Reads the same YAML keys the reference's configs use
+(``model.model_name``, ``model.num_retrieved``, ``data.data_path``, ``data.corpus_path``,
+``data.eval_batch_size``, ``data.max_seq_len``; retrieval/confs/*.yaml) and writes
+``<log_dir>/predictions.pickle`` exactly as ``on_predict_epoch_end`` does (model.py:329-336).
+Lightning itself is out of scope; the hooks' bodies live in ``model.py`` here as they do upstream.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+from typing import Any, Dict, Optional
+
+import torch
+import yaml
+
+from .datamodule import RetrievalDataModule
+from .evaluate import recall_and_mrr
+from .model import PremiseRetriever
+
+
+def run_predict(model: PremiseRetriever, dm: RetrievalDataModule, log_dir: Optional[str]) -> int:
+    """on_predict_start → predict_step over the predict split → on_predict_epoch_end."""
+    dm.setup("predict")
+    model.on_predict_start(dm.corpus, dm.eval_batch_size)
+    n = 0
+    for batch in dm.predict_dataloader():
+        batch["context_ids"] = batch["context_ids"].to(model.device)
+        batch["context_mask"] = batch["context_mask"].to(model.device)
+        model.predict_step(batch, n)
+        n += 1
+    count = len(model.predict_step_outputs)
+    model.on_predict_epoch_end(log_dir)
+    return count
+
+
+def run_validate(model: PremiseRetriever, dm: RetrievalDataModule) -> Dict[str, Any]:
+    """on_validation_start + validation_step over the val split (model.py:212-268); returns the
+    epoch-level Recall@k (k = 1..num_retrieved, in %) and MRR, weighted by examples with premises as
+    the reference's ``self.log(..., batch_size=num_with_premises)`` does."""
+    dm.setup("validate")
+    model.load_corpus(dm.corpus)
+    model.reindex_corpus(dm.eval_batch_size)
+    k = model.num_retrieved
+    tot_recall = [0.0] * k
+    tot_mrr, tot_n = 0.0, 0
+    for batch in dm.val_dataloader():
+        emb = model._encode(batch["context_ids"].to(model.device), batch["context_mask"].to(model.device))
+        retrieved, _ = model.corpus.get_nearest_premises(model.corpus_embeddings, batch["context"], emb, k)
+        if not any(len(p) for p in batch["all_pos_premises"]):
+            continue
+        recall, mrr, n = recall_and_mrr(batch["all_pos_premises"], retrieved, k)
+        for j in range(k):
+            tot_recall[j] += recall[j] * n
+        tot_mrr += mrr * n
+        tot_n += n
+    out = {f"Recall@{j + 1}_val": tot_recall[j] / max(tot_n, 1) for j in range(k)}
+    out["MRR"] = tot_mrr / max(tot_n, 1)
+    out["num_with_premises"] = tot_n
+    return out
+
+
+def main(argv=None) -> None:
+    ap = argparse.ArgumentParser(description="Premise retriever: predict / validate on MI355X.")
+    ap.add_argument("subcommand", choices=["predict", "validate"])
+    ap.add_argument("--config", required=True, help="YAML with `model:` and `data:` sections (reference layout)")
+    ap.add_argument("--ckpt_path", default=None, help="HF checkpoint dir (overrides model.model_name)")
+    ap.add_argument("--log-dir", default=None, help="where predictions.pickle goes (trainer.log_dir upstream)")
+    args = ap.parse_args(argv)
+    with open(args.config) as fh:
+        cfg = yaml.safe_load(fh)
+    m, d = cfg["model"], cfg["data"]
+    if not torch.cuda.is_available():
+        raise RuntimeError("reprover_amd needs an MI355X (HIP) device; no CPU fallback exists")
+    model = PremiseRetriever.load_hf(args.ckpt_path or m["model_name"], d["max_seq_len"], torch.device("cuda"))
+    model.num_retrieved = m.get("num_retrieved", 100)
+    dm = RetrievalDataModule(d["data_path"], d["corpus_path"], d["eval_batch_size"], d["max_seq_len"], model.tokenizer)
+    if args.subcommand == "predict":
+        log_dir = args.log_dir or cfg.get("trainer", {}).get("default_root_dir") or os.getcwd()
+        os.makedirs(log_dir, exist_ok=True)
+        n = run_predict(model, dm, log_dir)
+        print(f"{n} retrieval predictions saved to {os.path.join(log_dir, 'predictions.pickle')}")
+    else:
+        for k, v in run_validate(model, dm).items():
+            print(f"{k}: {v}")
+
+
+if __name__ == "__main__":
+    main()

@@ -218,3 +218,38 @@ def synth_state(rng: np.random.Generator, n_bytes: int) -> str:
     head = synth_text(rng, (n_bytes - 4) // 2)
     tail = synth_text(rng, n_bytes - 4 - len(head.encode()))
     return head + " ⊢" + tail  # ' ' + 3-byte turnstile = 4 bytes
+
+
+# ----------------------------------------------------------------------------------------------
+# Dataset splits ({train,val,test}.json of SURVEY.md App. B.2)
+# ----------------------------------------------------------------------------------------------
+def synth_split(records: Sequence[dict], n_theorems: int, seed: int, min_file: int = 0) -> List[dict]:
+    """Theorems with traced tactics whose annotated tactics point at premises of the corpus records
+    (positions inside real premises, plus some that resolve to nothing and some tactics with no
+    premises at all)."""
+    rng = np.random.default_rng(seed)
+    usable = [i for i, r in enumerate(records) if i >= min_file]
+    out = []
+    for t in range(n_theorems):
+        f = int(rng.choice(usable))
+        rec = records[f]
+        start = [int(rng.integers(1, 400)), int(rng.integers(0, 30))]
+        tactics = []
+        for k in range(int(rng.integers(1, 5))):
+            provs = []
+            for _ in range(int(rng.integers(0, 4))):
+                g = int(rng.integers(0, f + 1))
+                prem = [p for p in records[g]["premises"] if p["full_name"]]
+                if prem and rng.random() < 0.85:
+                    p = prem[int(rng.integers(len(prem)))]
+                    pos = [int(p["start"][0]), int(p["start"][1])]
+                else:
+                    pos = [100000, 0]  # resolves to no premise
+                provs.append({"full_name": "x", "def_path": records[g]["path"], "def_pos": pos, "def_end_pos": pos})
+            state = synth_state(rng, int(rng.integers(30, 160)))
+            tactics.append({"tactic": f"simp [l{k}]", "annotated_tactic": [f"simp [<a>l{k}</a>]", provs],
+                            "state_before": state, "state_after": "no goals"})
+        out.append({"url": "https://example.org/synth", "commit": "0" * 40, "file_path": rec["path"],
+                    "full_name": f"Synth.thm_{seed}_{t}", "start": start, "end": [start[0] + 3, 0],
+                    "traced_tactics": tactics})
+    return out

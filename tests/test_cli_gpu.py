@@ -1,0 +1,106 @@
+"""The CLI-level drop-ins on the GPU with a tiny checkpoint written in HuggingFace layout:
+load_hf (config.json + model.safetensors), retrieval/index.py (same flags as the reference),
+predict / validate drivers, evaluate.py."""
+import json
+import os
+import pickle
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import yaml
+from safetensors.torch import save_file
+
+from oracle import common_ref, eval_ref, t5_ref
+from reprover_amd import synth
+from reprover_amd.common import IndexedCorpus
+from reprover_amd.retrieval import evaluate as evaluate_cli
+from reprover_amd.retrieval import index as index_cli
+from reprover_amd.retrieval import main as main_cli
+from reprover_amd.retrieval.model import PremiseRetriever
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def workdir(tiny_weights):
+    cfg, sd = tiny_weights
+    d = tempfile.mkdtemp()
+    ckpt = os.path.join(d, "ckpt")
+    os.makedirs(ckpt)
+    hf_cfg = {k: cfg[k] for k in ("vocab_size", "d_model", "d_kv", "num_heads", "d_ff", "num_layers",
+                                  "relative_attention_num_buckets", "relative_attention_max_distance",
+                                  "layer_norm_epsilon", "feed_forward_proj")}
+    json.dump(hf_cfg, open(os.path.join(ckpt, "config.json"), "w"))
+    save_file({k: v.clone().contiguous() for k, v in sd.items() if k != "encoder.embed_tokens.weight"},
+              os.path.join(ckpt, "model.safetensors"))
+    files = synth.synth_corpus_records(30, 500, seed=91, max_imports=6)
+    cpath = os.path.join(d, "corpus.jsonl")
+    synth.write_corpus_jsonl(cpath, files)
+    sdir = os.path.join(d, "split")
+    os.makedirs(sdir)
+    splits = {"train": synth.synth_split(files, 12, seed=92, min_file=15),
+              "val": synth.synth_split(files, 10, seed=93, min_file=15),
+              "test": synth.synth_split(files, 8, seed=94, min_file=15)}
+    for name, sp in splits.items():
+        json.dump(sp, open(os.path.join(sdir, f"{name}.json"), "w"))
+    conf = {"model": {"model_name": ckpt, "num_retrieved": 10},
+            "data": {"data_path": sdir, "corpus_path": cpath, "eval_batch_size": 16, "max_seq_len": 256}}
+    yaml.safe_dump(conf, open(os.path.join(d, "conf.yaml"), "w"))
+    return d, ckpt, cpath, sdir, splits, cfg, sd
+
+
+def test_index_cli_writes_reference_style_pickle(workdir):
+    d, ckpt, cpath, sdir, splits, cfg, sd = workdir
+    out = os.path.join(d, "indexed.pickle")
+    index_cli.main(["--ckpt_path", ckpt, "--corpus-path", cpath, "--output-path", out, "--batch-size", "32"])
+    ic = pickle.load(open(out, "rb"))
+    assert isinstance(ic, IndexedCorpus) and ic.embeddings.dtype == torch.float32 and ic.embeddings.device.type == "cpu"
+    assert ic.embeddings.shape == (len(ic.corpus), cfg["d_model"])
+    texts = [p.serialize() for p in common_ref.CorpusRef(cpath).all_premises]
+    ref = t5_ref.encode_texts(cfg, sd, texts[:64], 2048, 16)
+    cos = torch.nn.functional.cosine_similarity(ic.embeddings[:64], ref, dim=1)
+    assert cos.min().item() > 0.999
+    with pytest.raises(FileExistsError):
+        PremiseRetriever.load_hf(os.path.join(d, "no_such_ckpt"), 256, "cuda:0")
+
+
+def test_predict_validate_and_evaluate(workdir):
+    d, ckpt, cpath, sdir, splits, cfg, sd = workdir
+    log_dir = os.path.join(d, "logs")
+    main_cli.main(["predict", "--config", os.path.join(d, "conf.yaml"), "--log-dir", log_dir])
+    preds = pickle.load(open(os.path.join(log_dir, "predictions.pickle"), "rb"))
+    n_examples = sum(len(t["traced_tactics"]) for sp in splits.values() for t in sp)
+    assert len(preds) == n_examples and all(len(p["retrieved_premises"]) == 10 for p in preds)
+    # every retrieved premise is accessible and scores are sorted
+    oc = common_ref.CorpusRef(cpath)
+    for p in preds[:20]:
+        keys = oc.accessible_keys(p["context"].path, common_ref.Pos(*p["context"].theorem_pos))
+        assert all((q.path, q.full_name) in keys for q in p["retrieved_premises"])
+        assert all(a >= b for a, b in zip(p["scores"], p["scores"][1:]))
+    # evaluate.py on the pickle == the oracle's metrics on the same retrieved lists
+    pm = evaluate_cli.load_preds_map(os.path.join(log_dir, "predictions.pickle"))
+    for name, sp in splits.items():
+        r = evaluate_cli._eval(sp, pm)
+        ex = eval_ref.load_eval_examples(os.path.join(sdir, f"{name}.json"), oc)
+        where = {(q.path, q.full_name, tuple(q.start)): i for i, q in enumerate(oc.all_premises)}
+        retrieved = [[where[(q.path, q.full_name, tuple(q.start))] for q in
+                      pm[(e["file_path"], e["full_name"], tuple(e["start"]), e["tactic_idx"])]["retrieved_premises"]]
+                     for e in ex]
+        assert np.allclose(r, eval_ref.eval_predictions(ex, retrieved), atol=1e-9)
+    # validate: Recall@k / MRR as validation_step logs them
+    model = PremiseRetriever.load_hf(ckpt, 256, "cuda:0")
+    model.num_retrieved = 10
+    from reprover_amd.retrieval.datamodule import RetrievalDataModule
+
+    dm = RetrievalDataModule(sdir, cpath, 16, 256, model.tokenizer)
+    m = main_cli.run_validate(model, dm)
+    ex = eval_ref.load_eval_examples(os.path.join(sdir, "val.json"), oc)
+    keymap = {(e["file_path"], e["full_name"], tuple(e["start"]), e["tactic_idx"]): i for i, e in enumerate(ex)}
+    retrieved = [None] * len(ex)
+    for key, p in pm.items():
+        if key in keymap:
+            retrieved[keymap[key]] = [where[(q.path, q.full_name, tuple(q.start))] for q in p["retrieved_premises"]]
+    rec, mrr = eval_ref.validation_metrics([e["all_pos_premises"] for e in ex], retrieved, 10)
+    assert abs(m["MRR"] - mrr) < 1e-9 and np.allclose([m[f"Recall@{j + 1}_val"] for j in range(10)], rec, atol=1e-9)

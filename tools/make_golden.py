@@ -398,9 +398,70 @@ def g7_predict():
     print("g7 ok")
 
 
+# ----------------------------------------------------------------------------------------------
+def g8_eval_data():
+    """Evaluation-side host logic: the reference's RetrievalDataset (is_train=False) examples and
+    collate, and retrieval/evaluate.py::_eval on a synthetic predictions list."""
+    import importlib
+    from oracle import eval_ref
+
+    dmod = importlib.import_module("retrieval.datamodule")
+    emod = importlib.import_module("retrieval.evaluate")
+    files = synth.synth_corpus_records(30, 500, seed=81, max_imports=5)
+    td = tempfile.mkdtemp()
+    cpath = os.path.join(td, "corpus.jsonl")
+    synth.write_corpus_jsonl(cpath, files)
+    split = synth.synth_split(files, 40, seed=82, min_file=8)
+    spath = os.path.join(td, "val.json")
+    json.dump(split, open(spath, "w"))
+    corpus = common.Corpus(cpath)
+    ocorpus = common_ref.CorpusRef(cpath)
+    tok = ByT5Tokenizer()
+    ds = dmod.RetrievalDataset([spath], corpus, 3, 1, 256, tok, is_train=False)
+    where = {id(p): i for i, p in enumerate(corpus.all_premises)}
+    examples = []
+    for ex in ds.data:
+        examples.append({"file_path": ex["file_path"], "full_name": ex["full_name"], "start": ex["start"],
+                         "tactic_idx": ex["tactic_idx"], "state": ex["context"].state,
+                         "all_pos_premises": sorted(where[id(p)] for p in ex["all_pos_premises"])})
+    mine = eval_ref.load_eval_examples(spath, ocorpus)
+    assert mine == examples, "oracle eval-example drift"
+    batch = ds.collate(ds.data[:7])
+    assert set(batch) == {"context", "context_ids", "context_mask", "url", "commit", "file_path", "full_name",
+                          "start", "tactic_idx", "all_pos_premises"}
+    # synthetic predictions: 20 distinct premises per example, positives sprinkled in
+    rng = np.random.default_rng(83)
+    N = len(corpus)
+    retrieved, preds = [], []
+    for ex_ref, ex in zip(ds.data, examples):
+        got = [int(x) for x in rng.choice(N, size=20, replace=False)]
+        for p in ex["all_pos_premises"]:
+            if rng.random() < 0.6 and p not in got:
+                got[int(rng.integers(0, 20))] = p
+        assert len(set(got)) == 20
+        retrieved.append(got)
+        preds.append({"file_path": ex["file_path"], "full_name": ex["full_name"], "start": ex["start"],
+                      "tactic_idx": ex["tactic_idx"], "all_pos_premises": ex_ref["all_pos_premises"],
+                      "retrieved_premises": [corpus.all_premises[i] for i in got]})
+    preds_map = {(p["file_path"], p["full_name"], tuple(p["start"]), p["tactic_idx"]): p for p in preds}
+    assert len(preds_map) == len(preds)
+    R1, R10, MRR = emod._eval(split, preds_map)
+    o = eval_ref.eval_predictions(examples, retrieved)
+    assert np.allclose(o, (R1, R10, MRR), atol=1e-9), (o, R1, R10, MRR)
+    rec, mrr = eval_ref.validation_metrics([e["all_pos_premises"] for e in examples], retrieved, 20)
+    assert abs(rec[0] - R1) < 1e-9 and abs(rec[9] - R10) < 1e-9 and abs(mrr - MRR) < 1e-12  # the two reference formulas agree
+    json.dump({"corpus_seed": 81, "n_files": 30, "n_premises": 500, "max_imports": 5, "split_seed": 82,
+               "n_theorems": 40, "min_file": 8, "examples": examples, "retrieved": retrieved,
+               "R1": R1, "R10": R10, "MRR": MRR, "recall_at_k": rec,
+               "collate_keys": sorted(batch), "collate_ids_first7": batch["context_ids"].tolist()},
+              open(os.path.join(OUT, "g8_eval.json"), "w"), ensure_ascii=False)
+    print(f"g8 ok: {len(examples)} examples, {sum(1 for e in examples if e['all_pos_premises'])} with premises; "
+          f"R@1 {R1:.3f} R@10 {R10:.3f} MRR {MRR:.4f}")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     torch.manual_seed(0)
     for name in which:
         {"g1": g1_tokenizer, "g2": g2_serialize, "g3": g3_buckets, "g4": g4_tiny, "g5": g5_small,
-         "g6": g6_nearest, "g7": g7_predict}[name]()
+         "g6": g6_nearest, "g7": g7_predict, "g8": g8_eval_data}[name]()
