@@ -223,7 +223,7 @@ def synth_state(rng: np.random.Generator, n_bytes: int) -> str:
 # ----------------------------------------------------------------------------------------------
 # Dataset splits ({train,val,test}.json of SURVEY.md App. B.2)
 # ----------------------------------------------------------------------------------------------
-def synth_split(records: Sequence[dict], n_theorems: int, seed: int, min_file: int = 0) -> List[dict]:
+def synth_split(records: Sequence[dict], n_theorems: int, seed: int, min_file: int = 0, accept=None) -> List[dict]:
     """Theorems with traced tactics whose annotated tactics point at premises of the corpus records
     (positions inside real premises, plus some that resolve to nothing and some tactics with no
     premises at all)."""
@@ -232,8 +232,11 @@ def synth_split(records: Sequence[dict], n_theorems: int, seed: int, min_file: i
     out = []
     for t in range(n_theorems):
         f = int(rng.choice(usable))
-        rec = records[f]
         start = [int(rng.integers(1, 400)), int(rng.integers(0, 30))]
+        while accept is not None and not accept(records[f]["path"], start):  # e.g. "enough accessible premises"
+            f = int(rng.choice(usable))
+            start = [int(rng.integers(1, 400)), int(rng.integers(0, 30))]
+        rec = records[f]
         tactics = []
         for k in range(int(rng.integers(1, 5))):
             provs = []

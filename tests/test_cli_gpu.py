@@ -40,9 +40,16 @@ def workdir(tiny_weights):
     synth.write_corpus_jsonl(cpath, files)
     sdir = os.path.join(d, "split")
     os.makedirs(sdir)
-    splits = {"train": synth.synth_split(files, 12, seed=92, min_file=15),
-              "val": synth.synth_split(files, 10, seed=93, min_file=15),
-              "test": synth.synth_split(files, 8, seed=94, min_file=15)}
+    from reprover_amd.common import Corpus, Pos
+
+    corpus = Corpus(cpath)
+
+    def enough(path, start):  # the reference raises ValueError below k accessible premises
+        return corpus.accessible_mask(path, Pos(*start)).sum() >= 12
+
+    splits = {"train": synth.synth_split(files, 12, seed=92, min_file=15, accept=enough),
+              "val": synth.synth_split(files, 10, seed=93, min_file=15, accept=enough),
+              "test": synth.synth_split(files, 8, seed=94, min_file=15, accept=enough)}
     for name, sp in splits.items():
         json.dump(sp, open(os.path.join(sdir, f"{name}.json"), "w"))
     conf = {"model": {"model_name": ckpt, "num_retrieved": 10},
