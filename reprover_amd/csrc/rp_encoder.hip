@@ -29,6 +29,8 @@ thread_local std::string g_last_error;
 extern int g_scan_cfg;
 static int g_gemm_group_m = 8;
 static int g_gemm_variant = 6;
+static int g_gemm_variant_o = 11;  // the K = H*64 attention-output projection is epilogue-bound: 2 blocks/CU
+static int g_gemm_skinny = 1;   // use the small-token-count GEMM configuration automatically
 static int g_attn_variant = 1;  // 0: register-staged kernel, 1: LDS-DMA + transpose-read kernel  // tile/pipeline configuration, see launch_gemm()
 
 // ------------------------------------------------------------------------------------------
@@ -180,27 +182,44 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 // CONSECUTIVE output features (row = 8g + 4hi + 0..3) — so every epilogue moves 8 B (bf16x4) or 16 B
 // (fp32x4) per lane per access instead of 2-4 B, a quarter of the store instructions.
 //   acc[i][j][4g + e]  <->  feature m_base + 32 i + 8 g + 4 hi + e,  token n_base + 32 j + (lane & 31)
+// Each epilogue goes through the wave's private LDS staging area (EPI_STAGE_BYTES, rows of
+// EPI_ROW_BYTES): the accumulators are written token-row-major with ds_write_b128 / b64 (4
+// consecutive features per lane), then read back so that 8 or 16 consecutive lanes cover one token's
+// contiguous 128-B (fp32 x 32) or 64/128-B (bf16) span: global accesses become full cache lines,
+// 16 B per lane, instead of 8-16 B scattered over 32 rows.
 struct EpiStoreBf16 {  // out[token, feature] = bf16(acc)
   bf16_t* out;
-  int ldo, n_valid;  // n_valid = number of real output features
+  int ldo, n_valid;  // n_valid = number of real output features (multiple of 8)
   template <int FM, int FN>
-  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane) {
+  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
     const int hi = lane >> 5, cl = lane & 31;
+    // 64 token rows at a time: rows of FM*32 features bf16 (FM*64 B <= 128 B)
+    constexpr int LPR = FM * 4;         // lanes per token row (16 B each)
+    constexpr int RPI = 64 / LPR;       // token rows per pass
+    const int sub = lane % LPR, rr = lane / LPR;
+    const int f = m_base + sub * 8;
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      bf16_t* row = out + (size_t)(n_base + j * 32 + cl) * ldo;
+    for (int jb = 0; jb < FN; jb += 2) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+      for (int jj = 0; jj < 2 && jb + jj < FN; ++jj)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int f = m_base + i * 32 + 8 * g + 4 * hi;
-          if (f < n_valid) {  // n_valid is a multiple of 4
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
             uint2 v;
-            v.x = pack_bf2(acc[i][j][4 * g], acc[i][j][4 * g + 1]);
-            v.y = pack_bf2(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-            *reinterpret_cast<uint2*>(row + f) = v;
+            v.x = pack_bf2(acc[i][jb + jj][4 * g], acc[i][jb + jj][4 * g + 1]);
+            v.y = pack_bf2(acc[i][jb + jj][4 * g + 2], acc[i][jb + jj][4 * g + 3]);
+            *reinterpret_cast<uint2*>(stage + (jj * 32 + cl) * EPI_ROW_BYTES + (i * 32 + 8 * g + 4 * hi) * 2) = v;
           }
+      const int nrows = (FN - jb >= 2) ? 64 : 32;
+#pragma unroll
+      for (int t0 = 0; t0 < 64; t0 += RPI) {
+        const int t = t0 + rr;
+        if (t < nrows) {
+          const uint4 v = *reinterpret_cast<const uint4*>(stage + t * EPI_ROW_BYTES + sub * 16);
+          if (f < n_valid) *reinterpret_cast<uint4*>(out + (size_t)(n_base + jb * 32 + t) * ldo + f) = v;
         }
+      }
     }
   }
 };
@@ -209,26 +228,38 @@ struct EpiResidF32 {  // x[token, feature] += acc   (residual stream, fp32)
   float* x;
   int ldx, n_valid;
   template <int FM, int FN>
-  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane) {
+  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
     const int hi = lane >> 5, cl = lane & 31;
+    const int sub = lane & 7, rr = lane >> 3;  // 8 lanes x 16 B = one token's 32 features; 8 tokens per pass
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      float* row = x + (size_t)(n_base + j * 32 + cl) * ldx;
+    for (int i = 0; i < FM; ++i) {  // 32 features at a time: rows of 128 B
+      const int f = m_base + i * 32 + sub * 4;
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+      for (int jb = 0; jb < FN; jb += 2) {  // 64 token rows at a time
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int f = m_base + i * 32 + 8 * g + 4 * hi;
-          if (f < n_valid) {
-            float4* p = reinterpret_cast<float4*>(row + f);
-            float4 v = *p;
-            v.x += acc[i][j][4 * g];
-            v.y += acc[i][j][4 * g + 1];
-            v.z += acc[i][j][4 * g + 2];
-            v.w += acc[i][j][4 * g + 3];
-            *p = v;
+        for (int jj = 0; jj < 2 && jb + jj < FN; ++jj)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(stage + (jj * 32 + cl) * EPI_ROW_BYTES + (8 * g + 4 * hi) * 4) = make_float4(
+                acc[i][jb + jj][4 * g], acc[i][jb + jj][4 * g + 1], acc[i][jb + jj][4 * g + 2], acc[i][jb + jj][4 * g + 3]);
+        const int nrows = (FN - jb >= 2) ? 64 : 32;
+#pragma unroll
+        for (int t0 = 0; t0 < 64; t0 += 8) {
+          const int t = t0 + rr;
+          if (t < nrows) {
+            const float4 d = *reinterpret_cast<const float4*>(stage + t * EPI_ROW_BYTES + sub * 16);
+            if (f < n_valid) {
+              float4* p = reinterpret_cast<float4*>(x + (size_t)(n_base + jb * 32 + t) * ldx + f);
+              float4 v = *p;
+              v.x += d.x;
+              v.y += d.y;
+              v.z += d.z;
+              v.w += d.w;
+              *p = v;
+            }
           }
         }
+      }
     }
   }
 };
@@ -237,25 +268,37 @@ struct EpiGegluBf16 {  // W rows interleaved 32 gate / 32 up: even row-fragments
   bf16_t* out;         // [tokens, n_valid/2]
   int ldo, n_valid;    // n_valid counts interleaved rows (= 2 * d_ff)
   template <int FM, int FN>
-  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane) {
+  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
     static_assert(FM % 2 == 0, "gate/up pairs");
     const int hi = lane >> 5, cl = lane & 31;
+    // 64 token rows at a time: rows of FM/2*32 outputs bf16 (FM*32 B)
+    constexpr int LPR = FM * 2;         // lanes per token row (16 B each)
+    constexpr int RPI = 64 / LPR;
+    const int sub = lane % LPR, rr = lane / LPR;
+    const int f = (m_base >> 1) + sub * 8;
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      bf16_t* row = out + (size_t)(n_base + j * 32 + cl) * ldo;
+    for (int jb = 0; jb < FN; jb += 2) {
 #pragma unroll
-      for (int i = 0; i < FM; i += 2) {
-        if (m_base + i * 32 >= n_valid) continue;
-        const int f0 = ((m_base + i * 32) >> 1) + 4 * hi;
+      for (int jj = 0; jj < 2 && jb + jj < FN; ++jj)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float y[4];
+        for (int i = 0; i < FM; i += 2)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) y[e] = gelu_new(acc[i][j][4 * g + e]) * acc[i + 1][j][4 * g + e];
-          uint2 v;
-          v.x = pack_bf2(y[0], y[1]);
-          v.y = pack_bf2(y[2], y[3]);
-          *reinterpret_cast<uint2*>(row + f0 + 8 * g) = v;
+          for (int g = 0; g < 4; ++g) {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = gelu_new(acc[i][jb + jj][4 * g + e]) * acc[i + 1][jb + jj][4 * g + e];
+            uint2 v;
+            v.x = pack_bf2(y[0], y[1]);
+            v.y = pack_bf2(y[2], y[3]);
+            *reinterpret_cast<uint2*>(stage + (jj * 32 + cl) * EPI_ROW_BYTES + ((i >> 1) * 32 + 8 * g + 4 * hi) * 2) = v;
+          }
+      const int nrows = (FN - jb >= 2) ? 64 : 32;
+#pragma unroll
+      for (int t0 = 0; t0 < 64; t0 += RPI) {
+        const int t = t0 + rr;
+        if (t < nrows) {
+          const uint4 v = *reinterpret_cast<const uint4*>(stage + t * EPI_ROW_BYTES + sub * 16);
+          if (2 * f < n_valid) *reinterpret_cast<uint4*>(out + (size_t)(n_base + jb * 32 + t) * ldo + f) = v;
         }
       }
     }
@@ -321,8 +364,12 @@ template <class Epi>
 static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, int ldw, int n_rows_w,
                             int K, Epi epi, hipStream_t stream, int prof_class) {
   GemmOperand a{A, lda, M}, w{W, ldw, n_rows_w};
-  int v = g_gemm_variant;
+  int v = (prof_class == RP_K_GEMM_O) ? g_gemm_variant_o : g_gemm_variant;
   const bool k64 = (K % 64 == 0), m256 = (M % 256 == 0);
+  // Few tokens (the prover's single-state query): the 256 x 256 tiling would leave
+  // most CUs idle and each workgroup latency-bound on its K loop.  Switch to 64-feature tiles with a
+  // 7-deep LDS ring so every workgroup streams its weight slab with ~6 K-steps of DMA in flight.
+  if (g_gemm_skinny && m256 && ((n_rows_w + 255) / 256) * (M / 256) < 96) v = 12;
   if ((v == 1 || v == 6) && !k64) v = (v == 6 && m256) ? 9 : 0;
   if (v >= 5 && !m256) v = 0;
   // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages>; measured on
@@ -333,6 +380,7 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
     case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
     case 10: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, true>(w, a, K, epi, stream, prof_class);
     case 11: return launch_gemm_cfg<GemmCfg<256, 128, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
+    case 12: return launch_gemm_cfg<GemmCfg<64, 256, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class);
     default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class);
   }
 }
@@ -874,8 +922,17 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     return RP_OK;
   }
   if (!strcmp(name, "gemm_variant")) {
-    RP_REQUIRE(value >= 0 && value <= 11, "gemm_variant out of range");
+    RP_REQUIRE(value >= 0 && value <= 12, "gemm_variant out of range");
     g_gemm_variant = value;
+    return RP_OK;
+  }
+  if (!strcmp(name, "gemm_variant_o")) {
+    RP_REQUIRE(value >= 0 && value <= 12, "gemm_variant_o out of range");
+    g_gemm_variant_o = value;
+    return RP_OK;
+  }
+  if (!strcmp(name, "gemm_skinny")) {
+    g_gemm_skinny = value != 0;
     return RP_OK;
   }
   if (!strcmp(name, "attn_variant")) {
@@ -1125,7 +1182,7 @@ extern "C" RpStatus rp_dbg_gemm(const void* A, const void* W, void* out, int32_t
     case RP_EPI_STORE_BF16:
       return launch_gemm(a, K, M, w, K, N, K, EpiStoreBf16{(bf16_t*)out, n_valid, n_valid}, stream, RP_K_GEMM_QKV);
     case RP_EPI_RESID_F32:
-      return launch_gemm(a, K, M, w, K, N, K, EpiResidF32{(float*)out, n_valid, n_valid}, stream, RP_K_GEMM_O);
+      return launch_gemm(a, K, M, w, K, N, K, EpiResidF32{(float*)out, n_valid, n_valid}, stream, RP_K_GEMM_WO);
     case RP_EPI_GEGLU_BF16:
       return launch_gemm(a, K, M, w, K, N, K, EpiGegluBf16{(bf16_t*)out, n_valid / 2, n_valid}, stream, RP_K_GEMM_WI);
   }

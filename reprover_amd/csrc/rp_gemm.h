@@ -27,13 +27,15 @@ __device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * 
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSTAGE_>
 struct GemmCfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_;
+  static constexpr int NWAVES_ = WM_ * WN_;
   static constexpr int NWAVES = WM * WN, THREADS = NWAVES * 64;
   static constexpr int FM = BM / WM / 32, FN = BN / WN / 32;  // 32x32 accumulator fragments per wave
   static constexpr int ROW_BYTES = BK * 2;
   static constexpr int SLOTS = ROW_BYTES / 16;           // 16-B chunks per row: 4 (BK=32) / 8 (BK=64)
   static constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES;
   static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-  static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
+  static constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;
+  static constexpr int LDS_BYTES = RING_BYTES > NWAVES_ * 9216 ? RING_BYTES : NWAVES_ * 9216;
   static constexpr int ROWS_PER_DMA = 1024 / ROW_BYTES;  // rows covered by one wave-instruction
   static constexpr int A_DMA = BM / ROWS_PER_DMA / NWAVES, W_DMA = BN / ROWS_PER_DMA / NWAVES;  // per wave
   static_assert(BM % (ROWS_PER_DMA * NWAVES) == 0 && BN % (ROWS_PER_DMA * NWAVES) == 0, "DMA split");
@@ -43,6 +45,12 @@ struct GemmCfg {
   __device__ static __forceinline__ int swz(int row) { return (BK == 32) ? ((row >> 2) & 3) : ((row >> 1) & 7); }
   __device__ static __forceinline__ int off(int row, int kc) { return row * ROW_BYTES + ((kc ^ swz(row)) << 4); }
 };
+
+// Per-wave LDS staging area the epilogues may use after the main loop (the ring is dead by then) to
+// turn the accumulator layout (lane = column) into row-contiguous 16-B-per-lane global accesses:
+// up to 64 rows of 128 B + 16 B pad.
+constexpr int EPI_ROW_BYTES = 144;
+constexpr int EPI_STAGE_BYTES = 64 * EPI_ROW_BYTES;  // 9216 B per wave
 
 struct GemmOperand {
   const bf16_t* ptr;  // [rows, ld] row-major, K-contiguous
@@ -156,7 +164,8 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
   }
   __syncthreads();  // all waves done with LDS before an epilogue reuses it
 
-  epi.template run<FM, FN>(acc, tile_m * C::BM + wave_row * (FM * 32), tile_n * C::BN + wave_col * (FN * 32), lane);
+  epi.template run<FM, FN>(acc, tile_m * C::BM + wave_row * (FM * 32), tile_n * C::BN + wave_col * (FN * 32), lane,
+                           smem + wave * EPI_STAGE_BYTES);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -283,7 +292,8 @@ __device__ __forceinline__ void gemm_tile_pingpong(const GemmOperand A, const Ge
   if (grp == 0) __builtin_amdgcn_s_barrier();  // group 0 waits out group 1's last COMPUTE
   __syncthreads();
 
-  epi.template run<FM, FN>(acc, tile_m * C::BM + wave_row * (FM * 32), tile_n * C::BN + wave_col * (FN * 32), lane);
+  epi.template run<FM, FN>(acc, tile_m * C::BM + wave_row * (FM * 32), tile_n * C::BN + wave_col * (FN * 32), lane,
+                           smem + wave * EPI_STAGE_BYTES);
 }
 
 // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (observed, speed only), so consecutive

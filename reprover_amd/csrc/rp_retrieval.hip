@@ -70,7 +70,7 @@ struct EpiSim {
   }
 
   template <int FM, int FN>
-  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane) {
+  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* /*stage*/) {
     const int hi = lane >> 5, cl = lane & 31;
     // stage the tile's queries: own_file / q_key / threshold key / float lower bound of the threshold
     int32_t* s_own = reinterpret_cast<int32_t*>(smem);                  // [bm]

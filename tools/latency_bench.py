@@ -1,0 +1,38 @@
+"""B=1 retrieve() latency (the prover's call pattern, prover/tactic_generator.py:286-292)."""
+import os, sys, time, tempfile
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reprover_amd import _lib, synth
+from reprover_amd.common import Pos
+from reprover_amd.retrieval.model import PremiseRetriever
+import importlib.util
+spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+bench = importlib.util.module_from_spec(spec); sys.argv = ["x"]; spec.loader.exec_module(bench)
+dev = torch.device("cuda")
+cfg = synth.t5_config("byt5-small")
+sd = bench.random_init_state_dict(cfg, dev, 1)
+from reprover_amd.encoder import HipT5Encoder
+model = PremiseRetriever(HipT5Encoder(cfg, sd, dev), max_seq_len=2048)
+d = tempfile.mkdtemp(); cp = os.path.join(d, "c.jsonl")
+synth.write_corpus_jsonl(cp, bench.fast_corpus_records(5000, 130000, 1))
+model.load_corpus(cp)
+N = len(model.corpus)
+g = torch.Generator(device=dev); g.manual_seed(0)
+model.corpus_embeddings = torch.nn.functional.normalize(torch.randn(N, 1472, generator=g, device=dev), dim=1).to(torch.bfloat16)
+model.embeddings_staled = False
+rng = np.random.default_rng(0)
+for nbytes in (100, 300, 1000):
+    states = [synth.synth_state(rng, nbytes) for _ in range(30)]
+    for s in states[:5]:
+        model.retrieve(s, "M/F4000.lean", "t", Pos(30, 0), 100)
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for s in states[5:]:
+        model.retrieve(s, "M/F4000.lean", "t", Pos(30, 0), 100)
+    dt = (time.perf_counter() - t0) / 25
+    prof = _lib.profile_read(); _lib.profile_enable(False)
+    gpu_ms = sum(v[0] for v in prof.values()) / 25
+    top = sorted(prof.items(), key=lambda kv: -kv[1][0])[:6]
+    print(f"state {nbytes:5d} B: retrieve() {dt*1e3:7.3f} ms wall; GPU kernels {gpu_ms:6.3f} ms; " +
+          ", ".join(f"{k} {v[0]/25*1e3:.0f}us" for k, v in top), flush=True)
