@@ -84,6 +84,11 @@ SIGNATURES = {
         C.c_int32,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
     ),
+    "rp_dbg_gemm_fused": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+         C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p],
+    ),
     "rp_dbg_rmsnorm": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "rp_dbg_attention": (
         C.c_int32,

@@ -30,6 +30,7 @@ extern int g_scan_cfg;
 static int g_gemm_group_m = 8;
 static int g_gemm_variant = 6;
 static int g_gemm_variant_o = 11;  // the K = H*64 attention-output projection is epilogue-bound: 2 blocks/CU
+static int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 static int g_gemm_skinny = 1;   // use the small-token-count GEMM configuration automatically
 static int g_attn_variant = 1;  // 0: register-staged kernel, 1: LDS-DMA + transpose-read kernel  // tile/pipeline configuration, see launch_gemm()
 
@@ -85,9 +86,11 @@ enum PackMode { PACK_CONCAT3 = 0, PACK_GEGLU = 1, PACK_COPY = 2 };
 //   CONCAT3: rows [0,n) from s0, [n,2n) from s1, [2n,3n) from s2      (fused q|k|v)
 //   GEGLU  : 64-row blocks: 32 rows of s0 (gate, wi_0) then 32 rows of s1 (up, wi_1)
 //   COPY   : row r from s0
+//   colscale (optional, fp32 [cols]): every row is multiplied column-wise before rounding — used to
+//   fold the T5 RMSNorm weight into the projection that consumes the normalised activations.
 template <typename T>
 __global__ void pack_rows_kernel(bf16_t* dst, const void* s0, const void* s1, const void* s2,
-                                 int rows_dst, int cols, int n, int mode) {
+                                 int rows_dst, int cols, int n, int mode, const float* colscale) {
   const int r = blockIdx.x;
   const void* src;
   int sr;
@@ -101,8 +104,11 @@ __global__ void pack_rows_kernel(bf16_t* dst, const void* s0, const void* s1, co
     src = s0;
     sr = r;
   }
-  for (int c = threadIdx.x; c < cols; c += blockDim.x)
-    dst[(size_t)r * cols + c] = f2bf(load_as_f32<T>(src, (size_t)sr * cols + c));
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    float v = load_as_f32<T>(src, (size_t)sr * cols + c);
+    if (colscale) v *= colscale[c];
+    dst[(size_t)r * cols + c] = f2bf(v);
+  }
 }
 
 template <typename T>
@@ -113,12 +119,14 @@ __global__ void to_f32_kernel(float* dst, const void* src, int n) {
 
 // ------------------------------------------------------------------------------------------
 // K1: byte-token embedding gather  x[t] = embed[ids[t]]   (HF:678); the table (vocab x D fp32,
-//   2.3 MB for ByT5-small) is L2-resident.
+//   2.3 MB for ByT5-small) is L2-resident.  Also emits the bf16 copy of x (the A operand of the first
+//   projection) and the row's sum of squares (RMSNorm statistic, applied in that GEMM's epilogue).
 //   rows >= T (tile padding) get token 0 so every workspace row stays finite.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ ids,
                                                     const float* __restrict__ table,
-                                                    float* __restrict__ x, int T, int Tp, int D,
+                                                    float* __restrict__ x, bf16_t* __restrict__ xb,
+                                                    float* __restrict__ ssp, int np, int T, int Tp, int D,
                                                     int vocab) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -127,7 +135,20 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ 
   id = min(max(id, 0), vocab - 1);
   const float4* src = reinterpret_cast<const float4*>(table + (size_t)id * D);
   float4* dst = reinterpret_cast<float4*>(x + (size_t)row * D);
-  for (int c = lane; c < (D >> 2); c += 64) dst[c] = src[c];
+  uint2* dstb = reinterpret_cast<uint2*>(xb + (size_t)row * D);
+  float ss = 0.f;
+  for (int c = lane; c < (D >> 2); c += 64) {
+    const float4 v = src[c];
+    dst[c] = v;
+    uint2 o;
+    o.x = pack_bf2(v.x, v.y);
+    o.y = pack_bf2(v.z, v.w);
+    dstb[c] = o;
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ss = wave_sum(ss);
+  // sum-of-squares partials of the row (see EpiResidF32): slot 0 carries the whole row here
+  for (int p = lane; p < np; p += 64) ssp[(size_t)row * np + p] = (p == 0) ? ss : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -187,12 +208,37 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 // consecutive features per lane), then read back so that 8 or 16 consecutive lanes cover one token's
 // contiguous 128-B (fp32 x 32) or 64/128-B (bf16) span: global accesses become full cache lines,
 // 16 B per lane, instead of 8-16 B scattered over 32 rows.
-struct EpiStoreBf16 {  // out[token, feature] = bf16(acc)
+// T5 RMSNorm folded into the GEMMs (HF:59-72).  h = w * x * rsqrt(mean(x^2) + eps) feeds only the QKV
+// and FFN-in projections, so:  (a) w is folded into those weights when they are packed;  (b) the
+// producer of x (embedding kernel / residual-add epilogue) also stores xb = bf16(x), the GEMM A operand,
+// and per-row partial sums of squares ssp[token][p], one slot per 64-feature wave tile (deterministic:
+// no atomics);  (c) the consuming epilogue multiplies each accumulator by rs[token] =
+// rsqrt(sum_p ssp[token][p] / D + eps), reduced once per sub-layer by the tiny rowscale_kernel.  No separate
+// normalisation pass over x remains.
+struct RowScale {
+  const float* rs;  // [tokens] or NULL (no scaling); produced by rowscale_kernel from the ssp partials
+  __device__ __forceinline__ float get(int token) const { return rs ? rs[token] : 1.f; }
+};
+
+// rs[token] = rsqrt(sum_p ssp[token][p] / D + eps), slots summed in index order
+__global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ ssp, float* __restrict__ rs, int rows,
+                                                       int np, float inv_d, float eps) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= rows) return;
+  const float* p = ssp + (size_t)t * np;
+  float s = 0.f;
+  for (int i = 0; i < np; ++i) s += p[i];
+  rs[t] = rsqrtf(s * inv_d + eps);
+}
+
+struct EpiStoreBf16 {  // out[token, feature] = bf16(acc * rs[token])
   bf16_t* out;
   int ldo, n_valid;  // n_valid = number of real output features (multiple of 8)
+  RowScale rs;
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
     const int hi = lane >> 5, cl = lane & 31;
+    static_assert(FM == 2, "staging rows hold one 64-feature wave tile");
     // 64 token rows at a time: rows of FM*32 features bf16 (FM*64 B <= 128 B)
     constexpr int LPR = FM * 4;         // lanes per token row (16 B each)
     constexpr int RPI = 64 / LPR;       // token rows per pass
@@ -201,16 +247,18 @@ struct EpiStoreBf16 {  // out[token, feature] = bf16(acc)
 #pragma unroll
     for (int jb = 0; jb < FN; jb += 2) {
 #pragma unroll
-      for (int jj = 0; jj < 2 && jb + jj < FN; ++jj)
+      for (int jj = 0; jj < 2 && jb + jj < FN; ++jj) {
+        const float sc = rs.get(n_base + (jb + jj) * 32 + cl);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             uint2 v;
-            v.x = pack_bf2(acc[i][jb + jj][4 * g], acc[i][jb + jj][4 * g + 1]);
-            v.y = pack_bf2(acc[i][jb + jj][4 * g + 2], acc[i][jb + jj][4 * g + 3]);
+            v.x = pack_bf2(acc[i][jb + jj][4 * g] * sc, acc[i][jb + jj][4 * g + 1] * sc);
+            v.y = pack_bf2(acc[i][jb + jj][4 * g + 2] * sc, acc[i][jb + jj][4 * g + 3] * sc);
             *reinterpret_cast<uint2*>(stage + (jj * 32 + cl) * EPI_ROW_BYTES + (i * 32 + 8 * g + 4 * hi) * 2) = v;
           }
+      }
       const int nrows = (FN - jb >= 2) ? 64 : 32;
 #pragma unroll
       for (int t0 = 0; t0 < 64; t0 += RPI) {
@@ -224,13 +272,24 @@ struct EpiStoreBf16 {  // out[token, feature] = bf16(acc)
   }
 };
 
-struct EpiResidF32 {  // x[token, feature] += acc   (residual stream, fp32)
+struct EpiResidF32 {  // x[token, feature] += acc  (residual stream, fp32) [+ xb = bf16(x), + ssp partials]
   float* x;
   int ldx, n_valid;
+  bf16_t* xb;   // optional: bf16 copy of the updated rows (same leading dimension)
+  float* ssp;   // optional: [tokens, np] partial sums of squares, slot = feature / 64
+  int np;
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
+    static_assert(FM == 2, "staging rows hold one 64-feature wave tile");
     const int hi = lane >> 5, cl = lane & 31;
     const int sub = lane & 7, rr = lane >> 3;  // 8 lanes x 16 B = one token's 32 features; 8 tokens per pass
+    float ssq[FM / 2][(FN + 1) / 2][8];
+#pragma unroll
+    for (int q = 0; q < FM / 2; ++q)
+#pragma unroll
+      for (int a = 0; a < (FN + 1) / 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) ssq[q][a][c] = 0.f;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {  // 32 features at a time: rows of 128 B
       const int f = m_base + i * 32 + sub * 4;
@@ -249,14 +308,44 @@ struct EpiResidF32 {  // x[token, feature] += acc   (residual stream, fp32)
           if (t < nrows) {
             const float4 d = *reinterpret_cast<const float4*>(stage + t * EPI_ROW_BYTES + sub * 16);
             if (f < n_valid) {
-              float4* p = reinterpret_cast<float4*>(x + (size_t)(n_base + jb * 32 + t) * ldx + f);
+              const size_t off = (size_t)(n_base + jb * 32 + t) * ldx + f;
+              float4* p = reinterpret_cast<float4*>(x + off);
               float4 v = *p;
               v.x += d.x;
               v.y += d.y;
               v.z += d.z;
               v.w += d.w;
               *p = v;
+              if (xb) {
+                uint2 o;
+                o.x = pack_bf2(v.x, v.y);
+                o.y = pack_bf2(v.z, v.w);
+                *reinterpret_cast<uint2*>(xb + off) = o;
+              }
+              // explicit fma chain: the same rounding sequence in every unrolled instance, so a
+              // token's statistic does not depend on where it sits in the batch
+              float& q = ssq[i >> 1][jb >> 1][t0 >> 3];
+              q = __fmaf_rn(v.w, v.w, __fmaf_rn(v.z, v.z, __fmaf_rn(v.y, v.y, __fmaf_rn(v.x, v.x, q))));
             }
+          }
+        }
+      }
+    }
+    if (ssp) {
+#pragma unroll
+      for (int q = 0; q < FM / 2; ++q) {
+        const int slot = (m_base >> 6) + q;
+#pragma unroll
+        for (int jb = 0; jb < FN; jb += 2) {
+          const int nrows = (FN - jb >= 2) ? 64 : 32;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            float v = ssq[q][jb >> 1][c];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            const int t = c * 8 + rr;
+            if (sub == 0 && t < nrows && slot < np) ssp[(size_t)(n_base + jb * 32 + t) * np + slot] = v;
           }
         }
       }
@@ -267,9 +356,10 @@ struct EpiResidF32 {  // x[token, feature] += acc   (residual stream, fp32)
 struct EpiGegluBf16 {  // W rows interleaved 32 gate / 32 up: even row-fragments gate, odd up
   bf16_t* out;         // [tokens, n_valid/2]
   int ldo, n_valid;    // n_valid counts interleaved rows (= 2 * d_ff)
+  RowScale rs;
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
-    static_assert(FM % 2 == 0, "gate/up pairs");
+    static_assert(FM == 2, "one gate/up fragment pair per wave tile");
     const int hi = lane >> 5, cl = lane & 31;
     // 64 token rows at a time: rows of FM/2*32 outputs bf16 (FM*32 B)
     constexpr int LPR = FM * 2;         // lanes per token row (16 B each)
@@ -279,19 +369,22 @@ struct EpiGegluBf16 {  // W rows interleaved 32 gate / 32 up: even row-fragments
 #pragma unroll
     for (int jb = 0; jb < FN; jb += 2) {
 #pragma unroll
-      for (int jj = 0; jj < 2 && jb + jj < FN; ++jj)
+      for (int jj = 0; jj < 2 && jb + jj < FN; ++jj) {
+        const float sc = rs.get(n_base + (jb + jj) * 32 + cl);
 #pragma unroll
         for (int i = 0; i < FM; i += 2)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             float y[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = gelu_new(acc[i][jb + jj][4 * g + e]) * acc[i + 1][jb + jj][4 * g + e];
+            for (int e = 0; e < 4; ++e)
+              y[e] = gelu_new(acc[i][jb + jj][4 * g + e] * sc) * (acc[i + 1][jb + jj][4 * g + e] * sc);
             uint2 v;
             v.x = pack_bf2(y[0], y[1]);
             v.y = pack_bf2(y[2], y[3]);
             *reinterpret_cast<uint2*>(stage + (jj * 32 + cl) * EPI_ROW_BYTES + ((i >> 1) * 32 + 8 * g + 4 * hi) * 2) = v;
           }
+      }
       const int nrows = (FN - jb >= 2) ? 64 : 32;
 #pragma unroll
       for (int t0 = 0; t0 < 64; t0 += RPI) {
@@ -315,31 +408,12 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOpe
   gemm_tile<C>(A, W, K, tm, tn, epi, smem);
 }
 
-template <class C, class Epi>
-__global__ __launch_bounds__(C::THREADS) void gemm_pp_kernel(GemmOperand A, GemmOperand W, int K, int tiles_m,
-                                                             int tiles_n, int group_m, Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  int tm, tn;
-  tile_coords(logical, tiles_n, tiles_m, group_m, tn, tm);
-  gemm_tile_pingpong<C>(A, W, K, tm, tn, epi, smem);
-}
-
-template <class C, class Epi, bool PP>
-struct KernelSel {
-  static auto get() { return gemm_kernel<C, Epi>; }
-};
-template <class C, class Epi>
-struct KernelSel<C, Epi, true> {
-  static auto get() { return gemm_pp_kernel<C, Epi>; }
-};
-
 // `w` = weight matrix [n_rows_w, K] (row operand: tile rows = output features, clamped at the edge),
 // `a` = activations [M, K] (column operand: tile cols = tokens, M a multiple of the token tile).
-template <class C, class Epi, bool PINGPONG = false>
+template <class C, class Epi>
 static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hipStream_t stream,
                                 int prof_class) {
-  auto kern = KernelSel<C, Epi, PINGPONG>::get();
+  auto kern = gemm_kernel<C, Epi>;
   static bool attr_done = false;
   if (!attr_done) {
     RP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
@@ -378,7 +452,6 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
     case 1: return launch_gemm_cfg<GemmCfg<128, 128, 64, 2, 2, 2>>(w, a, K, epi, stream, prof_class);
     case 6: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2>>(w, a, K, epi, stream, prof_class);
     case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
-    case 10: return launch_gemm_cfg<GemmCfg<256, 256, 32, 2, 4, 4>, Epi, true>(w, a, K, epi, stream, prof_class);
     case 11: return launch_gemm_cfg<GemmCfg<256, 128, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
     case 12: return launch_gemm_cfg<GemmCfg<64, 256, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class);
     default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class);
@@ -931,6 +1004,10 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     g_gemm_variant_o = value;
     return RP_OK;
   }
+  if (!strcmp(name, "debug_skip_ffn")) {
+    g_debug_skip_ffn = value != 0;
+    return RP_OK;
+  }
   if (!strcmp(name, "gemm_skinny")) {
     g_gemm_skinny = value != 0;
     return RP_OK;
@@ -1017,13 +1094,13 @@ static RpStatus pack_all(RpEncoder* e, const RpT5Weights* w) {
     hipLaunchKernelGGL((to_f32_kernel<T>), dim3((D + 255) / 256), dim3(256), 0, 0, L.ln_attn, s.ln_attn, D);
     hipLaunchKernelGGL((to_f32_kernel<T>), dim3((D + 255) / 256), dim3(256), 0, 0, L.ln_ff, s.ln_ff, D);
     hipLaunchKernelGGL((pack_rows_kernel<T>), dim3(3 * inner), dim3(256), 0, 0, L.wqkv, s.q, s.k, s.v, 3 * inner,
-                       D, inner, (int)PACK_CONCAT3);
+                       D, inner, (int)PACK_CONCAT3, (const float*)L.ln_attn);
     hipLaunchKernelGGL((pack_rows_kernel<T>), dim3(D), dim3(256), 0, 0, L.wo, s.o, nullptr, nullptr, D, inner, 0,
-                       (int)PACK_COPY);
+                       (int)PACK_COPY, (const float*)nullptr);
     hipLaunchKernelGGL((pack_rows_kernel<T>), dim3(2 * F), dim3(256), 0, 0, L.wi, s.wi_0, s.wi_1, nullptr, 2 * F,
-                       D, 0, (int)PACK_GEGLU);
+                       D, 0, (int)PACK_GEGLU, (const float*)L.ln_ff);
     hipLaunchKernelGGL((pack_rows_kernel<T>), dim3(D), dim3(256), 0, 0, L.wo2, s.wo, nullptr, nullptr, D, F, 0,
-                       (int)PACK_COPY);
+                       (int)PACK_COPY, (const float*)nullptr);
     RP_CHECK_LAUNCH();
   }
   // relative-position bias -> [H, 2*maxd+1] table (host; the raw table is tiny)
@@ -1079,7 +1156,9 @@ extern "C" void rp_encoder_destroy(RpEncoder* e) {
 namespace {
 struct Workspace {
   float* x;
-  bf16_t *h, *qkv, *att, *ff;
+  bf16_t *xb, *qkv, *att, *ff;  // xb = bf16 copy of x (A operand of the QKV / FFN-in GEMMs)
+  float* ssp;   // [Tp, ceil(D/64)] per-row partial sums of squares of x
+  float* rs;    // [Tp] rsqrt(mean(x^2) + eps)
   float* pool;  // [Tp / 128 + batch, D] partial column sums of the pooling pass
   size_t bytes;
 };
@@ -1094,7 +1173,9 @@ Workspace carve(const RpEncoder* e, int T, int batch, char* base) {
     return p;
   };
   w.x = (float*)take(Tp * D * 4);
-  w.h = (bf16_t*)take(Tp * D * 2);
+  w.xb = (bf16_t*)take(Tp * D * 2);
+  w.ssp = (float*)take(Tp * ((D + 63) / 64) * 4);
+  w.rs = (float*)take(Tp * 4);
   w.qkv = (bf16_t*)take(Tp * 3 * inner * 2);
   w.att = (bf16_t*)take(Tp * inner * 2);
   w.ff = (bf16_t*)take(Tp * F * 2);
@@ -1125,21 +1206,25 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
   const int Tp = (int)align_up((size_t)T, GEMM_M_ALIGN);
   RpStatus st;
 
+  const int np = (D + 63) / 64;
+  const RowScale rs{w.rs};
+  auto launch_rowscale = [&]() {
+    ProfScope ps(stream, RP_K_RMSNORM);
+    hipLaunchKernelGGL(rowscale_kernel, dim3((Tp + 255) / 256), dim3(256), 0, stream, w.ssp, w.rs, Tp, np,
+                       1.f / (float)D, c.layer_norm_eps);
+  };
   {
     ProfScope ps(stream, RP_K_EMBED);
-    hipLaunchKernelGGL(embed_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.x, T, Tp, D,
-                       c.vocab_size);
+    hipLaunchKernelGGL(embed_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.x, w.xb, w.ssp, np, T,
+                       Tp, D, c.vocab_size);
   }
   RP_CHECK_LAUNCH();
   const dim3 att_grid((max_len + ATT_Q - 1) / ATT_Q, batch, H);
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerPacked& L = e->layers[i];
-    {
-      ProfScope ps(stream, RP_K_RMSNORM);
-      hipLaunchKernelGGL(rmsnorm_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, w.x, L.ln_attn, w.h, Tp, D,
-                         c.layer_norm_eps);
-    }
-    if ((st = launch_gemm(w.h, D, Tp, L.wqkv, D, 3 * inner, D, EpiStoreBf16{w.qkv, 3 * inner, 3 * inner}, stream,
+    // attention sub-layer: qkv = rs * (xb Wqkv'^T)  ->  attention  ->  x += att Wo^T  (+ xb, ssp refreshed)
+    launch_rowscale();
+    if ((st = launch_gemm(w.xb, D, Tp, L.wqkv, D, 3 * inner, D, EpiStoreBf16{w.qkv, 3 * inner, 3 * inner, rs}, stream,
                           RP_K_GEMM_QKV)))
       return st;
     {
@@ -1147,16 +1232,16 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
       hipLaunchKernelGGL(g_attn_variant ? attention2_kernel : attention_kernel, att_grid, dim3(256), 0, stream, w.qkv,
                          cu_seqlens, e->bias_tab, w.att, H, e->maxd, Tp);
     }
-    if ((st = launch_gemm(w.att, inner, Tp, L.wo, inner, D, inner, EpiResidF32{w.x, D, D}, stream, RP_K_GEMM_O)))
+    if ((st = launch_gemm(w.att, inner, Tp, L.wo, inner, D, inner, EpiResidF32{w.x, D, D, w.xb, w.ssp, np}, stream,
+                          RP_K_GEMM_O)))
       return st;
-    {
-      ProfScope ps(stream, RP_K_RMSNORM);
-      hipLaunchKernelGGL(rmsnorm_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, w.x, L.ln_ff, w.h, Tp, D,
-                         c.layer_norm_eps);
-    }
-    if ((st = launch_gemm(w.h, D, Tp, L.wi, D, 2 * F, D, EpiGegluBf16{w.ff, F, 2 * F}, stream, RP_K_GEMM_WI)))
+    if (g_debug_skip_ffn) continue;
+    launch_rowscale();
+    // feed-forward sub-layer: ff = gelu(rs * g) * (rs * u)  ->  x += ff Wo2^T  (+ xb, ssp refreshed)
+    if ((st = launch_gemm(w.xb, D, Tp, L.wi, D, 2 * F, D, EpiGegluBf16{w.ff, F, 2 * F, rs}, stream, RP_K_GEMM_WI)))
       return st;
-    if ((st = launch_gemm(w.ff, F, Tp, L.wo2, F, D, F, EpiResidF32{w.x, D, D}, stream, RP_K_GEMM_WO)))
+    if ((st = launch_gemm(w.ff, F, Tp, L.wo2, F, D, F, EpiResidF32{w.x, D, D, w.xb, w.ssp, np}, stream,
+                          RP_K_GEMM_WO)))
       return st;
   }
   {
@@ -1180,11 +1265,49 @@ extern "C" RpStatus rp_dbg_gemm(const void* A, const void* W, void* out, int32_t
   const bf16_t* w = (const bf16_t*)W;
   switch (epilogue) {
     case RP_EPI_STORE_BF16:
-      return launch_gemm(a, K, M, w, K, N, K, EpiStoreBf16{(bf16_t*)out, n_valid, n_valid}, stream, RP_K_GEMM_QKV);
+      return launch_gemm(a, K, M, w, K, N, K, EpiStoreBf16{(bf16_t*)out, n_valid, n_valid, RowScale{nullptr}}, stream,
+                         RP_K_GEMM_QKV);
     case RP_EPI_RESID_F32:
-      return launch_gemm(a, K, M, w, K, N, K, EpiResidF32{(float*)out, n_valid, n_valid}, stream, RP_K_GEMM_WO);
+      return launch_gemm(a, K, M, w, K, N, K, EpiResidF32{(float*)out, n_valid, n_valid, nullptr, nullptr, 0}, stream, RP_K_GEMM_WO);
     case RP_EPI_GEGLU_BF16:
-      return launch_gemm(a, K, M, w, K, N, K, EpiGegluBf16{(bf16_t*)out, n_valid / 2, n_valid}, stream, RP_K_GEMM_WI);
+      return launch_gemm(a, K, M, w, K, N, K, EpiGegluBf16{(bf16_t*)out, n_valid / 2, n_valid, RowScale{nullptr}}, stream,
+                         RP_K_GEMM_WI);
+  }
+  return fail(RP_E_INVALID, "unknown epilogue %d", epilogue);
+}
+
+extern "C" RpStatus rp_dbg_gemm_fused(const void* A, const void* W, void* out, int32_t M, int32_t N, int32_t K,
+                                      int32_t n_valid, int32_t epilogue, const float* ssp_in, int32_t np_in,
+                                      float inv_d, float eps, void* xb_out, float* ssp_out, int32_t np_out,
+                                      void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const bf16_t* a = (const bf16_t*)A;
+  const bf16_t* w = (const bf16_t*)W;
+  float* rs_buf = nullptr;
+  if (ssp_in) {  // test entry only: a scratch allocation is fine here
+    RP_HIP(hipMalloc((void**)&rs_buf, (size_t)M * 4));
+    hipLaunchKernelGGL(rowscale_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, ssp_in, rs_buf, M, np_in, inv_d, eps);
+  }
+  const RowScale rs{rs_buf};
+  struct Free {
+    float* p;
+    hipStream_t s;
+    ~Free() {
+      if (p) {
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(p);
+      }
+    }
+  } free_rs{rs_buf, stream};
+  switch (epilogue) {
+    case RP_EPI_STORE_BF16:
+      return launch_gemm(a, K, M, w, K, N, K, EpiStoreBf16{(bf16_t*)out, n_valid, n_valid, rs}, stream, RP_K_GEMM_QKV);
+    case RP_EPI_RESID_F32:
+      return launch_gemm(a, K, M, w, K, N, K, EpiResidF32{(float*)out, n_valid, n_valid, (bf16_t*)xb_out, ssp_out, np_out},
+                         stream, RP_K_GEMM_WO);
+    case RP_EPI_GEGLU_BF16:
+      return launch_gemm(a, K, M, w, K, N, K, EpiGegluBf16{(bf16_t*)out, n_valid / 2, n_valid, rs}, stream,
+                         RP_K_GEMM_WI);
   }
   return fail(RP_E_INVALID, "unknown epilogue %d", epilogue);
 }

@@ -168,134 +168,6 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
                            smem + wave * EPI_STAGE_BYTES);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Ping-pong schedule for the 8-wave 256 x 256 x 32 tile (one workgroup per CU, two waves per SIMD).
-//
-// The waves form two groups (waves 0-3 = upper 128 rows, waves 4-7 = lower 128 rows; each group has
-// one wave on every SIMD).  Every K-tile is split into a LOAD part (issue the LDS-DMA of tile kt+3,
-// read this wave's 12 operand fragments of tile kt with ds_read_b128) and a COMPUTE part (16 MFMAs),
-// separated by workgroup barriers, and group 1 runs ONE barrier behind group 0.  So in every
-// barrier interval one wave of each SIMD is inside its MFMA cluster (at raised priority) while its
-// partner fetches: the matrix pipe sees back-to-back MFMAs and the LDS/DMA traffic hides beneath.
-//   interval 2kt   : group0 LOAD(kt)      group1 COMPUTE(kt-1)
-//   interval 2kt+1 : group0 COMPUTE(kt)   group1 LOAD(kt)
-// LDS ring of 4 stages (4 x 32 KiB): tile kt+3 overwrites the stage of tile kt-1, whose last reader
-// (group1, interval 2kt-1) has drained its ds_reads (lgkmcnt(0)) before the barrier that precedes the
-// first overwrite (group0, interval 2kt).  Tile kt+1 is complete in LDS before interval 2kt+2: every
-// wave ends LOAD(kt) with a counted vmcnt that leaves only tiles kt+2, kt+3 in flight.
-// ------------------------------------------------------------------------------------------------
-template <class C, class Epilogue>
-__device__ __forceinline__ void gemm_tile_pingpong(const GemmOperand A, const GemmOperand W, int K, int tile_m,
-                                                   int tile_n, Epilogue& epi, char* smem) {
-  static_assert(C::NWAVES == 8 && C::WM == 2 && C::NSTAGE == 4 && C::BK == 32, "ping-pong geometry");
-  constexpr int BK = C::BK, FM = C::FM, FN = C::FN;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_row = wave / C::WN, wave_col = wave % C::WN;
-  const int grp = wave_row;  // 0: leads, 1: one barrier behind
-  const int hi = lane >> 5;
-
-  f32x16 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const bf16_t* a_src[C::A_DMA];
-  const bf16_t* w_src[C::W_DMA];
-#pragma unroll
-  for (int d = 0; d < C::A_DMA; ++d) {
-    const int row = (wave * C::A_DMA + d) * C::ROWS_PER_DMA + lane / C::SLOTS;
-    const int kc = (lane % C::SLOTS) ^ C::swz(row);
-    a_src[d] = A.ptr + (size_t)min(tile_m * C::BM + row, A.rows - 1) * A.ld + kc * 8;
-  }
-#pragma unroll
-  for (int d = 0; d < C::W_DMA; ++d) {
-    const int row = (wave * C::W_DMA + d) * C::ROWS_PER_DMA + lane / C::SLOTS;
-    const int kc = (lane % C::SLOTS) ^ C::swz(row);
-    w_src[d] = W.ptr + (size_t)min(tile_n * C::BN + row, W.rows - 1) * W.ld + kc * 8;
-  }
-  auto stage = [&](int kt, int buf) {
-    char* base = smem + buf * C::STAGE_BYTES;
-    const size_t kstep = (size_t)kt * BK;
-#pragma unroll
-    for (int d = 0; d < C::A_DMA; ++d)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + kstep),
-                                       (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int d = 0; d < C::W_DMA; ++d)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[d] + kstep),
-                                       (lds_ptr_t)(base + C::A_BYTES + (wave * C::W_DMA + d) * 1024), 16, 0, 0);
-  };
-  constexpr int DPS = C::A_DMA + C::W_DMA;  // DMA instructions per stage per wave
-
-  int a_off[FM][2], b_off[FN][2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-    for (int f = 0; f < FM; ++f) a_off[f][ks] = C::off(wave_row * (FM * 32) + f * 32 + (lane & 31), ks * 2 + hi);
-#pragma unroll
-    for (int f = 0; f < FN; ++f) b_off[f][ks] = C::off(wave_col * (FN * 32) + f * 32 + (lane & 31), ks * 2 + hi);
-  }
-
-  const int nk = K / BK;
-#pragma unroll
-  for (int s = 0; s < 3; ++s)
-    if (s < nk) stage(s, s);
-  if (nk >= 3)
-    wait_vmcnt<2 * DPS>();  // tile 0 landed; tiles 1, 2 may still fly
-  else
-    wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-  if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one interval behind
-
-  int buf = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // ---------------- LOAD part
-    if (kt + 3 < nk) stage(kt + 3, (buf + 3) & 3);
-    const char* sa = smem + buf * C::STAGE_BYTES;
-    const char* sb = sa + C::A_BYTES;
-    bf16x8 af[FM][2], bfr[FN][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int f = 0; f < FN; ++f) bfr[f][ks] = *reinterpret_cast<const bf16x8*>(sb + b_off[f][ks]);
-#pragma unroll
-      for (int f = 0; f < FM; ++f) af[f][ks] = *reinterpret_cast<const bf16x8*>(sa + a_off[f][ks]);
-    }
-    if (kt + 3 < nk)
-      wait_vmcnt<2 * DPS>();  // tile kt+1 complete (this wave's share); kt+2, kt+3 in flight
-    else
-      wait_vmcnt<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers, stage kt released
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---------------- COMPUTE part
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ks], bfr[j][ks], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    buf = (buf + 1) & 3;
-  }
-  if (grp == 0) __builtin_amdgcn_s_barrier();  // group 0 waits out group 1's last COMPUTE
-  __syncthreads();
-
-  epi.template run<FM, FN>(acc, tile_m * C::BM + wave_row * (FM * 32), tile_n * C::BN + wave_col * (FN * 32), lane,
-                           smem + wave * EPI_STAGE_BYTES);
-}
-
 // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (observed, speed only), so consecutive
 // "logical" ids are handed out per XCD: logical = (b % 8) * ceil-chunk + b / 8 (bijective form),
 // then logical ids walk the tile grid in column-groups of GROUP_M row-tiles so that the

@@ -201,3 +201,43 @@ def test_shard_merge_equals_single_shot(gen):
     g_c = torch.stack([p[2] for p in parts])
     mi, ms, mc = hh.topk_merge(g_s, g_i, g_c)
     assert torch.equal(mi, ids) and torch.equal(ms, sc) and torch.equal(mc, cnt)
+
+
+@pytest.mark.parametrize("variant", [6, 11, 12, 1, 0, 9])
+@pytest.mark.parametrize("M", [256, 768])
+def test_gemm_fused_rmsnorm_pieces_all_variants(gen, variant, M):
+    """Residual epilogue with its bf16 copy + per-64-feature sums of squares, and the row-scaled
+    store / GEGLU epilogues, for every tile configuration (the auto small-M switch disabled)."""
+    lib = _lib.load()
+    N, K = 1472, 384
+    np_ = (N + 63) // 64
+    _lib.check(lib.rp_set_option(b"gemm_skinny", 0), "opt")
+    _lib.check(lib.rp_set_option(b"gemm_variant", variant), "opt")
+    try:
+        A, W = _rand_bf16(gen, M, K), _rand_bf16(gen, N, K, scale=K ** -0.5)
+        x0 = torch.randn(M, N, generator=gen, device="cuda")
+        x = x0.clone()
+        xb = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        ssp = torch.full((M, np_), float("nan"), device="cuda")
+        _lib.check(lib.rp_dbg_gemm_fused(A.data_ptr(), W.data_ptr(), x.data_ptr(), M, N, K, N, _lib.RP_EPI_RESID_F32, None,
+                                         0, 0.0, 0.0, xb.data_ptr(), ssp.data_ptr(), np_, _lib.current_stream()), "fused")
+        torch.cuda.synchronize()
+        ref = x0 + A.float() @ W.float().T
+        assert (x - ref).abs().max().item() < 2e-4
+        assert torch.equal(xb, x.to(torch.bfloat16)), "xb must be the bf16 rounding of the updated x"
+        want = (x.double() ** 2).view(M, np_, 64).sum(-1).float()
+        assert not torch.isnan(ssp).any(), "a sum-of-squares slot was never written"
+        assert (ssp - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+        # consumer side: row-scaled store
+        K2, N2 = N, 1152
+        W2 = _rand_bf16(gen, N2, K2, scale=K2 ** -0.5)
+        out = torch.empty(M, N2, dtype=torch.bfloat16, device="cuda")
+        _lib.check(lib.rp_dbg_gemm_fused(xb.data_ptr(), W2.data_ptr(), out.data_ptr(), M, N2, K2, N2, _lib.RP_EPI_STORE_BF16,
+                                         ssp.data_ptr(), np_, 1.0 / N, 1e-6, None, None, 0, _lib.current_stream()), "fused")
+        torch.cuda.synchronize()
+        rs = torch.rsqrt(ssp.sum(1) / N + 1e-6)
+        ref2 = (xb.float() @ W2.float().T) * rs[:, None]
+        assert (out.float() - ref2).abs().max().item() <= 2 ** -8 * ref2.abs().max().item() + 1e-3
+    finally:
+        _lib.check(lib.rp_set_option(b"gemm_skinny", 1), "opt")
+        _lib.check(lib.rp_set_option(b"gemm_variant", 6), "opt")

@@ -6,7 +6,7 @@ from reprover_amd import _lib
 lib = _lib.load()
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 variants = [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3,4").split(",")]
-groups = [int(v) for v in os.environ.get("GROUPS", "8").split(",")]
+groups = [int(v) for v in os.environ.get("GROUP_M", "8").split(",")]
 dev = torch.device("cuda")
 g = torch.Generator(device=dev); g.manual_seed(0)
 only = os.environ.get('ONLY')
@@ -18,7 +18,8 @@ for name, N, K, epi in shapes:
         continue
     A = (torch.randn(M, K, generator=g, device=dev)).to(torch.bfloat16)
     W = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.bfloat16)
-    ref = A[:256].float() @ W.float().T
+    CH = M if M <= 4096 else 256
+    ref = A[:CH].float() @ W.float().T
     if epi == _lib.RP_EPI_RESID_F32:
         out = torch.zeros(M, N, device=dev)
     elif epi == _lib.RP_EPI_GEGLU_BF16:
@@ -41,14 +42,14 @@ for name, N, K, epi in shapes:
                         out.zero_()
                     run(); torch.cuda.synchronize()
                     if epi == _lib.RP_EPI_RESID_F32:
-                        err = (out[:256] - ref).abs().max().item()
+                        err = (out[:CH] - ref).abs().max().item()
                     elif epi == _lib.RP_EPI_STORE_BF16:
-                        err = (out[:256].float() - ref).abs().max().item()
+                        err = (out[:CH].float() - ref).abs().max().item()
                     else:
-                        r = ref.view(256, N // 64, 2, 32)
-                        gg, uu = r[:, :, 0].reshape(256, -1), r[:, :, 1].reshape(256, -1)
+                        r = ref.view(CH, N // 64, 2, 32)
+                        gg, uu = r[:, :, 0].reshape(CH, -1), r[:, :, 1].reshape(CH, -1)
                         want = 0.5 * gg * (1 + torch.tanh(0.7978845608 * (gg + 0.044715 * gg ** 3))) * uu
-                        err = (out[:256].float() - want).abs().max().item()
+                        err = (out[:CH].float() - want).abs().max().item()
                     errs[(v, gm)] = err
                     continue
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
