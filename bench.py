@@ -142,12 +142,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    # RP_BENCH_SHARE_GPU=1 + RP_BENCH_BACKEND=gloo: functional smoke run of the N > 1 code path on a
+    # single-GPU box (every rank on device 0; not a measurement).
+    share = os.environ.get("RP_BENCH_SHARE_GPU") == "1"
+    local = 0 if share else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("RP_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     build.build()
     lib = _lib.load()
 
@@ -216,15 +224,21 @@ def main():
                                    qk_d.data_ptr(), lo, TOP_K, 0, out_s.data_ptr(), out_i.data_ptr(),
                                    out_c.data_ptr(), ws.data_ptr(), ws_bytes, _lib.current_stream()), "rp_sim_topk")
 
+    def gather(dst, src):  # one all-gather: RCCL ncclAllGather on GPUs
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(dst, src)
+        else:
+            dist.all_gather(list(dst.view((world,) + tuple(src.shape)).unbind(0)), src)
+
     def step():
         enc.encode_packed_device(ids_d, cu_d, B_STATES, T, max_len, q_loc)
         if world > 1:
-            dist.all_gather_into_tensor(q_all, q_loc)
+            gather(q_all, q_loc)
         scan()
         if world > 1:
-            dist.all_gather_into_tensor(g_s, out_s)
-            dist.all_gather_into_tensor(g_i, out_i)
-            dist.all_gather_into_tensor(g_c, out_c)
+            gather(g_s, out_s)
+            gather(g_i, out_i)
+            gather(g_c, out_c)
             sl = slice(rank * B_STATES, (rank + 1) * B_STATES)
             ms_, mi_, mc_ = g_s[:, sl].contiguous(), g_i[:, sl].contiguous(), g_c[:, sl].contiguous()
             _lib.check(lib.rp_topk_merge(ms_.data_ptr(), mi_.data_ptr(), mc_.data_ptr(), world, B_STATES, TOP_K,
@@ -254,6 +268,26 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     counts_ok = bool(((f_c if world > 1 else out_c).cpu() == TOP_K).all())
+    merged_ok = None
+    if world > 1 and rank == 0:
+        # shard + all-gather + merge must equal the single-GPU answer: check rank 0's own queries against a
+        # scan of the whole (unsharded) matrix
+        fo, eo = torch.from_numpy(corpus.file_of).to(dev), torch.from_numpy(corpus.end_key).to(dev)
+        b0, o0, k0 = corpus.query_masks(all_ctx[:B_STATES])
+        b0d = torch.from_numpy(b0.view(np.int32)).to(dev)
+        o0d, k0d = torch.from_numpy(o0).to(dev), torch.from_numpy(k0).to(dev)
+        r_s = torch.empty((B_STATES, TOP_K), dtype=torch.float32, device=dev)
+        r_i = torch.empty((B_STATES, TOP_K), dtype=torch.int32, device=dev)
+        r_c = torch.empty((B_STATES,), dtype=torch.int32, device=dev)
+        wb = lib.rp_sim_topk_workspace_bytes(B_STATES, N, D, TOP_K, 0)
+        wsx = torch.empty(wb, dtype=torch.uint8, device=dev)
+        q0 = q_all[:B_STATES].contiguous()
+        _lib.check(lib.rp_sim_topk(q0.data_ptr(), E_full.data_ptr(), B_STATES, N, D, fo.data_ptr(), eo.data_ptr(),
+                                   b0d.data_ptr(), corpus.num_files, o0d.data_ptr(), k0d.data_ptr(), 0, TOP_K, 0,
+                                   r_s.data_ptr(), r_i.data_ptr(), r_c.data_ptr(), wsx.data_ptr(), wb,
+                                   _lib.current_stream()), "rp_sim_topk")
+        torch.cuda.synchronize()
+        merged_ok = bool(torch.equal(r_i, f_i) and torch.equal(r_s, f_s))
     ms_per_step = dt / args.steps * 1e3
     qps = BQ * args.steps / dt
 
@@ -318,7 +352,7 @@ def main():
             "state_tokens_per_gpu": T, "state_len_mix": "clip(round(LogNormal(ln 180, 0.9)), 16, 2048) bytes",
             "index": "row-sharded %d-way, bf16 unit-norm random rows" % world,
             "weights": "random-init ByT5-small (d_model 1472, 12 layers, 6 heads, d_ff 3584)",
-            "accessible_premises_first_queries": n_acc.tolist(), "all_counts_eq_k": counts_ok,
+            "accessible_premises_first_queries": n_acc.tolist(), "all_counts_eq_k": counts_ok, "sharded_merge_equals_single_gpu": merged_ok,
         },
         "premises_per_s": prem_per_s,
         "premise_tokens_per_s": prem_tok_per_s,

@@ -31,7 +31,8 @@ static int g_gemm_group_m = 8;
 static int g_gemm_variant = 6;
 static int g_gemm_variant_o = 11;  // the K = H*64 attention-output projection is epilogue-bound: 2 blocks/CU
 static int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
-static int g_gemm_skinny = 1;   // use the small-token-count GEMM configuration automatically
+static int g_gemm_skinny = 1;
+static int g_gemm_skinny_variant = 12;   // use the small-token-count GEMM configuration automatically
 static int g_attn_variant = 1;  // 0: register-staged kernel, 1: LDS-DMA + transpose-read kernel  // tile/pipeline configuration, see launch_gemm()
 
 // ------------------------------------------------------------------------------------------
@@ -443,8 +444,8 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
   // Few tokens (the prover's single-state query): the 256 x 256 tiling would leave
   // most CUs idle and each workgroup latency-bound on its K loop.  Switch to 64-feature tiles with a
   // 7-deep LDS ring so every workgroup streams its weight slab with ~6 K-steps of DMA in flight.
-  if (g_gemm_skinny && m256 && ((n_rows_w + 255) / 256) * (M / 256) < 96) v = 12;
-  if ((v == 1 || v == 6) && !k64) v = (v == 6 && m256) ? 9 : 0;
+  if (g_gemm_skinny && m256 && ((n_rows_w + 255) / 256) * (M / 256) < 96) v = g_gemm_skinny_variant;
+  if ((v == 1 || v == 6 || v == 14) && !k64) v = (v == 6 && m256) ? 9 : (v == 14 ? 13 : 0);
   if (v >= 5 && !m256) v = 0;
   // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages>; measured on
   // MI355X at M = 65536 (tools/gemm_bench.py): 6 is the best all-rounder, 11 is 2-3 % ahead on FFN-in.
@@ -454,6 +455,8 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
     case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
     case 11: return launch_gemm_cfg<GemmCfg<256, 128, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
     case 12: return launch_gemm_cfg<GemmCfg<64, 256, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class);
+    case 13: return launch_gemm_cfg<GemmCfg<128, 256, 32, 2, 4, 6>>(w, a, K, epi, stream, prof_class);
+    case 14: return launch_gemm_cfg<GemmCfg<128, 256, 64, 2, 4, 3>>(w, a, K, epi, stream, prof_class);
     default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class);
   }
 }
@@ -995,7 +998,7 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     return RP_OK;
   }
   if (!strcmp(name, "gemm_variant")) {
-    RP_REQUIRE(value >= 0 && value <= 12, "gemm_variant out of range");
+    RP_REQUIRE(value >= 0 && value <= 14, "gemm_variant out of range");
     g_gemm_variant = value;
     return RP_OK;
   }
@@ -1006,6 +1009,11 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   }
   if (!strcmp(name, "debug_skip_ffn")) {
     g_debug_skip_ffn = value != 0;
+    return RP_OK;
+  }
+  if (!strcmp(name, "gemm_skinny_variant")) {
+    RP_REQUIRE(value >= 0 && value <= 14, "gemm_skinny_variant out of range");
+    g_gemm_skinny_variant = value;
     return RP_OK;
   }
   if (!strcmp(name, "gemm_skinny")) {

@@ -241,3 +241,15 @@ def test_gemm_fused_rmsnorm_pieces_all_variants(gen, variant, M):
     finally:
         _lib.check(lib.rp_set_option(b"gemm_skinny", 1), "opt")
         _lib.check(lib.rp_set_option(b"gemm_variant", 6), "opt")
+
+
+def test_sim_topk_multi_gpu_shard_shape(gen):
+    """The per-rank call of the 8-GPU bench: all 8 x 256 queries against one 16,250-row shard."""
+    rng = np.random.default_rng(21)
+    B, N, D, k = 2048, 16250, 1472, 100
+    E = torch.nn.functional.normalize(torch.randn(N, D, generator=gen, device="cuda"), dim=1).to(torch.bfloat16)
+    Q = torch.nn.functional.normalize(torch.randn(B, D, generator=gen, device="cuda"), dim=1).to(torch.bfloat16)
+    m, acc = hh.synth_masks(rng, N, B, F=600)
+    ids, sc, cnt = hh.sim_topk(Q, E, k, hh.masks_to_device(m, Q.device), id_offset=5 * N)
+    S = (Q.float() @ E.float().T).cpu().numpy()
+    hh.check_topk_against_scores(ids.cpu().numpy() - 5 * N, sc.cpu().numpy(), cnt.cpu().numpy(), S, acc, k, tol=2e-5)

@@ -21,18 +21,22 @@ g = torch.Generator(device=dev); g.manual_seed(0)
 model.corpus_embeddings = torch.nn.functional.normalize(torch.randn(N, 1472, generator=g, device=dev), dim=1).to(torch.bfloat16)
 model.embeddings_staled = False
 rng = np.random.default_rng(0)
-for nbytes in (100, 300, 1000):
-    states = [synth.synth_state(rng, nbytes) for _ in range(30)]
-    for s in states[:5]:
-        model.retrieve(s, "M/F4000.lean", "t", Pos(30, 0), 100)
-    torch.cuda.synchronize()
-    _lib.profile_enable(True)
-    t0 = time.perf_counter()
-    for s in states[5:]:
-        model.retrieve(s, "M/F4000.lean", "t", Pos(30, 0), 100)
-    dt = (time.perf_counter() - t0) / 25
-    prof = _lib.profile_read(); _lib.profile_enable(False)
-    gpu_ms = sum(v[0] for v in prof.values()) / 25
-    top = sorted(prof.items(), key=lambda kv: -kv[1][0])[:6]
-    print(f"state {nbytes:5d} B: retrieve() {dt*1e3:7.3f} ms wall; GPU kernels {gpu_ms:6.3f} ms; " +
-          ", ".join(f"{k} {v[0]/25*1e3:.0f}us" for k, v in top), flush=True)
+lib = _lib.load()
+for sv in [int(x) for x in os.environ.get('SKINNY', '12').split(',')]:
+  lib.rp_set_option(b'gemm_skinny_variant', sv)
+  print('skinny variant', sv)
+  for nbytes in (100, 300, 1000):
+      states = [synth.synth_state(rng, nbytes) for _ in range(30)]
+      for s in states[:5]:
+          model.retrieve(s, "M/F4000.lean", "t", Pos(30, 0), 100)
+      torch.cuda.synchronize()
+      _lib.profile_enable(True)
+      t0 = time.perf_counter()
+      for s in states[5:]:
+          model.retrieve(s, "M/F4000.lean", "t", Pos(30, 0), 100)
+      dt = (time.perf_counter() - t0) / 25
+      prof = _lib.profile_read(); _lib.profile_enable(False)
+      gpu_ms = sum(v[0] for v in prof.values()) / 25
+      top = sorted(prof.items(), key=lambda kv: -kv[1][0])[:6]
+      print(f"state {nbytes:5d} B: retrieve() {dt*1e3:7.3f} ms wall; GPU kernels {gpu_ms:6.3f} ms; " +
+            ", ".join(f"{k} {v[0]/25*1e3:.0f}us" for k, v in top), flush=True)
