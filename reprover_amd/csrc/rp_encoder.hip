@@ -32,7 +32,9 @@ static int g_gemm_variant = 6;
 static int g_gemm_variant_o = 11;  // the K = H*64 attention-output projection is epilogue-bound: 2 blocks/CU
 static int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 static int g_gemm_skinny = 1;
-static int g_gemm_skinny_variant = 12;   // use the small-token-count GEMM configuration automatically
+static int g_gemm_skinny_variant = 12;
+static int g_tokens_valid = 0;  // real token count of the pass being launched (0: all rows); lets the
+                                // small-token configurations skip tiles that hold only padding rows   // use the small-token-count GEMM configuration automatically
 static int g_attn_variant = 1;  // 0: register-staged kernel, 1: LDS-DMA + transpose-read kernel  // tile/pipeline configuration, see launch_gemm()
 
 // ------------------------------------------------------------------------------------------
@@ -422,7 +424,8 @@ static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hi
   }
   RP_REQUIRE(K % C::BK == 0 && a.rows % C::BN == 0, "gemm: K=%d must be a multiple of %d, M=%d of %d", K, C::BK,
              a.rows, C::BN);
-  const int tiles_f = (w.rows + C::BM - 1) / C::BM, tiles_t = a.rows / C::BN;
+  const int rows_needed = (g_tokens_valid > 0 && g_tokens_valid < a.rows) ? g_tokens_valid : a.rows;
+  const int tiles_f = (w.rows + C::BM - 1) / C::BM, tiles_t = (rows_needed + C::BN - 1) / C::BN;
   // tile order: feature tiles fastest inside groups of `group` token tiles (shared activation panels)
   const int group = max(1, g_gemm_group_m * 128 / C::BN);
   ProfScope ps(stream, prof_class);
@@ -444,8 +447,9 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
   // Few tokens (the prover's single-state query): the 256 x 256 tiling would leave
   // most CUs idle and each workgroup latency-bound on its K loop.  Switch to 64-feature tiles with a
   // 7-deep LDS ring so every workgroup streams its weight slab with ~6 K-steps of DMA in flight.
-  if (g_gemm_skinny && m256 && ((n_rows_w + 255) / 256) * (M / 256) < 96) v = g_gemm_skinny_variant;
-  if ((v == 1 || v == 6 || v == 14) && !k64) v = (v == 6 && m256) ? 9 : (v == 14 ? 13 : 0);
+  if (g_gemm_skinny && m256 && ((n_rows_w + 255) / 256) * (M / 256) < 96)
+    v = (g_tokens_valid > 0 && g_tokens_valid <= 128 && g_gemm_skinny_variant == 12) ? 15 : g_gemm_skinny_variant;
+  if ((v == 1 || v == 6) && !k64) v = (v == 6 && m256) ? 9 : 0;
   if (v >= 5 && !m256) v = 0;
   // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages>; measured on
   // MI355X at M = 65536 (tools/gemm_bench.py): 6 is the best all-rounder, 11 is 2-3 % ahead on FFN-in.
@@ -455,8 +459,7 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
     case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
     case 11: return launch_gemm_cfg<GemmCfg<256, 128, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
     case 12: return launch_gemm_cfg<GemmCfg<64, 256, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class);
-    case 13: return launch_gemm_cfg<GemmCfg<128, 256, 32, 2, 4, 6>>(w, a, K, epi, stream, prof_class);
-    case 14: return launch_gemm_cfg<GemmCfg<128, 256, 64, 2, 4, 3>>(w, a, K, epi, stream, prof_class);
+    case 15: return launch_gemm_cfg<GemmCfg<64, 128, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class);
     default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class);
   }
 }
@@ -998,7 +1001,7 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     return RP_OK;
   }
   if (!strcmp(name, "gemm_variant")) {
-    RP_REQUIRE(value >= 0 && value <= 14, "gemm_variant out of range");
+    RP_REQUIRE(value >= 0 && value <= 15, "gemm_variant out of range");
     g_gemm_variant = value;
     return RP_OK;
   }
@@ -1012,7 +1015,7 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     return RP_OK;
   }
   if (!strcmp(name, "gemm_skinny_variant")) {
-    RP_REQUIRE(value >= 0 && value <= 14, "gemm_skinny_variant out of range");
+    RP_REQUIRE(value == 12 || value == 15, "gemm_skinny_variant must be 12 or 15");
     g_gemm_skinny_variant = value;
     return RP_OK;
   }
@@ -1215,6 +1218,10 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
   RpStatus st;
 
   const int np = (D + 63) / 64;
+  g_tokens_valid = T;
+  struct ClearHint {
+    ~ClearHint() { g_tokens_valid = 0; }
+  } clear_hint;
   const RowScale rs{w.rs};
   auto launch_rowscale = [&]() {
     ProfScope ps(stream, RP_K_RMSNORM);
