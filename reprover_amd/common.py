@@ -442,6 +442,50 @@ class IndexedCorpus:
         assert len(self.embeddings) == len(self.corpus)
 
 
+# ----------------------------------------------------------------------------------------------
+# Native on-disk index.  The reference persists ``pickle(IndexedCorpus(corpus,
+# fp32 embeddings))`` (retrieval/index.py:37-40): 765 MB of fp32 plus a pickled object graph that
+# drags in networkx and lean_dojo class identities.  The native form is a directory:
+#     corpus.jsonl            the corpus exactly as given (App. B.1), so every field survives
+#     embeddings.safetensors  "embeddings": [N, D] in the encoder's dtype (bf16: 383 MB at 130k x 1472)
+#     meta.json               {"format": 1, "n_premises": N, "d_model": D, "dtype": "..."}
+# ``PremiseRetriever.load_corpus`` accepts a ``.jsonl``, a pickle, or such a directory.
+# ----------------------------------------------------------------------------------------------
+INDEX_FORMAT_VERSION = 1
+
+
+def save_index(dir_path: str, corpus_jsonl_path: str, embeddings: torch.Tensor) -> None:
+    import os
+    import shutil
+
+    from safetensors.torch import save_file
+
+    os.makedirs(dir_path, exist_ok=True)
+    dst = os.path.join(dir_path, "corpus.jsonl")
+    if os.path.abspath(corpus_jsonl_path) != os.path.abspath(dst):
+        shutil.copyfile(corpus_jsonl_path, dst)
+    emb = embeddings.detach().cpu().contiguous()
+    save_file({"embeddings": emb}, os.path.join(dir_path, "embeddings.safetensors"))
+    with open(os.path.join(dir_path, "meta.json"), "w") as fh:
+        json.dump({"format": INDEX_FORMAT_VERSION, "n_premises": int(emb.shape[0]), "d_model": int(emb.shape[1]),
+                   "dtype": str(emb.dtype).replace("torch.", "")}, fh)
+
+
+def load_index(dir_path: str) -> Tuple[Corpus, torch.Tensor]:
+    import os
+
+    from safetensors.torch import load_file
+
+    with open(os.path.join(dir_path, "meta.json")) as fh:
+        meta = json.load(fh)
+    if meta.get("format") != INDEX_FORMAT_VERSION:
+        raise ValueError(f"unsupported index format {meta.get('format')!r} in {dir_path}")
+    corpus = Corpus(os.path.join(dir_path, "corpus.jsonl"))
+    emb = load_file(os.path.join(dir_path, "embeddings.safetensors"))["embeddings"]
+    assert emb.shape == (meta["n_premises"], meta["d_model"]) and len(corpus) == meta["n_premises"]
+    return corpus, emb
+
+
 def get_all_pos_premises(annot_tac, corpus: Corpus) -> List[Premise]:
     """Premises used by an annotated tactic: each provenance ``{def_path, def_pos}`` is resolved with
     ``corpus.locate_premise``; unresolvable ones are skipped (common.py:341-354)."""

@@ -10,7 +10,7 @@ import pickle
 
 import torch
 
-from ..common import IndexedCorpus
+from ..common import IndexedCorpus, save_index
 from .model import PremiseRetriever
 
 logger = logging.getLogger(__name__)
@@ -33,8 +33,12 @@ def main(argv=None) -> None:
     model = PremiseRetriever.load_hf(args.ckpt_path, 2048, device)
     model.load_corpus(args.corpus_path)
     model.reindex_corpus(batch_size=args.batch_size)
-    with open(args.output_path, "wb") as oup:
-        pickle.dump(IndexedCorpus(model.corpus, model.corpus_embeddings.to(torch.float32).cpu()), oup)
+    if args.output_path.endswith(("/", ".rpidx")):
+        # native index directory: bf16 embeddings as safetensors + the corpus jsonl (no pickle)
+        save_index(args.output_path, args.corpus_path, model.corpus_embeddings)
+    else:  # the reference's format: pickled IndexedCorpus with fp32 CPU embeddings (index.py:37-40)
+        with open(args.output_path, "wb") as oup:
+            pickle.dump(IndexedCorpus(model.corpus, model.corpus_embeddings.to(torch.float32).cpu()), oup)
     logger.info(f"Indexed corpus saved to {args.output_path}")
 
 

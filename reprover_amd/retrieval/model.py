@@ -20,7 +20,7 @@ from typing import Any, Dict, List, Optional, Tuple, Union
 import numpy as np
 import torch
 
-from ..common import Context, Corpus, IndexedCorpus, Pos, Premise, zip_strict
+from ..common import Context, Corpus, IndexedCorpus, Pos, Premise, load_index, zip_strict
 from ..encoder import HipT5Encoder
 from ..tokenizer import ByT5Tokenizer
 
@@ -76,13 +76,18 @@ class PremiseRetriever:
     # -- corpus (model.py:68-85) --------------------------------------------------------------------
     def load_corpus(self, path_or_corpus: Union[str, Corpus]) -> None:
         """Associate the retriever with a corpus: a ``Corpus``, a ``corpus.jsonl`` (embeddings
-        stale) or a pickled ``IndexedCorpus`` with pre-computed embeddings."""
+        stale), a pickled ``IndexedCorpus`` with pre-computed embeddings, or a native index
+        directory written by ``common.save_index`` / ``index.py --output-path <dir>/``."""
         if isinstance(path_or_corpus, Corpus):
             self.corpus = path_or_corpus
             self.corpus_embeddings = None
             self.embeddings_staled = True
             return
         path = path_or_corpus
+        if os.path.isdir(path):  # native index directory (common.save_index)
+            self.corpus, self.corpus_embeddings = load_index(path)
+            self.embeddings_staled = False
+            return
         if path.endswith(".jsonl"):
             self.corpus = Corpus(path)
             self.corpus_embeddings = None

@@ -111,3 +111,22 @@ def test_predict_validate_and_evaluate(workdir):
             retrieved[keymap[key]] = [where[(q.path, q.full_name, tuple(q.start))] for q in p["retrieved_premises"]]
     rec, mrr = eval_ref.validation_metrics([e["all_pos_premises"] for e in ex], retrieved, 10)
     assert abs(m["MRR"] - mrr) < 1e-9 and np.allclose([m[f"Recall@{j + 1}_val"] for j in range(10)], rec, atol=1e-9)
+
+
+def test_native_index_directory_via_cli(workdir):
+    d, ckpt, cpath, sdir, splits, cfg, sd = workdir
+    out = os.path.join(d, "native.rpidx")
+    index_cli.main(["--ckpt_path", ckpt, "--corpus-path", cpath, "--output-path", out])
+    assert sorted(os.listdir(out)) == ["corpus.jsonl", "embeddings.safetensors", "meta.json"]
+    m = PremiseRetriever.load_hf(ckpt, 256, "cuda:0")
+    m.load_corpus(out)
+    assert not m.embeddings_staled and m.corpus_embeddings.dtype == torch.bfloat16
+    ref = PremiseRetriever.load_hf(ckpt, 256, "cuda:0")
+    ref.load_corpus(cpath)
+    ex = splits["val"][0]
+    state = ex["traced_tactics"][0]["state_before"]
+    from reprover_amd.common import Pos
+
+    a = m.retrieve(state, ex["file_path"], ex["full_name"], Pos(*ex["start"]), 10)
+    b = ref.retrieve(state, ex["file_path"], ex["full_name"], Pos(*ex["start"]), 10)
+    assert [p.full_name for p in a[0]] == [p.full_name for p in b[0]] and a[1] == b[1]

@@ -160,3 +160,22 @@ def test_product_does_not_import_the_oracle():
             if n.endswith(".py"):
                 src = open(os.path.join(dirpath, n)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, n)
+
+
+def test_native_index_roundtrip(g6):
+    """common.save_index / load_index: corpus and embeddings survive, dtype preserved, no pickle."""
+    from reprover_amd.common import load_index, save_index
+
+    g, z, path = g6
+    corpus = Corpus(path)
+    emb = torch.randn(len(corpus), 64).to(torch.bfloat16)
+    d = os.path.join(tempfile.mkdtemp(), "idx.rpidx")
+    save_index(d, path, emb)
+    assert sorted(os.listdir(d)) == ["corpus.jsonl", "embeddings.safetensors", "meta.json"]
+    c2, e2 = load_index(d)
+    assert torch.equal(e2, emb) and e2.dtype == torch.bfloat16
+    assert [p.full_name for p in c2.all_premises] == [p.full_name for p in corpus.all_premises]
+    assert np.array_equal(c2.file_of, corpus.file_of) and np.array_equal(c2.end_key, corpus.end_key)
+    json.dump({"format": 99}, open(os.path.join(d, "meta.json"), "w"))
+    with pytest.raises(ValueError):
+        load_index(d)
