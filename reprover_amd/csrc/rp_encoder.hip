@@ -1029,7 +1029,7 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     return RP_OK;
   }
   if (!strcmp(name, "scan_cfg")) {
-    RP_REQUIRE(value >= 0 && value <= 2, "scan_cfg out of range");
+    RP_REQUIRE(value >= 0 && value <= 3, "scan_cfg out of range");
     g_scan_cfg = value;
     return RP_OK;
   }

@@ -29,10 +29,11 @@ constexpr int SIM_COUNT_STRIDE = 32;  // one candidate counter per 128-B line: c
 // sampled-tile bookkeeping is independent of the query tile)
 typedef GemmCfg<256, 128, 32, 4, 2, 3> SimCfgQ256;  // B > 128: 8 waves, one workgroup sees up to 256 queries
 typedef GemmCfg<256, 128, 64, 4, 2, 2> SimCfgQ256K64;  // same, 128-B rows per K-step (full cache lines of E)
+typedef GemmCfg<256, 256, 64, 4, 2, 2> SimCfgQ256P256;  // 256-premise tiles: half of the DMA traffic is E
 typedef GemmCfg<128, 128, 64, 2, 2, 2> SimCfgQ128;  // B <= 128, D % 64 == 0
 typedef GemmCfg<128, 128, 32, 2, 2, 3> SimCfgQ128K32;  // B <= 128, D % 32 == 0
 constexpr int GEMM_BN = 128;
-int g_scan_cfg = 0;  // 0: auto; 1: force 128-query tiles; 2: 256-query tiles with BK=64
+int g_scan_cfg = 0;  // 0: auto; 1: force 128-query tiles; 2: 256-query tiles with BK=64; 3: 256 x 256 tiles
 
 __device__ __forceinline__ uint64_t make_key(float score, int32_t id) {
   return ((uint64_t)f2ord(score) << 32) | (uint32_t)(~(uint32_t)id);
@@ -339,20 +340,21 @@ static void launch_select(const SelectArgs& a, int B, hipStream_t stream) {
 
 struct SimPlan {
   bool dense_only;
-  int bm, tiles_q, tiles_p, sample_tiles, filter_tiles;
+  int bm, bn, tiles_q, tiles_p, sample_tiles, filter_tiles;
   size_t dense_ld;
   size_t off_dense, off_cand, off_count, off_thr, bytes;
 };
 
-static SimPlan plan_sim(int B, int N, int k, int flags) {
+static SimPlan plan_sim(int B, int N, int D, int k, int flags) {
   SimPlan p;
   p.bm = (B > 128 && g_scan_cfg != 1) ? 256 : 128;
   p.tiles_q = (B + p.bm - 1) / p.bm;
-  p.tiles_p = (N + GEMM_BN - 1) / GEMM_BN;
+  p.bn = (p.bm == 256 && g_scan_cfg == 3 && D % 64 == 0) ? 256 : GEMM_BN;
+  p.tiles_p = (N + p.bn - 1) / p.bn;
   p.dense_only = (flags & RP_TOPK_DENSE) || N <= SIM_DENSE_MAX_N || p.tiles_p < 2 * SIM_STRIDE;
   p.sample_tiles = p.dense_only ? p.tiles_p : (p.tiles_p + SIM_STRIDE - 1) / SIM_STRIDE;
   p.filter_tiles = p.tiles_p - p.sample_tiles;
-  p.dense_ld = (size_t)p.sample_tiles * GEMM_BN;
+  p.dense_ld = (size_t)p.sample_tiles * p.bn;
   size_t off = 0;
   p.off_dense = off;
   off += align_up((size_t)B * p.dense_ld * 8, 256);
@@ -385,6 +387,7 @@ static RpStatus launch_scan_cfg(GemmOperand q, GemmOperand e, int D, int tiles_q
 static RpStatus launch_scan(const SimPlan& p, GemmOperand q, GemmOperand e, int D, int n_ptiles, int stride,
                             const EpiSim& epi, hipStream_t stream) {
   if (n_ptiles <= 0) return RP_OK;
+  if (p.bn == 256) return launch_scan_cfg<SimCfgQ256P256>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
   if (p.bm == 256 && g_scan_cfg == 2 && D % 64 == 0)
     return launch_scan_cfg<SimCfgQ256K64>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
   if (p.bm == 256) return launch_scan_cfg<SimCfgQ256>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
@@ -397,9 +400,8 @@ static RpStatus launch_scan(const SimPlan& p, GemmOperand q, GemmOperand e, int 
 using namespace rp;
 
 extern "C" size_t rp_sim_topk_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t k, int32_t flags) {
-  (void)D;
   if (B <= 0 || N <= 0 || k <= 0) return 0;
-  return plan_sim(B, N, k, flags).bytes;
+  return plan_sim(B, N, D, k, flags).bytes;
 }
 
 extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t N, int32_t D,
@@ -412,7 +414,7 @@ extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t
   RP_REQUIRE(k > 0 && k <= SIM_MAX_K, "k=%d out of range (1..%d)", k, SIM_MAX_K);
   if (file_of) RP_REQUIRE(end_key && file_bits_t && own_file && q_key && F > 0, "mask arrays incomplete");
   hipStream_t stream = (hipStream_t)stream_;
-  const SimPlan p = plan_sim(B, N, k, flags);
+  const SimPlan p = plan_sim(B, N, D, k, flags);
   if (!workspace || workspace_bytes < p.bytes)
     return fail(RP_E_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, p.bytes);
   char* ws = (char*)workspace;
