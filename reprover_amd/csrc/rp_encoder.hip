@@ -28,8 +28,14 @@ thread_local std::string g_last_error;
 // ------------------------------------------------------------------------------------------
 extern int g_scan_cfg;
 static int g_gemm_group_m = 8;
-static int g_gemm_variant = 6;
-static int g_gemm_variant_o = 11;  // the K = H*64 attention-output projection is epilogue-bound: 2 blocks/CU
+// Tile configuration per encoder GEMM (see launch_gemm()), measured at 65536 tokens (tools/gemm_bench.py,
+// profiles/): the 4-wave software-pipelined 256 x 256 tile wins where the epilogue is light (QKV store,
+// gated-GELU); the residual GEMMs are bound by their fp32 read-modify-write of x, which needs many
+// waves to keep loads in flight: 8 waves for the long-K FFN-out, two 4-wave blocks per CU for K = H*64.
+static int g_gemm_variant = 20;      // FFN-in (wi_0|wi_1 + gated GELU)
+static int g_gemm_variant_qkv = 20;  // QKV
+static int g_gemm_variant_wo = 6;    // FFN-out (+ residual)
+static int g_gemm_variant_o = 0;     // attention output (+ residual)
 static int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 static int g_gemm_skinny = 1;
 static int g_gemm_skinny_variant = 12;
@@ -241,34 +247,40 @@ struct EpiStoreBf16 {  // out[token, feature] = bf16(acc * rs[token])
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
     const int hi = lane >> 5, cl = lane & 31;
-    static_assert(FM == 2, "staging rows hold one 64-feature wave tile");
-    // 64 token rows at a time: rows of FM*32 features bf16 (FM*64 B <= 128 B)
-    constexpr int LPR = FM * 4;         // lanes per token row (16 B each)
+    static_assert(FM % 2 == 0, "staging rows hold 64 features (two row fragments)");
+    // 64 token rows x 64 features at a time: staging rows of 128 B
+    constexpr int LPR = 8;              // lanes per token row (16 B each)
     constexpr int RPI = 64 / LPR;       // token rows per pass
     const int sub = lane % LPR, rr = lane / LPR;
-    const int f = m_base + sub * 8;
+    float scv[FN];
 #pragma unroll
-    for (int jb = 0; jb < FN; jb += 2) {
+    for (int j = 0; j < FN; ++j) scv[j] = rs.get(n_base + j * 32 + cl);
 #pragma unroll
-      for (int jj = 0; jj < 2 && jb + jj < FN; ++jj) {
-        const float sc = rs.get(n_base + (jb + jj) * 32 + cl);
+    for (int ih = 0; ih < FM; ih += 2) {
+      const int f = m_base + ih * 32 + sub * 8;
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+      for (int jb = 0; jb < FN; jb += 2) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            uint2 v;
-            v.x = pack_bf2(acc[i][jb + jj][4 * g] * sc, acc[i][jb + jj][4 * g + 1] * sc);
-            v.y = pack_bf2(acc[i][jb + jj][4 * g + 2] * sc, acc[i][jb + jj][4 * g + 3] * sc);
-            *reinterpret_cast<uint2*>(stage + (jj * 32 + cl) * EPI_ROW_BYTES + (i * 32 + 8 * g + 4 * hi) * 2) = v;
+        for (int jj = 0; jj < 2 && jb + jj < FN; ++jj) {
+          const float sc = scv[jb + jj];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              uint2 v;
+              v.x = pack_bf2(acc[ih + i][jb + jj][4 * g] * sc, acc[ih + i][jb + jj][4 * g + 1] * sc);
+              v.y = pack_bf2(acc[ih + i][jb + jj][4 * g + 2] * sc, acc[ih + i][jb + jj][4 * g + 3] * sc);
+              *reinterpret_cast<uint2*>(stage + (jj * 32 + cl) * EPI_ROW_BYTES + (i * 32 + 8 * g + 4 * hi) * 2) = v;
+            }
+        }
+        const int nrows = (FN - jb >= 2) ? 64 : 32;
+#pragma unroll
+        for (int t0 = 0; t0 < 64; t0 += RPI) {
+          const int t = t0 + rr;
+          if (t < nrows) {
+            const uint4 v = *reinterpret_cast<const uint4*>(stage + t * EPI_ROW_BYTES + sub * 16);
+            if (f < n_valid) *reinterpret_cast<uint4*>(out + (size_t)(n_base + jb * 32 + t) * ldo + f) = v;
           }
-      }
-      const int nrows = (FN - jb >= 2) ? 64 : 32;
-#pragma unroll
-      for (int t0 = 0; t0 < 64; t0 += RPI) {
-        const int t = t0 + rr;
-        if (t < nrows) {
-          const uint4 v = *reinterpret_cast<const uint4*>(stage + t * EPI_ROW_BYTES + sub * 16);
-          if (f < n_valid) *reinterpret_cast<uint4*>(out + (size_t)(n_base + jb * 32 + t) * ldo + f) = v;
         }
       }
     }
@@ -276,60 +288,77 @@ struct EpiStoreBf16 {  // out[token, feature] = bf16(acc * rs[token])
 };
 
 struct EpiResidF32 {  // x[token, feature] += acc  (residual stream, fp32) [+ xb = bf16(x), + ssp partials]
-  float* x;
+  float* __restrict__ x;
   int ldx, n_valid;
-  bf16_t* xb;   // optional: bf16 copy of the updated rows (same leading dimension)
-  float* ssp;   // optional: [tokens, np] partial sums of squares, slot = feature / 64
+  bf16_t* __restrict__ xb;   // optional: bf16 copy of the updated rows (same leading dimension)
+  float* __restrict__ ssp;   // optional: [tokens, np] partial sums of squares, slot = feature / 64
   int np;
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
-    static_assert(FM == 2, "staging rows hold one 64-feature wave tile");
+    static_assert(FM % 2 == 0, "one statistic slot per 64 features (two row fragments)");
     const int hi = lane >> 5, cl = lane & 31;
     const int sub = lane & 7, rr = lane >> 3;  // 8 lanes x 16 B = one token's 32 features; 8 tokens per pass
-    float ssq[FM / 2][(FN + 1) / 2][8];
+    constexpr int NJB = (FN + 1) / 2, NB = FM * NJB;  // blocks of 32 features x 64 tokens
+    float ssq[FM / 2][NJB][8];
 #pragma unroll
     for (int q = 0; q < FM / 2; ++q)
 #pragma unroll
-      for (int a = 0; a < (FN + 1) / 2; ++a)
+      for (int a = 0; a < NJB; ++a)
 #pragma unroll
         for (int c = 0; c < 8; ++c) ssq[q][a][c] = 0.f;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {  // 32 features at a time: rows of 128 B
+    // The read-modify-write of x is latency-bound unless many loads are in flight: the old values
+    // of block b+1 are requested before block b is staged, added and stored.
+    // (wave tiles of 128 x 128 keep their accumulators in AGPRs and have the VGPRs for 3 blocks ahead)
+    constexpr int DEPTH = (FM * FN >= 16) ? 4 : 2;
+    float4 xin[DEPTH][8];
+    auto fetch = [&](int b, int p) {
+      const int i = b / NJB, jb = (b % NJB) * 2;
       const int f = m_base + i * 32 + sub * 4;
+      const int nrows = (FN - jb >= 2) ? 64 : 32;
 #pragma unroll
-      for (int jb = 0; jb < FN; jb += 2) {  // 64 token rows at a time
+      for (int c = 0; c < 8; ++c) {
+        const int t = c * 8 + rr;
+        if (t < nrows && f < n_valid)
+          xin[p][c] = *reinterpret_cast<const float4*>(x + (size_t)(n_base + jb * 32 + t) * ldx + f);
+      }
+    };
 #pragma unroll
-        for (int jj = 0; jj < 2 && jb + jj < FN; ++jj)
+    for (int b = 0; b < DEPTH - 1 && b < NB; ++b) fetch(b, b);
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(stage + (jj * 32 + cl) * EPI_ROW_BYTES + (8 * g + 4 * hi) * 4) = make_float4(
-                acc[i][jb + jj][4 * g], acc[i][jb + jj][4 * g + 1], acc[i][jb + jj][4 * g + 2], acc[i][jb + jj][4 * g + 3]);
-        const int nrows = (FN - jb >= 2) ? 64 : 32;
+    for (int b = 0; b < NB; ++b) {
+      const int i = b / NJB, jb = (b % NJB) * 2;
+      const int f = m_base + i * 32 + sub * 4;
+      if (b + DEPTH - 1 < NB) fetch(b + DEPTH - 1, (b + DEPTH - 1) % DEPTH);
 #pragma unroll
-        for (int t0 = 0; t0 < 64; t0 += 8) {
-          const int t = t0 + rr;
-          if (t < nrows) {
-            const float4 d = *reinterpret_cast<const float4*>(stage + t * EPI_ROW_BYTES + sub * 16);
-            if (f < n_valid) {
-              const size_t off = (size_t)(n_base + jb * 32 + t) * ldx + f;
-              float4* p = reinterpret_cast<float4*>(x + off);
-              float4 v = *p;
-              v.x += d.x;
-              v.y += d.y;
-              v.z += d.z;
-              v.w += d.w;
-              *p = v;
-              if (xb) {
-                uint2 o;
-                o.x = pack_bf2(v.x, v.y);
-                o.y = pack_bf2(v.z, v.w);
-                *reinterpret_cast<uint2*>(xb + off) = o;
-              }
-              // explicit fma chain: the same rounding sequence in every unrolled instance, so a
-              // token's statistic does not depend on where it sits in the batch
-              float& q = ssq[i >> 1][jb >> 1][t0 >> 3];
-              q = __fmaf_rn(v.w, v.w, __fmaf_rn(v.z, v.z, __fmaf_rn(v.y, v.y, __fmaf_rn(v.x, v.x, q))));
+      for (int jj = 0; jj < 2 && jb + jj < FN; ++jj)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(stage + (jj * 32 + cl) * EPI_ROW_BYTES + (8 * g + 4 * hi) * 4) = make_float4(
+              acc[i][jb + jj][4 * g], acc[i][jb + jj][4 * g + 1], acc[i][jb + jj][4 * g + 2], acc[i][jb + jj][4 * g + 3]);
+      const int nrows = (FN - jb >= 2) ? 64 : 32;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int t = c * 8 + rr;
+        if (t < nrows) {
+          const float4 d = *reinterpret_cast<const float4*>(stage + t * EPI_ROW_BYTES + sub * 16);
+          if (f < n_valid) {
+            const size_t off = (size_t)(n_base + jb * 32 + t) * ldx + f;
+            float4 v = xin[b % DEPTH][c];
+            v.x += d.x;
+            v.y += d.y;
+            v.z += d.z;
+            v.w += d.w;
+            *reinterpret_cast<float4*>(x + off) = v;
+            if (xb) {
+              uint2 o;
+              o.x = pack_bf2(v.x, v.y);
+              o.y = pack_bf2(v.z, v.w);
+              *reinterpret_cast<uint2*>(xb + off) = o;
             }
+            // explicit fma chain: the same rounding sequence in every unrolled instance, so a
+            // token's statistic does not depend on where it sits in the batch
+            float& q = ssq[i >> 1][jb >> 1][c];
+            q = __fmaf_rn(v.w, v.w, __fmaf_rn(v.z, v.z, __fmaf_rn(v.y, v.y, __fmaf_rn(v.x, v.x, q))));
           }
         }
       }
@@ -362,18 +391,22 @@ struct EpiGegluBf16 {  // W rows interleaved 32 gate / 32 up: even row-fragments
   RowScale rs;
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
-    static_assert(FM == 2, "one gate/up fragment pair per wave tile");
+    static_assert(FM % 2 == 0, "gate/up fragment pairs");
     const int hi = lane >> 5, cl = lane & 31;
-    // 64 token rows at a time: rows of FM/2*32 outputs bf16 (FM*32 B)
+    // 64 token rows at a time: staging rows of FM/2*32 outputs bf16 (FM*32 B <= 128 B)
     constexpr int LPR = FM * 2;         // lanes per token row (16 B each)
     constexpr int RPI = 64 / LPR;
+    static_assert(FM * 32 <= 128, "staging row");
     const int sub = lane % LPR, rr = lane / LPR;
     const int f = (m_base >> 1) + sub * 8;
+    float scv[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) scv[j] = rs.get(n_base + j * 32 + cl);
 #pragma unroll
     for (int jb = 0; jb < FN; jb += 2) {
 #pragma unroll
       for (int jj = 0; jj < 2 && jb + jj < FN; ++jj) {
-        const float sc = rs.get(n_base + (jb + jj) * 32 + cl);
+        const float sc = scv[jb + jj];
 #pragma unroll
         for (int i = 0; i < FM; i += 2)
 #pragma unroll
@@ -408,7 +441,10 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOpe
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   int tm, tn;
   tile_coords(logical, tiles_n, tiles_m, group_m, tn, tm);  // token tiles grouped, feature tiles inside
-  gemm_tile<C>(A, W, K, tm, tn, epi, smem);
+  if constexpr (C::PIPE != 0)
+    gemm_tile_pipe<C>(A, W, K, tm, tn, epi, smem);
+  else
+    gemm_tile<C>(A, W, K, tm, tn, epi, smem);
 }
 
 // `w` = weight matrix [n_rows_w, K] (row operand: tile rows = output features, clamped at the edge),
@@ -442,20 +478,24 @@ template <class Epi>
 static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, int ldw, int n_rows_w,
                             int K, Epi epi, hipStream_t stream, int prof_class) {
   GemmOperand a{A, lda, M}, w{W, ldw, n_rows_w};
-  int v = (prof_class == RP_K_GEMM_O) ? g_gemm_variant_o : g_gemm_variant;
+  int v = prof_class == RP_K_GEMM_O     ? g_gemm_variant_o
+          : prof_class == RP_K_GEMM_WO  ? g_gemm_variant_wo
+          : prof_class == RP_K_GEMM_QKV ? g_gemm_variant_qkv
+                                        : g_gemm_variant;
   const bool k64 = (K % 64 == 0), m256 = (M % 256 == 0);
   // Few tokens (the prover's single-state query): the 256 x 256 tiling would leave
   // most CUs idle and each workgroup latency-bound on its K loop.  Switch to 64-feature tiles with a
   // 7-deep LDS ring so every workgroup streams its weight slab with ~6 K-steps of DMA in flight.
   if (g_gemm_skinny && m256 && ((n_rows_w + 255) / 256) * (M / 256) < 96)
     v = (g_tokens_valid > 0 && g_tokens_valid <= 128 && g_gemm_skinny_variant == 12) ? 15 : g_gemm_skinny_variant;
-  if ((v == 1 || v == 6) && !k64) v = (v == 6 && m256) ? 9 : 0;
+  if ((v == 1 || v == 6 || v == 20) && !k64) v = (v != 1 && m256) ? 9 : 0;
   if (v >= 5 && !m256) v = 0;
   // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages>; measured on
   // MI355X at M = 65536 (tools/gemm_bench.py): 6 is the best all-rounder, 11 is 2-3 % ahead on FFN-in.
   switch (v) {
     case 1: return launch_gemm_cfg<GemmCfg<128, 128, 64, 2, 2, 2>>(w, a, K, epi, stream, prof_class);
     case 6: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2>>(w, a, K, epi, stream, prof_class);
+    case 20: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class);
     case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
     case 11: return launch_gemm_cfg<GemmCfg<256, 128, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
     case 12: return launch_gemm_cfg<GemmCfg<64, 256, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class);
@@ -1001,12 +1041,33 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     return RP_OK;
   }
   if (!strcmp(name, "gemm_variant")) {
-    RP_REQUIRE(value >= 0 && value <= 15, "gemm_variant out of range");
+    RP_REQUIRE(value >= 0 && value <= 30, "gemm_variant out of range");
     g_gemm_variant = value;
     return RP_OK;
   }
+  if (!strcmp(name, "gemm_variant_all")) {  // benches/tests: one configuration for every GEMM; -1 = defaults
+    RP_REQUIRE(value >= -1 && value <= 30, "gemm_variant_all out of range");
+    if (value < 0) {
+      g_gemm_variant = g_gemm_variant_qkv = 20;
+      g_gemm_variant_wo = 6;
+      g_gemm_variant_o = 0;
+    } else {
+      g_gemm_variant = g_gemm_variant_qkv = g_gemm_variant_wo = g_gemm_variant_o = value;
+    }
+    return RP_OK;
+  }
+  if (!strcmp(name, "gemm_variant_qkv")) {
+    RP_REQUIRE(value >= 0 && value <= 30, "gemm_variant_qkv out of range");
+    g_gemm_variant_qkv = value;
+    return RP_OK;
+  }
+  if (!strcmp(name, "gemm_variant_wo")) {
+    RP_REQUIRE(value >= 0 && value <= 30, "gemm_variant_wo out of range");
+    g_gemm_variant_wo = value;
+    return RP_OK;
+  }
   if (!strcmp(name, "gemm_variant_o")) {
-    RP_REQUIRE(value >= 0 && value <= 12, "gemm_variant_o out of range");
+    RP_REQUIRE(value >= 0 && value <= 30, "gemm_variant_o out of range");
     g_gemm_variant_o = value;
     return RP_OK;
   }
@@ -1345,3 +1406,13 @@ extern "C" RpStatus rp_dbg_attention(const void* qkv, const int32_t* cu, const f
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
+
+#ifdef RP_PHASE_PROBE
+// probe build only (tools/probes/gemm_phase.py): copy the per-workgroup phase timestamps to the host
+extern "C" int rp_probe_read_phase_ts(unsigned long long* host_out, int n_words) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(rp::g_phase_ts), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int rp_probe_read_handover_ts(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(rp::g_handover_ts), sizeof(rp::g_handover_ts), 0, hipMemcpyDeviceToHost);
+}
+#endif

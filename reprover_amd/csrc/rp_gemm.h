@@ -16,17 +16,45 @@
 // The epilogue is a functor so the same core serves the encoder GEMMs (bf16 store, fp32
 // residual add, gated-GELU) and the similarity scan (accessibility mask + top-k filter).
 #pragma once
+#include <type_traits>
 #include "rp_util.h"
 
 namespace rp {
+
+// tools/probes/gemm_phase.py builds a second copy of the library with -DRP_PHASE_PROBE: thread 0 of
+// every workgroup then records the 100 MHz wall clock at four points of its tile (start, first
+// K-tile landed, main loop done, epilogue done).  The product build compiles none of this.
+#ifdef RP_PHASE_PROBE
+__device__ unsigned long long g_phase_ts[4 * 16384];
+#define RP_TS(slot)                                                                          \
+  do {                                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < 16384) g_phase_ts[blockIdx.x * 4 + (slot)] = wall_clock64(); \
+  } while (0)
+// hand-over detail of workgroup 1000, every wave: [wave][kt][0..2] = shader clock before the waits,
+// after the counted vmcnt wait, after the barrier
+__device__ unsigned long long g_handover_ts[8 * 64 * 3];
+#define RP_HTS(kt, which)                                                                         \
+  do {                                                                                            \
+    if (blockIdx.x == 1000 && (threadIdx.x & 63) == 0 && (kt) < 64)                                \
+      g_handover_ts[((threadIdx.x >> 6) * 64 + (kt)) * 3 + (which)] = clock64();                  \
+  } while (0)
+#else
+#define RP_HTS(kt, which) \
+  do {                    \
+  } while (0)
+#define RP_TS(slot) \
+  do {              \
+  } while (0)
+#endif
 
 // C/D layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 __device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 // Tile configuration: block tile BM x BN x BK, WM x WN waves, NSTAGE-deep LDS ring.
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSTAGE_>
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSTAGE_, int PIPE_ = 0>
 struct GemmCfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_;
+  static constexpr int PIPE = PIPE_;  // 1: one wave per SIMD, fragment reads software-pipelined (gemm_tile_pipe)
   static constexpr int NWAVES_ = WM_ * WN_;
   static constexpr int NWAVES = WM * WN, THREADS = NWAVES * 64;
   static constexpr int FM = BM / WM / 32, FN = BN / WN / 32;  // 32x32 accumulator fragments per wave
@@ -71,6 +99,7 @@ template <class C, class Epilogue>
 __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand W, int K, int tile_m,
                                           int tile_n, Epilogue& epi, char* smem) {
   constexpr int BK = C::BK, NSTAGE = C::NSTAGE, FM = C::FM, FN = C::FN;
+  RP_TS(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -140,6 +169,9 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
     else
       wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // every wave's share of tile kt is in LDS; tile kt-1 fully consumed
+#ifdef RP_PHASE_PROBE
+    if (kt == 0) RP_TS(1);
+#endif
     if (kt + NSTAGE - 1 < nk) {
       int nb = buf + NSTAGE - 1;
       if (nb >= NSTAGE) nb -= NSTAGE;
@@ -163,9 +195,211 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
     if (++buf == NSTAGE) buf = 0;
   }
   __syncthreads();  // all waves done with LDS before an epilogue reuses it
+  RP_TS(2);
 
   epi.template run<FM, FN>(acc, tile_m * C::BM + wave_row * (FM * 32), tile_n * C::BN + wave_col * (FN * 32), lane,
                            smem + wave * EPI_STAGE_BYTES);
+  RP_TS(3);
+}
+
+// One-wave-per-SIMD variant (WM*WN = 4 waves, 128x128 per wave at BM = BN = 256): each fragment
+// read from LDS feeds 4 MFMAs instead of 2.67, so the LDS pipe (fragment reads + DMA writes) needs
+// 1536 clk per 256x256x64 tile against 2048 clk of MFMA issue, where the 8-wave tiling needs
+// 2048 / 2048.  With a single wave per SIMD nothing else hides latency, so the k-steps are
+// software-pipelined by hand: the fragments of k-step s+1 are read while the MFMAs of k-step s
+// issue, and the tile hand-over (counted wait, barrier, next DMA issue, first fragment read of the
+// next tile) sits in front of the last k-step's MFMAs.
+template <class C, class Epilogue>
+__device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOperand W, int K, int tile_m,
+                                               int tile_n, Epilogue& epi, char* smem) {
+  constexpr int BK = C::BK, FM = C::FM, FN = C::FN, KS = BK / 16;
+  RP_TS(0);
+  static_assert(KS % 2 == 0 && KS >= 2, "even number of k-steps (fragment double-buffer parity)");
+  static_assert(FM * FN >= FM + FN + C::A_DMA && FM * FN >= FM + FN + C::W_DMA, "one DMA per MFMA slot");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_row = wave / C::WN, wave_col = wave % C::WN;
+  const int hi = lane >> 5;
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const bf16_t* a_src[C::A_DMA];
+  const bf16_t* w_src[C::W_DMA];
+#pragma unroll
+  for (int d = 0; d < C::A_DMA; ++d) {
+    const int row = (wave * C::A_DMA + d) * C::ROWS_PER_DMA + lane / C::SLOTS;
+    const int kc = (lane % C::SLOTS) ^ C::swz(row);
+    a_src[d] = A.ptr + (size_t)min(tile_m * C::BM + row, A.rows - 1) * A.ld + kc * 8;
+  }
+#pragma unroll
+  for (int d = 0; d < C::W_DMA; ++d) {
+    const int row = (wave * C::W_DMA + d) * C::ROWS_PER_DMA + lane / C::SLOTS;
+    const int kc = (lane % C::SLOTS) ^ C::swz(row);
+    w_src[d] = W.ptr + (size_t)min(tile_n * C::BN + row, W.rows - 1) * W.ld + kc * 8;
+  }
+  const int nk = K / BK;
+  // half 0: the A image of a stage, half 1: the W image (issued one k-step apart, see tile_body)
+  auto stage_half = [&](int kt, int buf, int half) {
+    char* base = smem + buf * C::STAGE_BYTES;
+#if defined(RP_PHASE_PROBE) && defined(RP_PROBE_NO_DMA)
+    if (kt > 1) return;
+#endif
+    if (half == 0) {
+#pragma unroll
+      for (int d = 0; d < C::A_DMA; ++d)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + (size_t)kt * BK),
+                                         (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int d = 0; d < C::W_DMA; ++d)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[d] + (size_t)kt * BK),
+                                         (lds_ptr_t)(base + C::A_BYTES + (wave * C::W_DMA + d) * 1024), 16, 0, 0);
+    }
+  };
+  auto stage = [&](int kt, int buf) {
+    stage_half(kt, buf, 0);
+    stage_half(kt, buf, 1);
+  };
+
+  int a_off[FM][KS], b_off[FN][KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int f = 0; f < FM; ++f) a_off[f][ks] = C::off(wave_row * (FM * 32) + f * 32 + (lane & 31), ks * 2 + hi);
+#pragma unroll
+    for (int f = 0; f < FN; ++f)
+      b_off[f][ks] = C::A_BYTES + C::off(wave_col * (FN * 32) + f * 32 + (lane & 31), ks * 2 + hi);
+  }
+
+  bf16x8 af[2][FM], bfr[2][FN];  // double-buffered fragments, parity = k-step & 1
+#if defined(RP_PHASE_PROBE) && defined(RP_PROBE_NO_READS)
+  bool probe_reads_on = true;
+#endif
+  auto read_frags = [&](const char* st, int ks, int p) {
+#if defined(RP_PHASE_PROBE) && defined(RP_PROBE_NO_READS)
+    if (!probe_reads_on) return;  // keep what the prologue read
+#endif
+#pragma unroll
+    for (int f = 0; f < FM; ++f) af[p][f] = *reinterpret_cast<const bf16x8*>(st + a_off[f][ks]);
+#pragma unroll
+    for (int f = 0; f < FN; ++f) bfr[p][f] = *reinterpret_cast<const bf16x8*>(st + b_off[f][ks]);
+  };
+  auto mma = [&](int p) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[p][i], bfr[p][j], acc[i][j], 0, 0, 0);
+  };
+
+  constexpr int NSTAGE = C::NSTAGE, DPS = C::A_DMA + C::W_DMA;
+#pragma unroll
+  for (int t = 0; t < NSTAGE; ++t)
+    if (t < nk) stage(t, t);
+  if (nk >= NSTAGE)
+    wait_vmcnt<(NSTAGE - 1) * DPS>();
+  else
+    wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  RP_TS(1);
+  read_frags(smem, 0, 0);
+#if defined(RP_PHASE_PROBE) && defined(RP_PROBE_NO_READS)
+  read_frags(smem, 1, 1);
+  probe_reads_on = false;
+#endif
+
+  // Tile kt lives in ring slot kt % NSTAGE.  MODE 2: hand over to tile kt+1 and refill this slot with
+  // tile kt+NSTAGE; 1: hand over only (tail of the K loop); 0: last tile.  A refill is issued in two
+  // halves so that no more than one LDS-DMA instruction sits between two MFMAs (a DMA issue costs the
+  // wave ~20 clk, an MFMA slot is 32 clk): the A image right after the hand-over, between the last
+  // k-step's MFMAs, and the W image (PEND) between the MFMAs of the next tile's first k-step.
+  int buf = 0;
+  auto tile_body = [&](int kt, auto mode_tag, auto pend_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool PEND = decltype(pend_tag)::value != 0;
+    const char* st = smem + buf * C::STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < KS - 1; ++ks) {
+      read_frags(st, ks + 1, (ks + 1) & 1);
+      if (PEND && ks == 0) stage_half(kt - 1 + NSTAGE, buf == 0 ? NSTAGE - 1 : buf - 1, 1);
+      mma(ks & 1);
+      // issue order: the next k-step's fragment reads go out between the first MFMAs of this one
+#pragma unroll
+      for (int n = 0; n < FM + FN; ++n) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+      }
+      if (PEND && ks == 0) {
+#pragma unroll
+        for (int n = 0; n < C::W_DMA; ++n) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (LDS-DMA)
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - (FM + FN) - C::W_DMA, 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - (FM + FN), 0);
+      }
+    }
+    if (MODE >= 1) {
+      // every fragment of tile kt is in registers once this wave's LDS reads have returned
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      RP_HTS(kt, 0);
+      if (MODE == 2)
+        wait_vmcnt<(NSTAGE - 2) * DPS>();  // this wave's share of tile kt+1 has landed
+      else
+        wait_vmcnt<0>();
+      RP_HTS(kt, 1);
+      __builtin_amdgcn_s_barrier();  // ... and everyone's; the slot of tile kt is free
+      RP_HTS(kt, 2);
+        const int freed = buf;
+      if (++buf == NSTAGE) buf = 0;
+      read_frags(smem + buf * C::STAGE_BYTES, 0, 0);
+      if (MODE == 2) stage_half(kt + NSTAGE, freed, 0);
+    }
+    mma((KS - 1) & 1);
+    if (MODE >= 1) {
+#pragma unroll
+      for (int n = 0; n < FM + FN; ++n) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      if (MODE == 2) {
+#pragma unroll
+        for (int n = 0; n < C::A_DMA; ++n) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - (FM + FN) - C::A_DMA, 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - (FM + FN), 0);
+      }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  int kt = 0;
+  if (nk > NSTAGE) {
+    tile_body(0, I2(), I0());
+    for (kt = 1; kt + NSTAGE < nk; ++kt) tile_body(kt, I2(), I1());
+    tile_body(kt, I1(), I1());  // kt == nk - NSTAGE: completes the last refill
+    ++kt;
+  }
+  for (; kt + 1 < nk; ++kt) tile_body(kt, I1(), I0());
+  tile_body(kt, I0(), I0());
+  __syncthreads();
+  RP_TS(2);
+
+  epi.template run<FM, FN>(acc, tile_m * C::BM + wave_row * (FM * 32), tile_n * C::BN + wave_col * (FN * 32), lane,
+                           smem + wave * EPI_STAGE_BYTES);
+  RP_TS(3);
 }
 
 // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (observed, speed only), so consecutive

@@ -75,11 +75,15 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, h);
 }
 
-// gelu_new (tanh form), transformers/activations.py NewGELUActivation
+// gelu_new (tanh form), transformers/activations.py NewGELUActivation:
+//   0.5 u (1 + tanh(z)),  z = sqrt(2/pi) (u + 0.044715 u^3)   ==   u * sigmoid(2 z)   ==   u / (1 + 2^(-2 z log2 e))
+// evaluated with one v_exp_f32 and one v_rcp_f32 (both ~1 ulp; the result is rounded to bf16 by the
+// caller).  u -> -inf gives 2^(+big) = inf, rcp = 0, result -0; u -> +inf gives u.
 __device__ __forceinline__ float gelu_new(float u) {
-  const float c = 0.7978845608028654f;  // sqrt(2/pi)
-  float t = tanhf(c * (u + 0.044715f * u * u * u));
-  return 0.5f * u * (1.0f + t);
+  constexpr float k1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+  constexpr float k2 = k1 * 0.044715f;
+  const float a = u * __builtin_fmaf(k2, u * u, k1);
+  return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -203,7 +203,7 @@ def test_shard_merge_equals_single_shot(gen):
     assert torch.equal(mi, ids) and torch.equal(ms, sc) and torch.equal(mc, cnt)
 
 
-@pytest.mark.parametrize("variant", [6, 11, 12, 1, 0, 9])
+@pytest.mark.parametrize("variant", [20, 6, 11, 12, 1, 0, 9])
 @pytest.mark.parametrize("M", [256, 768])
 def test_gemm_fused_rmsnorm_pieces_all_variants(gen, variant, M):
     """Residual epilogue with its bf16 copy + per-64-feature sums of squares, and the row-scaled
@@ -212,7 +212,7 @@ def test_gemm_fused_rmsnorm_pieces_all_variants(gen, variant, M):
     N, K = 1472, 384
     np_ = (N + 63) // 64
     _lib.check(lib.rp_set_option(b"gemm_skinny", 0), "opt")
-    _lib.check(lib.rp_set_option(b"gemm_variant", variant), "opt")
+    _lib.check(lib.rp_set_option(b"gemm_variant_all", variant), "opt")
     try:
         A, W = _rand_bf16(gen, M, K), _rand_bf16(gen, N, K, scale=K ** -0.5)
         x0 = torch.randn(M, N, generator=gen, device="cuda")
@@ -240,7 +240,7 @@ def test_gemm_fused_rmsnorm_pieces_all_variants(gen, variant, M):
         assert (out.float() - ref2).abs().max().item() <= 2 ** -8 * ref2.abs().max().item() + 1e-3
     finally:
         _lib.check(lib.rp_set_option(b"gemm_skinny", 1), "opt")
-        _lib.check(lib.rp_set_option(b"gemm_variant", 6), "opt")
+        _lib.check(lib.rp_set_option(b"gemm_variant_all", -1), "opt")
 
 
 def test_sim_topk_multi_gpu_shard_shape(gen):

@@ -35,7 +35,7 @@ for name, N, K, epi in shapes:
     for rnd in range(ROUNDS + 1):  # round 0 = correctness + warm-up; then interleaved timing rounds
         for v in variants:
             for gm in groups:
-                _lib.check(lib.rp_set_option(b"gemm_variant", v), "opt")
+                _lib.check(lib.rp_set_option(b"gemm_variant_all", v), "opt")
                 _lib.check(lib.rp_set_option(b"gemm_group_m", gm), "opt")
                 if rnd == 0:
                     if epi == _lib.RP_EPI_RESID_F32:
