@@ -184,8 +184,8 @@ enum { RP_EPI_STORE_BF16 = 0, RP_EPI_RESID_F32 = 1, RP_EPI_GEGLU_BF16 = 2 };
 RpStatus rp_dbg_gemm(const void* A, const void* W, void* out, int32_t M, int32_t N, int32_t K,
                      int32_t n_valid, int32_t epilogue, void* stream);
 /* The same GEMM with the fused T5-RMSNorm pieces (rp_encoder.hip "RMSNorm folded into the GEMMs"):
- *   STORE / GEGLU: accumulators are scaled by rs[row] = rsqrt(sum_p ssp_in[row, p] * inv_d + eps) (ssp_in NULL = 1);
- *   RESID: additionally writes xb_out = bf16(out) and ssp_out[row, p] = sum of out^2 over features [64p, 64p+64). */
+ *   STORE / GEGLU: accumulators are scaled by rs[row] = rsqrt(sum_p ssp_in[p, row] * inv_d + eps), ssp slot-major [np, M] (ssp_in NULL = 1);
+ *   RESID: additionally writes xb_out = bf16(out) and ssp_out[p, row] = sum of out^2 over features [64p, 64p+64). */
 RpStatus rp_dbg_gemm_fused(const void* A, const void* W, void* out, int32_t M, int32_t N, int32_t K,
                            int32_t n_valid, int32_t epilogue, const float* ssp_in, int32_t np_in, float inv_d,
                            float eps, void* xb_out, float* ssp_out, int32_t np_out, void* stream);

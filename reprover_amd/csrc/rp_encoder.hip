@@ -29,13 +29,12 @@ thread_local std::string g_last_error;
 extern int g_scan_cfg;
 static int g_gemm_group_m = 8;
 // Tile configuration per encoder GEMM (see launch_gemm()), measured at 65536 tokens (tools/gemm_bench.py,
-// profiles/): the 4-wave software-pipelined 256 x 256 tile wins where the epilogue is light (QKV store,
-// gated-GELU); the residual GEMMs are bound by their fp32 read-modify-write of x, which needs many
-// waves to keep loads in flight: 8 waves for the long-K FFN-out, two 4-wave blocks per CU for K = H*64.
+// profiles/): the 4-wave software-pipelined 256 x 256 tile is the fastest main loop for all four; the
+// K = H*64 attention-output projection is bound by the fp32 read-modify-write of x whatever the tiling.
 static int g_gemm_variant = 20;      // FFN-in (wi_0|wi_1 + gated GELU)
 static int g_gemm_variant_qkv = 20;  // QKV
-static int g_gemm_variant_wo = 6;    // FFN-out (+ residual)
-static int g_gemm_variant_o = 0;     // attention output (+ residual)
+static int g_gemm_variant_wo = 20;   // FFN-out (+ residual)
+static int g_gemm_variant_o = 0;     // attention output (+ residual): two 4-wave 128 x 128 blocks per CU
 static int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 static int g_gemm_skinny = 1;
 static int g_gemm_skinny_variant = 12;
@@ -157,7 +156,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ 
   }
   ss = wave_sum(ss);
   // sum-of-squares partials of the row (see EpiResidF32): slot 0 carries the whole row here
-  for (int p = lane; p < np; p += 64) ssp[(size_t)row * np + p] = (p == 0) ? ss : 0.f;
+  for (int p = lane; p < np; p += 64) ssp[(size_t)p * Tp + row] = (p == 0) ? ss : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -229,14 +228,13 @@ struct RowScale {
   __device__ __forceinline__ float get(int token) const { return rs ? rs[token] : 1.f; }
 };
 
-// rs[token] = rsqrt(sum_p ssp[token][p] / D + eps), slots summed in index order
+// rs[token] = rsqrt(sum_p ssp[p][token] / D + eps), slots summed in index order
 __global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ ssp, float* __restrict__ rs, int rows,
                                                        int np, float inv_d, float eps) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= rows) return;
-  const float* p = ssp + (size_t)t * np;
   float s = 0.f;
-  for (int i = 0; i < np; ++i) s += p[i];
+  for (int i = 0; i < np; ++i) s += ssp[(size_t)i * rows + t];  // slot-major: coalesced over tokens
   rs[t] = rsqrtf(s * inv_d + eps);
 }
 
@@ -291,8 +289,10 @@ struct EpiResidF32 {  // x[token, feature] += acc  (residual stream, fp32) [+ xb
   float* __restrict__ x;
   int ldx, n_valid;
   bf16_t* __restrict__ xb;   // optional: bf16 copy of the updated rows (same leading dimension)
-  float* __restrict__ ssp;   // optional: [tokens, np] partial sums of squares, slot = feature / 64
-  int np;
+  float* __restrict__ ssp;   // optional: [np, ssp_ld] partial sums of squares, slot = feature / 64; slot-major so
+                             // that a workgroup's statistics land in whole cache lines (token-major they were
+                             // 16-B fragments of lines shared with workgroups on other XCDs)
+  int np, ssp_ld;
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
     static_assert(FM % 2 == 0, "one statistic slot per 64 features (two row fragments)");
@@ -311,14 +311,16 @@ struct EpiResidF32 {  // x[token, feature] += acc  (residual stream, fp32) [+ xb
     // (wave tiles of 128 x 128 keep their accumulators in AGPRs and have the VGPRs for 3 blocks ahead)
     constexpr int DEPTH = (FM * FN >= 16) ? 4 : 2;
     float4 xin[DEPTH][8];
+    // (unconditional, from a clamped address: a predicated load would sit in its own basic block and
+    // make hipcc drain vmcnt to 0 around it, which serialises the whole read-modify-write)
     auto fetch = [&](int b, int p) {
       const int i = b / NJB, jb = (b % NJB) * 2;
-      const int f = m_base + i * 32 + sub * 4;
-      const int nrows = (FN - jb >= 2) ? 64 : 32;
+      const int f = min(m_base + i * 32 + sub * 4, n_valid - 4);
+      constexpr int ROWS = 64;  // the token side is padded to whole tiles: rows past FN*32 are never used
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const int t = c * 8 + rr;
-        if (t < nrows && f < n_valid)
+        if (jb * 32 + t < FN * 32 || ROWS == 0)
           xin[p][c] = *reinterpret_cast<const float4*>(x + (size_t)(n_base + jb * 32 + t) * ldx + f);
       }
     };
@@ -348,7 +350,9 @@ struct EpiResidF32 {  // x[token, feature] += acc  (residual stream, fp32) [+ xb
             v.y += d.y;
             v.z += d.z;
             v.w += d.w;
+#if !(defined(RP_PHASE_PROBE) && defined(RP_PROBE_NO_XSTORE))
             *reinterpret_cast<float4*>(x + off) = v;
+#endif
             if (xb) {
               uint2 o;
               o.x = pack_bf2(v.x, v.y);
@@ -377,7 +381,7 @@ struct EpiResidF32 {  // x[token, feature] += acc  (residual stream, fp32) [+ xb
             v += __shfl_xor(v, 2, 64);
             v += __shfl_xor(v, 4, 64);
             const int t = c * 8 + rr;
-            if (sub == 0 && t < nrows && slot < np) ssp[(size_t)(n_base + jb * 32 + t) * np + slot] = v;
+            if (sub == 0 && t < nrows && slot < np) ssp[(size_t)slot * ssp_ld + n_base + jb * 32 + t] = v;
           }
         }
       }
@@ -1048,8 +1052,7 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   if (!strcmp(name, "gemm_variant_all")) {  // benches/tests: one configuration for every GEMM; -1 = defaults
     RP_REQUIRE(value >= -1 && value <= 30, "gemm_variant_all out of range");
     if (value < 0) {
-      g_gemm_variant = g_gemm_variant_qkv = 20;
-      g_gemm_variant_wo = 6;
+      g_gemm_variant = g_gemm_variant_qkv = g_gemm_variant_wo = 20;
       g_gemm_variant_o = 0;
     } else {
       g_gemm_variant = g_gemm_variant_qkv = g_gemm_variant_wo = g_gemm_variant_o = value;
@@ -1308,7 +1311,7 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
       hipLaunchKernelGGL(g_attn_variant ? attention2_kernel : attention_kernel, att_grid, dim3(256), 0, stream, w.qkv,
                          cu_seqlens, e->bias_tab, w.att, H, e->maxd, Tp);
     }
-    if ((st = launch_gemm(w.att, inner, Tp, L.wo, inner, D, inner, EpiResidF32{w.x, D, D, w.xb, w.ssp, np}, stream,
+    if ((st = launch_gemm(w.att, inner, Tp, L.wo, inner, D, inner, EpiResidF32{w.x, D, D, w.xb, w.ssp, np, Tp}, stream,
                           RP_K_GEMM_O)))
       return st;
     if (g_debug_skip_ffn) continue;
@@ -1316,7 +1319,7 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
     // feed-forward sub-layer: ff = gelu(rs * g) * (rs * u)  ->  x += ff Wo2^T  (+ xb, ssp refreshed)
     if ((st = launch_gemm(w.xb, D, Tp, L.wi, D, 2 * F, D, EpiGegluBf16{w.ff, F, 2 * F, rs}, stream, RP_K_GEMM_WI)))
       return st;
-    if ((st = launch_gemm(w.ff, F, Tp, L.wo2, F, D, F, EpiResidF32{w.x, D, D, w.xb, w.ssp, np}, stream,
+    if ((st = launch_gemm(w.ff, F, Tp, L.wo2, F, D, F, EpiResidF32{w.x, D, D, w.xb, w.ssp, np, Tp}, stream,
                           RP_K_GEMM_WO)))
       return st;
   }
@@ -1344,7 +1347,7 @@ extern "C" RpStatus rp_dbg_gemm(const void* A, const void* W, void* out, int32_t
       return launch_gemm(a, K, M, w, K, N, K, EpiStoreBf16{(bf16_t*)out, n_valid, n_valid, RowScale{nullptr}}, stream,
                          RP_K_GEMM_QKV);
     case RP_EPI_RESID_F32:
-      return launch_gemm(a, K, M, w, K, N, K, EpiResidF32{(float*)out, n_valid, n_valid, nullptr, nullptr, 0}, stream, RP_K_GEMM_WO);
+      return launch_gemm(a, K, M, w, K, N, K, EpiResidF32{(float*)out, n_valid, n_valid, nullptr, nullptr, 0, 0}, stream, RP_K_GEMM_WO);
     case RP_EPI_GEGLU_BF16:
       return launch_gemm(a, K, M, w, K, N, K, EpiGegluBf16{(bf16_t*)out, n_valid / 2, n_valid, RowScale{nullptr}}, stream,
                          RP_K_GEMM_WI);
@@ -1379,7 +1382,7 @@ extern "C" RpStatus rp_dbg_gemm_fused(const void* A, const void* W, void* out, i
     case RP_EPI_STORE_BF16:
       return launch_gemm(a, K, M, w, K, N, K, EpiStoreBf16{(bf16_t*)out, n_valid, n_valid, rs}, stream, RP_K_GEMM_QKV);
     case RP_EPI_RESID_F32:
-      return launch_gemm(a, K, M, w, K, N, K, EpiResidF32{(float*)out, n_valid, n_valid, (bf16_t*)xb_out, ssp_out, np_out},
+      return launch_gemm(a, K, M, w, K, N, K, EpiResidF32{(float*)out, n_valid, n_valid, (bf16_t*)xb_out, ssp_out, np_out, M},
                          stream, RP_K_GEMM_WO);
     case RP_EPI_GEGLU_BF16:
       return launch_gemm(a, K, M, w, K, N, K, EpiGegluBf16{(bf16_t*)out, n_valid / 2, n_valid, rs}, stream,

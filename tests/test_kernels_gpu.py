@@ -218,14 +218,14 @@ def test_gemm_fused_rmsnorm_pieces_all_variants(gen, variant, M):
         x0 = torch.randn(M, N, generator=gen, device="cuda")
         x = x0.clone()
         xb = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
-        ssp = torch.full((M, np_), float("nan"), device="cuda")
+        ssp = torch.full((np_, M), float("nan"), device="cuda")  # slot-major
         _lib.check(lib.rp_dbg_gemm_fused(A.data_ptr(), W.data_ptr(), x.data_ptr(), M, N, K, N, _lib.RP_EPI_RESID_F32, None,
                                          0, 0.0, 0.0, xb.data_ptr(), ssp.data_ptr(), np_, _lib.current_stream()), "fused")
         torch.cuda.synchronize()
         ref = x0 + A.float() @ W.float().T
         assert (x - ref).abs().max().item() < 2e-4
         assert torch.equal(xb, x.to(torch.bfloat16)), "xb must be the bf16 rounding of the updated x"
-        want = (x.double() ** 2).view(M, np_, 64).sum(-1).float()
+        want = (x.double() ** 2).view(M, np_, 64).sum(-1).float().T
         assert not torch.isnan(ssp).any(), "a sum-of-squares slot was never written"
         assert (ssp - want).abs().max().item() <= 1e-4 * want.abs().max().item()
         # consumer side: row-scaled store
@@ -235,7 +235,7 @@ def test_gemm_fused_rmsnorm_pieces_all_variants(gen, variant, M):
         _lib.check(lib.rp_dbg_gemm_fused(xb.data_ptr(), W2.data_ptr(), out.data_ptr(), M, N2, K2, N2, _lib.RP_EPI_STORE_BF16,
                                          ssp.data_ptr(), np_, 1.0 / N, 1e-6, None, None, 0, _lib.current_stream()), "fused")
         torch.cuda.synchronize()
-        rs = torch.rsqrt(ssp.sum(1) / N + 1e-6)
+        rs = torch.rsqrt(ssp.sum(0) / N + 1e-6)
         ref2 = (xb.float() @ W2.float().T) * rs[:, None]
         assert (out.float() - ref2).abs().max().item() <= 2 ** -8 * ref2.abs().max().item() + 1e-3
     finally:

@@ -27,9 +27,20 @@ for name, N, K, epi in shapes:
     else:
         out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
 
+    # FUSED=1: the encoder's real epilogues (residual GEMMs also write the bf16 copy and the
+    # sum-of-squares partials); default: the bare GEMM + epilogue arithmetic
+    fused = os.environ.get("FUSED") == "1" and epi == _lib.RP_EPI_RESID_F32
+    np_ = (N + 63) // 64
+    xb = torch.empty(M, N, dtype=torch.bfloat16, device=dev) if fused else None
+    ssp = torch.empty(np_, M, device=dev) if fused else None
+
     def run():
-        _lib.check(lib.rp_dbg_gemm(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, N, epi,
-                                   _lib.current_stream()), "gemm")
+        if fused:
+            _lib.check(lib.rp_dbg_gemm_fused(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, N, epi, None, 0, 0.0,
+                                             0.0, xb.data_ptr(), ssp.data_ptr(), np_, _lib.current_stream()), "gemm")
+        else:
+            _lib.check(lib.rp_dbg_gemm(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, N, epi,
+                                       _lib.current_stream()), "gemm")
     times = {}
     errs = {}
     for rnd in range(ROUNDS + 1):  # round 0 = correctness + warm-up; then interleaved timing rounds

@@ -22,6 +22,7 @@ lib.rp_probe_read_handover_ts.argtypes = [C.c_void_p]
 dev = torch.device("cuda")
 M = int(os.environ.get("M", 65536))
 shapes = {"wi": (7168, 1472, _lib.RP_EPI_GEGLU_BF16), "wo": (1472, 3584, _lib.RP_EPI_RESID_F32),
+          "o": (1472, 384, _lib.RP_EPI_RESID_F32),
           "qkv": (1152, 1472, _lib.RP_EPI_STORE_BF16)}
 for name in os.environ.get("ONLY", "wi,wo").split(","):
     N, K, epi = shapes[name]
@@ -31,8 +32,16 @@ for name in os.environ.get("ONLY", "wi,wo").split(","):
            torch.empty(M, N // 2 if epi == _lib.RP_EPI_GEGLU_BF16 else N, dtype=torch.bfloat16, device=dev))
     for v in [int(x) for x in os.environ.get("VARIANTS", "6,20").split(",")]:
         _lib.check(lib.rp_set_option(b"gemm_variant_all", v), "opt")
+        fused = epi == _lib.RP_EPI_RESID_F32
+        np_ = (N + 63) // 64
+        xb = torch.empty(M, N, dtype=torch.bfloat16, device=dev) if fused else None
+        ssp = torch.empty(np_, M, device=dev) if fused else None
         for _ in range(12):
-            _lib.check(lib.rp_dbg_gemm(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, N, epi, _lib.current_stream()), "gemm")
+            if fused:
+                _lib.check(lib.rp_dbg_gemm_fused(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, N, epi, None, 0, 0.0,
+                                                 0.0, xb.data_ptr(), ssp.data_ptr(), np_, _lib.current_stream()), "gemm")
+            else:
+                _lib.check(lib.rp_dbg_gemm(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, N, epi, _lib.current_stream()), "gemm")
         torch.cuda.synchronize()
         tiles = ((N + 255) // 256) * (M // 256)
         ts = np.zeros(4 * tiles, dtype=np.uint64)
