@@ -151,6 +151,27 @@ RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t N, int32_t
                      float* out_scores, int32_t* out_ids, int32_t* out_count,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * e4m3 index (BASELINE.json configs[4]: fp8 similarity).  No reference counterpart: the reference
+ * keeps the index in the model dtype (retrieval/model.py:190-194).  Rows are quantised one by one,
+ *   scale[r] = max|x[r,:]| / 448 (1.0 for an all-zero row),
+ *   q[r,c]   = round-to-nearest-even to OCP e4m3fn of x[r,c] * (448 / max|x[r,:]|),
+ * and the score of (query j, premise i) is  (sum_c q8[j,c] * e8[i,c]) * q_scale[j] * e_scale[i]
+ * with the sum accumulated in fp32 by the block-scaled MFMA (all block scales 2^0).  Mask, ordering,
+ * outputs, workspace (rp_sim_topk_workspace_bytes) and flags are exactly rp_sim_topk's; D % 64 == 0.
+ * ------------------------------------------------------------------------------------------- */
+RpStatus rp_quantize_rows_e4m3(const void* X, int32_t x_dtype /* RP_DT_F32 | RP_DT_BF16 */, int64_t rows,
+                               int32_t D, void* out_fp8 /* u8 [rows, D] */, float* out_scale /* [rows] */,
+                               void* stream);
+RpStatus rp_sim_topk_fp8(const void* Q8, const float* q_scale, const void* E8, const float* e_scale,
+                         int32_t B, int32_t N, int32_t D,
+                         const int32_t* file_of, const int64_t* end_key,
+                         const uint32_t* file_bits_t, int32_t F,
+                         const int32_t* own_file, const int64_t* q_key,
+                         int32_t id_offset, int32_t k, int32_t flags,
+                         float* out_scores, int32_t* out_ids, int32_t* out_count,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* Merge R per-rank results (as gathered by an RCCL all-gather) into the global top-k.
  *   scores device f32 [R, B, k], ids device int32 [R, B, k], counts device int32 [R, B]
  *   workspace: rp_topk_merge_workspace_bytes(R, B, k) bytes.                                   */

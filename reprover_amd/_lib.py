@@ -74,6 +74,16 @@ SIGNATURES = {
          C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
          C.c_size_t, C.c_void_p],
     ),
+    "rp_quantize_rows_e4m3": (
+        C.c_int32,
+        [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "rp_sim_topk_fp8": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+         C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
     "rp_topk_merge_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "rp_topk_merge": (
         C.c_int32,

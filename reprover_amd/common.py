@@ -335,7 +335,7 @@ class Corpus:
 
     def nearest_premise_ids(
         self,
-        premise_embeddings: torch.Tensor,
+        premise_embeddings: "torch.Tensor | Fp8Index",
         batch_context: Sequence[Context],
         batch_context_emb: torch.Tensor,
         k: int,
@@ -346,8 +346,14 @@ class Corpus:
         dev = batch_context_emb.device
         if dev.type != "cuda":
             raise _lib.HipLibraryError("nearest-premise search runs on the GPU only (no CPU fallback)")
-        E = as_bf16_matrix(premise_embeddings, dev)
-        Q = as_bf16_matrix(batch_context_emb, dev)
+        fp8 = isinstance(premise_embeddings, Fp8Index)
+        if fp8:
+            E = premise_embeddings
+            assert E.device == dev, "the e4m3 index must live on the query device"
+            Q = Fp8Index.quantize(batch_context_emb)
+        else:
+            E = as_bf16_matrix(premise_embeddings, dev)
+            Q = as_bf16_matrix(batch_context_emb, dev)
         B, D = Q.shape
         N = E.shape[0]
         assert N == len(self.all_premises) and E.shape[1] == D
@@ -362,6 +368,17 @@ class Corpus:
         flags = _lib.RP_TOPK_DENSE if dense else _lib.RP_TOPK_AUTO
         ws_bytes = lib.rp_sim_topk_workspace_bytes(B, N, D, k, flags)
         ws = _workspace(dev, ws_bytes)
+        if fp8:
+            _lib.check(
+                lib.rp_sim_topk_fp8(
+                    _lib.ptr(Q.codes), _lib.ptr(Q.scale), _lib.ptr(E.codes), _lib.ptr(E.scale), B, N, D,
+                    _lib.ptr(file_of), _lib.ptr(end_key), _lib.ptr(d_bits), len(self._files), _lib.ptr(d_own),
+                    _lib.ptr(d_qk), 0, k, flags, _lib.ptr(out_s), _lib.ptr(out_i), _lib.ptr(out_c), _lib.ptr(ws),
+                    ws_bytes, _lib.current_stream(),
+                ),
+                "rp_sim_topk_fp8",
+            )
+            return out_i, out_s, out_c
         _lib.check(
             lib.rp_sim_topk(
                 _lib.ptr(Q), _lib.ptr(E), B, N, D, _lib.ptr(file_of), _lib.ptr(end_key), _lib.ptr(d_bits),
@@ -395,6 +412,51 @@ class Corpus:
         scores_h = scores.cpu().tolist()
         prem = self.all_premises
         return [[prem[i] for i in row] for row in ids_h], scores_h
+
+
+@dataclass
+class Fp8Index:
+    """An embedding matrix in OCP e4m3 with one fp32 scale per row (BASELINE.json configs[4]; no
+    reference counterpart — the reference keeps the index in the model dtype).  Row i dequantises
+    to ``codes[i].float8_e4m3fn * scale[i]``; half the bytes of the bf16 index for the scan to read.
+    Accepted wherever ``premise_embeddings`` is: ``Corpus.get_nearest_premises(Fp8Index, ...)``."""
+
+    codes: torch.Tensor  # uint8 [N, D], device
+    scale: torch.Tensor  # float32 [N], device
+
+    @classmethod
+    def quantize(cls, embeddings: torch.Tensor, device: Optional[torch.device] = None) -> "Fp8Index":
+        """``rp_quantize_rows_e4m3`` over a [N, D] fp32 / bf16 matrix (moved to ``device`` first)."""
+        lib = _lib.load()
+        dev = torch.device(device) if device is not None else embeddings.device
+        if dev.type != "cuda":
+            raise _lib.HipLibraryError("e4m3 quantisation runs on the GPU only (no CPU fallback)")
+        X = embeddings.to(dev)
+        if X.dtype not in (torch.float32, torch.bfloat16):
+            X = X.float()
+        X = X.contiguous()
+        N, D = X.shape
+        codes = torch.empty((N, D), dtype=torch.uint8, device=dev)
+        scale = torch.empty((N,), dtype=torch.float32, device=dev)
+        dt = _lib.RP_DT_F32 if X.dtype == torch.float32 else _lib.RP_DT_BF16
+        _lib.check(lib.rp_quantize_rows_e4m3(_lib.ptr(X), dt, N, D, _lib.ptr(codes), _lib.ptr(scale),
+                                             _lib.current_stream()), "rp_quantize_rows_e4m3")
+        return cls(codes, scale)
+
+    @property
+    def shape(self) -> Tuple[int, int]:
+        return tuple(self.codes.shape)
+
+    @property
+    def device(self) -> torch.device:
+        return self.codes.device
+
+    def __len__(self) -> int:
+        return self.codes.shape[0]
+
+    def dequantize(self) -> torch.Tensor:
+        """fp32 [N, D] (checks and tests; the scan never materialises this)."""
+        return self.codes.view(torch.float8_e4m3fn).float() * self.scale[:, None]
 
 
 _ws_cache: Dict[str, torch.Tensor] = {}

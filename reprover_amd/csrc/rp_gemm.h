@@ -51,8 +51,11 @@ __device__ unsigned long long g_handover_ts[8 * 64 * 3];
 __device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 // Tile configuration: block tile BM x BN x BK, WM x WN waves, NSTAGE-deep LDS ring.
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSTAGE_, int PIPE_ = 0>
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSTAGE_, int PIPE_ = 0, int FP8_ = 0>
 struct GemmCfg {
+  // FP8 = 1: the operands are e4m3 bytes, addressed as if they were bf16 rows of half the length (BK,
+  // K and the operands' ld all count 2-byte units); only the fragment reads and the MFMA differ.
+  static constexpr int FP8 = FP8_;
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_;
   static constexpr int PIPE = PIPE_;  // 1: one wave per SIMD, fragment reads software-pipelined (gemm_tile_pipe)
   static constexpr int NWAVES_ = WM_ * WN_;
@@ -179,6 +182,36 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
     }
     const char* sa = smem + buf * C::STAGE_BYTES;
     const char* sb = sa + C::A_BYTES;
+    if constexpr (C::FP8 != 0) {
+      // 64 e4m3 values per MFMA step = 4 x 16-B slots of a row: lanes 0-31 take slots 0,1, lanes 32-63
+      // slots 2,3 (any split works as long as both operands use the same one).  The two halves are
+      // read in LOGICAL slot order: the swizzle may swap their physical order differently per row.
+#pragma unroll
+      for (int ks = 0; ks < C::ROW_BYTES / 64; ++ks) {
+        i32x8 af8[FM], bf8[FN];
+#pragma unroll
+        for (int f = 0; f < FM; ++f) {
+          const int row = wave_row * (FM * 32) + f * 32 + (lane & 31);
+          const i32x4 lo = *reinterpret_cast<const i32x4*>(sa + C::off(row, ks * 4 + hi * 2));
+          const i32x4 up = *reinterpret_cast<const i32x4*>(sa + C::off(row, ks * 4 + hi * 2 + 1));
+          af8[f] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+        }
+#pragma unroll
+        for (int f = 0; f < FN; ++f) {
+          const int row = wave_col * (FN * 32) + f * 32 + (lane & 31);
+          const i32x4 lo = *reinterpret_cast<const i32x4*>(sb + C::off(row, ks * 4 + hi * 2));
+          const i32x4 up = *reinterpret_cast<const i32x4*>(sb + C::off(row, ks * 4 + hi * 2 + 1));
+          bf8[f] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+        }
+        // block-scaled MFMA with every E8M0 scale = 127 (2^0): plain e4m3 x e4m3 at the MX rate
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af8[i], bf8[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f,
+                                                                        0, 0x7f7f7f7f);
+      }
+    } else
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 af[FM], bfr[FN];

@@ -20,7 +20,7 @@
 namespace rp {
 
 constexpr int SIM_DENSE_MAX_N = 16384;
-constexpr int SIM_STRIDE = 16;
+constexpr int SIM_STRIDE_MAX = 64;
 constexpr int SIM_CAND_CAP = 8192;
 constexpr int SIM_MAX_K = 1024;
 constexpr int SIM_COUNT_STRIDE = 32;  // one candidate counter per 128-B line: contended atomics of different
@@ -28,12 +28,13 @@ constexpr int SIM_COUNT_STRIDE = 32;  // one candidate counter per 128-B line: c
 // scan tile configurations: BM queries x 128 premises (premise tiles are always 128 rows so that the
 // sampled-tile bookkeeping is independent of the query tile)
 typedef GemmCfg<256, 128, 32, 4, 2, 3> SimCfgQ256;  // B > 128: 8 waves, one workgroup sees up to 256 queries
-typedef GemmCfg<256, 128, 64, 4, 2, 2> SimCfgQ256K64;  // same, 128-B rows per K-step (full cache lines of E)
-typedef GemmCfg<256, 256, 64, 4, 2, 2> SimCfgQ256P256;  // 256-premise tiles: half of the DMA traffic is E
 typedef GemmCfg<128, 128, 64, 2, 2, 2> SimCfgQ128;  // B <= 128, D % 64 == 0
 typedef GemmCfg<128, 128, 32, 2, 2, 3> SimCfgQ128K32;  // B <= 128, D % 32 == 0
+// e4m3 index (rp_sim_topk_fp8): 64 fp8 values per K-step = the 64-B rows of the "BK = 32" geometry
+typedef GemmCfg<256, 128, 32, 4, 2, 3, 0, 1> SimCfg8Q256;
+typedef GemmCfg<128, 128, 32, 2, 2, 3, 0, 1> SimCfg8Q128;
 constexpr int GEMM_BN = 128;
-int g_scan_cfg = 0;  // 0: auto; 1: force 128-query tiles; 2: 256-query tiles with BK=64; 3: 256 x 256 tiles
+int g_scan_cfg = 0;  // 0: auto; 1: force 128-query tiles
 
 __device__ __forceinline__ uint64_t make_key(float score, int32_t id) {
   return ((uint64_t)f2ord(score) << 32) | (uint32_t)(~(uint32_t)id);
@@ -51,6 +52,9 @@ struct EpiSim {
   const int64_t* q_key;
   int B;
   int id_offset;
+  // e4m3 operands: score = acc * q_scale[query] * e_scale[premise] (NULL: bf16 operands, score = acc)
+  const float* q_scale;
+  const float* e_scale;
   // output
   int filter;          // 0: dense write, 1: append keys > thr
   uint64_t* dense;     // [B, dense_ld]
@@ -78,9 +82,11 @@ struct EpiSim {
     float* s_tau = reinterpret_cast<float*>(smem + 1024);               // [bm]
     int64_t* s_qk = reinterpret_cast<int64_t*>(smem + 2048);            // [bm]
     uint64_t* s_thr = reinterpret_cast<uint64_t*>(smem + 2048 + 2048);  // [bm]
+    float* s_qs = reinterpret_cast<float*>(smem + 6144);                // [bm]
     for (int t = threadIdx.x; t < bm; t += blockDim.x) {
       const int q = tile_q0 + t;
       const bool ok = q < B;
+      s_qs[t] = (ok && q_scale) ? q_scale[q] : 1.f;
       s_own[t] = (ok && file_of) ? own_file[q] : -1;
       s_qk[t] = (ok && file_of) ? q_key[q] : 0;
       const uint64_t th = (ok && filter) ? thr[q] : 0ull;
@@ -112,6 +118,7 @@ struct EpiSim {
         }
       }
       const int32_t id = p + id_offset;
+      const float es = (e_scale && pvalid) ? e_scale[p] : 1.f;
       if (!filter) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
@@ -122,7 +129,8 @@ struct EpiSim {
             const int q = tile_q0 + ql;
             bool ok = pvalid && (q < B);
             if (file_of) ok = ok && accessible(w[i], rr, f, ek, s_own[ql], s_qk[ql]);
-            const uint64_t key = ok ? make_key(acc[i][j][r], id) : 0ull;
+            const float sc = q_scale ? (acc[i][j][r] * s_qs[ql]) * es : acc[i][j][r];
+            const uint64_t key = ok ? make_key(sc, id) : 0ull;
             if (q < B && (p + slot_shift) < (int)dense_ld) dense[(size_t)q * dense_ld + p + slot_shift] = key;
           }
       } else {
@@ -134,7 +142,7 @@ struct EpiSim {
           for (int r = 0; r < 16; ++r) {
             const int rr = mfma32_row(r, hi);
             const int ql = ql0 + i * 32 + rr;
-            const float sc = acc[i][j][r];
+            const float sc = q_scale ? (acc[i][j][r] * s_qs[ql]) * es : acc[i][j][r];
             if (sc >= s_tau[ql]) {
               const int q = tile_q0 + ql;
               bool ok = pvalid && (q < B);
@@ -340,6 +348,7 @@ static void launch_select(const SelectArgs& a, int B, hipStream_t stream) {
 
 struct SimPlan {
   bool dense_only;
+  int stride;  // pass 0 scans every stride-th premise tile
   int bm, bn, tiles_q, tiles_p, sample_tiles, filter_tiles;
   size_t dense_ld;
   size_t off_dense, off_cand, off_count, off_thr, bytes;
@@ -349,10 +358,19 @@ static SimPlan plan_sim(int B, int N, int D, int k, int flags) {
   SimPlan p;
   p.bm = (B > 128 && g_scan_cfg != 1) ? 256 : 128;
   p.tiles_q = (B + p.bm - 1) / p.bm;
-  p.bn = (p.bm == 256 && g_scan_cfg == 3 && D % 64 == 0) ? 256 : GEMM_BN;
+  p.bn = GEMM_BN;
   p.tiles_p = (N + p.bn - 1) / p.bn;
-  p.dense_only = (flags & RP_TOPK_DENSE) || N <= SIM_DENSE_MAX_N || p.tiles_p < 2 * SIM_STRIDE;
-  p.sample_tiles = p.dense_only ? p.tiles_p : (p.tiles_p + SIM_STRIDE - 1) / SIM_STRIDE;
+  // Sampling stride: the k-th best of a 1/stride sample leaves ~k*stride candidates above it in the
+  // full set (spread ~stride*sqrt(k)), and the sample select reads N/stride keys per query.  The two
+  // select costs balance near stride ~ sqrt(N/k) / 2 (measured: 16 at N = 130k, 32 at N = 1M for k = 100: the filter
+  // pass pays an atomic append per candidate); k*stride is kept <= half the candidate capacity.
+  int stride = 2;
+  while (stride * 2 <= SIM_STRIDE_MAX && (int64_t)(stride * 2) * (stride * 2) * k * 4 <= N &&
+         (int64_t)(stride * 2) * k <= SIM_CAND_CAP / 2)
+    stride *= 2;
+  p.stride = stride;
+  p.dense_only = (flags & RP_TOPK_DENSE) || N <= SIM_DENSE_MAX_N || p.tiles_p < 2 * stride;
+  p.sample_tiles = p.dense_only ? p.tiles_p : (p.tiles_p + stride - 1) / stride;
   p.filter_tiles = p.tiles_p - p.sample_tiles;
   p.dense_ld = (size_t)p.sample_tiles * p.bn;
   size_t off = 0;
@@ -384,12 +402,14 @@ static RpStatus launch_scan_cfg(GemmOperand q, GemmOperand e, int D, int tiles_q
   return RP_OK;
 }
 
+// D counts 2-byte units of an operand row (= elements for bf16, elements / 2 for e4m3)
 static RpStatus launch_scan(const SimPlan& p, GemmOperand q, GemmOperand e, int D, int n_ptiles, int stride,
                             const EpiSim& epi, hipStream_t stream) {
   if (n_ptiles <= 0) return RP_OK;
-  if (p.bn == 256) return launch_scan_cfg<SimCfgQ256P256>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
-  if (p.bm == 256 && g_scan_cfg == 2 && D % 64 == 0)
-    return launch_scan_cfg<SimCfgQ256K64>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
+  if (epi.q_scale) {
+    if (p.bm == 256) return launch_scan_cfg<SimCfg8Q256>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
+    return launch_scan_cfg<SimCfg8Q128>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
+  }
   if (p.bm == 256) return launch_scan_cfg<SimCfgQ256>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
   if (D % 64 == 0) return launch_scan_cfg<SimCfgQ128>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
   return launch_scan_cfg<SimCfgQ128K32>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
@@ -404,13 +424,18 @@ extern "C" size_t rp_sim_topk_workspace_bytes(int32_t B, int32_t N, int32_t D, i
   return plan_sim(B, N, D, k, flags).bytes;
 }
 
-extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t N, int32_t D,
-                                const int32_t* file_of, const int64_t* end_key, const uint32_t* file_bits_t,
-                                int32_t F, const int32_t* own_file, const int64_t* q_key, int32_t id_offset,
-                                int32_t k, int32_t flags, float* out_scores, int32_t* out_ids, int32_t* out_count,
-                                void* workspace, size_t workspace_bytes, void* stream_) {
+// shared by the bf16 and the e4m3 entry points (q_scale/e_scale NULL = bf16 operands)
+static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale, const float* e_scale, int32_t B,
+                              int32_t N, int32_t D, const int32_t* file_of, const int64_t* end_key,
+                              const uint32_t* file_bits_t, int32_t F, const int32_t* own_file, const int64_t* q_key,
+                              int32_t id_offset, int32_t k, int32_t flags, float* out_scores, int32_t* out_ids,
+                              int32_t* out_count, void* workspace, size_t workspace_bytes, void* stream_) {
   RP_REQUIRE(Q && E && out_scores && out_ids && out_count, "null argument");
-  RP_REQUIRE(B > 0 && N > 0 && D > 0 && D % 32 == 0, "B=%d N=%d D=%d (D must be a multiple of 32)", B, N, D);
+  const bool fp8 = q_scale != nullptr;
+  if (fp8)
+    RP_REQUIRE(B > 0 && N > 0 && D > 0 && D % 64 == 0, "B=%d N=%d D=%d (D must be a multiple of 64 for e4m3)", B, N, D);
+  else
+    RP_REQUIRE(B > 0 && N > 0 && D > 0 && D % 32 == 0, "B=%d N=%d D=%d (D must be a multiple of 32)", B, N, D);
   RP_REQUIRE(k > 0 && k <= SIM_MAX_K, "k=%d out of range (1..%d)", k, SIM_MAX_K);
   if (file_of) RP_REQUIRE(end_key && file_bits_t && own_file && q_key && F > 0, "mask arrays incomplete");
   hipStream_t stream = (hipStream_t)stream_;
@@ -424,8 +449,11 @@ extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t
   uint64_t* thr = (uint64_t*)(ws + p.off_thr);
   const int cap = SIM_CAND_CAP + k;
 
-  GemmOperand qop{(const bf16_t*)Q, D, B}, eop{(const bf16_t*)E, D, N};
+  const int D2 = fp8 ? D / 2 : D;  // row length in 2-byte units
+  GemmOperand qop{(const bf16_t*)Q, D2, B}, eop{(const bf16_t*)E, D2, N};
   EpiSim epi;
+  epi.q_scale = q_scale;
+  epi.e_scale = e_scale;
   epi.file_of = file_of;
   epi.end_key = end_key;
   epi.N = N;
@@ -448,9 +476,9 @@ extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t
   epi.bm = p.bm;
 
   // pass 0: dense keys of the sampled (or all) premise tiles
-  const int stride0 = p.dense_only ? 1 : SIM_STRIDE;
+  const int stride0 = p.dense_only ? 1 : p.stride;
   RpStatus st;
-  if ((st = launch_scan(p, qop, eop, D, p.sample_tiles, stride0, epi, stream))) return st;
+  if ((st = launch_scan(p, qop, eop, D2, p.sample_tiles, stride0, epi, stream))) return st;
   SelectArgs sa;
   sa.keys = dense;
   sa.ld = p.dense_ld;
@@ -482,7 +510,7 @@ extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t
   RP_CHECK_LAUNCH();
   // pass 1: remaining tiles, keep only keys above each query's bound
   epi.filter = 1;
-  if ((st = launch_scan(p, qop, eop, D, p.filter_tiles, SIM_STRIDE, epi, stream))) return st;
+  if ((st = launch_scan(p, qop, eop, D2, p.filter_tiles, p.stride, epi, stream))) return st;
   SelectArgs sb;
   sb.keys = cand;
   sb.ld = cap;
@@ -499,6 +527,90 @@ extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t
   sb.out_ids = out_ids;
   sb.out_count = out_count;
   launch_select(sb, B, stream);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t N, int32_t D,
+                                const int32_t* file_of, const int64_t* end_key, const uint32_t* file_bits_t,
+                                int32_t F, const int32_t* own_file, const int64_t* q_key, int32_t id_offset,
+                                int32_t k, int32_t flags, float* out_scores, int32_t* out_ids, int32_t* out_count,
+                                void* workspace, size_t workspace_bytes, void* stream_) {
+  return sim_topk_impl(Q, E, nullptr, nullptr, B, N, D, file_of, end_key, file_bits_t, F, own_file, q_key, id_offset, k,
+                       flags, out_scores, out_ids, out_count, workspace, workspace_bytes, stream_);
+}
+
+extern "C" RpStatus rp_sim_topk_fp8(const void* Q8, const float* q_scale, const void* E8, const float* e_scale,
+                                    int32_t B, int32_t N, int32_t D, const int32_t* file_of, const int64_t* end_key,
+                                    const uint32_t* file_bits_t, int32_t F, const int32_t* own_file,
+                                    const int64_t* q_key, int32_t id_offset, int32_t k, int32_t flags,
+                                    float* out_scores, int32_t* out_ids, int32_t* out_count, void* workspace,
+                                    size_t workspace_bytes, void* stream_) {
+  RP_REQUIRE(q_scale && e_scale, "null scale array");
+  return sim_topk_impl(Q8, E8, q_scale, e_scale, B, N, D, file_of, end_key, file_bits_t, F, own_file, q_key, id_offset,
+                       k, flags, out_scores, out_ids, out_count, workspace, workspace_bytes, stream_);
+}
+
+// ------------------------------------------------------------------------------------------
+// Row-wise e4m3 quantisation of an embedding matrix: scale[r] = max|x[r,:]| / 448 (1 if the row is
+// zero), q = RNE_e4m3(x * (448 / max|x|)).  OCP e4m3fn: 4 exponent bits (bias 7), 3 mantissa bits,
+// max 448, subnormals k * 2^-9.  The rounding is done in integer arithmetic so the oracle
+// (oracle/fp8_ref.py) can restate it bit for bit.
+// ------------------------------------------------------------------------------------------
+namespace rp {
+__device__ __forceinline__ uint32_t f32_to_e4m3(float y) {
+  const uint32_t sign = (__float_as_uint(y) >> 24) & 0x80u;
+  const float a = fminf(fabsf(y), 448.f);
+  uint32_t code;
+  if (a >= 0.015625f) {  // normal range [2^-6, 448]: round the fp32 mantissa to 3 bits, nearest-even
+    uint32_t u = __float_as_uint(a);
+    u += 0x7FFFFu + ((u >> 20) & 1u);
+    code = (((u >> 23) - 120u) << 3) | ((u >> 20) & 7u);  // exponent re-biased 127 -> 7
+    code = min(code, 0x7Eu);
+  } else {
+    code = (uint32_t)rintf(a * 512.f);  // subnormals: multiples of 2^-9; 8 = the smallest normal
+  }
+  return sign | code;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void quantize_rows_kernel(const T* __restrict__ X, int64_t rows, int D,
+                                                            uint8_t* __restrict__ out, float* __restrict__ scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const T* x = X + r * D;
+  float amax = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(to_f32(x[c + e])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  const float inv = amax > 0.f ? 448.f / amax : 0.f;
+  if (lane == 0) scale[r] = amax > 0.f ? amax / 448.f : 1.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w |= f32_to_e4m3(to_f32(x[c + e]) * inv) << (8 * e);
+    *reinterpret_cast<uint32_t*>(out + r * D + c) = w;
+  }
+}
+}  // namespace rp
+
+extern "C" RpStatus rp_quantize_rows_e4m3(const void* X, int32_t x_dtype, int64_t rows, int32_t D, void* out_fp8,
+                                          float* out_scale, void* stream_) {
+  RP_REQUIRE(X && out_fp8 && out_scale, "null argument");
+  RP_REQUIRE(rows > 0 && D > 0 && D % 4 == 0, "rows=%lld D=%d (D must be a multiple of 4)", (long long)rows, D);
+  RP_REQUIRE(x_dtype == RP_DT_F32 || x_dtype == RP_DT_BF16, "x_dtype %d", x_dtype);
+  hipStream_t stream = (hipStream_t)stream_;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  if (x_dtype == RP_DT_F32)
+    hipLaunchKernelGGL(quantize_rows_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, (int64_t)rows, D,
+                       (uint8_t*)out_fp8, out_scale);
+  else
+    hipLaunchKernelGGL(quantize_rows_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)X, (int64_t)rows, D,
+                       (uint8_t*)out_fp8, out_scale);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

@@ -56,8 +56,12 @@ typedef uint16_t bf16_t;  // raw bfloat16 bits
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA A/B operand: 8 bf16 = 4 VGPRs
 typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;  // MX MFMA A/B operand: 32 fp8 = 8 VGPRs
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return bf2f(v); }
 
 // float -> bfloat16, round-to-nearest-even (as torch's conversion).  Going through the native
 // __bf16 type lets hipcc emit the gfx950 hardware conversion (v_cvt_pk_bf16_f32) instead of the

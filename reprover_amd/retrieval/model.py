@@ -20,7 +20,7 @@ from typing import Any, Dict, List, Optional, Tuple, Union
 import numpy as np
 import torch
 
-from ..common import Context, Corpus, IndexedCorpus, Pos, Premise, load_index, zip_strict
+from ..common import Context, Corpus, Fp8Index, IndexedCorpus, Pos, Premise, load_index, zip_strict
 from ..encoder import HipT5Encoder
 from ..tokenizer import ByT5Tokenizer
 
@@ -35,6 +35,7 @@ class PremiseRetriever:
         num_retrieved: int = 100,
         device: Union[str, torch.device] = "cuda",
         dtype: torch.dtype = torch.bfloat16,
+        index_dtype: str = "bf16",
     ) -> None:
         self.lr = lr
         self.warmup_steps = warmup_steps
@@ -49,6 +50,13 @@ class PremiseRetriever:
         self.corpus_embeddings: Optional[torch.Tensor] = None
         self.embeddings_staled = True
         self.predict_step_outputs: List[Dict[str, Any]] = []
+        # "bf16": search the embedding matrix as it is (the reference's behaviour).  "fp8": search an
+        # e4m3 copy with per-row scales (BASELINE.json configs[4]); ``corpus_embeddings`` stays what the
+        # reference exposes, the quantised copy is derived from it lazily.
+        assert index_dtype in ("bf16", "fp8")
+        self.index_dtype = index_dtype
+        self._fp8_index: Optional[Fp8Index] = None
+        self._fp8_source: Optional[Tuple[int, int]] = None
 
     # -- construction (model.py:52-66) --------------------------------------------------------------
     @classmethod
@@ -99,6 +107,17 @@ class PremiseRetriever:
             self.corpus_embeddings = indexed_corpus.embeddings
             self.embeddings_staled = False
 
+    def _search_operand(self):
+        """What ``get_nearest_premises`` scans: the embeddings, or their e4m3 copy (rebuilt whenever
+        ``corpus_embeddings`` is replaced or written)."""
+        if self.index_dtype != "fp8":
+            return self.corpus_embeddings
+        tag = (self.corpus_embeddings.data_ptr(), self.corpus_embeddings._version)
+        if self._fp8_index is None or self._fp8_source != tag:
+            self._fp8_index = Fp8Index.quantize(self.corpus_embeddings, self.device)
+            self._fp8_source = tag
+        return self._fp8_index
+
     @property
     def embedding_size(self) -> int:
         return self.encoder.config.hidden_size
@@ -145,7 +164,7 @@ class PremiseRetriever:
         context_emb = self._encode(batch["context_ids"], batch["context_mask"])
         assert not self.embeddings_staled
         retrieved_premises, scores = self.corpus.get_nearest_premises(
-            self.corpus_embeddings, batch["context"], context_emb, self.num_retrieved
+            self._search_operand(), batch["context"], context_emb, self.num_retrieved
         )
         for url, commit, file_path, full_name, start, tactic_idx, ctx, pos_premises, premises, s in zip_strict(
             batch["url"], batch["commit"], batch["file_path"], batch["full_name"], batch["start"],
@@ -185,6 +204,6 @@ class PremiseRetriever:
         if self.corpus_embeddings.device != context_emb.device or self.corpus_embeddings.dtype != torch.bfloat16:
             # a pickled index arrives as fp32 on the CPU (index.py:37-40): move + cast once
             self.corpus_embeddings = self.corpus_embeddings.to(device=context_emb.device, dtype=torch.bfloat16)
-        retrieved_premises, scores = self.corpus.get_nearest_premises(self.corpus_embeddings, [ctx], context_emb, k)
+        retrieved_premises, scores = self.corpus.get_nearest_premises(self._search_operand(), [ctx], context_emb, k)
         assert len(retrieved_premises) == len(scores) == 1
         return retrieved_premises[0], scores[0]

@@ -63,6 +63,44 @@ def sim_topk(Q, E, k, masks=None, id_offset=0, flags=0):
     return out_i, out_s, out_c
 
 
+def quantize_e4m3(X):
+    """(codes uint8 [R, D], scale f32 [R]) device tensors via rp_quantize_rows_e4m3."""
+    lib = _lib.load()
+    X = X.contiguous()
+    R, D = X.shape
+    codes = torch.empty((R, D), dtype=torch.uint8, device=X.device)
+    scale = torch.empty((R,), dtype=torch.float32, device=X.device)
+    dt = _lib.RP_DT_F32 if X.dtype == torch.float32 else _lib.RP_DT_BF16
+    _lib.check(lib.rp_quantize_rows_e4m3(_lib.ptr(X), dt, R, D, _lib.ptr(codes), _lib.ptr(scale),
+                                         _lib.current_stream()), "rp_quantize_rows_e4m3")
+    torch.cuda.synchronize()
+    return codes, scale
+
+
+def sim_topk_fp8(Q8, qs, E8, es, k, masks=None, id_offset=0, flags=0):
+    """rp_sim_topk_fp8 on e4m3 codes (uint8) + per-row scales; masks as in sim_topk."""
+    lib = _lib.load()
+    B, D = Q8.shape
+    N = E8.shape[0]
+    out_s = torch.empty((B, k), dtype=torch.float32, device=Q8.device)
+    out_i = torch.empty((B, k), dtype=torch.int32, device=Q8.device)
+    out_c = torch.empty((B,), dtype=torch.int32, device=Q8.device)
+    nbytes = lib.rp_sim_topk_workspace_bytes(B, N, D, k, flags)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=Q8.device)
+    if masks is None:
+        f = ek = bt = own = qk = None
+        F = 0
+    else:
+        f, ek, bt, own, qk = masks
+        F = bt.shape[0]
+    _lib.check(lib.rp_sim_topk_fp8(_lib.ptr(Q8), _lib.ptr(qs), _lib.ptr(E8), _lib.ptr(es), B, N, D, _lib.ptr(f),
+                                   _lib.ptr(ek), _lib.ptr(bt), F, _lib.ptr(own), _lib.ptr(qk), id_offset, k, flags,
+                                   _lib.ptr(out_s), _lib.ptr(out_i), _lib.ptr(out_c), _lib.ptr(ws), nbytes,
+                                   _lib.current_stream()), "rp_sim_topk_fp8")
+    torch.cuda.synchronize()
+    return out_i, out_s, out_c
+
+
 def topk_merge(scores, ids, counts):
     lib = _lib.load()
     R, B, k = scores.shape
