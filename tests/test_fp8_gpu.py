@@ -163,3 +163,60 @@ def test_host_fp8_index_search_and_value_error():
     first = Context(files[0], "T", Pos(0, 0), "⊢ s")  # nothing before it, nothing imported
     with pytest.raises(ValueError):
         corpus.get_nearest_premises(idx, [first], torch.from_numpy(Q[:1]).cuda(), k)
+
+
+def test_retriever_fp8_index_c5_slice():
+    """BASELINE configs[4] in miniature: ByT5-base geometry (d_model 1536, 12 heads, d_ff 3968; 3 layers)
+    + e4m3 index.  reindex -> quantised copy -> retrieve / predict_step; the fp8 results must be the
+    oracle's masked top-k on the quantised operands, and agree with the bf16 index on most of the top-10."""
+    import os, tempfile
+    from reprover_amd import synth
+    from reprover_amd.common import Context, Pos
+    from reprover_amd.retrieval.model import PremiseRetriever
+
+    cfg = synth.t5_config("byt5-base")
+    cfg["num_layers"] = 3
+    sd = synth.synth_state_dict(cfg, seed=5)
+    model = PremiseRetriever.from_state_dict(cfg, sd, 512, "cuda:0")
+    files = synth.synth_corpus_records(40, 1500, seed=13)
+    path = os.path.join(tempfile.mkdtemp(), "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    model.load_corpus(path)
+    model.reindex_corpus(64)
+    corpus = model.corpus
+    rng = np.random.default_rng(2)
+    last = corpus.files[-1].path
+    ctxs = [Context(last, f"t{j}", Pos(10 ** 6, 0), "h : " + synth.synth_text(rng, 60 + 17 * j) + " ⊢ goal") for j in range(8)]
+    k = 10
+    where = {id(p): i for i, p in enumerate(corpus.all_premises)}
+    bf = [model.retrieve(c.state, c.path, c.theorem_full_name, c.theorem_pos, k) for c in ctxs]
+    model.index_dtype = "fp8"
+    f8 = [model.retrieve(c.state, c.path, c.theorem_full_name, c.theorem_pos, k) for c in ctxs]
+    idx = model._search_operand()
+    assert isinstance(idx, Fp8Index) and idx.shape == (len(corpus.all_premises), 1536)
+    assert model.corpus_embeddings.dtype == torch.bfloat16  # what the reference exposes is untouched
+    # oracle on the quantised operands
+    Qe = model.encode_texts([c.serialize() for c in ctxs])
+    Q8, qs = fp8_ref.quantize_rows_e4m3(Qe.float().cpu().numpy())
+    S = fp8_ref.scores_fp8(Q8, qs, idx.codes.cpu().numpy(), idx.scale.cpu().numpy())
+    acc = np.stack([corpus.accessible_mask(c.path, c.theorem_pos) for c in ctxs])
+    want_i, want_s = common_ref.masked_topk(S, acc, k)
+    got_i = np.array([[where[id(p)] for p in prem] for prem, _ in f8])
+    got_s = np.array([sc for _, sc in f8])
+    assert np.abs(got_s - want_s).max() < 5e-6
+    checked, bad = hh.gap_rule_ids(got_i.tolist(), want_i.tolist(), want_s.tolist(), tol=5e-6)
+    assert bad == 0
+    overlap = np.mean([len({where[id(p)] for p in a[0]} & {where[id(p)] for p in b[0]}) / k for a, b in zip(bf, f8)])
+    dscore = max(abs(x - y) for a, b in zip(bf, f8) for x, y in zip(sorted(a[1]), sorted(b[1])))
+    print(f"c5 slice: fp8 vs bf16 index: top-{k} overlap {overlap:.3f}, max |sorted score diff| {dscore:.3e}")
+    assert overlap >= 0.8 and dscore < 2e-2
+    # batch path (predict_step) uses the same operand
+    model.num_retrieved = k
+    tok = model.tokenizer([c.serialize() for c in ctxs], padding="longest", max_length=512, truncation=True,
+                          return_tensors="pt")
+    b = {"context": ctxs, "context_ids": tok.input_ids.cuda(), "context_mask": tok.attention_mask.cuda()}
+    for key in ("url", "commit", "file_path", "full_name", "start", "tactic_idx", "all_pos_premises"):
+        b[key] = [None] * len(ctxs)
+    model.predict_step_outputs = []
+    model.predict_step(b, 0)
+    assert [[where[id(p)] for p in r["retrieved_premises"]] for r in model.predict_step_outputs] == got_i.tolist()
