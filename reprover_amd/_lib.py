@@ -135,6 +135,10 @@ def load() -> C.CDLL:
     if got != ABI_VERSION:
         raise HipLibraryError(f"libreprover_hip ABI {got} != binding {ABI_VERSION}; rebuild the library")
     _lib = lib
+    # experiments: RP_OPTIONS="name=value,name=value" -> rp_set_option (tuning knobs only; unknown names raise)
+    for item in filter(None, os.environ.get("RP_OPTIONS", "").split(",")):
+        name, _, value = item.partition("=")
+        check(lib.rp_set_option(name.strip().encode(), int(value)), f"RP_OPTIONS {item}")
     return lib
 
 

@@ -29,12 +29,15 @@ thread_local std::string g_last_error;
 extern int g_scan_cfg;
 static int g_gemm_group_m = 8;
 // Tile configuration per encoder GEMM (see launch_gemm()), measured at 65536 tokens (tools/gemm_bench.py,
-// profiles/): the 4-wave software-pipelined 256 x 256 tile is the fastest main loop for all four; the
-// K = H*64 attention-output projection is bound by the fp32 read-modify-write of x whatever the tiling.
+// profiles/).  20 / 26 = the software-pipelined 256 x 256 x 64 tile with 4 / 8 waves: the same main
+// loop; 8 waves finish the heavier epilogues (bf16 store of 1152 features, fp32 residual
+// read-modify-write) sooner, 4 waves win by a hair on the gated-GELU GEMM.  The K = H*64
+// attention-output projection is bound by the read-modify-write of x whatever the tiling: two small
+// blocks per CU overlap one block's epilogue with the other's main loop.
 static int g_gemm_variant = 20;      // FFN-in (wi_0|wi_1 + gated GELU)
-static int g_gemm_variant_qkv = 20;  // QKV
-static int g_gemm_variant_wo = 20;   // FFN-out (+ residual)
-static int g_gemm_variant_o = 0;     // attention output (+ residual): two 4-wave 128 x 128 blocks per CU
+static int g_gemm_variant_qkv = 26;  // QKV
+static int g_gemm_variant_wo = 26;   // FFN-out (+ residual)
+static int g_gemm_variant_o = 0;     // attention output (+ residual)
 static int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 static int g_gemm_skinny = 1;
 static int g_gemm_skinny_variant = 12;
@@ -496,7 +499,7 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
   // 7-deep LDS ring so every workgroup streams its weight slab with ~6 K-steps of DMA in flight.
   if (g_gemm_skinny && m256 && ((n_rows_w + 255) / 256) * (M / 256) < 96)
     v = (g_tokens_valid > 0 && g_tokens_valid <= 128 && g_gemm_skinny_variant == 12) ? 15 : g_gemm_skinny_variant;
-  if ((v == 1 || v == 6 || v == 20) && !k64) v = (v != 1 && m256) ? 9 : 0;
+  if ((v == 1 || v == 6 || v == 20 || v == 26) && !k64) v = (v != 1 && m256) ? 9 : 0;
   if (v >= 5 && !m256) v = 0;
   // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages>; measured on
   // MI355X at M = 65536 (tools/gemm_bench.py): 6 is the best all-rounder, 11 is 2-3 % ahead on FFN-in.
@@ -504,6 +507,7 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
     case 1: return launch_gemm_cfg<GemmCfg<128, 128, 64, 2, 2, 2>>(w, a, K, epi, stream, prof_class);
     case 6: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2>>(w, a, K, epi, stream, prof_class);
     case 20: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class);
+    case 26: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class);
     case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
     case 11: return launch_gemm_cfg<GemmCfg<256, 128, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
     case 12: return launch_gemm_cfg<GemmCfg<64, 256, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class);
@@ -1056,7 +1060,8 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   if (!strcmp(name, "gemm_variant_all")) {  // benches/tests: one configuration for every GEMM; -1 = defaults
     RP_REQUIRE(value >= -1 && value <= 30, "gemm_variant_all out of range");
     if (value < 0) {
-      g_gemm_variant = g_gemm_variant_qkv = g_gemm_variant_wo = 20;
+      g_gemm_variant = 20;
+      g_gemm_variant_qkv = g_gemm_variant_wo = 26;
       g_gemm_variant_o = 0;
     } else {
       g_gemm_variant = g_gemm_variant_qkv = g_gemm_variant_wo = g_gemm_variant_o = value;

@@ -248,7 +248,6 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
   constexpr int BK = C::BK, FM = C::FM, FN = C::FN, KS = BK / 16;
   RP_TS(0);
   static_assert(KS % 2 == 0 && KS >= 2, "even number of k-steps (fragment double-buffer parity)");
-  static_assert(FM * FN >= FM + FN + C::A_DMA && FM * FN >= FM + FN + C::W_DMA, "one DMA per MFMA slot");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -283,6 +282,12 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
     char* base = smem + buf * C::STAGE_BYTES;
 #if defined(RP_PHASE_PROBE) && defined(RP_PROBE_NO_DMA)
     if (kt > 1) return;
+#endif
+#if defined(RP_PHASE_PROBE) && defined(RP_PROBE_HALF_DMA)
+    if (kt > 1 && half == 1) return;  // timing only: half the bytes
+#endif
+#if defined(RP_PHASE_PROBE) && defined(RP_PROBE_SAME_TILE)
+    kt = kt & 1;  // timing only: every refill re-reads the first two K-tiles (L2 hits)
 #endif
     if (half == 0) {
 #pragma unroll
@@ -353,6 +358,29 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
   // halves so that no more than one LDS-DMA instruction sits between two MFMAs (a DMA issue costs the
   // wave ~20 clk, an MFMA slot is 32 clk): the A image right after the hand-over, between the last
   // k-step's MFMAs, and the W image (PEND) between the MFMAs of the next tile's first k-step.
+  // issue-order hint for one k-step: after every MFMA at most ceil(ops / MFMAs) of the pending
+  // non-MFMA operations, fragment reads first (the next k-step waits on them), then DMA issues
+  auto hint_order = [](auto nread_tag, auto ndma_tag) {
+    constexpr int NREAD = decltype(nread_tag)::value, NDMA = decltype(ndma_tag)::value, NM = FM * FN;
+    constexpr int PER = (NREAD + NDMA + NM - 1) / NM;
+    int rd = NREAD, dm = NDMA;
+#pragma unroll
+    for (int n = 0; n < NM; ++n) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        if (rd > 0) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+          --rd;
+        } else if (dm > 0) {
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (LDS-DMA)
+          --dm;
+        }
+      }
+    }
+  };
+  using NoDma = std::integral_constant<int, 0>;
+  using Reads = std::integral_constant<int, FM + FN>;
   int buf = 0;
   auto tile_body = [&](int kt, auto mode_tag, auto pend_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
@@ -363,22 +391,10 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
       read_frags(st, ks + 1, (ks + 1) & 1);
       if (PEND && ks == 0) stage_half(kt - 1 + NSTAGE, buf == 0 ? NSTAGE - 1 : buf - 1, 1);
       mma(ks & 1);
-      // issue order: the next k-step's fragment reads go out between the first MFMAs of this one
-#pragma unroll
-      for (int n = 0; n < FM + FN; ++n) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-      }
-      if (PEND && ks == 0) {
-#pragma unroll
-        for (int n = 0; n < C::W_DMA; ++n) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (LDS-DMA)
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - (FM + FN) - C::W_DMA, 0);
-      } else {
-        __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - (FM + FN), 0);
-      }
+      if (PEND && ks == 0)
+        hint_order(Reads(), std::integral_constant<int, C::W_DMA>());
+      else
+        hint_order(Reads(), NoDma());
     }
     if (MODE >= 1) {
       // every fragment of tile kt is in registers once this wave's LDS reads have returned
@@ -397,23 +413,10 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
       if (MODE == 2) stage_half(kt + NSTAGE, freed, 0);
     }
     mma((KS - 1) & 1);
-    if (MODE >= 1) {
-#pragma unroll
-      for (int n = 0; n < FM + FN; ++n) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      if (MODE == 2) {
-#pragma unroll
-        for (int n = 0; n < C::A_DMA; ++n) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - (FM + FN) - C::A_DMA, 0);
-      } else {
-        __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - (FM + FN), 0);
-      }
-    }
+    if (MODE == 2)
+      hint_order(Reads(), std::integral_constant<int, C::A_DMA>());
+    else if (MODE == 1)
+      hint_order(Reads(), NoDma());
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
