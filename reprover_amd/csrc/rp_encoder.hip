@@ -499,17 +499,17 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
   // 7-deep LDS ring so every workgroup streams its weight slab with ~6 K-steps of DMA in flight.
   if (g_gemm_skinny && m256 && ((n_rows_w + 255) / 256) * (M / 256) < 96)
     v = (g_tokens_valid > 0 && g_tokens_valid <= 128 && g_gemm_skinny_variant == 12) ? 15 : g_gemm_skinny_variant;
-  if ((v == 1 || v == 6 || v == 20 || v == 26) && !k64) v = (v != 1 && m256) ? 9 : 0;
+  if ((v == 20 || v == 26) && !k64) v = 9;  // 64-wide K tiles need K % 64 == 0
   if (v >= 5 && !m256) v = 0;
-  // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages>; measured on
-  // MI355X at M = 65536 (tools/gemm_bench.py): 6 is the best all-rounder, 11 is 2-3 % ahead on FFN-in.
+  // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages[, pipelined]>:
+  //   20 / 26  pipelined 256 x 256 x 64, 4 / 8 waves     (the encoder's big GEMMs)
+  //   9        plain 256 x 256 x 32, 3 stages             (K % 64 != 0)
+  //   0        plain 128 x 128 x 32, 3 stages, 2 blocks/CU (attention-out; token counts not a multiple of 256)
+  //   12 / 15  64 x 256 / 64 x 128 x 32, 7 stages         (few tokens: single-state queries)
   switch (v) {
-    case 1: return launch_gemm_cfg<GemmCfg<128, 128, 64, 2, 2, 2>>(w, a, K, epi, stream, prof_class);
-    case 6: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2>>(w, a, K, epi, stream, prof_class);
     case 20: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class);
     case 26: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class);
     case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
-    case 11: return launch_gemm_cfg<GemmCfg<256, 128, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
     case 12: return launch_gemm_cfg<GemmCfg<64, 256, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class);
     case 15: return launch_gemm_cfg<GemmCfg<64, 128, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class);
     default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class);

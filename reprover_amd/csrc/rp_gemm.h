@@ -5,13 +5,17 @@
 // sub-tile as FM x FN v_mfma_f32_32x32x16_bf16 accumulators (16 fp32 registers each).
 //
 // Staging: A and W tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round
-// trip, 1 KiB per wave-instruction) into an NSTAGE-deep ring; tile t+NSTAGE-1 is issued while
-// tile t is consumed, with a COUNTED s_waitcnt vmcnt(...) and a raw s_barrier per K-step so the
-// DMAs stay in flight across barriers (cdna_hip_programming.md §5 "Pipelining across barriers").
-// The LDS image is lane-linear per DMA instruction, so the bank-conflict swizzle is applied to the
-// per-lane SOURCE address and again on the ds_read_b128 fragment reads (rule 21): 16-B slot index
-// ^= f(row), with f chosen per BK so that the 16-lane groups ds_read_b128 is serviced in hit 16
-// distinct slots of the 256-B bank row (conflict-free).
+// trip, 1 KiB per wave-instruction) into an NSTAGE-deep ring, with a COUNTED s_waitcnt vmcnt(...)
+// and a raw s_barrier per K-tile so the DMAs stay in flight across barriers
+// (cdna_hip_programming.md §5 "Pipelining across barriers").  The LDS image is lane-linear per DMA
+// instruction, so the bank-conflict swizzle is applied to the per-lane SOURCE address and again on
+// the ds_read_b128 fragment reads: 16-B slot index ^= f(row), with f chosen per BK so that the
+// 16-lane groups ds_read_b128 is serviced in hit 16 distinct slots of the 256-B bank row.
+//
+// Two main loops:
+//   gemm_tile       the plain loop (compiler-scheduled): small tiles with several blocks per CU, the
+//                   few-token configurations, the similarity scan (bf16 or e4m3 operands);
+//   gemm_tile_pipe  the hand-software-pipelined loop of the encoder's big GEMMs (GemmCfg<..., PIPE=1>).
 //
 // The epilogue is a functor so the same core serves the encoder GEMMs (bf16 store, fp32
 // residual add, gated-GELU) and the similarity scan (accessibility mask + top-k filter).

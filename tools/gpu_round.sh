@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
 KEXPR="${KEXPR:-}"
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt
-for f in test_kernels_gpu test_encoder_gpu test_retriever_gpu; do
+for f in test_kernels_gpu test_fp8_gpu test_encoder_gpu test_edge_cases_gpu test_retriever_gpu test_cli_gpu; do
   echo "=== $f" | tee -a gpurun_out/pytest.log
   if [ -n "$KEXPR" ]; then
     timeout 1200 python -m pytest tests/$f.py -m gpu -q --tb=short -s -k "$KEXPR" 2>&1 | tail -150 | tee -a gpurun_out/pytest.log

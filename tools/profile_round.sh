@@ -3,7 +3,7 @@
 # (separate runs, --kernel-trace only, as the guide prescribes).  Summaries -> gpurun_out/prof_*/
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 R=${ROUND:-r01}
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$R -o bench --output-format csv -- \
+timeout -k 5 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$R -o bench --output-format csv -- \
   python bench.py --steps 5 --warmup 2 --no-cpu-baseline --headline-only > gpurun_out/prof_$R.log 2>&1
 tail -1 gpurun_out/prof_$R.log | cut -c1-400
 python - <<PY
@@ -20,7 +20,7 @@ print("\n".join(out[:16]))
 PY
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
   tag=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $grp -d gpurun_out/pmc_${R}_$tag -o bench --output-format csv -- \
+  timeout -k 5 180 rocprofv3 --kernel-trace --pmc $grp -d gpurun_out/pmc_${R}_$tag -o bench --output-format csv -- \
     python bench.py --steps 2 --warmup 1 --no-cpu-baseline --headline-only > gpurun_out/pmc_${R}_$tag.log 2>&1
 done
 python - <<PY
@@ -31,7 +31,7 @@ for f in glob.glob("gpurun_out/pmc_${R}_*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
         if "rp::" not in k: continue
-        key = (k[:90], row["Counter_Name"])
+        key = (k[:110], row["Counter_Name"])
         agg[key][0] += float(row["Counter_Value"]); agg[key][1] += 1
     for (k, c), (v, n) in agg.items():
         res[k][c] = (v / n, n)
