@@ -304,92 +304,70 @@ struct EpiResidF32 {  // x[token, feature] += acc  (residual stream, fp32) [+ xb
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
     static_assert(FM % 2 == 0, "one statistic slot per 64 features (two row fragments)");
     const int hi = lane >> 5, cl = lane & 31;
-    const int sub = lane & 7, rr = lane >> 3;  // 8 lanes x 16 B = one token's 32 features; 8 tokens per pass
-    constexpr int NJB = (FN + 1) / 2, NB = FM * NJB;  // blocks of 32 features x 64 tokens
-    float ssq[FM / 2][NJB][8];
-#pragma unroll
-    for (int q = 0; q < FM / 2; ++q)
-#pragma unroll
-      for (int a = 0; a < NJB; ++a)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) ssq[q][a][c] = 0.f;
-    // The read-modify-write of x is latency-bound unless many loads are in flight: the old values
-    // of block b+1 are requested before block b is staged, added and stored.
+    // Blocks of 64 features x 32 tokens.  16 lanes x 16 B cover one token's 64 features = 256
+    // contiguous bytes of its x row (4 tokens per wave-instruction): read-modify-write in 256-B row
+    // segments streams at ~4.5 TB/s on this chip, in 128-B segments at ~3 (tools/probes/rmw_probe.hip).
+    const int sub = lane & 15, rr = lane >> 4;
+    constexpr int RB = 272;  // staging row: 64 floats + 16 B pad (32 rows = 8704 B <= EPI_STAGE_BYTES)
+    constexpr int NB = (FM / 2) * FN;
+    // The read-modify-write of x is latency-bound unless many loads are in flight: the old values of
+    // the next block(s) are requested before the current one is staged, added and stored.  Loads are
+    // unconditional, from a clamped address: a predicated load would sit in its own basic block and
+    // make hipcc drain vmcnt to 0 around it, which serialises the whole epilogue.
     // (wave tiles of 128 x 128 keep their accumulators in AGPRs and have the VGPRs for 3 blocks ahead)
     constexpr int DEPTH = (FM * FN >= 16) ? 4 : 2;
     float4 xin[DEPTH][8];
-    // (unconditional, from a clamped address: a predicated load would sit in its own basic block and
-    // make hipcc drain vmcnt to 0 around it, which serialises the whole read-modify-write)
     auto fetch = [&](int b, int p) {
-      const int i = b / NJB, jb = (b % NJB) * 2;
-      const int f = min(m_base + i * 32 + sub * 4, n_valid - 4);
-      constexpr int ROWS = 64;  // the token side is padded to whole tiles: rows past FN*32 are never used
+      const int q = b / FN, j = b % FN;
+      const int f = min(m_base + q * 64 + sub * 4, n_valid - 4);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int t = c * 8 + rr;
-        if (jb * 32 + t < FN * 32 || ROWS == 0)
-          xin[p][c] = *reinterpret_cast<const float4*>(x + (size_t)(n_base + jb * 32 + t) * ldx + f);
-      }
+      for (int c = 0; c < 8; ++c)
+        xin[p][c] = *reinterpret_cast<const float4*>(x + (size_t)(n_base + j * 32 + c * 4 + rr) * ldx + f);
     };
 #pragma unroll
     for (int b = 0; b < DEPTH - 1 && b < NB; ++b) fetch(b, b);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const int i = b / NJB, jb = (b % NJB) * 2;
-      const int f = m_base + i * 32 + sub * 4;
+      const int q = b / FN, j = b % FN;
+      const int f = m_base + q * 64 + sub * 4;
+      const int slot = (m_base >> 6) + q;
       if (b + DEPTH - 1 < NB) fetch(b + DEPTH - 1, (b + DEPTH - 1) % DEPTH);
 #pragma unroll
-      for (int jj = 0; jj < 2 && jb + jj < FN; ++jj)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(stage + (jj * 32 + cl) * EPI_ROW_BYTES + (8 * g + 4 * hi) * 4) = make_float4(
-              acc[i][jb + jj][4 * g], acc[i][jb + jj][4 * g + 1], acc[i][jb + jj][4 * g + 2], acc[i][jb + jj][4 * g + 3]);
-      const int nrows = (FN - jb >= 2) ? 64 : 32;
+          *reinterpret_cast<float4*>(stage + cl * RB + (i * 32 + 8 * g + 4 * hi) * 4) =
+              make_float4(acc[2 * q + i][j][4 * g], acc[2 * q + i][j][4 * g + 1], acc[2 * q + i][j][4 * g + 2],
+                          acc[2 * q + i][j][4 * g + 3]);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const int t = c * 8 + rr;
-        if (t < nrows) {
-          const float4 d = *reinterpret_cast<const float4*>(stage + t * EPI_ROW_BYTES + sub * 16);
-          if (f < n_valid) {
-            const size_t off = (size_t)(n_base + jb * 32 + t) * ldx + f;
-            float4 v = xin[b % DEPTH][c];
-            v.x += d.x;
-            v.y += d.y;
-            v.z += d.z;
-            v.w += d.w;
-#if !(defined(RP_PHASE_PROBE) && defined(RP_PROBE_NO_XSTORE))
-            *reinterpret_cast<float4*>(x + off) = v;
-#endif
-            if (xb) {
-              uint2 o;
-              o.x = pack_bf2(v.x, v.y);
-              o.y = pack_bf2(v.z, v.w);
-              *reinterpret_cast<uint2*>(xb + off) = o;
-            }
-            // explicit fma chain: the same rounding sequence in every unrolled instance, so a
-            // token's statistic does not depend on where it sits in the batch
-            float& q = ssq[i >> 1][jb >> 1][c];
-            q = __fmaf_rn(v.w, v.w, __fmaf_rn(v.z, v.z, __fmaf_rn(v.y, v.y, __fmaf_rn(v.x, v.x, q))));
+        const int t = c * 4 + rr;
+        const float4 d = *reinterpret_cast<const float4*>(stage + t * RB + sub * 16);
+        float ss = 0.f;
+        if (f < n_valid) {
+          const size_t off = (size_t)(n_base + j * 32 + t) * ldx + f;
+          float4 v = xin[b % DEPTH][c];
+          v.x += d.x;
+          v.y += d.y;
+          v.z += d.z;
+          v.w += d.w;
+          *reinterpret_cast<float4*>(x + off) = v;
+          if (xb) {
+            uint2 o;
+            o.x = pack_bf2(v.x, v.y);
+            o.y = pack_bf2(v.z, v.w);
+            *reinterpret_cast<uint2*>(xb + off) = o;
           }
+          // explicit fma chain + fixed shuffle tree: the same rounding sequence for every token,
+          // wherever it sits in the batch
+          ss = __fmaf_rn(v.w, v.w, __fmaf_rn(v.z, v.z, __fmaf_rn(v.y, v.y, v.x * v.x)));
         }
-      }
-    }
-    if (ssp) {
-#pragma unroll
-      for (int q = 0; q < FM / 2; ++q) {
-        const int slot = (m_base >> 6) + q;
-#pragma unroll
-        for (int jb = 0; jb < FN; jb += 2) {
-          const int nrows = (FN - jb >= 2) ? 64 : 32;
-#pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            float v = ssq[q][jb >> 1][c];
-            v += __shfl_xor(v, 1, 64);
-            v += __shfl_xor(v, 2, 64);
-            v += __shfl_xor(v, 4, 64);
-            const int t = c * 8 + rr;
-            if (sub == 0 && t < nrows && slot < np) ssp[(size_t)slot * ssp_ld + n_base + jb * 32 + t] = v;
-          }
+        if (ssp) {
+          ss += __shfl_xor(ss, 1, 64);
+          ss += __shfl_xor(ss, 2, 64);
+          ss += __shfl_xor(ss, 4, 64);
+          ss += __shfl_xor(ss, 8, 64);
+          if (sub == 0 && slot < np) ssp[(size_t)slot * ssp_ld + n_base + j * 32 + t] = ss;
         }
       }
     }

@@ -1,0 +1,68 @@
+// How fast can the chip read-modify-write an fp32 [T, 1472] matrix in tile-shaped pieces?
+// Each workgroup owns a (TOK tokens x FEAT features) tile, as a GEMM epilogue would, and updates it
+// CHUNK bytes of a row at a time (x += 1; also writes a bf16 copy).  Prints TB/s per variant.
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/rmw_probe.hip -o gpurun_out/rmw_probe && gpurun_out/rmw_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+template <int CHUNK_LANES>  // lanes (16 B each) covering one row segment: 8 -> 128 B, 16 -> 256 B, 32 -> 512 B
+__global__ __launch_bounds__(256) void rmw(float* __restrict__ x, uint16_t* __restrict__ xb, int T, int D, int tile_tok,
+                                           int tile_feat, int tiles_f) {
+  const int tf = blockIdx.x % tiles_f, tt = blockIdx.x / tiles_f;
+  const int f0 = tf * tile_feat, t0 = tt * tile_tok;
+  const int lane_in = threadIdx.x % CHUNK_LANES, row_in = threadIdx.x / CHUNK_LANES;
+  constexpr int ROWS = 256 / CHUNK_LANES;
+  for (int fc = 0; fc < tile_feat; fc += CHUNK_LANES * 4) {
+    const int f = f0 + fc + lane_in * 4;
+    float4 v[8];
+    for (int tb = 0; tb < tile_tok; tb += ROWS * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + tb + u * ROWS + row_in;
+        v[u] = (t < T && f < D) ? *reinterpret_cast<const float4*>(x + (size_t)t * D + f) : make_float4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + tb + u * ROWS + row_in;
+        if (t < T && f < D) {
+          float4 w = v[u];
+          w.x += 1.f; w.y += 1.f; w.z += 1.f; w.w += 1.f;
+          *reinterpret_cast<float4*>(x + (size_t)t * D + f) = w;
+          uint2 o;
+          o.x = (__float_as_uint(w.x) >> 16) | (__float_as_uint(w.y) & 0xffff0000u);
+          o.y = (__float_as_uint(w.z) >> 16) | (__float_as_uint(w.w) & 0xffff0000u);
+          *reinterpret_cast<uint2*>(xb + (size_t)t * D + f) = o;
+        }
+      }
+    }
+  }
+}
+
+int main() {
+  const int T = 70144, D = 1472;
+  float* x; uint16_t* xb;
+  hipMalloc(&x, (size_t)T * D * 4); hipMalloc(&xb, (size_t)T * D * 2);
+  hipMemset(x, 0, (size_t)T * D * 4);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const double bytes = (double)T * D * 10.0;
+  auto run = [&](const char* name, auto kern, int tile_tok, int tile_feat) {
+    const int tiles_f = (D + tile_feat - 1) / tile_feat, tiles_t = (T + tile_tok - 1) / tile_tok;
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(tiles_f * tiles_t), dim3(256), 0, 0, x, xb, T, D, tile_tok, tile_feat, tiles_f);
+    hipEventRecord(e0);
+    const int it = 10;
+    for (int i = 0; i < it; ++i) hipLaunchKernelGGL(kern, dim3(tiles_f * tiles_t), dim3(256), 0, 0, x, xb, T, D, tile_tok, tile_feat, tiles_f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= it;
+    printf("%-34s tile %3d tok x %4d feat: %.3f ms  %.2f TB/s\n", name, tile_tok, tile_feat, ms, bytes / ms / 1e9);
+  };
+  run("128-B row segments", rmw<8>, 128, 128);
+  run("256-B row segments", rmw<16>, 128, 128);
+  run("512-B row segments", rmw<32>, 128, 128);
+  run("128-B row segments", rmw<8>, 256, 256);
+  run("256-B row segments", rmw<16>, 256, 256);
+  run("512-B row segments", rmw<32>, 256, 256);
+  run("512-B segments, full rows", rmw<32>, 64, 1472);
+  return 0;
+}
