@@ -902,7 +902,8 @@ __global__ __launch_bounds__(256) void attention2_kernel(const bf16_t* __restric
 //   mean_t(w * x_t * rs_t) = w * mean_t(x_t * rs_t); e / max(||e||, 1e-12)  (model.py:108-114)
 //   Two deterministic passes (no atomics, so results are bit-reproducible whatever the batch):
 //   pool_partial_kernel: one workgroup per 128-token chunk of a sequence; wave w takes tokens
-//     w, w+4, ...; per-lane partial column sums of x_t * rs_t in registers, combined through LDS,
+//     w, w+4, ...; rs_t from the last residual epilogue's statistics (as for every other RMSNorm);
+//     per-lane partial column sums of x_t * rs_t in registers, combined through LDS,
 //     written to partial[chunk_base(b) + c][D]   (chunk_base(b) = cu[b] / 128 + b);
 //   pool_finish_kernel: one workgroup per sequence sums its chunks in order, applies w / len and
 //     the L2 normalisation.
@@ -910,8 +911,9 @@ __global__ __launch_bounds__(256) void attention2_kernel(const bf16_t* __restric
 constexpr int POOL_CHUNK = 128;
 
 __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ rs,
                                                            const int32_t* __restrict__ cu,
-                                                           float* __restrict__ partial, int D, float eps) {
+                                                           float* __restrict__ partial, int D) {
   __shared__ float red[4][RMS_MAX_V4 * 64 * 4];
   const int b = blockIdx.y, c = blockIdx.x;
   const int s0 = cu[b], len = cu[b + 1] - s0;
@@ -923,29 +925,27 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restri
   float4 acc[RMS_MAX_V4];
 #pragma unroll
   for (int i = 0; i < RMS_MAX_V4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int t = t0 + wave; t < t1; t += 4) {
-    const float4* src = reinterpret_cast<const float4*>(x + (size_t)(s0 + t) * D);
-    float4 v[RMS_MAX_V4];
-    float ss = 0.f;
+  // rs[token] comes from the last residual epilogue's statistics (rowscale_kernel), so the rows are
+  // independent streams: two tokens' loads are in flight per wave before the first is consumed.
+  // Tokens are accumulated in index order per wave (w, w+4, ...), whatever the unrolling.
+  for (int t = t0 + wave; t < t1; t += 8) {
+    const bool two = t + 4 < t1;
+    const float4* src0 = reinterpret_cast<const float4*>(x + (size_t)(s0 + t) * D);
+    const float4* src1 = reinterpret_cast<const float4*>(x + (size_t)(s0 + (two ? t + 4 : t)) * D);
+    const float r0 = rs[s0 + t], r1 = two ? rs[s0 + t + 4] : 0.f;
+    float4 v0[RMS_MAX_V4], v1[RMS_MAX_V4];
 #pragma unroll
     for (int i = 0; i < RMS_MAX_V4; ++i) {
-      int col = lane + 64 * i;
-      if (col < nv) {
-        v[i] = src[col];
-        ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
-      }
+      const int col = min(lane + 64 * i, nv - 1);  // clamped, unpredicated: keeps the loads in one block
+      v0[i] = src0[col];
+      v1[i] = src1[col];
     }
-    ss = wave_sum(ss);
-    const float rs = rsqrtf(ss / (float)D + eps);
 #pragma unroll
     for (int i = 0; i < RMS_MAX_V4; ++i) {
-      int col = lane + 64 * i;
-      if (col < nv) {
-        acc[i].x += v[i].x * rs;
-        acc[i].y += v[i].y * rs;
-        acc[i].z += v[i].z * rs;
-        acc[i].w += v[i].w * rs;
-      }
+      acc[i].x = fmaf(v1[i].x, r1, fmaf(v0[i].x, r0, acc[i].x));
+      acc[i].y = fmaf(v1[i].y, r1, fmaf(v0[i].y, r0, acc[i].y));
+      acc[i].z = fmaf(v1[i].z, r1, fmaf(v0[i].z, r0, acc[i].z));
+      acc[i].w = fmaf(v1[i].w, r1, fmaf(v0[i].w, r0, acc[i].w));
     }
   }
 #pragma unroll
@@ -1310,10 +1310,11 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
                           RP_K_GEMM_WO)))
       return st;
   }
+  launch_rowscale();  // final RMSNorm statistic
   {
     ProfScope ps(stream, RP_K_POOL);
     hipLaunchKernelGGL(pool_partial_kernel, dim3((max_len + POOL_CHUNK - 1) / POOL_CHUNK, batch), dim3(256), 0, stream,
-                       w.x, cu_seqlens, w.pool, D, c.layer_norm_eps);
+                       w.x, w.rs, cu_seqlens, w.pool, D);
     hipLaunchKernelGGL(pool_finish_kernel, dim3(batch), dim3(256), 0, stream, w.pool, e->final_ln, cu_seqlens, out,
                        out_dtype == RP_DT_BF16 ? 1 : 0, D);
   }
