@@ -43,7 +43,6 @@ static int g_gemm_skinny = 1;
 static int g_gemm_skinny_variant = 12;
 static int g_tokens_valid = 0;  // real token count of the pass being launched (0: all rows); lets the
                                 // small-token configurations skip tiles that hold only padding rows   // use the small-token-count GEMM configuration automatically
-static int g_attn_variant = 1;  // 0: register-staged kernel, 1: LDS-DMA + transpose-read kernel  // tile/pipeline configuration, see launch_gemm()
 
 // ------------------------------------------------------------------------------------------
 // per-kernel event timing
@@ -510,189 +509,7 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
 //   by the accumulator layout is applied to V^T when its A fragment is read from LDS).
 // ------------------------------------------------------------------------------------------
 constexpr int ATT_Q = 128, ATT_KV = 64;
-constexpr int ATT_KS_STRIDE = 144;  // bytes per staged K row: 64 bf16 + 16 B pad
-constexpr int ATT_VT_STRIDE = 136;  // bytes per staged V^T row: 64 keys bf16 + 8 B pad
-constexpr int ATT_KS_BYTES = ATT_KV * ATT_KS_STRIDE;  // 9216
-constexpr int ATT_VT_BYTES = 64 * ATT_VT_STRIDE;      // 8704
-constexpr int ATT_TAB_MAX = 1024;                     // max table entries (2*max_distance+1)
-
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv,
-                                                        const int32_t* __restrict__ cu,
-                                                        const float* __restrict__ bias_tab,
-                                                        bf16_t* __restrict__ out, int H, int maxd,
-                                                        int rows_total) {
-  __shared__ __attribute__((aligned(16))) char smem[ATT_KS_BYTES + ATT_VT_BYTES + ATT_TAB_MAX * 4];
-  char* Ks = smem;
-  char* Vt = smem + ATT_KS_BYTES;
-  float* tab = reinterpret_cast<float*>(smem + ATT_KS_BYTES + ATT_VT_BYTES);
-
-  const int b = blockIdx.y, h = blockIdx.z;
-  const int s0 = cu[b];
-  const int len = cu[b + 1] - s0;
-  const int q0 = blockIdx.x * ATT_Q;
-  if (q0 >= len) return;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, cl = lane & 31;
-  const int inner = H * 64, ld = 3 * inner;
-  const int ntab = 2 * maxd + 1;
-  for (int i = tid; i < ntab; i += 256) tab[i] = bias_tab[h * ntab + i];
-
-  const int qi = q0 + wave * 32 + cl;  // this lane's query (position inside the sequence)
-  bf16x8 qf[4];
-  {
-    const bf16_t* qp = qkv + (size_t)(s0 + min(qi, len - 1)) * ld + h * 64 + hi * 8;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const bf16x8*>(qp + c * 16);
-  }
-
-  f32x16 o[2];
-#pragma unroll
-  for (int d = 0; d < 2; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  const int n_tiles = (len + ATT_KV - 1) / ATT_KV;
-  // staging: 64 keys x 8 chunks(16 B) = 512 chunks, two per thread
-  uint4 rk[2], rv[2];
-  auto load_tile = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c2 = tid + 256 * i;
-      const int key = c2 >> 3, dch = c2 & 7;
-      const int krow = s0 + min(kt * ATT_KV + key, len - 1);
-      const bf16_t* p = qkv + (size_t)krow * ld + inner + h * 64 + dch * 8;
-      rk[i] = *reinterpret_cast<const uint4*>(p);
-      rv[i] = *reinterpret_cast<const uint4*>(p + inner);
-    }
-  };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c2 = tid + 256 * i;
-      const int key = c2 >> 3, dch = c2 & 7;
-      *reinterpret_cast<uint4*>(Ks + key * ATT_KS_STRIDE + dch * 16) = rk[i];
-      const uint32_t w[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const bf16_t val = (bf16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
-        *reinterpret_cast<bf16_t*>(Vt + (dch * 8 + e) * ATT_VT_STRIDE + key * 2) = val;
-      }
-    }
-  };
-
-  load_tile(0);
-  for (int kt = 0; kt < n_tiles; ++kt) {
-    __syncthreads();  // previous tile fully consumed (and tab written, first iteration)
-    store_tile();
-    __syncthreads();
-    if (kt + 1 < n_tiles) load_tile(kt + 1);  // in flight during the MFMAs below
-
-    const int k0 = kt * ATT_KV;
-    // ---- S^T = K Q^T : s[kb][r] = score(key k0 + 32 kb + mfma32_row(r,hi), query qi)
-    f32x16 s[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-      const char* kp = Ks + (kb * 32 + cl) * ATT_KS_STRIDE + hi * 16;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + c * 32);
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], s[kb], 0, 0, 0);
-      }
-    }
-    // ---- relative-position bias + key-padding mask
-    const int w_qmin = q0 + wave * 32, w_qmax = w_qmin + 31;
-    const bool full = (k0 + ATT_KV <= len);
-    if (k0 - w_qmax >= maxd && full) {  // whole tile saturated on the right
-      const float bb = tab[2 * maxd];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] += bb;
-    } else if (k0 + ATT_KV - 1 - w_qmin <= -maxd && full) {  // saturated on the left
-      const float bb = tab[0];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] += bb;
-    } else {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int j = k0 + kb * 32 + mfma32_row(r, hi);
-          const int rel = min(max(j - qi, -maxd), maxd) + maxd;
-          s[kb][r] = (j < len) ? s[kb][r] + tab[rel] : -INFINITY;
-        }
-    }
-    // ---- online softmax (per query = per lane pair {lane, lane^32})
-    float mx = s[0][0];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);  // m_run = -inf on the first tile -> 0
-    float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __expf(s[kb][r] - m_new);
-        s[kb][r] = p;
-        psum += p;
-      }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-    // ---- O^T += V^T P^T over four 16-key slabs
-#pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
-      const int kb = sl >> 1, sub = sl & 1;
-      bf16x8 pf;
-      {
-        uint32_t pw[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pw[e] = pack_bf2(s[kb][8 * sub + 2 * e], s[kb][8 * sub + 2 * e + 1]);
-        uint4 t = make_uint4(pw[0], pw[1], pw[2], pw[3]);
-        pf = *reinterpret_cast<bf16x8*>(&t);
-      }
-#pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        const char* vp = Vt + (d * 32 + cl) * ATT_VT_STRIDE + (16 * sl + 4 * hi) * 2;
-        uint2 lo = *reinterpret_cast<const uint2*>(vp);
-        uint2 up = *reinterpret_cast<const uint2*>(vp + 16);
-        uint4 t = make_uint4(lo.x, lo.y, up.x, up.y);
-        bf16x8 vf = *reinterpret_cast<bf16x8*>(&t);
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
-      }
-    }
-  }
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.f / l_tot;
-  if (qi < len) {
-    bf16_t* op = out + (size_t)(s0 + qi) * inner + h * 64;
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 v;
-        v.x = pack_bf2(o[d][4 * g] * inv, o[d][4 * g + 1] * inv);
-        v.y = pack_bf2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
-        *reinterpret_cast<uint2*>(op + d * 32 + 8 * g + 4 * hi) = v;
-      }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// attention, second generation: same math and work split as attention_kernel, but
+constexpr int ATT_TAB_MAX = 1024;  // max table entries (2*max_distance+1)
 //   * K and V tiles go HBM -> LDS by LDS-DMA into a 2-stage ring (tile t+1 in flight under the
 //     MFMAs/softmax of tile t, one barrier per tile, no VGPR staging, no ds_write at all);
 //   * V stays row-major in LDS ([d-half][key][32 d], 64-B rows) and its MFMA A fragments
@@ -701,26 +518,40 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 //     V[k0 + i/4][d0 + 4 (i%4) .. +3] and lane l receives V[k0 .. k0+3][d0 + l]  (mapping measured
 //     with tools/probes/tr_probe.hip); 4 rows x 64 B = one 256-B bank row: conflict-free;
 //   * K is staged with the GEMM's XOR swizzle (slot ^= (row >> 1) & 7 on the DMA source address);
-//   * waves whose 32 queries lie past the sequence end only help with the DMA.
+//   * waves whose 32 queries lie past the sequence end only help with the DMA;
+//   * work list without a prefix-sum pass: query block q of sequence b is workgroup
+//     cu[b] / 128 + b + q (strictly increasing in b, at most T/128 + B ids in all), and a workgroup
+//     finds its b with two block-wide counting rounds over cu.  A (max_len/128) x B grid would launch
+//     ~6 empty workgroups per useful one on the benchmark's length mix.
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) short v4s16;
 constexpr int AT2_K_BYTES = 64 * 128, AT2_V_BYTES = 64 * 128, AT2_STAGE = AT2_K_BYTES + AT2_V_BYTES;
 
-__global__ __launch_bounds__(256) void attention2_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                          const int32_t* __restrict__ cu,
                                                          const float* __restrict__ bias_tab,
-                                                         bf16_t* __restrict__ out, int H, int maxd,
-                                                         int rows_total) {
+                                                        bf16_t* __restrict__ out, int H, int maxd,
+                                                        int batch) {
   __shared__ __attribute__((aligned(16))) char smem[2 * AT2_STAGE + ATT_TAB_MAX * 4];
   float* tab = reinterpret_cast<float*>(smem + 2 * AT2_STAGE);
 
-  const int b = blockIdx.y, h = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, cl = lane & 31;
+  // which sequence owns work id g?  base(b) = cu[b] / ATT_Q + b is increasing: count the candidates
+  // with base <= g, first every stride-th sequence, then inside the stride that was hit.
+  const int g = blockIdx.x, h = blockIdx.y;
+  const int stride = (batch + 255) / 256;
+  int c = tid * stride;
+  const int n1 = __syncthreads_count(c < batch && cu[min(c, batch - 1)] / ATT_Q + c <= g);
+  if (n1 == 0) return;
+  const int first = (n1 - 1) * stride;
+  c = first + tid;
+  const int n2 = __syncthreads_count(tid < stride && c < batch && cu[min(c, batch - 1)] / ATT_Q + c <= g);
+  const int b = first + n2 - 1;
   const int s0 = cu[b];
   const int len = cu[b + 1] - s0;
-  const int q0 = blockIdx.x * ATT_Q;
+  const int q0 = (g - (s0 / ATT_Q + b)) * ATT_Q;
   if (q0 >= len) return;
 
-  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, cl = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int inner = H * 64, ld = 3 * inner;
   const int ntab = 2 * maxd + 1;
@@ -1074,13 +905,8 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     g_gemm_skinny = value != 0;
     return RP_OK;
   }
-  if (!strcmp(name, "attn_variant")) {
-    RP_REQUIRE(value >= 0 && value <= 1, "attn_variant out of range");
-    g_attn_variant = value;
-    return RP_OK;
-  }
   if (!strcmp(name, "scan_cfg")) {
-    RP_REQUIRE(value >= 0 && value <= 3, "scan_cfg out of range");
+    RP_REQUIRE(value >= 0 && value <= 1, "scan_cfg out of range");
     g_scan_cfg = value;
     return RP_OK;
   }
@@ -1285,7 +1111,7 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
                        Tp, D, c.vocab_size);
   }
   RP_CHECK_LAUNCH();
-  const dim3 att_grid((max_len + ATT_Q - 1) / ATT_Q, batch, H);
+  const dim3 att_grid(T / ATT_Q + batch, H);  // upper bound of the work ids (see attention_kernel)
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerPacked& L = e->layers[i];
     // attention sub-layer: qkv = rs * (xb Wqkv'^T)  ->  attention  ->  x += att Wo^T  (+ xb, ssp refreshed)
@@ -1295,8 +1121,8 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
       return st;
     {
       ProfScope ps(stream, RP_K_ATTENTION);
-      hipLaunchKernelGGL(g_attn_variant ? attention2_kernel : attention_kernel, att_grid, dim3(256), 0, stream, w.qkv,
-                         cu_seqlens, e->bias_tab, w.att, H, e->maxd, Tp);
+      hipLaunchKernelGGL(attention_kernel, att_grid, dim3(256), 0, stream, w.qkv,
+                         cu_seqlens, e->bias_tab, w.att, H, e->maxd, batch);
     }
     if ((st = launch_gemm(w.att, inner, Tp, L.wo, inner, D, inner, EpiResidF32{w.x, D, D, w.xb, w.ssp, np, Tp}, stream,
                           RP_K_GEMM_O)))
@@ -1391,9 +1217,10 @@ extern "C" RpStatus rp_dbg_rmsnorm(const float* x, const float* w, void* out_bf1
 extern "C" RpStatus rp_dbg_attention(const void* qkv, const int32_t* cu, const float* bias_tab, void* out,
                                      int32_t batch, int32_t max_len, int32_t H, int32_t rows_total, void* stream_) {
   const int maxd = 128;
-  const dim3 grid((max_len + ATT_Q - 1) / ATT_Q, batch, H);
-  hipLaunchKernelGGL(g_attn_variant ? attention2_kernel : attention_kernel, grid, dim3(256), 0, (hipStream_t)stream_,
-                     (const bf16_t*)qkv, cu, bias_tab, (bf16_t*)out, H, maxd, rows_total);
+  (void)max_len;
+  const dim3 grid(rows_total / ATT_Q + batch, H);  // rows_total >= the packed token count
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)qkv, cu, bias_tab,
+                     (bf16_t*)out, H, maxd, batch);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
