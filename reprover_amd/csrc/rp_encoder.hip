@@ -527,6 +527,21 @@ constexpr int ATT_TAB_MAX = 1024;  // max table entries (2*max_distance+1)
 typedef __attribute__((ext_vector_type(4))) short v4s16;
 constexpr int AT2_K_BYTES = 64 * 128, AT2_V_BYTES = 64 * 128, AT2_STAGE = AT2_K_BYTES + AT2_V_BYTES;
 
+// Which sequence owns work id g of a "cu[b] / chunk + b + index" numbering (increasing in b)?  Two
+// block-wide counting rounds over cu: every stride-th sequence, then inside the stride that was hit.
+// Returns -1 (uniformly) for an id below the first sequence's base; 256 threads.
+__device__ __forceinline__ int find_sequence(const int32_t* __restrict__ cu, int batch, int g, int chunk) {
+  const int tid = threadIdx.x;
+  const int stride = (batch + 255) / 256;
+  int c = tid * stride;
+  const int n1 = __syncthreads_count(c < batch && cu[min(c, batch - 1)] / chunk + c <= g);
+  if (n1 == 0) return -1;
+  const int first = (n1 - 1) * stride;
+  c = first + tid;
+  const int n2 = __syncthreads_count(tid < stride && c < batch && cu[min(c, batch - 1)] / chunk + c <= g);
+  return first + n2 - 1;
+}
+
 __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                          const int32_t* __restrict__ cu,
                                                          const float* __restrict__ bias_tab,
@@ -536,17 +551,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
   float* tab = reinterpret_cast<float*>(smem + 2 * AT2_STAGE);
 
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, cl = lane & 31;
-  // which sequence owns work id g?  base(b) = cu[b] / ATT_Q + b is increasing: count the candidates
-  // with base <= g, first every stride-th sequence, then inside the stride that was hit.
   const int g = blockIdx.x, h = blockIdx.y;
-  const int stride = (batch + 255) / 256;
-  int c = tid * stride;
-  const int n1 = __syncthreads_count(c < batch && cu[min(c, batch - 1)] / ATT_Q + c <= g);
-  if (n1 == 0) return;
-  const int first = (n1 - 1) * stride;
-  c = first + tid;
-  const int n2 = __syncthreads_count(tid < stride && c < batch && cu[min(c, batch - 1)] / ATT_Q + c <= g);
-  const int b = first + n2 - 1;
+  const int b = find_sequence(cu, batch, g, ATT_Q);
+  if (b < 0) return;
   const int s0 = cu[b];
   const int len = cu[b + 1] - s0;
   const int q0 = (g - (s0 / ATT_Q + b)) * ATT_Q;
@@ -744,10 +751,12 @@ constexpr int POOL_CHUNK = 128;
 __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ rs,
                                                            const int32_t* __restrict__ cu,
-                                                           float* __restrict__ partial, int D) {
+                                                           float* __restrict__ partial, int D, int batch) {
   __shared__ float red[4][RMS_MAX_V4 * 64 * 4];
-  const int b = blockIdx.y, c = blockIdx.x;
+  const int b = find_sequence(cu, batch, blockIdx.x, POOL_CHUNK);  // work id = partial row (see above)
+  if (b < 0) return;
   const int s0 = cu[b], len = cu[b + 1] - s0;
+  const int c = blockIdx.x - (s0 / POOL_CHUNK + b);
   const int t0 = c * POOL_CHUNK;
   if (t0 >= len) return;
   const int t1 = min(len, t0 + POOL_CHUNK);
@@ -1139,8 +1148,8 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
   launch_rowscale();  // final RMSNorm statistic
   {
     ProfScope ps(stream, RP_K_POOL);
-    hipLaunchKernelGGL(pool_partial_kernel, dim3((max_len + POOL_CHUNK - 1) / POOL_CHUNK, batch), dim3(256), 0, stream,
-                       w.x, w.rs, cu_seqlens, w.pool, D);
+    hipLaunchKernelGGL(pool_partial_kernel, dim3(T / POOL_CHUNK + batch), dim3(256), 0, stream, w.x, w.rs, cu_seqlens,
+                       w.pool, D, batch);
     hipLaunchKernelGGL(pool_finish_kernel, dim3(batch), dim3(256), 0, stream, w.pool, e->final_ln, cu_seqlens, out,
                        out_dtype == RP_DT_BF16 ? 1 : 0, D);
   }
