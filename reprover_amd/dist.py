@@ -136,6 +136,21 @@ def all_gather_stack(t: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
+def gather_shards(local_rows: torch.Tensor, bounds: np.ndarray, group=None) -> torch.Tensor:
+    """Assemble the full [N, D] matrix from every rank's rows [bounds[r], bounds[r+1]) — the one
+    exchange of a multi-GPU re-index that has to persist a single index file (index.py).  Shards
+    differ in length (they balance tokens, not rows), so each rank contributes a block padded to the
+    longest shard and the padding is dropped after ONE all-gather."""
+    world = dist.get_world_size(group)
+    bounds = np.asarray(bounds, dtype=np.int64)
+    assert len(bounds) == world + 1 and local_rows.shape[0] == bounds[dist.get_rank(group) + 1] - bounds[dist.get_rank(group)]
+    longest = int(np.diff(bounds).max())
+    block = torch.zeros((longest,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype, device=local_rows.device)
+    block[: local_rows.shape[0]] = local_rows
+    stacked = all_gather_stack(block, group)
+    return torch.cat([stacked[r, : int(bounds[r + 1] - bounds[r])] for r in range(world)], dim=0)
+
+
 def sharded_nearest_premise_ids(
     shard: IndexShard,
     batch_context: Sequence[Context],

@@ -1,11 +1,17 @@
 """Index a corpus with the retriever — same CLI as the reference's ``retrieval/index.py``
 (lean-dojo/ReProver retrieval/index.py:13-41): ``--ckpt_path --corpus-path --output-path
 --batch-size``.  Output: a pickled ``IndexedCorpus(corpus, fp32 CPU embeddings [N, D])``.
+
+Multi-GPU (BASELINE.json configs[3]; the reference indexes on one device): launch under
+``python -m torch.distributed.run --nproc-per-node N -m reprover_amd.retrieval.index ...``; each rank
+encodes the contiguous row range that holds 1/N of the corpus' tokens (no communication), one
+all-gather assembles the matrix and rank 0 writes the same file a single-GPU run writes.
 """
 from __future__ import annotations
 
 import argparse
 import logging
+import os
 import pickle
 
 import torch
@@ -29,10 +35,37 @@ def main(argv=None) -> None:
     # path and says so instead of silently computing something else.
     if not torch.cuda.is_available():
         raise RuntimeError("reprover_amd needs an MI355X (HIP) device; no CPU fallback exists")
-    device = torch.device("cuda")
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # functional test of the N > 1 path on a one-GPU box: RP_DIST_SHARE_GPU=1 RP_DIST_BACKEND=gloo
+    # (RCCL refuses two ranks on one device)
+    if os.environ.get("RP_DIST_SHARE_GPU") == "1":
+        local = 0
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
     model = PremiseRetriever.load_hf(args.ckpt_path, 2048, device)
     model.load_corpus(args.corpus_path)
-    model.reindex_corpus(batch_size=args.batch_size)
+    if world > 1:
+        import torch.distributed as dist
+
+        from .. import dist as rdist
+
+        backend = os.environ.get("RP_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+        bounds = rdist.shard_bounds(rdist.premise_token_counts(model.corpus, model.max_seq_len), world)
+        shard = rdist.IndexShard(model.corpus, bounds, rank, device)
+        rdist.reindex_shard(model, shard)
+        model.corpus_embeddings = rdist.gather_shards(shard.embeddings, bounds)
+        model.embeddings_staled = False
+        dist.barrier()
+        if rank != 0:
+            dist.destroy_process_group()
+            return
+    else:
+        model.reindex_corpus(batch_size=args.batch_size)
     if args.output_path.endswith(("/", ".rpidx")):
         # native index directory: bf16 embeddings as safetensors + the corpus jsonl (no pickle)
         save_index(args.output_path, args.corpus_path, model.corpus_embeddings)
@@ -40,6 +73,8 @@ def main(argv=None) -> None:
         with open(args.output_path, "wb") as oup:
             pickle.dump(IndexedCorpus(model.corpus, model.corpus_embeddings.to(torch.float32).cpu()), oup)
     logger.info(f"Indexed corpus saved to {args.output_path}")
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -130,3 +130,26 @@ def test_native_index_directory_via_cli(workdir):
     a = m.retrieve(state, ex["file_path"], ex["full_name"], Pos(*ex["start"]), 10)
     b = ref.retrieve(state, ex["file_path"], ex["full_name"], Pos(*ex["start"]), 10)
     assert [p.full_name for p in a[0]] == [p.full_name for p in b[0]] and a[1] == b[1]
+
+
+def test_index_cli_two_ranks_equals_one(workdir):
+    """BASELINE configs[3] (re-index at 1 vs N GPUs), functionally: two ranks under torch.distributed.run
+    (both on this box's one GPU, gloo for the gather — RCCL refuses two ranks per device) must write the
+    same index a single process writes, bit for bit."""
+    import subprocess
+    import sys
+
+    d, ckpt, cpath, sdir, splits, cfg, sd = workdir
+    one = os.path.join(d, "one.pickle")
+    two = os.path.join(d, "two.pickle")
+    index_cli.main(["--ckpt_path", ckpt, "--corpus-path", cpath, "--output-path", one])
+    env = dict(os.environ, RP_DIST_SHARE_GPU="1", RP_DIST_BACKEND="gloo",
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    port = 29700 + os.getpid() % 1000
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), "-m",
+                          "reprover_amd.retrieval.index", "--ckpt_path", ckpt, "--corpus-path", cpath,
+                          "--output-path", two], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    a, b = pickle.load(open(one, "rb")), pickle.load(open(two, "rb"))
+    assert len(a.corpus) == len(b.corpus) and torch.equal(a.embeddings, b.embeddings)

@@ -15,7 +15,8 @@ import torch.multiprocessing as mp
 from oracle import common_ref
 from reprover_amd import synth
 from reprover_amd.common import Context, Corpus, Pos
-from reprover_amd.dist import IndexShard, shard_bounds, sharded_get_nearest_premises, sharded_nearest_premise_ids
+from reprover_amd.dist import (IndexShard, gather_shards, shard_bounds, sharded_get_nearest_premises,
+                                sharded_nearest_premise_ids)
 
 
 def test_shard_bounds_balance_tokens():
@@ -106,6 +107,9 @@ def _worker(rank, world, port, corpus_path, out_dir):
         except ValueError:
             raised = True
         assert raised == bool(short)
+        # multi-GPU re-index: uneven shards -> one padded all-gather -> the full matrix, rows in corpus order
+        full = gather_shards(shard.embeddings, shard.bounds)
+        assert full.shape == (N, D) and np.array_equal(full.numpy(), E)
         open(os.path.join(out_dir, f"ok{rank}"), "w").write(f"{shard.lo} {shard.hi}")
     finally:
         dist.destroy_process_group()
