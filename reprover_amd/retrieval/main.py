@@ -5,6 +5,11 @@ for the inference subcommands.  Reads the same YAML keys the reference's configs
 ``data.eval_batch_size``, ``data.max_seq_len``; retrieval/confs/*.yaml) and writes
 ``<log_dir>/predictions.pickle`` exactly as ``on_predict_epoch_end`` does (model.py:329-336).
 Lightning itself is out of scope; the hooks' bodies live in ``model.py`` here as they do upstream.
+
+Multi-GPU ``predict``: launch under ``python -m torch.distributed.run --nproc-per-node N -m
+reprover_amd.retrieval.main predict ...``.  Every rank walks the same batches; the index is row-sharded
+(each rank re-indexes 1/N of the corpus' tokens), per-rank top-k lists are merged through one
+all-gather, rank 0 writes ``predictions.pickle``.
 """
 from __future__ import annotations
 
@@ -73,17 +78,35 @@ def main(argv=None) -> None:
     m, d = cfg["model"], cfg["data"]
     if not torch.cuda.is_available():
         raise RuntimeError("reprover_amd needs an MI355X (HIP) device; no CPU fallback exists")
-    model = PremiseRetriever.load_hf(args.ckpt_path or m["model_name"], d["max_seq_len"], torch.device("cuda"))
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = 0 if os.environ.get("RP_DIST_SHARE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+
+        backend = os.environ.get("RP_DIST_BACKEND", "nccl")  # gloo: functional test on a one-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    model = PremiseRetriever.load_hf(args.ckpt_path or m["model_name"], d["max_seq_len"], device)
     model.num_retrieved = m.get("num_retrieved", 100)
+    model.shard_index_over_ranks = world > 1 and args.subcommand == "predict"
     dm = RetrievalDataModule(d["data_path"], d["corpus_path"], d["eval_batch_size"], d["max_seq_len"], model.tokenizer)
     if args.subcommand == "predict":
         log_dir = args.log_dir or cfg.get("trainer", {}).get("default_root_dir") or os.getcwd()
         os.makedirs(log_dir, exist_ok=True)
-        n = run_predict(model, dm, log_dir)
-        print(f"{n} retrieval predictions saved to {os.path.join(log_dir, 'predictions.pickle')}")
+        n = run_predict(model, dm, log_dir if rank == 0 else None)
+        if rank == 0:
+            print(f"{n} retrieval predictions saved to {os.path.join(log_dir, 'predictions.pickle')}")
     else:
         for k, v in run_validate(model, dm).items():
-            print(f"{k}: {v}")
+            if rank == 0:
+                print(f"{k}: {v}")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

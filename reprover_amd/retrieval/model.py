@@ -57,6 +57,12 @@ class PremiseRetriever:
         self.index_dtype = index_dtype
         self._fp8_index: Optional[Fp8Index] = None
         self._fp8_source: Optional[Tuple[int, int]] = None
+        # Multi-GPU predict (BASELINE.json configs[2]; the reference replicates the whole index per rank):
+        # when set, ``on_predict_start`` encodes only this rank's row shard and ``predict_step`` merges the
+        # per-rank top-k lists through one all-gather (reprover_amd/dist.py).  Set by retrieval/main.py
+        # under torch.distributed.run.
+        self.shard_index_over_ranks = False
+        self.index_shard = None
 
     # -- construction (model.py:52-66) --------------------------------------------------------------
     @classmethod
@@ -157,15 +163,31 @@ class PremiseRetriever:
         self.corpus = corpus
         self.corpus_embeddings = None
         self.embeddings_staled = True
-        self.reindex_corpus(eval_batch_size)
         self.predict_step_outputs = []
+        if self.shard_index_over_ranks:
+            import torch.distributed as dist
+
+            from .. import dist as rdist
+
+            bounds = rdist.shard_bounds(rdist.premise_token_counts(corpus, self.max_seq_len), dist.get_world_size())
+            self.index_shard = rdist.IndexShard(corpus, bounds, dist.get_rank(), self.device)
+            rdist.reindex_shard(self, self.index_shard)
+            return
+        self.reindex_corpus(eval_batch_size)
 
     def predict_step(self, batch: Dict[str, Any], _=None) -> None:
         context_emb = self._encode(batch["context_ids"], batch["context_mask"])
-        assert not self.embeddings_staled
-        retrieved_premises, scores = self.corpus.get_nearest_premises(
-            self._search_operand(), batch["context"], context_emb, self.num_retrieved
-        )
+        if self.index_shard is not None:  # every rank holds the batch; the index is row-sharded
+            from ..dist import sharded_get_nearest_premises
+
+            retrieved_premises, scores = sharded_get_nearest_premises(
+                self.index_shard, batch["context"], context_emb, self.num_retrieved
+            )
+        else:
+            assert not self.embeddings_staled
+            retrieved_premises, scores = self.corpus.get_nearest_premises(
+                self._search_operand(), batch["context"], context_emb, self.num_retrieved
+            )
         for url, commit, file_path, full_name, start, tactic_idx, ctx, pos_premises, premises, s in zip_strict(
             batch["url"], batch["commit"], batch["file_path"], batch["full_name"], batch["start"],
             batch["tactic_idx"], batch["context"], batch["all_pos_premises"], retrieved_premises, scores,

@@ -153,3 +153,30 @@ def test_index_cli_two_ranks_equals_one(workdir):
     assert res.returncode == 0, res.stderr[-2000:]
     a, b = pickle.load(open(one, "rb")), pickle.load(open(two, "rb"))
     assert len(a.corpus) == len(b.corpus) and torch.equal(a.embeddings, b.embeddings)
+
+
+def test_predict_two_ranks_sharded_index_equals_one(workdir):
+    """BASELINE configs[2] through the product driver: two ranks, row-sharded index, per-rank top-k
+    merged through one all-gather — the predictions must be those of the single-process run (same
+    premises, same scores bit for bit: masked top-k is a decomposable reduction)."""
+    import subprocess
+    import sys
+
+    d, ckpt, cpath, sdir, splits, cfg, sd = workdir
+    log1, log2 = os.path.join(d, "logs_one"), os.path.join(d, "logs_two")
+    main_cli.main(["predict", "--config", os.path.join(d, "conf.yaml"), "--log-dir", log1])
+    env = dict(os.environ, RP_DIST_SHARE_GPU="1", RP_DIST_BACKEND="gloo",
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    port = 29800 + os.getpid() % 1000
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), "-m",
+                          "reprover_amd.retrieval.main", "predict", "--config", os.path.join(d, "conf.yaml"),
+                          "--log-dir", log2], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    a = pickle.load(open(os.path.join(log1, "predictions.pickle"), "rb"))
+    b = pickle.load(open(os.path.join(log2, "predictions.pickle"), "rb"))
+    assert len(a) == len(b) > 0
+    for x, y in zip(a, b):
+        assert [(p.path, p.full_name, tuple(p.start)) for p in x["retrieved_premises"]] == \
+               [(p.path, p.full_name, tuple(p.start)) for p in y["retrieved_premises"]]
+        assert x["scores"] == y["scores"]
