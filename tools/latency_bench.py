@@ -30,13 +30,25 @@ for sv in [int(x) for x in os.environ.get('SKINNY', '12').split(',')]:
       for s in states[:5]:
           model.retrieve(s, "M/F4000.lean", "t", Pos(30, 0), 100)
       torch.cuda.synchronize()
-      _lib.profile_enable(True)
       t0 = time.perf_counter()
       for s in states[5:]:
           model.retrieve(s, "M/F4000.lean", "t", Pos(30, 0), 100)
-      dt = (time.perf_counter() - t0) / 25
+      dt = (time.perf_counter() - t0) / 25  # wall time without the per-kernel event pairs
+      _lib.profile_enable(True)
+      for s in states[5:]:
+          model.retrieve(s, "M/F4000.lean", "t", Pos(30, 0), 100)
       prof = _lib.profile_read(); _lib.profile_enable(False)
       gpu_ms = sum(v[0] for v in prof.values()) / 25
       top = sorted(prof.items(), key=lambda kv: -kv[1][0])[:6]
       print(f"state {nbytes:5d} B: retrieve() {dt*1e3:7.3f} ms wall; GPU kernels {gpu_ms:6.3f} ms; " +
             ", ".join(f"{k} {v[0]/25*1e3:.0f}us" for k, v in top), flush=True)
+if os.environ.get("CPROFILE") == "1":
+    import cProfile, pstats
+    states = [synth.synth_state(rng, 100) for _ in range(200)]
+    for s in states[:10]:
+        model.retrieve(s, "M/F4000.lean", "t", Pos(30, 0), 100)
+    pr = cProfile.Profile(); pr.enable()
+    for s in states[10:]:
+        model.retrieve(s, "M/F4000.lean", "t", Pos(30, 0), 100)
+    pr.disable()
+    st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(28)
