@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reprover_amd import _lib
 lib = _lib.load()
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-variants = [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3,4").split(",")]
+variants = [int(v) for v in os.environ.get("VARIANTS", "26,20,9,0").split(",")]
 groups = [int(v) for v in os.environ.get("GROUP_M", "8").split(",")]
 dev = torch.device("cuda")
 g = torch.Generator(device=dev); g.manual_seed(0)

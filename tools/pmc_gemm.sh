@@ -6,7 +6,7 @@ grep -oE "\b(SQ|TCC|TCP|GRBM|TA|TD|SPI)_[A-Za-z_0-9]+" gpurun_out/pmc/avail.txt 
 wc -l gpurun_out/pmc/counters.txt
 run() { # name, counters  (each pass under its own timeout: a rejected counter set can hang rocprofv3)
   rm -rf gpurun_out/pmc/$1
-  timeout -k 5 90 rocprofv3 --kernel-trace --pmc $2 -d gpurun_out/pmc/$1 -o out --output-format csv -- env VARIANTS=${VARIANTS:-6,20} ONLY=${ONLY:-wi} ROUNDS=1 python tools/gemm_bench.py > gpurun_out/pmc/$1.log 2>&1 || echo "pass $1 failed: $(grep -m1 -i 'error code' gpurun_out/pmc/$1.log)"
+  timeout -k 5 90 rocprofv3 --kernel-trace --pmc $2 -d gpurun_out/pmc/$1 -o out --output-format csv -- env VARIANTS=${VARIANTS:-26,20} ONLY=${ONLY:-wi} ROUNDS=1 python tools/gemm_bench.py > gpurun_out/pmc/$1.log 2>&1 || echo "pass $1 failed: $(grep -m1 -i 'error code' gpurun_out/pmc/$1.log)"
 }
 run ta1 "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum"
 run ta2 "TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_LDS_WAVEFRONTS_sum"
