@@ -307,13 +307,32 @@ def main():
 
     # ---- scan-only QPS and premise-encode throughput (reported beside the headline value) --------
     barrier()
-    scan_only_qps = prem_per_s = prem_tok_per_s = prem_per_s_host = None
+    scan_only_qps = scan_only_qps_fp8 = prem_per_s = prem_tok_per_s = prem_per_s_host = None
     if not args.headline_only:
         t0 = time.perf_counter()
         for _ in range(20):
             scan()
         torch.cuda.synchronize()
         scan_only_qps = BQ * 20 / (time.perf_counter() - t0)
+        # the same scan over the e4m3 copy of this rank's shard (BASELINE.json configs[4] flavour of the index)
+        from reprover_amd.common import Fp8Index
+
+        e8, q8 = Fp8Index.quantize(E), Fp8Index.quantize(q_all)
+
+        def scan8():
+            _lib.check(lib.rp_sim_topk_fp8(q8.codes.data_ptr(), q8.scale.data_ptr(), e8.codes.data_ptr(),
+                                           e8.scale.data_ptr(), BQ, hi - lo, D, file_of.data_ptr(), end_key.data_ptr(),
+                                           bits_d.data_ptr(), corpus.num_files, own_d.data_ptr(), qk_d.data_ptr(), lo,
+                                           TOP_K, 0, out_s.data_ptr(), out_i.data_ptr(), out_c.data_ptr(),
+                                           ws.data_ptr(), ws_bytes, _lib.current_stream()), "rp_sim_topk_fp8")
+
+        scan8()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            scan8()
+        torch.cuda.synchronize()
+        scan_only_qps_fp8 = BQ * 20 / (time.perf_counter() - t0)
         rngp = np.random.default_rng(synth.SEED + 7)
         plens = synth.synth_lengths(rngp, args.premise_sample, "mix", lo=8, hi=2048)
         pids, pcu = synth.synth_token_batch(rngp, plens)
@@ -339,12 +358,13 @@ def main():
         torch.cuda.synchronize()
         prem_per_s_host = args.premise_sample / (time.perf_counter() - t0)
     if world > 1 and not args.headline_only:
-        agg = torch.tensor([prem_per_s, scan_only_qps], dtype=torch.float64, device=dev)
+        agg = torch.tensor([prem_per_s, scan_only_qps, scan_only_qps_fp8], dtype=torch.float64, device=dev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)  # re-index shards by rank: throughputs add
         prem_per_s_host *= float(agg[0].item()) / prem_per_s  # same shard-parallel scaling
         prem_per_s = float(agg[0].item())
         prem_tok_per_s *= world
         scan_only_qps = float(agg[1].item()) / world  # every rank scanned all queries on its shard
+        scan_only_qps_fp8 = float(agg[2].item()) / world
 
     result = {
         "metric": "retrieve QPS@top-100 (state encode + masked similarity top-k), ByT5-small, 130k-premise corpus",
@@ -372,6 +392,7 @@ def main():
         "premise_tokens_per_s": prem_tok_per_s,
         "premise_len_mix": "clip(round(LogNormal(ln 180, 0.9)), 8, 2048) tokens, %d premises/GPU" % args.premise_sample,
         "scan_only_qps": scan_only_qps,
+        "scan_only_qps_e4m3_index": scan_only_qps_fp8,
         "roofline": {
             "kernel": "gemm_kernel<EpiGegluBf16> (FFN wi_0|wi_1 GEMM + gated-GELU epilogue; 58% of encoder FLOPs)",
             "bound": "mfma", "achieved": wi_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
