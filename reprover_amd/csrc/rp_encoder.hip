@@ -542,7 +542,7 @@ __device__ __forceinline__ int find_sequence(const int32_t* __restrict__ cu, int
   return first + n2 - 1;
 }
 
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256, 4) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                          const int32_t* __restrict__ cu,
                                                          const float* __restrict__ bias_tab,
                                                         bf16_t* __restrict__ out, int H, int maxd,
