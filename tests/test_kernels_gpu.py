@@ -73,6 +73,33 @@ def test_gemm_geglu(gen):
     assert (out.float() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-3
 
 
+def test_gemm_geglu_wide_range_of_gate_values(gen):
+    """gelu_new is evaluated as u * rcp(1 + exp2(-2 z log2 e)): check the whole range the exponential
+    sees, from gates where it overflows to +inf (u << 0: result -0) to gates where it underflows to 0
+    (u >> 0: result u), against the tanh form in fp64; relative error stays at bf16 rounding."""
+    M, F, K = 128, 64, 32
+    A = torch.zeros(M, K, device="cuda")
+    A[:, 0] = 1.0
+    w0 = torch.zeros(F, K, device="cuda")
+    w1 = torch.zeros(F, K, device="cuda")
+    gates = torch.linspace(-120.0, 120.0, F, device="cuda").to(torch.bfloat16).float()
+    gates[F // 2] = 0.0
+    w0[:, 0] = gates          # gate value of feature f = gates[f], the same for every token
+    w1[:, 0] = 1.5            # up value
+    W = torch.empty(2 * F, K, dtype=torch.bfloat16, device="cuda")
+    Wv = W.view(F // 32, 2, 32, K)
+    Wv[:, 0] = w0.to(torch.bfloat16).view(F // 32, 32, K)
+    Wv[:, 1] = w1.to(torch.bfloat16).view(F // 32, 32, K)
+    out = torch.full((M, F), float("nan"), dtype=torch.bfloat16, device="cuda")
+    hh.gemm(A.to(torch.bfloat16), W, 2 * F, _lib.RP_EPI_GEGLU_BF16, out)
+    g = gates.double()
+    ref = (0.5 * g * (1 + torch.tanh(math.sqrt(2 / math.pi) * (g + 0.044715 * g ** 3))) * 1.5).float()
+    got = out.float()
+    assert torch.isfinite(got).all()
+    assert (got - ref[None, :]).abs().max().item() <= 2 ** -8 * ref.abs().max().item()
+    assert ((got - ref[None, :]).abs() <= 2 ** -7 * ref.abs()[None, :] + 1e-30).all()
+
+
 @pytest.mark.parametrize("D", [128, 1472, 1536])
 def test_rmsnorm(gen, D):
     x = torch.randn(260, D, generator=gen, device="cuda") * 3
