@@ -20,6 +20,7 @@
 namespace rp {
 
 constexpr int SIM_DENSE_MAX_N = 16384;
+constexpr int64_t SIM_DENSE_MAX_KEYS = 16 << 20;  // B * N above which even a small shard is scanned in two passes
 constexpr int SIM_STRIDE_MAX = 64;
 constexpr int SIM_CAND_CAP = 8192;
 constexpr int SIM_MAX_K = 1024;
@@ -369,7 +370,10 @@ static SimPlan plan_sim(int B, int N, int D, int k, int flags) {
          (int64_t)(stride * 2) * k <= SIM_CAND_CAP / 2)
     stride *= 2;
   p.stride = stride;
-  p.dense_only = (flags & RP_TOPK_DENSE) || N <= SIM_DENSE_MAX_N || p.tiles_p < 2 * stride;
+  // small problems take the single dense pass; a shard of <= 16k rows still goes two-pass when many
+  // queries share it (the 8-GPU shape: 2048 queries x 16k rows would write and re-read 266 MB of keys)
+  p.dense_only = (flags & RP_TOPK_DENSE) || p.tiles_p < 2 * stride ||
+                 (N <= SIM_DENSE_MAX_N && (int64_t)B * N <= SIM_DENSE_MAX_KEYS);
   p.sample_tiles = p.dense_only ? p.tiles_p : (p.tiles_p + stride - 1) / stride;
   p.filter_tiles = p.tiles_p - p.sample_tiles;
   p.dense_ld = (size_t)p.sample_tiles * p.bn;
