@@ -220,3 +220,40 @@ def test_retriever_fp8_index_c5_slice():
     model.predict_step_outputs = []
     model.predict_step(b, 0)
     assert [[where[id(p)] for p in r["retrieved_premises"]] for r in model.predict_step_outputs] == got_i.tolist()
+
+
+def test_fp8_full_size_properties_1m_d1536():
+    """BASELINE configs[4] at its full index size: 1,000,000 premises x 1536 (ByT5-base width) in e4m3,
+    B = 256, k = 100.  The oracle does not finish this size in seconds, so: scores/top-k against a plain
+    torch fp32 evaluation of the same quantised operands, and the size-independent properties — sorted,
+    only accessible premises, count = k, dense pass == two-pass, 8-way shard + merge == single shot."""
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(2024)
+    rng = np.random.default_rng(2024)
+    N, D, B, k, F = 1_000_000, 1536, 256, 100, 5000
+    E8 = torch.empty((N, D), dtype=torch.uint8, device="cuda")
+    es = torch.empty((N,), dtype=torch.float32, device="cuda")
+    for lo in range(0, N, 125_000):
+        x = torch.nn.functional.normalize(torch.randn(125_000, D, generator=gen, device="cuda"), dim=1)
+        c, s_ = hh.quantize_e4m3(x)
+        E8[lo : lo + 125_000], es[lo : lo + 125_000] = c, s_
+    Q8, qs = hh.quantize_e4m3(torch.nn.functional.normalize(torch.randn(B, D, generator=gen, device="cuda"), dim=1))
+    m, acc = hh.synth_masks(rng, N, B, F)
+    dm = hh.masks_to_device(m, Q8.device)
+    ids, sc, cnt = hh.sim_topk_fp8(Q8, qs, E8, es, k, dm)
+    S = np.empty((B, N), dtype=np.float32)
+    qf = Q8.view(torch.float8_e4m3fn).float()
+    for lo in range(0, N, 125_000):
+        part = (qf @ E8[lo : lo + 125_000].view(torch.float8_e4m3fn).float().T) * qs[:, None] * es[None, lo : lo + 125_000]
+        S[:, lo : lo + 125_000] = part.cpu().numpy()
+    hh.check_topk_against_scores(ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy(), S, acc, k, tol=5e-6)
+    assert (cnt == k).all()
+    ids2, sc2, cnt2 = hh.sim_topk_fp8(Q8, qs, E8, es, k, dm, flags=_lib.RP_TOPK_DENSE)
+    assert torch.equal(ids, ids2) and torch.equal(sc, sc2) and torch.equal(cnt, cnt2)
+    f, ek, bt, own, qk = dm
+    bounds = np.linspace(0, N, 9).astype(int)
+    parts = [hh.sim_topk_fp8(Q8, qs, E8[lo:hi], es[lo:hi], k, (f[lo:hi], ek[lo:hi], bt, own, qk), id_offset=int(lo))
+             for lo, hi in zip(bounds[:-1], bounds[1:])]
+    mi, ms, mc = hh.topk_merge(torch.stack([p[1] for p in parts]), torch.stack([p[0] for p in parts]),
+                               torch.stack([p[2] for p in parts]))
+    assert torch.equal(mi, ids) and torch.equal(ms, sc) and torch.equal(mc, cnt)
