@@ -15,7 +15,7 @@ Who may import it: ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baselin
 ``reprover_amd/`` imports it; the product path fails loudly when the HIP library is missing.
 
 Parity pinning: the oracle is pinned against golden vectors generated in the authoring container
-by importing the reference itself and HuggingFace (``tools/make_golden.py`` →
+by importing the reference itself and HuggingFace (``tests/golden/make_golden.py`` →
 ``tests/golden/*.npz|json``; the reference has no tests or golden vectors of its own for this
 path — SURVEY.md §4, §8c).  ``tests/test_oracle_golden.py`` re-checks every fixture on each run.
 """

@@ -1,8 +1,8 @@
 """Generate tests/golden/* by running the REFERENCE itself (lean-dojo/ReProver, imported from
-/root/reference through tools/ref_harness.py) and HuggingFace transformers on CPU.
+/root/reference through tests/golden/ref_harness.py) and HuggingFace transformers on CPU.
 
 Authoring container only.  Only the resulting small data files are committed; no reference
-source travels.  Usage:  python tools/make_golden.py [g1 g2 g3 g4 g5 g6 g7]   (default: all)
+source travels.  Usage:  python tests/golden/make_golden.py [g1 g2 g3 g4 g5 g6 g7]   (default: all)
 
 Every fixture records the inputs and the reference's outputs; while generating, the oracle
 (oracle/) is checked against the reference so a drifting restatement fails here first.
@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(HERE)
+ROOT = os.path.dirname(os.path.dirname(HERE))  # tests/golden/ -> repo root
 sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 
@@ -32,7 +32,7 @@ from transformers.models.t5.modeling_t5 import T5Attention  # noqa: E402
 from oracle import common_ref, t5_ref  # noqa: E402
 from reprover_amd import synth  # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = HERE
 os.makedirs(OUT, exist_ok=True)
 
 

@@ -1,5 +1,5 @@
 """The oracle (oracle/) against the golden vectors produced by the reference + HuggingFace
-(tools/make_golden.py).  CPU only.  If these fail the oracle has drifted from the reference and
+(tests/golden/make_golden.py).  CPU only.  If these fail the oracle has drifted from the reference and
 no GPU parity claim means anything."""
 import json
 import os
