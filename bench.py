@@ -156,7 +156,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    build.build()
+    if world > 1:  # one builder per node; the others wait (the .so normally ships prebuilt and is up to date)
+        if local == 0 or share:
+            build.build()
+        dist.barrier()
+    else:
+        build.build()
     lib = _lib.load()
 
     cfg = synth.t5_config("byt5-small")

@@ -39,14 +39,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH + ".tmp"]
+    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"  # per-process: concurrent builders (one per rank) must not share it
+    cmd = [_hipcc(), *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", tmp]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)
         raise RuntimeError("hipcc failed building libreprover_hip.so")
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 
