@@ -472,23 +472,31 @@ def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     return buf
 
 
-_bf16_cache: Dict[Tuple[int, Tuple[int, ...], str], torch.Tensor] = {}
+_bf16_cache: List[Tuple[torch.Tensor, str, torch.Tensor]] = []  # at most one (source tensor, device, bf16 copy)
+
+
+def drop_cast_cache() -> None:
+    """Forget the cached bf16 cast (call after rewriting a cached source matrix in place)."""
+    _bf16_cache.clear()
 
 
 def as_bf16_matrix(t: torch.Tensor, device: torch.device) -> torch.Tensor:
-    """Contiguous bf16 device view/copy of an embedding matrix; large conversions are cached by
-    storage so that ``retrieve`` does not re-cast the corpus every call (the reference caches
-    the cast in ``self.corpus_embeddings``, model.py:363-366)."""
+    """Contiguous bf16 device view/copy of an embedding matrix; one large conversion is cached so that
+    ``retrieve`` does not re-cast the corpus every call (the reference caches the cast in
+    ``self.corpus_embeddings``, model.py:363-366).  The cache is keyed on the source tensor OBJECT, held
+    by a strong reference together with its ``_version``: a freed-and-recycled storage can therefore
+    never alias the key, and in-place torch writes invalidate it; writers that go through raw pointers
+    call ``drop_cast_cache``."""
     if t.dtype == torch.bfloat16 and t.device == device and t.is_contiguous():
         return t
     if t.numel() < (1 << 20):
         return t.to(device=device, dtype=torch.bfloat16).contiguous()
-    key = (t.data_ptr(), tuple(t.shape), str(t.dtype) + str(t.device) + str(t._version))
-    hit = _bf16_cache.get(key)
-    if hit is None:
-        _bf16_cache.clear()
-        hit = t.to(device=device, dtype=torch.bfloat16).contiguous()
-        _bf16_cache[key] = hit
+    for src, dev_key, hit in _bf16_cache:
+        if src is t and dev_key == f"{device}:{t._version}":
+            return hit
+    _bf16_cache.clear()
+    hit = t.to(device=device, dtype=torch.bfloat16).contiguous()
+    _bf16_cache.append((t, f"{device}:{t._version}", hit))
     return hit
 
 

@@ -26,7 +26,7 @@ thread_local std::string g_last_error;
 // ------------------------------------------------------------------------------------------
 // options
 // ------------------------------------------------------------------------------------------
-extern int g_scan_cfg;
+extern int g_scan_cfg, g_scan_impl;
 static int g_gemm_group_m = 8;
 // Tile configuration per encoder GEMM (see launch_gemm()), measured at 65536 tokens (tools/gemm_bench.py,
 // profiles/).  20 / 26 = the software-pipelined 256 x 256 x 64 tile with 4 / 8 waves: the same main
@@ -917,6 +917,11 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   if (!strcmp(name, "scan_cfg")) {
     RP_REQUIRE(value >= 0 && value <= 1, "scan_cfg out of range");
     g_scan_cfg = value;
+    return RP_OK;
+  }
+  if (!strcmp(name, "scan_impl")) {
+    RP_REQUIRE(value >= 0 && value <= 1, "scan_impl out of range");
+    g_scan_impl = value;
     return RP_OK;
   }
   return fail(RP_E_INVALID, "unknown option %s", name);

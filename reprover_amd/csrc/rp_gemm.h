@@ -93,6 +93,14 @@ struct GemmOperand {
   int rows;           // rows that may be read; tile rows beyond are clamped to rows-1
 };
 
+// An epilogue may declare `void prologue(char* extra_lds, int wave, int lane)`: gemm_tile_pipe calls it
+// before the first operand DMA so that per-tile metadata can ride into LDS (beyond the ring) by LDS-DMA
+// and be complete, by the in-order vmcnt accounting, long before the epilogue reads it.
+template <class E, class = void>
+struct has_prologue : std::false_type {};
+template <class E>
+struct has_prologue<E, std::void_t<decltype(&E::prologue)>> : std::true_type {};
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
@@ -249,7 +257,11 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
 template <class C, class Epilogue>
 __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOperand W, int K, int tile_m,
                                                int tile_n, Epilogue& epi, char* smem) {
-  constexpr int BK = C::BK, FM = C::FM, FN = C::FN, KS = BK / 16;
+  // bf16: one MFMA k-step = 16 values = two 16-B slots of a row (one per lane half); e4m3: one k-step =
+  // 64 values = four slots (two per lane half), so a 128-B row holds 4 bf16 or 2 e4m3 k-steps.
+  constexpr int BK = C::BK, FM = C::FM, FN = C::FN, KS = C::FP8 ? C::ROW_BYTES / 64 : BK / 16;
+  constexpr int RPF = C::FP8 ? 2 : 1;  // ds_read_b128 per fragment
+  using frag_t = std::conditional_t<C::FP8 != 0, i32x8, bf16x8>;
   RP_TS(0);
   static_assert(KS % 2 == 0 && KS >= 2, "even number of k-steps (fragment double-buffer parity)");
   const int tid = threadIdx.x;
@@ -281,6 +293,7 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
     w_src[d] = W.ptr + (size_t)min(tile_n * C::BN + row, W.rows - 1) * W.ld + kc * 8;
   }
   const int nk = K / BK;
+  if constexpr (has_prologue<Epilogue>::value) epi.prologue(smem + C::RING_BYTES, wave, lane);
   // half 0: the A image of a stage, half 1: the W image (issued one k-step apart, see tile_body)
   auto stage_half = [&](int kt, int buf, int half) {
     char* base = smem + buf * C::STAGE_BYTES;
@@ -310,17 +323,18 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
     stage_half(kt, buf, 1);
   };
 
-  int a_off[FM][KS], b_off[FN][KS];
+  int a_off[FM][KS * RPF], b_off[FN][KS * RPF];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
+  for (int ks = 0; ks < KS * RPF; ++ks) {
+    // bf16: slot 2 ks + hi.  e4m3: k-step s = ks / 2 takes slots 4 s + 2 hi + {0, 1} (both operands split alike)
+    const int slot = C::FP8 ? ((ks >> 1) * 4 + hi * 2 + (ks & 1)) : (ks * 2 + hi);
 #pragma unroll
-    for (int f = 0; f < FM; ++f) a_off[f][ks] = C::off(wave_row * (FM * 32) + f * 32 + (lane & 31), ks * 2 + hi);
+    for (int f = 0; f < FM; ++f) a_off[f][ks] = C::off(wave_row * (FM * 32) + f * 32 + (lane & 31), slot);
 #pragma unroll
-    for (int f = 0; f < FN; ++f)
-      b_off[f][ks] = C::A_BYTES + C::off(wave_col * (FN * 32) + f * 32 + (lane & 31), ks * 2 + hi);
+    for (int f = 0; f < FN; ++f) b_off[f][ks] = C::A_BYTES + C::off(wave_col * (FN * 32) + f * 32 + (lane & 31), slot);
   }
 
-  bf16x8 af[2][FM], bfr[2][FN];  // double-buffered fragments, parity = k-step & 1
+  frag_t af[2][FM], bfr[2][FN];  // double-buffered fragments, parity = k-step & 1
 #if defined(RP_PHASE_PROBE) && defined(RP_PROBE_NO_READS)
   bool probe_reads_on = true;
 #endif
@@ -328,17 +342,37 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
 #if defined(RP_PHASE_PROBE) && defined(RP_PROBE_NO_READS)
     if (!probe_reads_on) return;  // keep what the prologue read
 #endif
+    if constexpr (C::FP8 != 0) {
 #pragma unroll
-    for (int f = 0; f < FM; ++f) af[p][f] = *reinterpret_cast<const bf16x8*>(st + a_off[f][ks]);
+      for (int f = 0; f < FM; ++f) {
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(st + a_off[f][2 * ks]);
+        const i32x4 up = *reinterpret_cast<const i32x4*>(st + a_off[f][2 * ks + 1]);
+        af[p][f] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+      }
 #pragma unroll
-    for (int f = 0; f < FN; ++f) bfr[p][f] = *reinterpret_cast<const bf16x8*>(st + b_off[f][ks]);
+      for (int f = 0; f < FN; ++f) {
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(st + b_off[f][2 * ks]);
+        const i32x4 up = *reinterpret_cast<const i32x4*>(st + b_off[f][2 * ks + 1]);
+        bfr[p][f] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < FM; ++f) af[p][f] = *reinterpret_cast<const bf16x8*>(st + a_off[f][ks]);
+#pragma unroll
+      for (int f = 0; f < FN; ++f) bfr[p][f] = *reinterpret_cast<const bf16x8*>(st + b_off[f][ks]);
+    }
   };
   auto mma = [&](int p) {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[p][i], bfr[p][j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < FN; ++j) {
+        if constexpr (C::FP8 != 0)  // block-scaled MFMA with every E8M0 scale = 127 (2^0): e4m3 x e4m3 at the MX rate
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[p][i], bfr[p][j], acc[i][j], 0, 0, 0, 0x7f7f7f7f,
+                                                                      0, 0x7f7f7f7f);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[p][i], bfr[p][j], acc[i][j], 0, 0, 0);
+      }
   };
 
   constexpr int NSTAGE = C::NSTAGE, DPS = C::A_DMA + C::W_DMA;
@@ -384,7 +418,7 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
     }
   };
   using NoDma = std::integral_constant<int, 0>;
-  using Reads = std::integral_constant<int, FM + FN>;
+  using Reads = std::integral_constant<int, (FM + FN) * RPF>;
   int buf = 0;
   auto tile_body = [&](int kt, auto mode_tag, auto pend_tag) {
     constexpr int MODE = decltype(mode_tag)::value;

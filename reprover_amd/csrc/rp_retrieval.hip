@@ -22,20 +22,31 @@ namespace rp {
 constexpr int SIM_DENSE_MAX_N = 16384;
 constexpr int64_t SIM_DENSE_MAX_KEYS = 16 << 20;  // B * N above which even a small shard is scanned in two passes
 constexpr int SIM_STRIDE_MAX = 64;
-constexpr int SIM_CAND_CAP = 8192;
 constexpr int SIM_MAX_K = 1024;
 constexpr int SIM_COUNT_STRIDE = 32;  // one candidate counter per 128-B line: contended atomics of different
                                       // queries must not serialise in the same L2 line
-// scan tile configurations: BM queries x 128 premises (premise tiles are always 128 rows so that the
-// sampled-tile bookkeeping is independent of the query tile)
+constexpr int SIM_PB = 256;           // two-pass plan: premises are sampled / skipped in blocks of 256 rows
+// Dense single-pass configurations (small shards, RP_TOPK_DENSE): BM queries x 128 premises, queries are the
+// MFMA row operand, premises the column operand (lane = premise: dense key rows are written coalesced).
 typedef GemmCfg<256, 128, 32, 4, 2, 3> SimCfgQ256;  // B > 128: 8 waves, one workgroup sees up to 256 queries
 typedef GemmCfg<128, 128, 64, 2, 2, 2> SimCfgQ128;  // B <= 128, D % 64 == 0
 typedef GemmCfg<128, 128, 32, 2, 2, 3> SimCfgQ128K32;  // B <= 128, D % 32 == 0
 // e4m3 index (rp_sim_topk_fp8): 64 fp8 values per K-step = the 64-B rows of the "BK = 32" geometry
 typedef GemmCfg<256, 128, 32, 4, 2, 3, 0, 1> SimCfg8Q256;
 typedef GemmCfg<128, 128, 32, 2, 2, 3, 0, 1> SimCfg8Q128;
-constexpr int GEMM_BN = 128;
-int g_scan_cfg = 0;  // 0: auto; 1: force 128-query tiles
+// Sample pass of the two-pass plan: 1/stride of the rows, as many small workgroups as possible (128 queries x
+// 64 premises, 6-deep ring: every workgroup is a latency-bound K loop, so depth and count are what matter).
+typedef GemmCfg<128, 64, 32, 2, 2, 6> SimCfgSample;
+typedef GemmCfg<128, 64, 32, 2, 2, 6, 0, 1> SimCfg8Sample;
+// Filter pass: the encoder's software-pipelined 256 x 256 x 64 tile (one wave per SIMD, 128 x 128 per wave) with
+// PREMISES as the MFMA row operand and QUERIES as the column operand: a lane then owns ONE query per column
+// fragment, so the per-query bound sits in 4 registers and the pre-test is one v_cmp per score (EpiSimFilter).
+typedef GemmCfg<256, 256, 64, 2, 2, 2, 1> SimCfgFilter;
+typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 1> SimCfg8Filter;
+constexpr int SIM_FILTER_META_BYTES = 12288;  // per-tile metadata behind the ring (EpiSimFilter::prologue)
+constexpr int SIM_FILTER_LIST_BYTES = 32768;  // per-wave survivor list (the ring, dead after the main loop)
+int g_scan_cfg = 0;   // 0: auto; 1: force 128-query tiles in the dense path
+int g_scan_impl = 0;  // 0: auto (pipelined filter kernel when the shape allows); 1: first-generation filter kernel
 
 __device__ __forceinline__ uint64_t make_key(float score, int32_t id) {
   return ((uint64_t)f2ord(score) << 32) | (uint32_t)(~(uint32_t)id);
@@ -160,26 +171,204 @@ struct EpiSim {
   }
 };
 
-// pass 0 (dense): premise tile = ord * stride.   pass 1 (filter): all tiles with pt % stride != 0.
+// Tile -> premise rows.  The plan samples / skips premises in blocks of SIM_PB = 256 rows; a block holds
+// `sub` = 256 / C::BN tiles of this kernel.  (Dense-only plans pass stride = 1, sub = 1: tile = ord.)
+//   pass 0 (dense keys):  sub-tile s of sampled block j * stride  ->  key slots [ord * BN, +BN)
+//   pass 1 (filter):      sub-tile s of the fb-th block that is NOT a multiple of stride
 template <class C>
 __global__ __launch_bounds__(C::THREADS) void sim_scan_kernel(GemmOperand Qop, GemmOperand Eop, int K, int tiles_q,
-                                                              int stride, EpiSim epi) {
+                                                              int stride, int sub, EpiSim epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int qt = logical % tiles_q;
   const int ord = logical / tiles_q;
   int pt;
   if (!epi.filter) {
-    pt = ord * stride;
+    pt = (ord / sub) * stride * sub + ord % sub;
     epi.slot_shift = ord * C::BN - pt * C::BN;
   } else {
-    pt = ord + ord / (stride - 1) + 1;
+    const int fb = ord / sub;
+    pt = (fb + fb / (stride - 1) + 1) * sub + ord % sub;
     epi.slot_shift = 0;
   }
   epi.smem = smem;
   epi.tile_q0 = qt * C::BM;
   epi.bm = C::BM;
   gemm_tile<C>(Qop, Eop, K, qt, pt, epi, smem);
+}
+
+// ------------------------------------------------------------------------------------------
+// Filter pass, second generation: premises are the MFMA row operand, queries the column operand.
+//   acc[i][j][r]  <->  premise m_base + 32 i + (r & 3) + 8 (r >> 2) + 4 hi,   query n_base + 32 j + (lane & 31)
+// so a lane holds, per column fragment j, ONE query: its lower bound tau (the float of the sampled k-th key)
+// lives in a register and the pre-test is a single v_cmp per score.  Survivors (~k * stride / N of the scores,
+// ~1 %) are first compacted, wave-ballot + mbcnt, no atomics, into a per-wave list in LDS (the operand ring is
+// dead by then), and only the list is run through the accessibility predicate, the exact 64-bit key test and the
+// per-query append - densely, one survivor per lane - instead of a divergent slow path per score.
+// Per-tile metadata (tau / thr / own_file / q_key of the 256 queries, file_of / end_key of the 256 premises)
+// rides into LDS behind the ring by LDS-DMA issued before the first operand DMA (prologue hook of gemm_tile_pipe).
+// ------------------------------------------------------------------------------------------
+template <int FP8>
+struct EpiSimFilter {
+  // premise side (NULL file_of => no accessibility mask)
+  const int32_t* file_of;
+  const int64_t* end_key;
+  int N;
+  // query side
+  const uint32_t* bits_t;  // [F, bits_words]
+  int bits_words;
+  const int32_t* own_file;
+  const int64_t* q_key;
+  int B;
+  int id_offset;
+  const float* q_scale;  // FP8: score = (acc * q_scale[query]) * e_scale[premise]
+  const float* e_scale;
+  const uint64_t* thr;  // [B] sampled k-th key (0: fewer than k in the sample)
+  const float* tau;     // [B] its score (-inf when thr == 0)
+  uint64_t* cand;       // [B, cap]
+  size_t cap;
+  int32_t* count;       // [B * SIM_COUNT_STRIDE]
+  // per workgroup
+  char* smem;
+  int meta_off;  // byte offset of the metadata behind the ring
+  int p0, q0;    // first premise / query of this workgroup's tile
+
+  // metadata layout (bytes from meta_off)
+  static constexpr int M_TAU = 0, M_OWN = 1024, M_THR = 2048, M_QK = 4096, M_FILE = 6144, M_EK = 7168, M_QS = 9216,
+                       M_ES = 10240;
+
+  __device__ __forceinline__ void prologue(char* meta, int wave, int lane) {
+    auto dma4 = [&](const void* g, char* dst) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)dst, 4, 0, 0);
+    };
+    // 4-byte arrays: wave w brings entries [64 w, 64 w + 64); 8-byte arrays go as dwords [128 w, 128 w + 128)
+    const int e = wave * 64 + lane;
+    const int q = min(q0 + e, B - 1), p = min(p0 + e, N - 1);
+    dma4(tau + q, meta + M_TAU + wave * 256);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int d = wave * 128 + i * 64 + lane;
+      dma4(reinterpret_cast<const uint32_t*>(thr) + 2 * (size_t)min(q0 + (d >> 1), B - 1) + (d & 1),
+           meta + M_THR + wave * 512 + i * 256);
+    }
+    if (file_of) {
+      dma4(own_file + q, meta + M_OWN + wave * 256);
+      dma4(file_of + p, meta + M_FILE + wave * 256);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int d = wave * 128 + i * 64 + lane;
+        dma4(reinterpret_cast<const uint32_t*>(q_key) + 2 * (size_t)min(q0 + (d >> 1), B - 1) + (d & 1),
+             meta + M_QK + wave * 512 + i * 256);
+        dma4(reinterpret_cast<const uint32_t*>(end_key) + 2 * (size_t)min(p0 + (d >> 1), N - 1) + (d & 1),
+             meta + M_EK + wave * 512 + i * 256);
+      }
+    }
+    if constexpr (FP8 != 0) {
+      dma4(q_scale + q, meta + M_QS + wave * 256);
+      dma4(e_scale + p, meta + M_ES + wave * 256);
+    }
+  }
+
+  template <int FM, int FN>
+  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* /*stage*/) {
+    const int hi = lane >> 5, cl = lane & 31;
+    const char* meta = smem + meta_off;
+    const float* s_tau = reinterpret_cast<const float*>(meta + M_TAU);
+    const int32_t* s_own = reinterpret_cast<const int32_t*>(meta + M_OWN);
+    const uint64_t* s_thr = reinterpret_cast<const uint64_t*>(meta + M_THR);
+    const int64_t* s_qk = reinterpret_cast<const int64_t*>(meta + M_QK);
+    const int32_t* s_file = reinterpret_cast<const int32_t*>(meta + M_FILE);
+    const int64_t* s_ek = reinterpret_cast<const int64_t*>(meta + M_EK);
+    const float* s_qs = reinterpret_cast<const float*>(meta + M_QS);
+    const float* s_es = reinterpret_cast<const float*>(meta + M_ES);
+    const int pl0 = m_base - p0, ql0 = n_base - q0;  // this wave's first premise / query inside the tile
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint2* list = reinterpret_cast<uint2*>(smem + wave * SIM_FILTER_LIST_BYTES);
+    constexpr int LIST_CAP = SIM_FILTER_LIST_BYTES / 8;
+    static_assert(FM * 32 <= 256 && FN * 32 <= 256, "row / column codes are 8 bits");
+
+    // survivors [0, cnt) of the wave's list -> predicate, exact key test, append; one survivor per lane
+    auto drain = [&](int cnt) {
+      for (int e = lane; e < cnt; e += 64) {
+        const uint2 en = list[e];
+        const float sc = __uint_as_float(en.x);
+        const int pl = pl0 + (int)(en.y >> 16), ql = ql0 + (int)(en.y & 0xffffu);
+        const int p = p0 + pl, q = q0 + ql;
+        bool ok = (p < N) && (q < B);
+        if (file_of && ok) {
+          const int32_t f = s_file[pl];
+          const uint32_t word = bits_t[(size_t)f * bits_words + (q >> 5)];
+          ok = ((word >> (q & 31)) & 1u) || (f == s_own[ql] && s_ek[pl] <= s_qk[ql]);
+        }
+        if (ok) {
+          const uint64_t key = make_key(sc, p + id_offset);
+          if (key > s_thr[ql]) {
+            const int pos = atomicAdd(&count[(size_t)q * SIM_COUNT_STRIDE], 1);
+            cand[(size_t)q * cap + pos] = key;  // cap = rows + k: cannot overflow
+          }
+        }
+      }
+    };
+
+    float tauv[FN], qsv[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      tauv[j] = s_tau[ql0 + j * 32 + cl];
+      qsv[j] = FP8 ? s_qs[ql0 + j * 32 + cl] : 1.f;
+    }
+    const uint32_t lane_code = ((uint32_t)(4 * hi) << 16) | (uint32_t)cl;
+    int cnt = 0;  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      float esv[16];
+      if constexpr (FP8 != 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(s_es + pl0 + i * 32 + 8 * g + 4 * hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) esv[4 * g + e] = v[e];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        if (cnt > LIST_CAP - 1024) {  // a fragment adds at most 1024 entries
+          drain(cnt);
+          cnt = 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float sc = FP8 ? (acc[i][j][r] * qsv[j]) * esv[r] : acc[i][j][r];
+          const bool surv = sc >= tauv[j];
+          const unsigned long long ball = __ballot(surv);
+          if (ball) {
+            const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
+            if (surv)
+              list[pos] = make_uint2(__float_as_uint(sc),
+                                     lane_code + (((uint32_t)(i * 32 + (r & 3) + 8 * (r >> 2)) << 16) | (uint32_t)(j * 32)));
+            cnt += __popcll(ball);
+          }
+        }
+      }
+    }
+    drain(cnt);
+  }
+};
+
+template <class C>
+__global__ __launch_bounds__(C::THREADS) void sim_filter_kernel(GemmOperand Eop, GemmOperand Qop, int K, int tiles_q,
+                                                                int stride, EpiSimFilter<C::FP8> epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(C::BM == SIM_PB && C::RING_BYTES >= C::NWAVES * SIM_FILTER_LIST_BYTES, "filter tile geometry");
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = logical % tiles_q;
+  const int fb = logical / tiles_q;
+  const int pb = fb + fb / (stride - 1) + 1;  // the fb-th block that is not a multiple of stride
+  epi.smem = smem;
+  epi.meta_off = C::RING_BYTES;
+  epi.p0 = pb * C::BM;
+  epi.q0 = qt * C::BN;
+  gemm_tile_pipe<C>(Eop, Qop, K, pb, qt, epi, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -199,6 +388,7 @@ struct SelectArgs {
   size_t out_ld;
   int32_t* out_cnt;
   uint64_t* out_thr;
+  float* out_tau;  // score of out_thr (-inf when fewer than k keys were found): the filter pass's float pre-test
   // mode B outputs (final)
   float* out_scores;   // [B, k]
   int32_t* out_ids;    // [B, k]
@@ -316,7 +506,10 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
     for (int i = tid; i < kk; i += 256) a.out_keys[(size_t)q * a.out_ld + i] = sel[i];
     if (tid == 0) {
       a.out_cnt[(size_t)q * SIM_COUNT_STRIDE] = kk;
-      a.out_thr[q] = (kk == a.k) ? sel[kk - 1] : 0ull;
+      const uint64_t th = (kk == a.k) ? sel[kk - 1] : 0ull;
+      a.out_thr[q] = th;
+      // keys > th have ordered(score) >= th.hi, i.e. score >= ord2f(th.hi)
+      if (a.out_tau) a.out_tau[q] = th ? ord2f((uint32_t)(th >> 32)) : -INFINITY;
     }
   }
   if (a.out_scores) {
@@ -349,74 +542,82 @@ static void launch_select(const SelectArgs& a, int B, hipStream_t stream) {
 
 struct SimPlan {
   bool dense_only;
-  int stride;  // pass 0 scans every stride-th premise tile
-  int bm, bn, tiles_q, tiles_p, sample_tiles, filter_tiles;
-  size_t dense_ld;
-  size_t off_dense, off_cand, off_count, off_thr, bytes;
+  bool new_filter;  // two-pass: second-generation filter kernel (needs whole 128-B operand rows per K-tile)
+  int stride;       // two-pass: every stride-th 256-row block is sampled
+  int blocks, sample_blocks, filter_blocks;
+  int bm, tiles_q, tiles_p;  // dense-only: first-generation kernel, bm queries x 128 premises per tile
+  size_t dense_ld;           // keys per query in the dense buffer
+  size_t cap;                // candidate-list capacity per query: every row could pass, so it cannot overflow
+  size_t off_dense, off_cand, off_count, off_thr, off_tau, bytes;
 };
 
-static SimPlan plan_sim(int B, int N, int D, int k, int flags) {
+// D2 = operand row length in 2-byte units
+static SimPlan plan_sim(int B, int N, int D2, int k, int flags) {
   SimPlan p;
   p.bm = (B > 128 && g_scan_cfg != 1) ? 256 : 128;
   p.tiles_q = (B + p.bm - 1) / p.bm;
-  p.bn = GEMM_BN;
-  p.tiles_p = (N + p.bn - 1) / p.bn;
+  p.tiles_p = (N + 127) / 128;
+  p.blocks = (N + SIM_PB - 1) / SIM_PB;
   // Sampling stride: the k-th best of a 1/stride sample leaves ~k*stride candidates above it in the
   // full set (spread ~stride*sqrt(k)), and the sample select reads N/stride keys per query.  The two
-  // select costs balance near stride ~ sqrt(N/k) / 2 (measured: 16 at N = 130k, 32 at N = 1M for k = 100: the filter
-  // pass pays an atomic append per candidate); k*stride is kept <= half the candidate capacity.
+  // select costs balance near stride ~ sqrt(N/k) / 2 (measured: 16 at N = 130k, 32 at N = 1M for k = 100: the
+  // filter pass pays an atomic append per candidate).
   int stride = 2;
-  while (stride * 2 <= SIM_STRIDE_MAX && (int64_t)(stride * 2) * (stride * 2) * k * 4 <= N &&
-         (int64_t)(stride * 2) * k <= SIM_CAND_CAP / 2)
-    stride *= 2;
+  while (stride * 2 <= SIM_STRIDE_MAX && (int64_t)(stride * 2) * (stride * 2) * k * 4 <= N) stride *= 2;
   p.stride = stride;
   // small problems take the single dense pass; a shard of <= 16k rows still goes two-pass when many
   // queries share it (the 8-GPU shape: 2048 queries x 16k rows would write and re-read 266 MB of keys)
-  p.dense_only = (flags & RP_TOPK_DENSE) || p.tiles_p < 2 * stride ||
+  p.dense_only = (flags & RP_TOPK_DENSE) || p.blocks < 2 * stride ||
                  (N <= SIM_DENSE_MAX_N && (int64_t)B * N <= SIM_DENSE_MAX_KEYS);
-  p.sample_tiles = p.dense_only ? p.tiles_p : (p.tiles_p + stride - 1) / stride;
-  p.filter_tiles = p.tiles_p - p.sample_tiles;
-  p.dense_ld = (size_t)p.sample_tiles * p.bn;
+  p.new_filter = !p.dense_only && g_scan_impl == 0 && (D2 % 64 == 0);
+  p.sample_blocks = p.dense_only ? 0 : (p.blocks + stride - 1) / stride;
+  p.filter_blocks = p.dense_only ? 0 : p.blocks - p.sample_blocks;
+  p.dense_ld = p.dense_only ? (size_t)p.tiles_p * 128 : (size_t)p.sample_blocks * SIM_PB;
+  p.cap = (size_t)N + k;
   size_t off = 0;
   p.off_dense = off;
   off += align_up((size_t)B * p.dense_ld * 8, 256);
   p.off_cand = off;
-  off += align_up((size_t)B * (SIM_CAND_CAP + k) * 8, 256);
+  off += p.dense_only ? 0 : align_up((size_t)B * p.cap * 8, 256);
   p.off_count = off;
   off += align_up((size_t)B * 4 * SIM_COUNT_STRIDE, 256);
   p.off_thr = off;
   off += align_up((size_t)B * 8, 256);
+  p.off_tau = off;
+  off += align_up((size_t)B * 4, 256);
   p.bytes = off;
   return p;
 }
 
+// first-generation kernel (queries = MFMA rows): dense pass, sample pass, fallback filter pass
 template <class C>
-static RpStatus launch_scan_cfg(GemmOperand q, GemmOperand e, int D, int tiles_q, int n_ptiles, int stride,
-                                const EpiSim& epi, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    RP_HIP(hipFuncSetAttribute((const void*)sim_scan_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               C::LDS_BYTES));
-    attr_done = true;
-  }
+static RpStatus launch_scan_cfg(GemmOperand q, GemmOperand e, int D2, int n_tiles, int stride, const EpiSim& epi,
+                                hipStream_t stream) {
+  if (n_tiles <= 0) return RP_OK;
+  static LdsAttrOnce attr;
+  RP_HIP(attr.ensure((const void*)sim_scan_kernel<C>, C::LDS_BYTES));
+  const int tiles_q = (epi.B + C::BM - 1) / C::BM;
+  const int sub = (stride > 1 || epi.filter) ? SIM_PB / C::BN : 1;
   ProfScope ps(stream, RP_K_SCAN);
-  hipLaunchKernelGGL((sim_scan_kernel<C>), dim3(tiles_q * n_ptiles), dim3(C::THREADS), C::LDS_BYTES, stream, q, e,
-                     D, tiles_q, stride, epi);
+  hipLaunchKernelGGL((sim_scan_kernel<C>), dim3(tiles_q * n_tiles), dim3(C::THREADS), C::LDS_BYTES, stream, q, e, D2,
+                     tiles_q, stride, sub, epi);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
 
-// D counts 2-byte units of an operand row (= elements for bf16, elements / 2 for e4m3)
-static RpStatus launch_scan(const SimPlan& p, GemmOperand q, GemmOperand e, int D, int n_ptiles, int stride,
-                            const EpiSim& epi, hipStream_t stream) {
-  if (n_ptiles <= 0) return RP_OK;
-  if (epi.q_scale) {
-    if (p.bm == 256) return launch_scan_cfg<SimCfg8Q256>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
-    return launch_scan_cfg<SimCfg8Q128>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
-  }
-  if (p.bm == 256) return launch_scan_cfg<SimCfgQ256>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
-  if (D % 64 == 0) return launch_scan_cfg<SimCfgQ128>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
-  return launch_scan_cfg<SimCfgQ128K32>(q, e, D, p.tiles_q, n_ptiles, stride, epi, stream);
+template <class C>
+static RpStatus launch_filter_cfg(GemmOperand e, GemmOperand q, int D2, int n_blocks, int stride,
+                                  const EpiSimFilter<C::FP8>& epi, hipStream_t stream) {
+  if (n_blocks <= 0) return RP_OK;
+  constexpr int LDS = C::RING_BYTES + SIM_FILTER_META_BYTES;
+  static LdsAttrOnce attr;
+  RP_HIP(attr.ensure((const void*)sim_filter_kernel<C>, LDS));
+  const int tiles_q = (epi.B + C::BN - 1) / C::BN;
+  ProfScope ps(stream, RP_K_SCAN);
+  hipLaunchKernelGGL((sim_filter_kernel<C>), dim3(tiles_q * n_blocks), dim3(C::THREADS), LDS, stream, e, q, D2, tiles_q,
+                     stride, epi);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
 }
 
 }  // namespace rp
@@ -425,6 +626,8 @@ using namespace rp;
 
 extern "C" size_t rp_sim_topk_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t k, int32_t flags) {
   if (B <= 0 || N <= 0 || k <= 0) return 0;
+  // the e4m3 entry point has half the 2-byte units per row; its plan can only differ by taking the
+  // first-generation filter kernel, which needs the same workspace
   return plan_sim(B, N, D, k, flags).bytes;
 }
 
@@ -443,7 +646,8 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   RP_REQUIRE(k > 0 && k <= SIM_MAX_K, "k=%d out of range (1..%d)", k, SIM_MAX_K);
   if (file_of) RP_REQUIRE(end_key && file_bits_t && own_file && q_key && F > 0, "mask arrays incomplete");
   hipStream_t stream = (hipStream_t)stream_;
-  const SimPlan p = plan_sim(B, N, D, k, flags);
+  const int D2 = fp8 ? D / 2 : D;  // row length in 2-byte units
+  const SimPlan p = plan_sim(B, N, D2, k, flags);
   if (!workspace || workspace_bytes < p.bytes)
     return fail(RP_E_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, p.bytes);
   char* ws = (char*)workspace;
@@ -451,9 +655,8 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   uint64_t* cand = (uint64_t*)(ws + p.off_cand);
   int32_t* count = (int32_t*)(ws + p.off_count);
   uint64_t* thr = (uint64_t*)(ws + p.off_thr);
-  const int cap = SIM_CAND_CAP + k;
+  float* tau = (float*)(ws + p.off_tau);
 
-  const int D2 = fp8 ? D / 2 : D;  // row length in 2-byte units
   GemmOperand qop{(const bf16_t*)Q, D2, B}, eop{(const bf16_t*)E, D2, N};
   EpiSim epi;
   epi.q_scale = q_scale;
@@ -473,16 +676,13 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   epi.slot_shift = 0;
   epi.thr = thr;
   epi.cand = cand;
-  epi.cap = cap;
+  epi.cap = (int)p.cap;
   epi.count = count;
   epi.smem = nullptr;
   epi.tile_q0 = 0;
   epi.bm = p.bm;
 
-  // pass 0: dense keys of the sampled (or all) premise tiles
-  const int stride0 = p.dense_only ? 1 : p.stride;
   RpStatus st;
-  if ((st = launch_scan(p, qop, eop, D2, p.sample_tiles, stride0, epi, stream))) return st;
   SelectArgs sa;
   sa.keys = dense;
   sa.ld = p.dense_ld;
@@ -491,7 +691,18 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   sa.n_fixed = (int)p.dense_ld;
   sa.cap = (int)p.dense_ld;
   sa.k = k;
+  sa.out_tau = nullptr;
   if (p.dense_only) {
+    // single pass: dense keys of every premise tile, then one select
+    if (fp8)
+      st = (p.bm == 256) ? launch_scan_cfg<SimCfg8Q256>(qop, eop, D2, p.tiles_p, 1, epi, stream)
+                         : launch_scan_cfg<SimCfg8Q128>(qop, eop, D2, p.tiles_p, 1, epi, stream);
+    else if (p.bm == 256)
+      st = launch_scan_cfg<SimCfgQ256>(qop, eop, D2, p.tiles_p, 1, epi, stream);
+    else
+      st = (D2 % 64 == 0) ? launch_scan_cfg<SimCfgQ128>(qop, eop, D2, p.tiles_p, 1, epi, stream)
+                          : launch_scan_cfg<SimCfgQ128K32>(qop, eop, D2, p.tiles_p, 1, epi, stream);
+    if (st) return st;
     sa.out_keys = nullptr;
     sa.out_ld = 0;
     sa.out_cnt = nullptr;
@@ -503,30 +714,79 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
     RP_CHECK_LAUNCH();
     return RP_OK;
   }
+  // pass 0: dense keys of the sampled blocks (4 sub-tiles of 64 rows each), k best of the sample -> bound
+  const int n_sub = p.sample_blocks * (SIM_PB / SimCfgSample::BN);
+  st = fp8 ? launch_scan_cfg<SimCfg8Sample>(qop, eop, D2, n_sub, p.stride, epi, stream)
+           : launch_scan_cfg<SimCfgSample>(qop, eop, D2, n_sub, p.stride, epi, stream);
+  if (st) return st;
   sa.out_keys = cand;
-  sa.out_ld = cap;
+  sa.out_ld = p.cap;
   sa.out_cnt = count;
   sa.out_thr = thr;
+  sa.out_tau = tau;
   sa.out_scores = nullptr;
   sa.out_ids = nullptr;
   sa.out_count = nullptr;
   launch_select(sa, B, stream);
   RP_CHECK_LAUNCH();
-  // pass 1: remaining tiles, keep only keys above each query's bound
-  epi.filter = 1;
-  if ((st = launch_scan(p, qop, eop, D2, p.filter_tiles, p.stride, epi, stream))) return st;
+  // pass 1: remaining blocks, keep only keys above each query's bound
+  if (p.new_filter) {
+    auto fill = [&](auto& ef) {
+      ef.file_of = file_of;
+      ef.end_key = end_key;
+      ef.N = N;
+      ef.bits_t = file_bits_t;
+      ef.bits_words = (B + 31) / 32;
+      ef.own_file = own_file;
+      ef.q_key = q_key;
+      ef.B = B;
+      ef.id_offset = id_offset;
+      ef.q_scale = q_scale;
+      ef.e_scale = e_scale;
+      ef.thr = thr;
+      ef.tau = tau;
+      ef.cand = cand;
+      ef.cap = p.cap;
+      ef.count = count;
+      ef.smem = nullptr;
+      ef.meta_off = 0;
+      ef.p0 = ef.q0 = 0;
+    };
+    if (fp8) {
+      EpiSimFilter<1> ef;
+      fill(ef);
+      st = launch_filter_cfg<SimCfg8Filter>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+    } else {
+      EpiSimFilter<0> ef;
+      fill(ef);
+      st = launch_filter_cfg<SimCfgFilter>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+    }
+  } else {
+    epi.filter = 1;
+    const int n_t = p.filter_blocks * (SIM_PB / 128);
+    if (fp8)
+      st = (p.bm == 256) ? launch_scan_cfg<SimCfg8Q256>(qop, eop, D2, n_t, p.stride, epi, stream)
+                         : launch_scan_cfg<SimCfg8Q128>(qop, eop, D2, n_t, p.stride, epi, stream);
+    else if (p.bm == 256)
+      st = launch_scan_cfg<SimCfgQ256>(qop, eop, D2, n_t, p.stride, epi, stream);
+    else
+      st = (D2 % 64 == 0) ? launch_scan_cfg<SimCfgQ128>(qop, eop, D2, n_t, p.stride, epi, stream)
+                          : launch_scan_cfg<SimCfgQ128K32>(qop, eop, D2, n_t, p.stride, epi, stream);
+  }
+  if (st) return st;
   SelectArgs sb;
   sb.keys = cand;
-  sb.ld = cap;
+  sb.ld = p.cap;
   sb.counts = count;
   sb.count_stride = SIM_COUNT_STRIDE;
   sb.n_fixed = 0;
-  sb.cap = cap;
+  sb.cap = (int)p.cap;
   sb.k = k;
   sb.out_keys = nullptr;
   sb.out_ld = 0;
   sb.out_cnt = nullptr;
   sb.out_thr = nullptr;
+  sb.out_tau = nullptr;
   sb.out_scores = out_scores;
   sb.out_ids = out_ids;
   sb.out_count = out_count;

@@ -51,6 +51,22 @@ struct ProfScope {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: every launcher keeps one
+// flag per device ordinal (static, per template instantiation) and sets the attribute on first use there.
+constexpr int RP_MAX_DEVICES = 64;
+struct LdsAttrOnce {
+  bool done[RP_MAX_DEVICES] = {};
+  hipError_t ensure(const void* kern, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < RP_MAX_DEVICES && done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0 && dev < RP_MAX_DEVICES) done[dev] = true;
+    return e;
+  }
+};
+
 // ---- device types ----------------------------------------------------------------------------
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA A/B operand: 8 bf16 = 4 VGPRs

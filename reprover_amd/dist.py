@@ -93,16 +93,25 @@ def hip_local_topk(shard: IndexShard, batch_context: Sequence[Context], query_em
     out_s = torch.empty((B, k), dtype=torch.float32, device=dev)
     out_i = torch.empty((B, k), dtype=torch.int32, device=dev)
     out_c = torch.empty((B,), dtype=torch.int32, device=dev)
-    nbytes = lib.rp_sim_topk_workspace_bytes(B, len(shard), D, k, 0)
-    ws = _workspace(dev, nbytes)
-    _lib.check(
-        lib.rp_sim_topk(
-            _lib.ptr(Q), _lib.ptr(E), B, len(shard), D, _lib.ptr(shard.file_of), _lib.ptr(shard.end_key),
-            _lib.ptr(d_bits), shard.corpus.num_files, _lib.ptr(d_own), _lib.ptr(d_qk), shard.lo, k, 0,
-            _lib.ptr(out_s), _lib.ptr(out_i), _lib.ptr(out_c), _lib.ptr(ws), nbytes, _lib.current_stream(),
-        ),
-        "rp_sim_topk",
-    )
+    def scan(flags: int) -> None:
+        nbytes = lib.rp_sim_topk_workspace_bytes(B, len(shard), D, k, flags)
+        ws = _workspace(dev, nbytes)
+        _lib.check(
+            lib.rp_sim_topk(
+                _lib.ptr(Q), _lib.ptr(E), B, len(shard), D, _lib.ptr(shard.file_of), _lib.ptr(shard.end_key),
+                _lib.ptr(d_bits), shard.corpus.num_files, _lib.ptr(d_own), _lib.ptr(d_qk), shard.lo, k, flags,
+                _lib.ptr(out_s), _lib.ptr(out_i), _lib.ptr(out_c), _lib.ptr(ws), nbytes, _lib.current_stream(),
+            ),
+            "rp_sim_topk",
+        )
+
+    scan(_lib.RP_TOPK_AUTO)
+    # The C ABI reserves out_count = -1 for "candidate list overflow: call again with RP_TOPK_DENSE"
+    # (include/reprover_hip.h).  The current engine sizes the list so that it cannot overflow, but the contract is
+    # honoured here as in Corpus.get_nearest_premises: a rank whose list overflowed must not drop out of the
+    # merge (merge_keys treats a negative count as "no candidates").
+    if bool((out_c < 0).any()):
+        scan(_lib.RP_TOPK_DENSE)
     return out_i, out_s, out_c
 
 

@@ -56,7 +56,7 @@ class PremiseRetriever:
         assert index_dtype in ("bf16", "fp8")
         self.index_dtype = index_dtype
         self._fp8_index: Optional[Fp8Index] = None
-        self._fp8_source: Optional[Tuple[int, int]] = None
+        self._fp8_source: Optional[torch.Tensor] = None  # the tensor object the e4m3 copy was derived from
         # Multi-GPU predict (BASELINE.json configs[2]; the reference replicates the whole index per rank):
         # when set, ``on_predict_start`` encodes only this rank's row shard and ``predict_step`` merges the
         # per-rank top-k lists through one all-gather (reprover_amd/dist.py).  Set by retrieval/main.py
@@ -92,6 +92,7 @@ class PremiseRetriever:
         """Associate the retriever with a corpus: a ``Corpus``, a ``corpus.jsonl`` (embeddings
         stale), a pickled ``IndexedCorpus`` with pre-computed embeddings, or a native index
         directory written by ``common.save_index`` / ``index.py --output-path <dir>/``."""
+        self._drop_derived()
         if isinstance(path_or_corpus, Corpus):
             self.corpus = path_or_corpus
             self.corpus_embeddings = None
@@ -118,11 +119,21 @@ class PremiseRetriever:
         ``corpus_embeddings`` is replaced or written)."""
         if self.index_dtype != "fp8":
             return self.corpus_embeddings
-        tag = (self.corpus_embeddings.data_ptr(), self.corpus_embeddings._version)
-        if self._fp8_index is None or self._fp8_source != tag:
+        # Keyed on the tensor OBJECT (a strong reference, so its storage cannot be recycled under the tag) and
+        # dropped explicitly wherever the matrix is rewritten in place through raw pointers (_drop_derived):
+        # data_ptr()/_version would both survive an allocator-recycled block filled by rp_encode_varlen.
+        if self._fp8_index is None or self._fp8_source is not self.corpus_embeddings:
             self._fp8_index = Fp8Index.quantize(self.corpus_embeddings, self.device)
-            self._fp8_source = tag
+            self._fp8_source = self.corpus_embeddings
         return self._fp8_index
+
+    def _drop_derived(self) -> None:
+        """Forget every copy derived from ``corpus_embeddings`` (e4m3 index, cached bf16 cast)."""
+        from ..common import drop_cast_cache
+
+        self._fp8_index = None
+        self._fp8_source = None
+        drop_cast_cache()
 
     @property
     def embedding_size(self) -> int:
@@ -151,6 +162,7 @@ class PremiseRetriever:
         if not self.embeddings_staled:
             return
         N = len(self.corpus.all_premises)
+        self._drop_derived()
         self.corpus_embeddings = torch.zeros(N, self.embedding_size, dtype=self.encoder.dtype, device=self.device)
         step = max(int(batch_size), 4096)
         for i in range(0, N, step):
@@ -161,6 +173,7 @@ class PremiseRetriever:
     # -- prediction (model.py:274-336) --------------------------------------------------------------
     def on_predict_start(self, corpus: Corpus, eval_batch_size: int) -> None:
         self.corpus = corpus
+        self._drop_derived()
         self.corpus_embeddings = None
         self.embeddings_staled = True
         self.predict_step_outputs = []
@@ -225,6 +238,7 @@ class PremiseRetriever:
         context_emb = self.encode_texts([ctx.serialize()])
         if self.corpus_embeddings.device != context_emb.device or self.corpus_embeddings.dtype != torch.bfloat16:
             # a pickled index arrives as fp32 on the CPU (index.py:37-40): move + cast once
+            self._drop_derived()
             self.corpus_embeddings = self.corpus_embeddings.to(device=context_emb.device, dtype=torch.bfloat16)
         retrieved_premises, scores = self.corpus.get_nearest_premises(self._search_operand(), [ctx], context_emb, k)
         assert len(retrieved_premises) == len(scores) == 1

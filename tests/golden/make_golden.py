@@ -2,7 +2,7 @@
 /root/reference through tests/golden/ref_harness.py) and HuggingFace transformers on CPU.
 
 Authoring container only.  Only the resulting small data files are committed; no reference
-source travels.  Usage:  python tests/golden/make_golden.py [g1 g2 g3 g4 g5 g6 g7]   (default: all)
+source travels.  Usage:  python tests/golden/make_golden.py [g1 .. g9]   (default: all)
 
 Every fixture records the inputs and the reference's outputs; while generating, the oracle
 (oracle/) is checked against the reference so a drifting restatement fails here first.
@@ -394,7 +394,7 @@ def g7_predict():
                "hf_bf16_min_embedding_cosine": float(cos_hf.min())},
               open(os.path.join(OUT, "g7_predict.json"), "w"), ensure_ascii=False)
     np.savez_compressed(os.path.join(OUT, "g7_predict.npz"), E_probe=(E @ torch.from_numpy(probe)).numpy(),
-                        probe_seed=np.int64(73), E_head=E[:16].numpy())
+                        probe_seed=np.int64(73), E_head=E[:16].numpy(), E_all_f16=E.numpy().astype(np.float16))
     print("g7 ok")
 
 
@@ -459,9 +459,40 @@ def g8_eval_data():
           f"R@1 {R1:.3f} R@10 {R10:.3f} MRR {MRR:.4f}")
 
 
+# ----------------------------------------------------------------------------------------------
+def g9_base_full_depth():
+    """BASELINE configs[4]'s encoder at FULL depth: ByT5-base geometry (d_model 1536, 12 heads, d_ff 3968,
+    18 layers) through the reference's tokenise -> _encode with HuggingFace fp32, plus HF-bf16 (the
+    reference's GPU numerics) for the tolerance envelope.  8 short texts keep the fp32 CPU run short."""
+    cfg = synth.t5_config("byt5-base")
+    t0 = time.time()
+    sd = synth.synth_state_dict(cfg)
+    print(f"g9: weights generated in {time.time() - t0:.1f}s")
+    model = H.offline_retriever(rm, hf_cfg(cfg), sd, max_seq_len=1024)
+    assert model.encoder.config.num_layers == 18
+    rng = np.random.default_rng(9)
+    lens = [6, 23, 64, 97, 129, 200, 333, 520]
+    texts = _texts_with_lengths(rng, lens)
+    texts[2] = "n m : ℕ\nh : n ≤ m\n⊢ n + 0 ≤ m" + synth.synth_text(rng, 30)
+    t0 = time.time()
+    emb = _ref_encode(model, texts, 1024, 4)
+    print(f"g9: HF fp32 encode of {sum(lens)} tokens in {time.time() - t0:.1f}s")
+    o_emb = t5_ref.encode_texts(cfg, sd, texts, 1024, 4)
+    de = (emb - o_emb).abs().max().item()
+    print(f"g9: oracle vs HF max|Δemb| = {de:.2e}")
+    assert de < 5e-5
+    model_bf = model.to(torch.bfloat16)
+    emb_bf = _ref_encode(model_bf, texts, 1024, 4).float()
+    print(f"g9: HF bf16 vs fp32 max|Δemb| = {(emb_bf - emb).abs().max().item():.2e}; "
+          f"min cos = {torch.nn.functional.cosine_similarity(emb_bf, emb).min().item():.5f}")
+    np.savez_compressed(os.path.join(OUT, "g9_byt5_base.npz"), texts=np.array(texts, dtype=object), emb=emb.numpy(),
+                        emb_hf_bf16=emb_bf.numpy().astype(np.float16), seed=np.int64(synth.SEED))
+    print("g9 ok")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     torch.manual_seed(0)
     for name in which:
         {"g1": g1_tokenizer, "g2": g2_serialize, "g3": g3_buckets, "g4": g4_tiny, "g5": g5_small,
-         "g6": g6_nearest, "g7": g7_predict, "g8": g8_eval_data}[name]()
+         "g6": g6_nearest, "g7": g7_predict, "g8": g8_eval_data, "g9": g9_base_full_depth}[name]()

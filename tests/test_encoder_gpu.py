@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from oracle import t5_ref
+from reprover_amd import synth
 from reprover_amd.retrieval.model import PremiseRetriever
 
 pytestmark = pytest.mark.gpu
@@ -88,6 +89,27 @@ def test_byt5_small_matches_hf_golden(small, golden_dir):
     assert err <= err_hf, "further from the fp32 oracle than the reference's own bf16 mode"
     # retrieval scores of these rows against each other: within 1e-2 absolute of the oracle's
     assert ((emb @ emb.T) - (gold @ gold.T)).abs().max().item() < 1e-2
+
+
+def test_byt5_base_full_depth_matches_hf_golden(golden_dir):
+    """BASELINE configs[4]'s encoder at its FULL depth (18 layers, d_model 1536, 12 heads, d_ff 3968) against
+    the reference + HuggingFace fp32 fixture G9, with the G5 rule: no row further from fp32 than HF-bf16."""
+    g = np.load(os.path.join(golden_dir, "g9_byt5_base.npz"), allow_pickle=True)
+    cfg = synth.t5_config("byt5-base")
+    assert cfg["num_layers"] == 18
+    model = PremiseRetriever.from_state_dict(cfg, synth.synth_state_dict(cfg), 1024, "cuda:0", dtype=torch.float32)
+    texts = list(g["texts"])
+    gold = torch.from_numpy(g["emb"])
+    hf_bf16 = torch.from_numpy(g["emb_hf_bf16"].astype(np.float32))
+    emb = model.encode_texts(texts).cpu()
+    cos, cos_hf = _cos(emb, gold), _cos(hf_bf16, gold)
+    err, err_hf = (emb - gold).abs().max().item(), (hf_bf16 - gold).abs().max().item()
+    print(f"byt5-base x18: ours min cos {cos.min().item():.6f} max|Δ| {err:.3e};  HF-bf16 min cos "
+          f"{cos_hf.min().item():.6f} max|Δ| {err_hf:.3e}")
+    assert cos.min().item() >= max(0.995, cos_hf.min().item())
+    assert (cos >= cos_hf - 1e-4).all(), "a row is further from the oracle than HF-bf16 is"
+    assert err <= err_hf, "further from the fp32 oracle than the reference's own bf16 mode"
+    assert ((emb @ emb.T) - (gold @ gold.T)).abs().max().item() < max(1e-2, ((hf_bf16 @ hf_bf16.T) - (gold @ gold.T)).abs().max().item())
 
 
 def test_bf16_output_and_chunked_passes_agree(small, golden_dir):

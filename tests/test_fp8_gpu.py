@@ -158,7 +158,10 @@ def test_host_fp8_index_search_and_value_error():
     want_i, want_s = common_ref.masked_topk(S, acc, k)
     got_i = np.array([[corpus.all_premises.index(p) for p in row] for row in prem])
     assert np.abs(np.array(scores) - want_s).max() < 1e-5  # D = 192: fp32 accumulation of a few large products
-    assert (got_i == want_i).mean() > 0.95  # rank swaps only between scores closer than the tolerance
+    # ids must agree wherever the oracle's score is separated from both neighbours by more than 2 x the score
+    # tolerance (the rule of every other id comparison; swaps are only possible between closer scores)
+    checked, bad = hh.gap_rule_ids(got_i.tolist(), want_i.tolist(), want_s.tolist(), tol=1e-5)
+    assert checked > 0.8 * want_i.size and bad == 0, (checked, bad)
     assert np.allclose(idx.dequantize().cpu().numpy(), fp8_ref.decode_e4m3(idx.codes.cpu().numpy()) * idx.scale.cpu().numpy()[:, None])
     first = Context(files[0], "T", Pos(0, 0), "⊢ s")  # nothing before it, nothing imported
     with pytest.raises(ValueError):

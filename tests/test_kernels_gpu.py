@@ -199,6 +199,77 @@ def test_sim_topk_exact_ties_and_order(gen):
         assert (cnt == k).all()
 
 
+def test_sim_topk_sample_gives_no_bound(gen):
+    """The adversarial case for the two-pass plan: every SAMPLED block (rows [256 j stride, +256)) is
+    inaccessible, so the sample yields no bound (thr = 0) and every accessible score of the other blocks is a
+    candidate - tens of thousands per query instead of ~k*stride.  The first-generation engine reported this as
+    out_count = -1 (list overflow, capacity 8192 + k); the list is now sized so that it cannot overflow, the
+    filter kernel drains its per-wave survivor list several times per tile, and the answer must stay exact."""
+    rng = np.random.default_rng(31)
+    B, N, D, k = 9, 70000, 128, 50
+    E, Q = _rand_bf16(gen, N, D), _rand_bf16(gen, B, D)
+    stride = 2
+    while stride * 2 <= 64 and (stride * 2) ** 2 * k * 4 <= N:  # plan_sim's sampling stride (rp_retrieval.hip)
+        stride *= 2
+    rows = np.arange(N)
+    sampled = (rows // 256) % stride == 0
+    # one file per 256-row block; queries import every block except the sampled ones (and own none)
+    file_of = (rows // 256).astype(np.int32)
+    F = int(file_of.max()) + 1
+    end_key = np.zeros(N, dtype=np.int64)
+    own = np.full(B, F, dtype=np.int32)  # a file index no premise has
+    qk = np.zeros(B, dtype=np.int64)
+    imp = np.ones((B, F + 1), dtype=bool)
+    imp[:, np.arange(0, F, stride)] = False
+    imp[:, F] = False
+    imp[3, :] = False          # one query with nothing accessible at all
+    imp[4, 5:] = False         # one with a handful of blocks only
+    words = (B + 31) // 32
+    padded = np.zeros((F + 1, words * 32), dtype=np.uint8)
+    padded[:, :B] = imp.T
+    bits_t = np.packbits(padded, axis=1, bitorder="little").view(np.uint32).reshape(F + 1, words)
+    acc = imp[:, file_of]
+    assert not acc[:, sampled].any() and acc[0].sum() > 8192 + k
+    S = _scores(Q, E)
+    dm = hh.masks_to_device((file_of, end_key, bits_t, own, qk), Q.device)
+    ids, sc, cnt = hh.sim_topk(Q, E, k, dm)
+    assert (cnt.cpu().numpy() >= 0).all(), "candidate-list overflow must not happen any more"
+    hh.check_topk_against_scores(ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy(), S, acc, k, tol=1e-4)
+    ids2, sc2, cnt2 = hh.sim_topk(Q, E, k, dm, flags=_lib.RP_TOPK_DENSE)
+    assert torch.equal(ids, ids2) and torch.equal(sc, sc2) and torch.equal(cnt, cnt2)
+    # the sharded form of the same search (dist.hip_local_topk per rank + rp_topk_merge): a shard whose
+    # sample gives no bound must still contribute its candidates to the merge
+    f, ek, bt, own_d, qk_d = dm
+    cut = 256 * stride * 8  # shard boundary on a sampled block, so shard 1 is adversarial too
+    parts = [hh.sim_topk(Q, E[lo:hi].contiguous(), k, (f[lo:hi].contiguous(), ek[lo:hi].contiguous(), bt, own_d, qk_d),
+                         id_offset=lo) for lo, hi in ((0, cut), (cut, N))]
+    assert all((p[2].cpu().numpy() >= 0).all() for p in parts)
+    mi, ms, mc = hh.topk_merge(torch.stack([p[1] for p in parts]), torch.stack([p[0] for p in parts]),
+                               torch.stack([p[2] for p in parts]))
+    assert torch.equal(mi, ids) and torch.equal(ms, sc) and torch.equal(mc, cnt)
+
+
+@pytest.mark.parametrize("B,N,D,k", [(256, 50000, 1472, 100), (300, 33000, 64, 10), (1, 40000, 192, 100)])
+def test_sim_topk_filter_generations_agree(gen, B, N, D, k):
+    """scan_impl = 1 (first-generation filter kernel: queries as MFMA rows, per-score slow path) and the default
+    (pipelined 256 x 256 tile, premises as MFMA rows, compacted survivors) must return identical tensors."""
+    rng = np.random.default_rng(B + N)
+    E, Q = _rand_bf16(gen, N, D, scale=D ** -0.5), _rand_bf16(gen, B, D, scale=D ** -0.5)
+    m, acc = hh.synth_masks(rng, N, B, F=max(2, N // 40))
+    dm = hh.masks_to_device(m, Q.device)
+    lib = _lib.load()
+    a = hh.sim_topk(Q, E, k, dm, id_offset=1000)
+    _lib.check(lib.rp_set_option(b"scan_impl", 1), "opt")
+    try:
+        b = hh.sim_topk(Q, E, k, dm, id_offset=1000)
+    finally:
+        _lib.check(lib.rp_set_option(b"scan_impl", 0), "opt")
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    hh.check_topk_against_scores(a[0].cpu().numpy() - 1000, a[1].cpu().numpy(), a[2].cpu().numpy(), _scores(Q, E), acc, k,
+                                 tol=1e-4)
+
+
 def test_sim_topk_fewer_than_k_accessible(gen):
     rng = np.random.default_rng(9)
     B, N, D, k = 8, 20000, 64, 100

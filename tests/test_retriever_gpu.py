@@ -83,10 +83,15 @@ def test_g7_reindex_corpus(g7):
     # HuggingFace's own bf16 mode (the reference's GPU numerics) reaches only this cosine with its
     # fp32 self on these sharp synthetic weights; the engine must be at least that close.
     assert cos.min().item() >= max(0.997, g["hf_bf16_min_embedding_cosine"])
-    probe = torch.from_numpy(np.random.default_rng(int(z["probe_seed"])).standard_normal((1472, 4)).astype(np.float32))
-    err = (Ef @ probe - torch.from_numpy(z["E_probe"])).abs().max().item()
-    print(f"g7: max|E·probe - golden| = {err:.3e} (|probe column| ~ {probe.norm(dim=0).mean().item():.1f})")
-    assert err < 0.25  # = 1e-2-scale embedding error times |probe| ~ 38, a loose all-rows checksum
+    # every row against the reference's fp32 matrix (stored as fp16: 5e-4 relative, far below the bar)
+    gold = torch.from_numpy(z["E_all_f16"].astype(np.float32))
+    cos_all = torch.nn.functional.cosine_similarity(Ef, gold, dim=1)
+    err_all = (Ef - gold).abs().max().item()
+    print(f"g7: all {g['N']} rows: min cosine {cos_all.min().item():.5f} (HF-bf16: {g['hf_bf16_min_embedding_cosine']:.5f}), "
+          f"mean {cos_all.mean().item():.6f}, max|Δ| {err_all:.3e}")
+    assert cos_all.min().item() >= g["hf_bf16_min_embedding_cosine"]  # no row further from fp32 than HF-bf16's worst
+    assert cos_all.mean().item() >= 0.999
+    assert err_all <= 2e-2
 
 
 def test_g7_predict_and_retrieve(g7):
