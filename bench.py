@@ -302,7 +302,7 @@ def main():
     wi_ms, wi_n = prof["gemm_wi"]
     wi_flops = 2.0 * Tp * D * 2 * F_
     wi_tf = wi_flops * wi_n / (wi_ms * 1e-3) / 1e12 if wi_ms > 0 else 0.0
-    scan_ms, scan_n = prof["scan"]
+    scan_ms, scan_n = prof["scan"][0] + prof["scan_sample"][0], prof["scan"][1] + prof["scan_sample"][1]
     n_loc = hi - lo
     scan_bytes = n_loc * D * 2 + n_loc * 12 + BQ * D * 2 + BQ * 12 + BQ * TOP_K * 8
     scan_gbs = scan_bytes * args.steps / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0

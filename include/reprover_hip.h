@@ -142,7 +142,10 @@ size_t   rp_sim_topk_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t k,
  *                entries past out_count[j] are -inf / -1)
  *   out_count    device int32 [B]: min(k, #accessible premises on this rank); the caller maps
  *                a global count < k to the reference's ValueError (common.py:323-324).
- *                -1 = internal candidate overflow: call again with RP_TOPK_DENSE.          */
+ *                -1 is reserved for "internal candidate overflow: call again with RP_TOPK_DENSE"; the
+ *                current engine sizes its candidate list (N + k keys per query, part of the
+ *                workspace) so that it cannot overflow, callers still honour the contract.
+ *   k <= 1024 (the final selection sorts in LDS); the reference accepts any k.              */
 RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t N, int32_t D,
                      const int32_t* file_of, const int64_t* end_key,
                      const uint32_t* file_bits_t, int32_t F,
@@ -187,7 +190,8 @@ RpStatus rp_topk_merge(const float* scores, const int32_t* ids, const int32_t* c
  * ------------------------------------------------------------------------------------------- */
 enum {
   RP_K_EMBED = 0, RP_K_RMSNORM = 1, RP_K_GEMM_QKV = 2, RP_K_ATTENTION = 3, RP_K_GEMM_O = 4,
-  RP_K_GEMM_WI = 5, RP_K_GEMM_WO = 6, RP_K_POOL = 7, RP_K_SCAN = 8, RP_K_SELECT = 9, RP_K_COUNT = 10
+  RP_K_GEMM_WI = 5, RP_K_GEMM_WO = 6, RP_K_POOL = 7, RP_K_SCAN = 8 /* dense / filter pass */, RP_K_SELECT = 9,
+  RP_K_SCAN_SAMPLE = 10 /* sample pass of the two-pass plan */, RP_K_COUNT = 11
 };
 RpStatus rp_profile_enable(int32_t on);   /* on != 0: start collecting (clears previous records) */
 /* Synchronises the recorded events; total_ms = sum of launch durations, launches = their number. */

@@ -20,7 +20,7 @@ RP_TOPK_AUTO, RP_TOPK_DENSE = 0, 1
 RP_EPI_STORE_BF16, RP_EPI_RESID_F32, RP_EPI_GEGLU_BF16 = 0, 1, 2
 ABI_VERSION = 1
 KERNEL_CLASSES = ["embed", "rmsnorm", "gemm_qkv", "attention", "gemm_o", "gemm_wi", "gemm_wo", "pool", "scan",
-                  "select"]
+                  "select", "scan_sample"]
 
 
 class RpT5Config(C.Structure):

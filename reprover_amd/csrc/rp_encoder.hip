@@ -41,8 +41,10 @@ static int g_gemm_variant_o = 0;     // attention output (+ residual)
 static int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 static int g_gemm_skinny = 1;
 static int g_gemm_skinny_variant = 12;
-static int g_tokens_valid = 0;  // real token count of the pass being launched (0: all rows); lets the
-                                // small-token configurations skip tiles that hold only padding rows   // use the small-token-count GEMM configuration automatically
+// Experiment knob: spread the first round of workgroups of the big GEMMs over this many microseconds (0 = off).
+// All 256 CUs otherwise reach their epilogues at the same moment, round after round (tiles take equal time), and
+// the epilogue traffic arrives in bursts.  Indexed by kernel class (RP_K_GEMM_*).
+static int g_gemm_stagger_us[RP_K_COUNT] = {};
 
 // ------------------------------------------------------------------------------------------
 // per-kernel event timing
@@ -424,8 +426,15 @@ struct EpiGegluBf16 {  // W rows interleaved 32 gate / 32 up: even row-fragments
 
 template <class C, class Epi>
 __global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOperand W, int K, int tiles_m,
-                                                          int tiles_n, int group_m, Epi epi) {
+                                                          int tiles_n, int group_m, int stagger_ticks, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (stagger_ticks > 0 && blockIdx.x < 256) {
+    // first round only (later workgroups inherit their CU's phase): phase = position among the 256 CUs, uniform
+    // inside every XCD (workgroup b runs on XCD b % 8)
+    const unsigned phase = ((blockIdx.x >> 3) & 31u) * 8u + (blockIdx.x & 7u);
+    const unsigned long long until = wall_clock64() + (unsigned long long)stagger_ticks * phase / 256u;  // 100 MHz
+    while (wall_clock64() < until) __builtin_amdgcn_s_sleep(16);
+  }
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   int tm, tn;
   tile_coords(logical, tiles_n, tiles_m, group_m, tn, tm);  // token tiles grouped, feature tiles inside
@@ -439,22 +448,20 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOpe
 // `a` = activations [M, K] (column operand: tile cols = tokens, M a multiple of the token tile).
 template <class C, class Epi>
 static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hipStream_t stream,
-                                int prof_class) {
+                                int prof_class, int tokens_valid) {
   auto kern = gemm_kernel<C, Epi>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    RP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    attr_done = true;
-  }
+  static LdsAttrOnce attr;
+  RP_HIP(attr.ensure((const void*)kern, C::LDS_BYTES));
   RP_REQUIRE(K % C::BK == 0 && a.rows % C::BN == 0, "gemm: K=%d must be a multiple of %d, M=%d of %d", K, C::BK,
              a.rows, C::BN);
-  const int rows_needed = (g_tokens_valid > 0 && g_tokens_valid < a.rows) ? g_tokens_valid : a.rows;
+  const int rows_needed = (tokens_valid > 0 && tokens_valid < a.rows) ? tokens_valid : a.rows;
   const int tiles_f = (w.rows + C::BM - 1) / C::BM, tiles_t = (rows_needed + C::BN - 1) / C::BN;
   // tile order: feature tiles fastest inside groups of `group` token tiles (shared activation panels)
   const int group = max(1, g_gemm_group_m * 128 / C::BN);
   ProfScope ps(stream, prof_class);
+  const int stagger_ticks = (C::PIPE != 0 && tiles_f * tiles_t > 512) ? g_gemm_stagger_us[prof_class] * 100 : 0;
   hipLaunchKernelGGL(kern, dim3(tiles_f * tiles_t), dim3(C::THREADS), C::LDS_BYTES, stream, w, a, K, tiles_f,
-                     tiles_t, group, epi);
+                     tiles_t, group, stagger_ticks, epi);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
@@ -463,8 +470,10 @@ static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hi
 constexpr int GEMM_M_ALIGN = 256;
 
 template <class Epi>
+// tokens_valid = real token count of the pass (0: all M rows): lets the small-token configurations skip tiles
+// that hold only padding rows
 static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, int ldw, int n_rows_w,
-                            int K, Epi epi, hipStream_t stream, int prof_class) {
+                            int K, Epi epi, hipStream_t stream, int prof_class, int tokens_valid = 0) {
   GemmOperand a{A, lda, M}, w{W, ldw, n_rows_w};
   int v = prof_class == RP_K_GEMM_O     ? g_gemm_variant_o
           : prof_class == RP_K_GEMM_WO  ? g_gemm_variant_wo
@@ -475,7 +484,7 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
   // most CUs idle and each workgroup latency-bound on its K loop.  Switch to 64-feature tiles with a
   // 7-deep LDS ring so every workgroup streams its weight slab with ~6 K-steps of DMA in flight.
   if (g_gemm_skinny && m256 && ((n_rows_w + 255) / 256) * (M / 256) < 96)
-    v = (g_tokens_valid > 0 && g_tokens_valid <= 128 && g_gemm_skinny_variant == 12) ? 15 : g_gemm_skinny_variant;
+    v = (tokens_valid > 0 && tokens_valid <= 128 && g_gemm_skinny_variant == 12) ? 15 : g_gemm_skinny_variant;
   if ((v == 20 || v == 26) && !k64) v = 9;  // 64-wide K tiles need K % 64 == 0
   if (v >= 5 && !m256) v = 0;
   // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages[, pipelined]>:
@@ -484,12 +493,12 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
   //   0        plain 128 x 128 x 32, 3 stages, 2 blocks/CU (attention-out; token counts not a multiple of 256)
   //   12 / 15  64 x 256 / 64 x 128 x 32, 7 stages         (few tokens: single-state queries)
   switch (v) {
-    case 20: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class);
-    case 26: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class);
-    case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class);
-    case 12: return launch_gemm_cfg<GemmCfg<64, 256, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class);
-    case 15: return launch_gemm_cfg<GemmCfg<64, 128, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class);
-    default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class);
+    case 20: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid);
+    case 26: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid);
+    case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid);
+    case 12: return launch_gemm_cfg<GemmCfg<64, 256, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid);
+    case 15: return launch_gemm_cfg<GemmCfg<64, 128, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid);
+    default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid);
   }
 }
 
@@ -919,6 +928,14 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     g_scan_cfg = value;
     return RP_OK;
   }
+  if (!strncmp(name, "gemm_stagger_us_", 16)) {  // gemm_stagger_us_{qkv,o,wi,wo}
+    const char* which = name + 16;
+    const int cls = !strcmp(which, "qkv") ? RP_K_GEMM_QKV : !strcmp(which, "o") ? RP_K_GEMM_O
+                    : !strcmp(which, "wi") ? RP_K_GEMM_WI : !strcmp(which, "wo") ? RP_K_GEMM_WO : -1;
+    RP_REQUIRE(cls >= 0 && value >= 0 && value <= 1000, "gemm_stagger_us: unknown GEMM or value out of range");
+    g_gemm_stagger_us[cls] = value;
+    return RP_OK;
+  }
   if (!strcmp(name, "scan_impl")) {
     RP_REQUIRE(value >= 0 && value <= 1, "scan_impl out of range");
     g_scan_impl = value;
@@ -1109,10 +1126,6 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
   RpStatus st;
 
   const int np = (D + 63) / 64;
-  g_tokens_valid = T;
-  struct ClearHint {
-    ~ClearHint() { g_tokens_valid = 0; }
-  } clear_hint;
   const RowScale rs{w.rs};
   auto launch_rowscale = [&]() {
     ProfScope ps(stream, RP_K_RMSNORM);
@@ -1131,7 +1144,7 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
     // attention sub-layer: qkv = rs * (xb Wqkv'^T)  ->  attention  ->  x += att Wo^T  (+ xb, ssp refreshed)
     launch_rowscale();
     if ((st = launch_gemm(w.xb, D, Tp, L.wqkv, D, 3 * inner, D, EpiStoreBf16{w.qkv, 3 * inner, 3 * inner, rs}, stream,
-                          RP_K_GEMM_QKV)))
+                          RP_K_GEMM_QKV, T)))
       return st;
     {
       ProfScope ps(stream, RP_K_ATTENTION);
@@ -1139,15 +1152,16 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
                          cu_seqlens, e->bias_tab, w.att, H, e->maxd, batch);
     }
     if ((st = launch_gemm(w.att, inner, Tp, L.wo, inner, D, inner, EpiResidF32{w.x, D, D, w.xb, w.ssp, np, Tp}, stream,
-                          RP_K_GEMM_O)))
+                          RP_K_GEMM_O, T)))
       return st;
     if (g_debug_skip_ffn) continue;
     launch_rowscale();
     // feed-forward sub-layer: ff = gelu(rs * g) * (rs * u)  ->  x += ff Wo2^T  (+ xb, ssp refreshed)
-    if ((st = launch_gemm(w.xb, D, Tp, L.wi, D, 2 * F, D, EpiGegluBf16{w.ff, F, 2 * F, rs}, stream, RP_K_GEMM_WI)))
+    if ((st = launch_gemm(w.xb, D, Tp, L.wi, D, 2 * F, D, EpiGegluBf16{w.ff, F, 2 * F, rs}, stream, RP_K_GEMM_WI,
+                          T)))
       return st;
     if ((st = launch_gemm(w.ff, F, Tp, L.wo2, F, D, F, EpiResidF32{w.x, D, D, w.xb, w.ssp, np, Tp}, stream,
-                          RP_K_GEMM_WO)))
+                          RP_K_GEMM_WO, T)))
       return st;
   }
   launch_rowscale();  // final RMSNorm statistic

@@ -598,7 +598,7 @@ static RpStatus launch_scan_cfg(GemmOperand q, GemmOperand e, int D2, int n_tile
   RP_HIP(attr.ensure((const void*)sim_scan_kernel<C>, C::LDS_BYTES));
   const int tiles_q = (epi.B + C::BM - 1) / C::BM;
   const int sub = (stride > 1 || epi.filter) ? SIM_PB / C::BN : 1;
-  ProfScope ps(stream, RP_K_SCAN);
+  ProfScope ps(stream, (stride > 1 && !epi.filter) ? RP_K_SCAN_SAMPLE : RP_K_SCAN);
   hipLaunchKernelGGL((sim_scan_kernel<C>), dim3(tiles_q * n_tiles), dim3(C::THREADS), C::LDS_BYTES, stream, q, e, D2,
                      tiles_q, stride, sub, epi);
   RP_CHECK_LAUNCH();

@@ -60,7 +60,7 @@ for name, fp8 in (("e4m3_index", True), ("bf16_index", False)):
     prof = _lib.profile_read(); _lib.profile_enable(False)
     Tp = (T + 255) // 256 * 256
     wi_ms, wi_n = prof["gemm_wi"]
-    scan_ms = prof["scan"][0] / args.steps
+    scan_ms = (prof["scan"][0] + prof["scan_sample"][0]) / args.steps
     res[name] = {"ms_per_step": dt * 1e3, "queries_per_s": B / dt, "counts_eq_k": bool((out_c == k).all()),
                  "scan_ms": scan_ms, "select_ms": prof["select"][0] / args.steps,
                  "scan_hbm_GBps": N * D * (1 if fp8 else 2) / (scan_ms * 1e-3) / 1e9,

@@ -10,6 +10,7 @@ lib = _lib.load()
 N, D, k = int(os.environ.get("N", 130000)), int(os.environ.get("D", 1472)), 100
 Bs = [int(b) for b in os.environ.get("BS", "256,128,1").split(",")]
 cfgs = [int(c) for c in os.environ.get("CFGS", "0").split(",")]
+impls = [int(c) for c in os.environ.get("IMPLS", "0,1").split(",")]  # scan_impl: 0 = pipelined filter kernel, 1 = first generation
 modes = [int(c) for c in os.environ.get("FP8", "0,1").split(",")]
 dev = torch.device("cuda")
 g = torch.Generator(device=dev); g.manual_seed(0)
@@ -26,8 +27,10 @@ for B in Bs:
     f, ek, bt, own, qk = hh.masks_to_device(m, dev)
     for fp8 in modes:
         for flags in (0, 1):
-            for cfg in cfgs:
+            for cfg in [(c, i) for c in cfgs for i in (impls if not flags else [0])]:
+                cfg, impl = cfg
                 _lib.check(lib.rp_set_option(b"scan_cfg", cfg), "opt")
+                _lib.check(lib.rp_set_option(b"scan_impl", impl), "opt")
                 out_s = torch.empty((B, k), dtype=torch.float32, device=dev); out_i = torch.empty((B, k), dtype=torch.int32, device=dev)
                 out_c = torch.empty((B,), dtype=torch.int32, device=dev)
                 nb = lib.rp_sim_topk_workspace_bytes(B, N, D, k, flags); ws = torch.empty(nb, dtype=torch.uint8, device=dev)
@@ -52,8 +55,8 @@ for B in Bs:
                 prof = _lib.profile_read(); _lib.profile_enable(False)
                 tot = e0.elapsed_time(e1) / it
                 byts = N * D * (1 if fp8 else 2) + N * (16 if fp8 else 12)
-                scan_s = prof['scan'][0] / it * 1e-3
-                print(f"B={B:4d} N={N} D={D} {'e4m3' if fp8 else 'bf16'} {'DENSE' if flags else 'AUTO '} scan_cfg={cfg}: total {tot*1e3:8.1f} us  "
-                      f"scan {scan_s*1e6:8.1f} us ({prof['scan'][1]//it} launches)  select {prof['select'][0]/it*1e3:7.1f} us   "
+                scan_s = (prof['scan'][0] + prof['scan_sample'][0]) / it * 1e-3
+                print(f"B={B:4d} N={N} D={D} {'e4m3' if fp8 else 'bf16'} {'DENSE' if flags else 'AUTO '} scan_cfg={cfg} impl={impl}: total {tot*1e3:8.1f} us  "
+                      f"scan {scan_s*1e6:8.1f} us (sample {prof['scan_sample'][0]/it*1e3:6.1f} + rest {prof['scan'][0]/it*1e3:6.1f})  select {prof['select'][0]/it*1e3:7.1f} us   "
                       f"E-stream {byts/scan_s/1e9:7.1f} GB/s  MFMA {2.0*B*N*D/scan_s/1e12:6.1f} TFLOP/s  QPS {B/(tot*1e-3):10.0f}  "
                       f"cnt_ok {bool((out_c == k).all())}", flush=True)
