@@ -110,6 +110,22 @@ RpStatus rp_encode_varlen(RpEncoder* enc, const int32_t* ids, const int32_t* cu_
                           void* out, int32_t out_dtype,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* The reference's own call form: PremiseRetriever._encode(input_ids, attention_mask) (retrieval/model.py:92-114)
+ * on a right-padded batch as the tokenizer / datamodule.py:130-144 collate produce it.
+ *   input_ids       device int64 [batch, padded_len]
+ *   attention_mask  device int64 [batch, padded_len]   1 on real tokens, then 0
+ *   out             device [batch, d_model] of out_dtype, as rp_encode_varlen
+ *   meta            device int32 [4], written asynchronously: meta[0] = total real tokens, meta[1] = longest
+ *                   sequence, meta[2] != 0 when some row is NOT right-padded (ones after a zero) or is empty -
+ *                   `out` is then meaningless and the caller must raise (read it at its next synchronisation).
+ * Lengths, cu_seqlens and the packed ids are derived on the device (no host round trip, no torch kernels); the
+ * encoder pass is launched for the upper bound batch * padded_len tokens and skips, on the device, every tile
+ * beyond the real count.  Results are bit-identical to rp_encode_varlen on the packed form of the same batch. */
+size_t   rp_encode_padded_workspace_bytes(const RpEncoder* enc, int32_t batch, int32_t padded_len);
+RpStatus rp_encode_padded(RpEncoder* enc, const int64_t* input_ids, const int64_t* attention_mask,
+                          int32_t batch, int32_t padded_len, void* out, int32_t out_dtype, int32_t* meta,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* Host-only helper, exact restatement of T5Attention._relative_position_bucket (bidirectional)
  * — modeling_t5.py:216-262; exported so the bucket table can be checked without a GPU. */
 int32_t  rp_relative_position_bucket(int32_t relative_position, int32_t num_buckets,

@@ -66,6 +66,12 @@ SIGNATURES = {
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
          C.c_size_t, C.c_void_p],
     ),
+    "rp_encode_padded_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
+    "rp_encode_padded": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+         C.c_size_t, C.c_void_p],
+    ),
     "rp_relative_position_bucket": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "rp_sim_topk_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rp_sim_topk": (

@@ -26,7 +26,7 @@ thread_local std::string g_last_error;
 // ------------------------------------------------------------------------------------------
 // options
 // ------------------------------------------------------------------------------------------
-extern int g_scan_cfg, g_scan_impl;
+extern int g_scan_cfg, g_scan_impl, g_scan_filter_cfg, g_scan_sample_cfg, g_scan_stride, g_scan_no_epilogue;
 static int g_gemm_group_m = 8;
 // Tile configuration per encoder GEMM (see launch_gemm()), measured at 65536 tokens (tools/gemm_bench.py,
 // profiles/).  20 / 26 = the software-pipelined 256 x 256 x 64 tile with 4 / 8 waves: the same main
@@ -139,9 +139,13 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ 
                                                     const float* __restrict__ table,
                                                     float* __restrict__ x, bf16_t* __restrict__ xb,
                                                     float* __restrict__ ssp, int np, int T, int Tp, int D,
-                                                    int vocab) {
+                                                    int vocab, const int32_t* __restrict__ t_dev) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t_dev) {  // token count known on the device only (rp_encode_padded): T / Tp are upper bounds
+    T = *t_dev;
+    Tp = min(Tp, (T + 255) & ~255);
+  }
   if (row >= Tp) return;
   int id = (row < T) ? ids[row] : 0;
   id = min(max(id, 0), vocab - 1);
@@ -426,7 +430,8 @@ struct EpiGegluBf16 {  // W rows interleaved 32 gate / 32 up: even row-fragments
 
 template <class C, class Epi>
 __global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOperand W, int K, int tiles_m,
-                                                          int tiles_n, int group_m, int stagger_ticks, Epi epi) {
+                                                          int tiles_n, int group_m, int stagger_ticks,
+                                                          const int32_t* __restrict__ t_dev, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (stagger_ticks > 0 && blockIdx.x < 256) {
     // first round only (later workgroups inherit their CU's phase): phase = position among the 256 CUs, uniform
@@ -438,6 +443,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOpe
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   int tm, tn;
   tile_coords(logical, tiles_n, tiles_m, group_m, tn, tm);  // token tiles grouped, feature tiles inside
+  if (t_dev && tn * C::BN >= *t_dev) return;  // rp_encode_padded: the grid covers an upper bound of the token count
   if constexpr (C::PIPE != 0)
     gemm_tile_pipe<C>(A, W, K, tm, tn, epi, smem);
   else
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOpe
 // `a` = activations [M, K] (column operand: tile cols = tokens, M a multiple of the token tile).
 template <class C, class Epi>
 static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hipStream_t stream,
-                                int prof_class, int tokens_valid) {
+                                int prof_class, int tokens_valid, const int32_t* t_dev) {
   auto kern = gemm_kernel<C, Epi>;
   static LdsAttrOnce attr;
   RP_HIP(attr.ensure((const void*)kern, C::LDS_BYTES));
@@ -461,7 +467,7 @@ static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hi
   ProfScope ps(stream, prof_class);
   const int stagger_ticks = (C::PIPE != 0 && tiles_f * tiles_t > 512) ? g_gemm_stagger_us[prof_class] * 100 : 0;
   hipLaunchKernelGGL(kern, dim3(tiles_f * tiles_t), dim3(C::THREADS), C::LDS_BYTES, stream, w, a, K, tiles_f,
-                     tiles_t, group, stagger_ticks, epi);
+                     tiles_t, group, stagger_ticks, t_dev, epi);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
@@ -473,7 +479,8 @@ template <class Epi>
 // tokens_valid = real token count of the pass (0: all M rows): lets the small-token configurations skip tiles
 // that hold only padding rows
 static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, int ldw, int n_rows_w,
-                            int K, Epi epi, hipStream_t stream, int prof_class, int tokens_valid = 0) {
+                            int K, Epi epi, hipStream_t stream, int prof_class, int tokens_valid = 0,
+                            const int32_t* t_dev = nullptr) {
   GemmOperand a{A, lda, M}, w{W, ldw, n_rows_w};
   int v = prof_class == RP_K_GEMM_O     ? g_gemm_variant_o
           : prof_class == RP_K_GEMM_WO  ? g_gemm_variant_wo
@@ -493,12 +500,12 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
   //   0        plain 128 x 128 x 32, 3 stages, 2 blocks/CU (attention-out; token counts not a multiple of 256)
   //   12 / 15  64 x 256 / 64 x 128 x 32, 7 stages         (few tokens: single-state queries)
   switch (v) {
-    case 20: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid);
-    case 26: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid);
-    case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid);
-    case 12: return launch_gemm_cfg<GemmCfg<64, 256, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid);
-    case 15: return launch_gemm_cfg<GemmCfg<64, 128, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid);
-    default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid);
+    case 20: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
+    case 26: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
+    case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
+    case 12: return launch_gemm_cfg<GemmCfg<64, 256, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
+    case 15: return launch_gemm_cfg<GemmCfg<64, 128, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
+    default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
   }
 }
 
@@ -936,6 +943,10 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     g_gemm_stagger_us[cls] = value;
     return RP_OK;
   }
+  if (!strcmp(name, "scan_filter_cfg")) { g_scan_filter_cfg = value; return RP_OK; }
+  if (!strcmp(name, "scan_sample_cfg")) { g_scan_sample_cfg = value; return RP_OK; }
+  if (!strcmp(name, "scan_stride")) { g_scan_stride = value; return RP_OK; }
+  if (!strcmp(name, "scan_no_epilogue")) { g_scan_no_epilogue = value; return RP_OK; }
   if (!strcmp(name, "scan_impl")) {
     RP_REQUIRE(value >= 0 && value <= 1, "scan_impl out of range");
     g_scan_impl = value;
@@ -1109,20 +1120,14 @@ extern "C" size_t rp_encoder_workspace_bytes(const RpEncoder* enc, int32_t total
   return carve(enc, total_tokens, batch, nullptr).bytes;
 }
 
-extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int32_t* cu_seqlens, int32_t batch,
-                                     int32_t T, int32_t max_len, void* out, int32_t out_dtype, void* workspace,
-                                     size_t workspace_bytes, void* stream_) {
-  RP_REQUIRE(e && ids && cu_seqlens && out, "null argument");
-  RP_REQUIRE(batch > 0 && T > 0 && max_len > 0 && max_len <= T, "batch=%d total_tokens=%d max_len=%d", batch, T,
-             max_len);
-  RP_REQUIRE(out_dtype == RP_DT_F32 || out_dtype == RP_DT_BF16, "out_dtype");
-  hipStream_t stream = (hipStream_t)stream_;
-  Workspace w = carve(e, T, batch, (char*)workspace);
-  if (!workspace || workspace_bytes < w.bytes)
-    return fail(RP_E_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, w.bytes);
+// The launch sequence of one encoder pass.  T / batch size the grids; when t_dev is given (rp_encode_padded) the
+// real token count is known on the device only: T is then an upper bound, kernels skip the rows beyond *t_dev.
+static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_seqlens, int32_t batch, int32_t T,
+                            const int32_t* t_dev, void* out, int32_t out_dtype, const Workspace& w, hipStream_t stream) {
   const RpT5Config& c = e->cfg;
   const int D = c.d_model, F = c.d_ff, inner = e->inner, H = c.num_heads;
   const int Tp = (int)align_up((size_t)T, GEMM_M_ALIGN);
+  const int tv = t_dev ? 0 : T;  // host-side hint for the small-token tile configurations
   RpStatus st;
 
   const int np = (D + 63) / 64;
@@ -1135,7 +1140,7 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
   {
     ProfScope ps(stream, RP_K_EMBED);
     hipLaunchKernelGGL(embed_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.x, w.xb, w.ssp, np, T,
-                       Tp, D, c.vocab_size);
+                       Tp, D, c.vocab_size, t_dev);
   }
   RP_CHECK_LAUNCH();
   const dim3 att_grid(T / ATT_Q + batch, H);  // upper bound of the work ids (see attention_kernel)
@@ -1144,7 +1149,7 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
     // attention sub-layer: qkv = rs * (xb Wqkv'^T)  ->  attention  ->  x += att Wo^T  (+ xb, ssp refreshed)
     launch_rowscale();
     if ((st = launch_gemm(w.xb, D, Tp, L.wqkv, D, 3 * inner, D, EpiStoreBf16{w.qkv, 3 * inner, 3 * inner, rs}, stream,
-                          RP_K_GEMM_QKV, T)))
+                          RP_K_GEMM_QKV, tv, t_dev)))
       return st;
     {
       ProfScope ps(stream, RP_K_ATTENTION);
@@ -1152,16 +1157,16 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
                          cu_seqlens, e->bias_tab, w.att, H, e->maxd, batch);
     }
     if ((st = launch_gemm(w.att, inner, Tp, L.wo, inner, D, inner, EpiResidF32{w.x, D, D, w.xb, w.ssp, np, Tp}, stream,
-                          RP_K_GEMM_O, T)))
+                          RP_K_GEMM_O, tv, t_dev)))
       return st;
     if (g_debug_skip_ffn) continue;
     launch_rowscale();
     // feed-forward sub-layer: ff = gelu(rs * g) * (rs * u)  ->  x += ff Wo2^T  (+ xb, ssp refreshed)
-    if ((st = launch_gemm(w.xb, D, Tp, L.wi, D, 2 * F, D, EpiGegluBf16{w.ff, F, 2 * F, rs}, stream, RP_K_GEMM_WI,
-                          T)))
+    if ((st = launch_gemm(w.xb, D, Tp, L.wi, D, 2 * F, D, EpiGegluBf16{w.ff, F, 2 * F, rs}, stream, RP_K_GEMM_WI, tv,
+                          t_dev)))
       return st;
     if ((st = launch_gemm(w.ff, F, Tp, L.wo2, F, D, F, EpiResidF32{w.x, D, D, w.xb, w.ssp, np, Tp}, stream,
-                          RP_K_GEMM_WO, T)))
+                          RP_K_GEMM_WO, tv, t_dev)))
       return st;
   }
   launch_rowscale();  // final RMSNorm statistic
@@ -1174,6 +1179,151 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
   }
   RP_CHECK_LAUNCH();
   return RP_OK;
+}
+
+extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int32_t* cu_seqlens, int32_t batch,
+                                     int32_t T, int32_t max_len, void* out, int32_t out_dtype, void* workspace,
+                                     size_t workspace_bytes, void* stream_) {
+  RP_REQUIRE(e && ids && cu_seqlens && out, "null argument");
+  RP_REQUIRE(batch > 0 && T > 0 && max_len > 0 && max_len <= T, "batch=%d total_tokens=%d max_len=%d", batch, T,
+             max_len);
+  RP_REQUIRE(out_dtype == RP_DT_F32 || out_dtype == RP_DT_BF16, "out_dtype");
+  Workspace w = carve(e, T, batch, (char*)workspace);
+  if (!workspace || workspace_bytes < w.bytes)
+    return fail(RP_E_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, w.bytes);
+  return encode_pass(e, ids, cu_seqlens, batch, T, nullptr, out, out_dtype, w, (hipStream_t)stream_);
+}
+
+// ------------------------------------------------------------------------------------------
+// rp_encode_padded: the reference's call form, _encode(input_ids [B, L], attention_mask [B, L]) (model.py:92-114;
+// the batches come from datamodule.py:130-144, right-padded by the tokenizer).  Three small kernels turn the
+// padded batch into the packed form WITHOUT a host round trip: per-row lengths + right-padding check, an
+// exclusive scan to cu_seqlens, id compaction (int64 -> int32).  The encoder pass is then launched for the upper
+// bound B * L of the token count and skips, on the device, what lies beyond the real count.
+// ------------------------------------------------------------------------------------------
+namespace rp {
+// lens[b] = number of non-zero mask entries; the row is right-padded iff that equals (last non-zero index + 1)
+__global__ __launch_bounds__(256) void padded_lens_kernel(const int64_t* __restrict__ mask, int L,
+                                                          int32_t* __restrict__ lens, int32_t* __restrict__ meta) {
+  __shared__ int s_cnt[4], s_last[4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t* row = mask + (size_t)b * L;
+  int cnt = 0, last = 0;
+  for (int i = threadIdx.x; i < L; i += 256)
+    if (row[i] != 0) {
+      ++cnt;
+      last = i + 1;  // i increases along the loop: the thread's largest
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    cnt += __shfl_xor(cnt, o, 64);
+    last = max(last, __shfl_xor(last, o, 64));
+  }
+  if (lane == 0) {
+    s_cnt[wave] = cnt;
+    s_last[wave] = last;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    cnt = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
+    lens[b] = cnt;
+    if (cnt != last || cnt == 0) atomicOr(&meta[2], 1);  // not right-padded, or an empty sequence
+  }
+}
+
+// cu[0] = 0, cu[b + 1] = sum of lens[0..b]; meta[0] = total, meta[1] = longest.  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void padded_scan_kernel(const int32_t* __restrict__ lens, int B,
+                                                           int32_t* __restrict__ cu, int32_t* __restrict__ meta) {
+  __shared__ int s_part[1024];
+  const int tid = threadIdx.x;
+  const int per = (B + 1023) / 1024;
+  const int lo = min(tid * per, B), hi = min(lo + per, B);
+  int sum = 0, mx = 0;
+  for (int i = lo; i < hi; ++i) {
+    sum += lens[i];
+    mx = max(mx, lens[i]);
+  }
+  s_part[tid] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan of the per-thread sums
+    const int v = (tid >= o) ? s_part[tid - o] : 0;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  int run = s_part[tid] - sum;  // exclusive prefix of this thread's chunk
+  const int total = s_part[1023];
+  if (tid == 0) cu[0] = 0;
+  for (int i = lo; i < hi; ++i) {
+    run += lens[i];
+    cu[i + 1] = run;
+  }
+  __syncthreads();  // everyone has read its prefix and the total: s_part is reused for the maximum
+  s_part[tid] = mx;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) s_part[tid] = max(s_part[tid], s_part[tid + o]);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    meta[0] = total;
+    meta[1] = s_part[0];
+  }
+}
+
+__global__ __launch_bounds__(256) void padded_pack_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ cu,
+                                                          int L, int32_t* __restrict__ packed) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  const int s0 = cu[b], len = cu[b + 1] - s0;
+  if (i < len) packed[s0 + i] = (int32_t)ids[(size_t)b * L + i];
+}
+
+struct PaddedPrep {
+  int32_t *lens, *cu, *packed;
+  size_t bytes;
+};
+static PaddedPrep carve_padded(int B, int L, char* base) {
+  PaddedPrep p;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* q = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return q;
+  };
+  p.lens = (int32_t*)take((size_t)B * 4);
+  p.cu = (int32_t*)take((size_t)(B + 1) * 4);
+  p.packed = (int32_t*)take((size_t)B * L * 4);
+  p.bytes = off;
+  return p;
+}
+}  // namespace rp
+
+extern "C" size_t rp_encode_padded_workspace_bytes(const RpEncoder* enc, int32_t batch, int32_t padded_len) {
+  if (!enc || batch <= 0 || padded_len <= 0) return 0;
+  return carve_padded(batch, padded_len, nullptr).bytes + carve(enc, batch * padded_len, batch, nullptr).bytes;
+}
+
+extern "C" RpStatus rp_encode_padded(RpEncoder* e, const int64_t* input_ids, const int64_t* attention_mask,
+                                     int32_t batch, int32_t padded_len, void* out, int32_t out_dtype, int32_t* meta,
+                                     void* workspace, size_t workspace_bytes, void* stream_) {
+  RP_REQUIRE(e && input_ids && attention_mask && out && meta, "null argument");
+  RP_REQUIRE(batch > 0 && padded_len > 0 && (int64_t)batch * padded_len < (1ll << 30), "batch=%d padded_len=%d", batch,
+             padded_len);
+  RP_REQUIRE(out_dtype == RP_DT_F32 || out_dtype == RP_DT_BF16, "out_dtype");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int T_max = batch * padded_len;
+  PaddedPrep pp = carve_padded(batch, padded_len, (char*)workspace);
+  Workspace w = carve(e, T_max, batch, workspace ? (char*)workspace + pp.bytes : nullptr);
+  if (!workspace || workspace_bytes < pp.bytes + w.bytes)
+    return fail(RP_E_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, pp.bytes + w.bytes);
+  RP_HIP(hipMemsetAsync(meta, 0, 4 * sizeof(int32_t), stream));
+  hipLaunchKernelGGL(padded_lens_kernel, dim3(batch), dim3(256), 0, stream, attention_mask, padded_len, pp.lens, meta);
+  hipLaunchKernelGGL(padded_scan_kernel, dim3(1), dim3(1024), 0, stream, pp.lens, batch, pp.cu, meta);
+  hipLaunchKernelGGL(padded_pack_kernel, dim3((padded_len + 255) / 256, batch), dim3(256), 0, stream, input_ids, pp.cu,
+                     padded_len, pp.packed);
+  RP_CHECK_LAUNCH();
+  return encode_pass(e, pp.packed, pp.cu, batch, T_max, meta /* meta[0] = token count */, out, out_dtype, w, stream);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -43,10 +43,18 @@ typedef GemmCfg<128, 64, 32, 2, 2, 6, 0, 1> SimCfg8Sample;
 // fragment, so the per-query bound sits in 4 registers and the pre-test is one v_cmp per score (EpiSimFilter).
 typedef GemmCfg<256, 256, 64, 2, 2, 2, 1> SimCfgFilter;
 typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 1> SimCfg8Filter;
+// the same tile with 32-wide K slices in a 4-deep ring: three slices (48 KB of premises) in flight per CU instead of
+// one (32 KB) - the premise operand streams from HBM, not from L2 like an encoder GEMM's weights
+typedef GemmCfg<256, 256, 32, 2, 2, 4, 1> SimCfgFilterK32;
+typedef GemmCfg<128, 64, 64, 2, 2, 3> SimCfgSampleK64;
 constexpr int SIM_FILTER_META_BYTES = 12288;  // per-tile metadata behind the ring (EpiSimFilter::prologue)
 constexpr int SIM_FILTER_LIST_BYTES = 32768;  // per-wave survivor list (the ring, dead after the main loop)
 int g_scan_cfg = 0;   // 0: auto; 1: force 128-query tiles in the dense path
 int g_scan_impl = 0;  // 0: auto (pipelined filter kernel when the shape allows); 1: first-generation filter kernel
+int g_scan_filter_cfg = 0;   // experiments: 0 = 256x256x64 2-stage, 1 = 256x256x32 4-stage
+int g_scan_sample_cfg = 0;   // experiments: 0 = 128x64x32 6-stage, 1 = 128x64x64 3-stage
+int g_scan_stride = 0;       // experiments: > 0 overrides the sampling stride (power of two)
+int g_scan_no_epilogue = 0;  // timing only: the filter pass drops every score (main loop in isolation)
 
 __device__ __forceinline__ uint64_t make_key(float score, int32_t id) {
   return ((uint64_t)f2ord(score) << 32) | (uint32_t)(~(uint32_t)id);
@@ -232,6 +240,7 @@ struct EpiSimFilter {
   char* smem;
   int meta_off;  // byte offset of the metadata behind the ring
   int p0, q0;    // first premise / query of this workgroup's tile
+  int debug_drop_all;
 
   // metadata layout (bytes from meta_off)
   static constexpr int M_TAU = 0, M_OWN = 1024, M_THR = 2048, M_QK = 4096, M_FILE = 6144, M_EK = 7168, M_QS = 9216,
@@ -313,7 +322,7 @@ struct EpiSimFilter {
     float tauv[FN], qsv[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      tauv[j] = s_tau[ql0 + j * 32 + cl];
+      tauv[j] = debug_drop_all ? INFINITY : s_tau[ql0 + j * 32 + cl];
       qsv[j] = FP8 ? s_qs[ql0 + j * 32 + cl] : 1.f;
     }
     const uint32_t lane_code = ((uint32_t)(4 * hi) << 16) | (uint32_t)cl;
@@ -564,6 +573,7 @@ static SimPlan plan_sim(int B, int N, int D2, int k, int flags) {
   // filter pass pays an atomic append per candidate).
   int stride = 2;
   while (stride * 2 <= SIM_STRIDE_MAX && (int64_t)(stride * 2) * (stride * 2) * k * 4 <= N) stride *= 2;
+  if (g_scan_stride > 1) stride = g_scan_stride;
   p.stride = stride;
   // small problems take the single dense pass; a shard of <= 16k rows still goes two-pass when many
   // queries share it (the 8-GPU shape: 2048 queries x 16k rows would write and re-read 266 MB of keys)
@@ -717,6 +727,8 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   // pass 0: dense keys of the sampled blocks (4 sub-tiles of 64 rows each), k best of the sample -> bound
   const int n_sub = p.sample_blocks * (SIM_PB / SimCfgSample::BN);
   st = fp8 ? launch_scan_cfg<SimCfg8Sample>(qop, eop, D2, n_sub, p.stride, epi, stream)
+       : (g_scan_sample_cfg == 1 && D2 % 64 == 0)
+           ? launch_scan_cfg<SimCfgSampleK64>(qop, eop, D2, n_sub, p.stride, epi, stream)
            : launch_scan_cfg<SimCfgSample>(qop, eop, D2, n_sub, p.stride, epi, stream);
   if (st) return st;
   sa.out_keys = cand;
@@ -751,6 +763,7 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
       ef.smem = nullptr;
       ef.meta_off = 0;
       ef.p0 = ef.q0 = 0;
+      ef.debug_drop_all = g_scan_no_epilogue;
     };
     if (fp8) {
       EpiSimFilter<1> ef;
@@ -759,7 +772,8 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
     } else {
       EpiSimFilter<0> ef;
       fill(ef);
-      st = launch_filter_cfg<SimCfgFilter>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+      st = g_scan_filter_cfg == 1 ? launch_filter_cfg<SimCfgFilterK32>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
+                                  : launch_filter_cfg<SimCfgFilter>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
     }
   } else {
     epi.filter = 1;

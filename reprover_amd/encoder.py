@@ -88,6 +88,7 @@ class HipT5Encoder:
         self._handle = handle
         self._lib = lib
         self._ws: Optional[torch.Tensor] = None
+        self._pending_meta: list = []
 
     # -- construction helpers ---------------------------------------------------------------------
     @classmethod
@@ -173,23 +174,42 @@ class HipT5Encoder:
             b0 = b1
         return out
 
-    def encode_padded(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
-        """Drop-in for ``_encode(input_ids, attention_mask)`` with right-padded [B, L] inputs."""
-        input_ids = input_ids.to(self.device)
-        attention_mask = attention_mask.to(self.device)
-        m = attention_mask.bool()
-        if input_ids.shape[1] > 1 and bool((m[:, 1:] & ~m[:, :-1]).any()):
-            raise ValueError("attention_mask must be right-padded (1s then 0s), as the tokenizer produces")
-        lens = m.sum(dim=1)
-        if bool((lens == 0).any()):
-            raise ValueError("empty sequence in batch")
-        cu = torch.zeros(input_ids.shape[0] + 1, dtype=torch.int32, device=self.device)
-        cu[1:] = torch.cumsum(lens, 0)
-        ids = input_ids[m].to(torch.int32).contiguous()
-        lens_h = lens.cpu()
-        B, T = input_ids.shape[0], int(lens_h.sum())
+    def encode_padded(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, defer_check: bool = False
+                      ) -> torch.Tensor:
+        """Drop-in for ``_encode(input_ids, attention_mask)`` with right-padded [B, L] inputs: one
+        ``rp_encode_padded`` launch sequence — lengths, cu_seqlens, id compaction and the right-padding check all
+        happen on the device; no torch kernels, no host round trip.  The check's verdict arrives asynchronously:
+        by default it is read back here (one 16-byte copy) and ``ValueError`` is raised, as the packed path does,
+        for a mask that is not right-padded or an empty row; with ``defer_check=True`` the call is launch-only and
+        the caller runs ``raise_pending()`` at its next synchronisation point (``predict_step`` does)."""
+        B, L = input_ids.shape
+        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
+        assert mask.shape == (B, L)
+        if B * L > self.max_tokens_per_pass:  # rare (huge padded batches): chunk the batch dimension
+            step = max(1, self.max_tokens_per_pass // L)
+            return torch.cat([self.encode_padded(ids[i : i + step], mask[i : i + step], defer_check)
+                              for i in range(0, B, step)])
         out = torch.empty((B, self.cfg["d_model"]), dtype=self.dtype, device=self.device)
-        if T <= self.max_tokens_per_pass:
-            self.encode_packed_device(ids, cu, B, T, int(lens_h.max()), out)
-            return out
-        return self.encode_packed(ids.cpu().numpy(), cu.cpu().numpy(), out)
+        meta = torch.empty(4, dtype=torch.int32, device=self.device)
+        nbytes = self._lib.rp_encode_padded_workspace_bytes(self._handle, B, L)
+        ws = self._workspace(nbytes)
+        out_dt = _lib.RP_DT_BF16 if out.dtype == torch.bfloat16 else _lib.RP_DT_F32
+        with torch.cuda.device(self.device):
+            _lib.check(
+                self._lib.rp_encode_padded(self._handle, _lib.ptr(ids), _lib.ptr(mask), B, L, out.data_ptr(), out_dt,
+                                           _lib.ptr(meta), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
+                "rp_encode_padded",
+            )
+        self._pending_meta.append(meta)
+        if not defer_check:
+            self.raise_pending()
+        return out
+
+    def raise_pending(self) -> None:
+        """Read the verdicts of the ``encode_padded`` calls issued since the last check (synchronises)."""
+        metas, self._pending_meta = self._pending_meta, []
+        for m in metas:
+            if int(m.cpu()[2]) != 0:
+                raise ValueError("attention_mask must be right-padded (1s then 0s) with at least one token per row, "
+                                 "as the tokenizer produces")

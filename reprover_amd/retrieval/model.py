@@ -189,7 +189,9 @@ class PremiseRetriever:
         self.reindex_corpus(eval_batch_size)
 
     def predict_step(self, batch: Dict[str, Any], _=None) -> None:
-        context_emb = self._encode(batch["context_ids"], batch["context_mask"])
+        # launch-only encode (mask -> lengths -> packed ids on the device); its right-padding verdict is read at
+        # the synchronisation the search needs anyway
+        context_emb = self.encoder.encode_padded(batch["context_ids"], batch["context_mask"], defer_check=True)
         if self.index_shard is not None:  # every rank holds the batch; the index is row-sharded
             from ..dist import sharded_get_nearest_premises
 
@@ -201,6 +203,7 @@ class PremiseRetriever:
             retrieved_premises, scores = self.corpus.get_nearest_premises(
                 self._search_operand(), batch["context"], context_emb, self.num_retrieved
             )
+        self.encoder.raise_pending()
         for url, commit, file_path, full_name, start, tactic_idx, ctx, pos_premises, premises, s in zip_strict(
             batch["url"], batch["commit"], batch["file_path"], batch["full_name"], batch["start"],
             batch["tactic_idx"], batch["context"], batch["all_pos_premises"], retrieved_premises, scores,

@@ -11,6 +11,9 @@ N, D, k = int(os.environ.get("N", 130000)), int(os.environ.get("D", 1472)), 100
 Bs = [int(b) for b in os.environ.get("BS", "256,128,1").split(",")]
 cfgs = [int(c) for c in os.environ.get("CFGS", "0").split(",")]
 impls = [int(c) for c in os.environ.get("IMPLS", "0,1").split(",")]  # scan_impl: 0 = pipelined filter kernel, 1 = first generation
+# CASES="name=val,name=val|name=val|..." : extra rp_set_option settings, one timing line per case (reset to 0 afterwards)
+cases = [c for c in os.environ.get("CASES", "").split("|")] if os.environ.get("CASES") is not None else [""]
+dense_too = os.environ.get("DENSE", "1") == "1"
 modes = [int(c) for c in os.environ.get("FP8", "0,1").split(",")]
 dev = torch.device("cuda")
 g = torch.Generator(device=dev); g.manual_seed(0)
@@ -26,11 +29,13 @@ for B in Bs:
     m, acc = hh.synth_masks(rng, N, B, 5000)
     f, ek, bt, own, qk = hh.masks_to_device(m, dev)
     for fp8 in modes:
-        for flags in (0, 1):
-            for cfg in [(c, i) for c in cfgs for i in (impls if not flags else [0])]:
-                cfg, impl = cfg
+        for flags in ((0, 1) if dense_too else (0,)):
+            for cfg in [(c, i, cs) for c in cfgs for i in (impls if not flags else [0]) for cs in (cases if not flags else [""])]:
+                cfg, impl, case = cfg
                 _lib.check(lib.rp_set_option(b"scan_cfg", cfg), "opt")
                 _lib.check(lib.rp_set_option(b"scan_impl", impl), "opt")
+                for kv in filter(None, case.split(",")):
+                    _lib.check(lib.rp_set_option(kv.split("=")[0].encode(), int(kv.split("=")[1])), "opt")
                 out_s = torch.empty((B, k), dtype=torch.float32, device=dev); out_i = torch.empty((B, k), dtype=torch.int32, device=dev)
                 out_c = torch.empty((B,), dtype=torch.int32, device=dev)
                 nb = lib.rp_sim_topk_workspace_bytes(B, N, D, k, flags); ws = torch.empty(nb, dtype=torch.uint8, device=dev)
@@ -59,4 +64,6 @@ for B in Bs:
                 print(f"B={B:4d} N={N} D={D} {'e4m3' if fp8 else 'bf16'} {'DENSE' if flags else 'AUTO '} scan_cfg={cfg} impl={impl}: total {tot*1e3:8.1f} us  "
                       f"scan {scan_s*1e6:8.1f} us (sample {prof['scan_sample'][0]/it*1e3:6.1f} + rest {prof['scan'][0]/it*1e3:6.1f})  select {prof['select'][0]/it*1e3:7.1f} us   "
                       f"E-stream {byts/scan_s/1e9:7.1f} GB/s  MFMA {2.0*B*N*D/scan_s/1e12:6.1f} TFLOP/s  QPS {B/(tot*1e-3):10.0f}  "
-                      f"cnt_ok {bool((out_c == k).all())}", flush=True)
+                      f"cnt_ok {bool((out_c == k).all())}  [{case}]", flush=True)
+                for kv in filter(None, case.split(",")):
+                    _lib.check(lib.rp_set_option(kv.split("=")[0].encode(), 0), "opt")
