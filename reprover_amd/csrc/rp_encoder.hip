@@ -142,11 +142,12 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ 
                                                     int vocab, const int32_t* __restrict__ t_dev) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t_dev) {  // token count known on the device only (rp_encode_padded): T / Tp are upper bounds
+  int rows = Tp;  // Tp stays the leading dimension of the slot-major statistics
+  if (t_dev) {    // token count known on the device only (rp_encode_padded): T / Tp are upper bounds
     T = *t_dev;
-    Tp = min(Tp, (T + 255) & ~255);
+    rows = min(Tp, (T + 255) & ~255);
   }
-  if (row >= Tp) return;
+  if (row >= rows) return;
   int id = (row < T) ? ids[row] : 0;
   id = min(max(id, 0), vocab - 1);
   const float4* src = reinterpret_cast<const float4*>(table + (size_t)id * D);

@@ -87,10 +87,29 @@ struct GemmCfg {
 constexpr int EPI_ROW_BYTES = 144;
 constexpr int EPI_STAGE_BYTES = 64 * EPI_ROW_BYTES;  // 9216 B per wave
 
+// Row-major operand: [rows, ld], K-contiguous; tile rows beyond `rows` are clamped to rows-1.
+// Blocked operand (nkb > 0): the matrix is stored in panels of 256 rows x 64 two-byte units (128 B per row piece),
+//   element (r, c) at ((r / 256) * nkb + c / 64) * 16384 + (r % 256) * 64 + c % 64,    nkb = K / 64,
+// padded with zero rows to a whole number of panels (no clamping).  One K-slice of one 256-row block is then a
+// single contiguous 32 KB run in memory: a workgroup that streams its block from HBM reads sequentially instead of
+// touching 256 different DRAM rows per K-step (the index of the similarity scan is kept in this form).
+constexpr int PANEL_ROWS = 256, PANEL_K = 64, PANEL_ELEMS = PANEL_ROWS * PANEL_K;
 struct GemmOperand {
-  const bf16_t* ptr;  // [rows, ld] row-major, K-contiguous
-  int ld;             // elements
-  int rows;           // rows that may be read; tile rows beyond are clamped to rows-1
+  const bf16_t* ptr;
+  int ld;    // elements (row-major form)
+  int rows;  // rows that may be read
+  int nkb;   // 0: row-major; > 0: blocked form with nkb K-panels per row block
+  // offset of (row r, 8-element chunk kc of K-tile 0)
+  __device__ __forceinline__ size_t row_off(int r, int kc) const {
+    if (nkb == 0) return (size_t)min(r, rows - 1) * ld + kc * 8;
+    return (size_t)(r >> 8) * nkb * PANEL_ELEMS + (r & 255) * PANEL_K + kc * 8;
+  }
+  // additional offset of K-tile kt (BK elements wide, BK divides 64)
+  __device__ __forceinline__ size_t k_off(int kt, int BK) const {
+    if (nkb == 0) return (size_t)kt * BK;
+    const int c = kt * BK;
+    return (size_t)(c >> 6) * PANEL_ELEMS + (c & 63);
+  }
 };
 
 // An epilogue may declare `void prologue(char* extra_lds, int wave, int lane)`: gemm_tile_pipe calls it
@@ -138,13 +157,13 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
   for (int d = 0; d < C::A_DMA; ++d) {
     const int row = (wave * C::A_DMA + d) * C::ROWS_PER_DMA + lane / C::SLOTS;
     const int kc = (lane % C::SLOTS) ^ C::swz(row);
-    a_src[d] = A.ptr + (size_t)min(tile_m * C::BM + row, A.rows - 1) * A.ld + kc * 8;
+    a_src[d] = A.ptr + A.row_off(tile_m * C::BM + row, kc);
   }
 #pragma unroll
   for (int d = 0; d < C::W_DMA; ++d) {
     const int row = (wave * C::W_DMA + d) * C::ROWS_PER_DMA + lane / C::SLOTS;
     const int kc = (lane % C::SLOTS) ^ C::swz(row);
-    w_src[d] = W.ptr + (size_t)min(tile_n * C::BN + row, W.rows - 1) * W.ld + kc * 8;
+    w_src[d] = W.ptr + W.row_off(tile_n * C::BN + row, kc);
   }
   const int nk = K / BK;
   auto stage = [&](int kt, int buf) {
@@ -152,11 +171,11 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
     const int ke = kt;
 #pragma unroll
     for (int d = 0; d < C::A_DMA; ++d)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + (size_t)ke * BK),
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + A.k_off(ke, BK)),
                                        (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024), 16, 0, 0);
 #pragma unroll
     for (int d = 0; d < C::W_DMA; ++d)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[d] + (size_t)ke * BK),
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[d] + W.k_off(ke, BK)),
                                        (lds_ptr_t)(base + C::A_BYTES + (wave * C::W_DMA + d) * 1024), 16, 0, 0);
   };
   constexpr int DMA_PER_STAGE = C::A_DMA + C::W_DMA;  // per wave
@@ -284,13 +303,13 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
   for (int d = 0; d < C::A_DMA; ++d) {
     const int row = (wave * C::A_DMA + d) * C::ROWS_PER_DMA + lane / C::SLOTS;
     const int kc = (lane % C::SLOTS) ^ C::swz(row);
-    a_src[d] = A.ptr + (size_t)min(tile_m * C::BM + row, A.rows - 1) * A.ld + kc * 8;
+    a_src[d] = A.ptr + A.row_off(tile_m * C::BM + row, kc);
   }
 #pragma unroll
   for (int d = 0; d < C::W_DMA; ++d) {
     const int row = (wave * C::W_DMA + d) * C::ROWS_PER_DMA + lane / C::SLOTS;
     const int kc = (lane % C::SLOTS) ^ C::swz(row);
-    w_src[d] = W.ptr + (size_t)min(tile_n * C::BN + row, W.rows - 1) * W.ld + kc * 8;
+    w_src[d] = W.ptr + W.row_off(tile_n * C::BN + row, kc);
   }
   const int nk = K / BK;
   if constexpr (has_prologue<Epilogue>::value) epi.prologue(smem + C::RING_BYTES, wave, lane);
@@ -309,12 +328,12 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
     if (half == 0) {
 #pragma unroll
       for (int d = 0; d < C::A_DMA; ++d)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + (size_t)kt * BK),
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + A.k_off(kt, BK)),
                                          (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024), 16, 0, 0);
     } else {
 #pragma unroll
       for (int d = 0; d < C::W_DMA; ++d)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[d] + (size_t)kt * BK),
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[d] + W.k_off(kt, BK)),
                                          (lds_ptr_t)(base + C::A_BYTES + (wave * C::W_DMA + d) * 1024), 16, 0, 0);
     }
   };

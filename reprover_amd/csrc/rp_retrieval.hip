@@ -577,7 +577,7 @@ static SimPlan plan_sim(int B, int N, int D2, int k, int flags) {
   p.stride = stride;
   // small problems take the single dense pass; a shard of <= 16k rows still goes two-pass when many
   // queries share it (the 8-GPU shape: 2048 queries x 16k rows would write and re-read 266 MB of keys)
-  p.dense_only = (flags & RP_TOPK_DENSE) || p.blocks < 2 * stride ||
+  p.dense_only = (flags & RP_TOPK_DENSE) != 0 || p.blocks < 2 * stride ||
                  (N <= SIM_DENSE_MAX_N && (int64_t)B * N <= SIM_DENSE_MAX_KEYS);
   p.new_filter = !p.dense_only && g_scan_impl == 0 && (D2 % 64 == 0);
   p.sample_blocks = p.dense_only ? 0 : (p.blocks + stride - 1) / stride;
@@ -667,7 +667,11 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   uint64_t* thr = (uint64_t*)(ws + p.off_thr);
   float* tau = (float*)(ws + p.off_tau);
 
-  GemmOperand qop{(const bf16_t*)Q, D2, B}, eop{(const bf16_t*)E, D2, N};
+  GemmOperand qop{(const bf16_t*)Q, D2, B, 0}, eop{(const bf16_t*)E, D2, N, 0};
+  if (flags & RP_TOPK_E_BLOCKED) {
+    RP_REQUIRE(D2 % PANEL_K == 0, "blocked index: D=%d must be a multiple of %d", D, fp8 ? 128 : 64);
+    eop.nkb = D2 / PANEL_K;
+  }
   EpiSim epi;
   epi.q_scale = q_scale;
   epi.e_scale = e_scale;
@@ -889,6 +893,45 @@ extern "C" RpStatus rp_quantize_rows_e4m3(const void* X, int32_t x_dtype, int64_
   else
     hipLaunchKernelGGL(quantize_rows_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)X, (int64_t)rows, D,
                        (uint8_t*)out_fp8, out_scale);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Blocked (panel) form of the index: see GemmOperand in rp_gemm.h.  units = 2-byte units per row.
+// ------------------------------------------------------------------------------------------
+namespace rp {
+__global__ __launch_bounds__(256) void pack_blocked_kernel(const uint4* __restrict__ src, int64_t rows, int units,
+                                                           uint4* __restrict__ dst, int64_t total_chunks) {
+  // one 16-B chunk (8 units) per thread; destination-linear so that the writes are the sequential side
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total_chunks) return;
+  const int nkb = units / PANEL_K;
+  const int kc = (int)(i & 7);                       // chunk inside the 128-B row piece
+  const int r = (int)((i >> 3) & (PANEL_ROWS - 1));  // row inside the panel
+  const int64_t panel = i >> 11;                     // 256 rows x 8 chunks per panel
+  const int kb = (int)(panel % nkb);
+  const int64_t row = (panel / nkb) * PANEL_ROWS + r;
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (row < rows) v = src[row * (units / 8) + kb * 8 + kc];
+  dst[i] = v;
+}
+}  // namespace rp
+
+extern "C" size_t rp_index_blocked_bytes(int64_t N, int32_t D, int32_t elem_bytes) {
+  if (N <= 0 || D <= 0 || (elem_bytes != 1 && elem_bytes != 2) || ((int64_t)D * elem_bytes) % 128) return 0;
+  return (size_t)((N + PANEL_ROWS - 1) / PANEL_ROWS) * PANEL_ROWS * D * elem_bytes;
+}
+
+extern "C" RpStatus rp_index_pack_blocked(const void* E, int64_t N, int32_t D, int32_t elem_bytes, void* out,
+                                          void* stream_) {
+  RP_REQUIRE(E && out && N > 0 && D > 0, "null / empty argument");
+  RP_REQUIRE((elem_bytes == 1 || elem_bytes == 2) && ((int64_t)D * elem_bytes) % 128 == 0,
+             "blocked index: rows must be whole 128-byte pieces (D=%d, %d-byte elements)", D, elem_bytes);
+  const int units = D * elem_bytes / 2;
+  const int64_t chunks = (int64_t)(rp_index_blocked_bytes(N, D, elem_bytes) / 16);
+  hipLaunchKernelGGL(pack_blocked_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
+                     (const uint4*)E, N, units, (uint4*)out, chunks);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

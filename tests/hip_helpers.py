@@ -40,11 +40,12 @@ def attention(qkv, cu, tab, H):
     return out
 
 
-def sim_topk(Q, E, k, masks=None, id_offset=0, flags=0):
-    """masks = (file_of i32 [N], end_key i64 [N], bits_t u32-as-i32 [F, W], own i32 [B], qk i64 [B]) device tensors."""
+def sim_topk(Q, E, k, masks=None, id_offset=0, flags=0, N=None):
+    """masks = (file_of i32 [N], end_key i64 [N], bits_t u32-as-i32 [F, W], own i32 [B], qk i64 [B]) device tensors.
+    With flags & RP_TOPK_E_BLOCKED, E is the flat blocked copy and N must be given."""
     lib = _lib.load()
     B, D = Q.shape
-    N = E.shape[0]
+    N = E.shape[0] if N is None else N
     out_s = torch.empty((B, k), dtype=torch.float32, device=Q.device)
     out_i = torch.empty((B, k), dtype=torch.int32, device=Q.device)
     out_c = torch.empty((B,), dtype=torch.int32, device=Q.device)
@@ -63,6 +64,20 @@ def sim_topk(Q, E, k, masks=None, id_offset=0, flags=0):
     return out_i, out_s, out_c
 
 
+def pack_blocked(E):
+    """Blocked (panel) form of a [N, D] bf16 / uint8 matrix via rp_index_pack_blocked (flat uint8 tensor)."""
+    lib = _lib.load()
+    E = E.contiguous()
+    eb = E.element_size()
+    nb = lib.rp_index_blocked_bytes(E.shape[0], E.shape[1], eb)
+    assert nb > 0
+    out = torch.empty(nb, dtype=torch.uint8, device=E.device)
+    _lib.check(lib.rp_index_pack_blocked(_lib.ptr(E), E.shape[0], E.shape[1], eb, _lib.ptr(out), _lib.current_stream()),
+               "rp_index_pack_blocked")
+    torch.cuda.synchronize()
+    return out
+
+
 def quantize_e4m3(X):
     """(codes uint8 [R, D], scale f32 [R]) device tensors via rp_quantize_rows_e4m3."""
     lib = _lib.load()
@@ -77,11 +92,11 @@ def quantize_e4m3(X):
     return codes, scale
 
 
-def sim_topk_fp8(Q8, qs, E8, es, k, masks=None, id_offset=0, flags=0):
+def sim_topk_fp8(Q8, qs, E8, es, k, masks=None, id_offset=0, flags=0, N=None):
     """rp_sim_topk_fp8 on e4m3 codes (uint8) + per-row scales; masks as in sim_topk."""
     lib = _lib.load()
     B, D = Q8.shape
-    N = E8.shape[0]
+    N = E8.shape[0] if N is None else N
     out_s = torch.empty((B, k), dtype=torch.float32, device=Q8.device)
     out_i = torch.empty((B, k), dtype=torch.int32, device=Q8.device)
     out_c = torch.empty((B,), dtype=torch.int32, device=Q8.device)

@@ -180,6 +180,26 @@ def test_sim_topk(gen, B, N, D, k, masked):
     # the dense single-pass path must give bit-identical answers
     ids2, sc2, cnt2 = hh.sim_topk(Q, E, k, dm, flags=_lib.RP_TOPK_DENSE)
     assert torch.equal(ids, ids2) and torch.equal(sc, sc2) and torch.equal(cnt, cnt2)
+    if D % 64 == 0:  # the blocked (panel) form of the index: same bytes in another order, identical answers
+        Eb = hh.pack_blocked(E)
+        for flags in (_lib.RP_TOPK_E_BLOCKED, _lib.RP_TOPK_E_BLOCKED | _lib.RP_TOPK_DENSE):
+            ids3, sc3, cnt3 = hh.sim_topk(Q, Eb, k, dm, flags=flags, N=N)
+            assert torch.equal(ids, ids3) and torch.equal(sc, sc3) and torch.equal(cnt, cnt3)
+
+
+def test_index_pack_blocked_layout(gen):
+    """rp_index_pack_blocked against the layout formula of include/reprover_hip.h (bit-exact byte shuffle)."""
+    for N, D, dt in ((1000, 128, torch.bfloat16), (513, 1472, torch.bfloat16), (300, 256, torch.uint8)):
+        X = torch.randint(0, 255, (N, D * (2 if dt == torch.bfloat16 else 1)), dtype=torch.uint8, device="cuda")
+        Xv = X.view(dt) if dt == torch.bfloat16 else X
+        got = hh.pack_blocked(Xv).cpu().numpy()
+        rb = X.shape[1]  # row bytes
+        blocks, nkb = (N + 255) // 256, rb // 128
+        want = np.zeros((blocks, nkb, 256, 128), dtype=np.uint8)
+        src = np.zeros((blocks * 256, rb), dtype=np.uint8)
+        src[:N] = X.cpu().numpy()
+        want[:] = src.reshape(blocks, 256, nkb, 128).transpose(0, 2, 1, 3)
+        assert np.array_equal(got, want.reshape(-1))
 
 
 def test_sim_topk_exact_ties_and_order(gen):

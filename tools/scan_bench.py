@@ -22,6 +22,14 @@ for lo in range(0, N, 100000):  # chunked: a 1M x 1536 fp32 temporary would be 6
     hi = min(N, lo + 100000)
     E[lo:hi] = torch.nn.functional.normalize(torch.randn(hi - lo, D, generator=g, device=dev), dim=1).to(torch.bfloat16)
 E8, es = hh.quantize_e4m3(E)
+def pack(X, eb):
+    nb = lib.rp_index_blocked_bytes(X.shape[0], X.shape[1], eb)
+    out = torch.empty(nb, dtype=torch.uint8, device=dev)
+    _lib.check(lib.rp_index_pack_blocked(X.data_ptr(), X.shape[0], X.shape[1], eb, out.data_ptr(), _lib.current_stream()), "pack")
+    return out
+blocked_modes = [int(c) for c in os.environ.get("BLOCKED", "0").split(",")]
+Eb = pack(E, 2) if 1 in blocked_modes else None
+E8b = pack(E8, 1) if (1 in blocked_modes and D % 128 == 0) else None
 rng = np.random.default_rng(0)
 for B in Bs:
     Q = torch.nn.functional.normalize(torch.randn(B, D, generator=g, device=dev), dim=1).to(torch.bfloat16)
@@ -30,8 +38,10 @@ for B in Bs:
     f, ek, bt, own, qk = hh.masks_to_device(m, dev)
     for fp8 in modes:
         for flags in ((0, 1) if dense_too else (0,)):
-            for cfg in [(c, i, cs) for c in cfgs for i in (impls if not flags else [0]) for cs in (cases if not flags else [""])]:
-                cfg, impl, case = cfg
+            for cfg in [(c, i, cs, bl) for c in cfgs for i in (impls if not flags else [0]) for cs in (cases if not flags else [""]) for bl in blocked_modes]:
+                cfg, impl, case, bl = cfg
+                if bl and fp8 and E8b is None: continue
+                Ex, E8x, fl = (Eb if bl else E), (E8b if bl else E8), flags | (2 if bl else 0)
                 _lib.check(lib.rp_set_option(b"scan_cfg", cfg), "opt")
                 _lib.check(lib.rp_set_option(b"scan_impl", impl), "opt")
                 for kv in filter(None, case.split(",")):
@@ -41,13 +51,13 @@ for B in Bs:
                 nb = lib.rp_sim_topk_workspace_bytes(B, N, D, k, flags); ws = torch.empty(nb, dtype=torch.uint8, device=dev)
                 def run():
                     if fp8:
-                        _lib.check(lib.rp_sim_topk_fp8(Q8.data_ptr(), qs.data_ptr(), E8.data_ptr(), es.data_ptr(), B, N, D, f.data_ptr(),
-                                                       ek.data_ptr(), bt.data_ptr(), bt.shape[0], own.data_ptr(), qk.data_ptr(), 0, k, flags,
+                        _lib.check(lib.rp_sim_topk_fp8(Q8.data_ptr(), qs.data_ptr(), E8x.data_ptr(), es.data_ptr(), B, N, D, f.data_ptr(),
+                                                       ek.data_ptr(), bt.data_ptr(), bt.shape[0], own.data_ptr(), qk.data_ptr(), 0, k, fl,
                                                        out_s.data_ptr(), out_i.data_ptr(), out_c.data_ptr(), ws.data_ptr(), nb,
                                                        _lib.current_stream()), "sim8")
                     else:
-                        _lib.check(lib.rp_sim_topk(Q.data_ptr(), E.data_ptr(), B, N, D, f.data_ptr(), ek.data_ptr(), bt.data_ptr(), bt.shape[0],
-                                                   own.data_ptr(), qk.data_ptr(), 0, k, flags, out_s.data_ptr(), out_i.data_ptr(), out_c.data_ptr(),
+                        _lib.check(lib.rp_sim_topk(Q.data_ptr(), Ex.data_ptr(), B, N, D, f.data_ptr(), ek.data_ptr(), bt.data_ptr(), bt.shape[0],
+                                                   own.data_ptr(), qk.data_ptr(), 0, k, fl, out_s.data_ptr(), out_i.data_ptr(), out_c.data_ptr(),
                                                    ws.data_ptr(), nb, _lib.current_stream()), "sim")
                 for _ in range(3): run()
                 torch.cuda.synchronize()
@@ -64,6 +74,6 @@ for B in Bs:
                 print(f"B={B:4d} N={N} D={D} {'e4m3' if fp8 else 'bf16'} {'DENSE' if flags else 'AUTO '} scan_cfg={cfg} impl={impl}: total {tot*1e3:8.1f} us  "
                       f"scan {scan_s*1e6:8.1f} us (sample {prof['scan_sample'][0]/it*1e3:6.1f} + rest {prof['scan'][0]/it*1e3:6.1f})  select {prof['select'][0]/it*1e3:7.1f} us   "
                       f"E-stream {byts/scan_s/1e9:7.1f} GB/s  MFMA {2.0*B*N*D/scan_s/1e12:6.1f} TFLOP/s  QPS {B/(tot*1e-3):10.0f}  "
-                      f"cnt_ok {bool((out_c == k).all())}  [{case}]", flush=True)
+                      f"cnt_ok {bool((out_c == k).all())}  [{case}]{' BLOCKED' if bl else ''} chk {int(out_i.sum())}", flush=True)
                 for kv in filter(None, case.split(",")):
                     _lib.check(lib.rp_set_option(kv.split("=")[0].encode(), 0), "opt")
