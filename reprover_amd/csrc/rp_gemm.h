@@ -55,8 +55,9 @@ __device__ unsigned long long g_handover_ts[8 * 64 * 3];
 __device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 // Tile configuration: block tile BM x BN x BK, WM x WN waves, NSTAGE-deep LDS ring.
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSTAGE_, int PIPE_ = 0, int FP8_ = 0>
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSTAGE_, int PIPE_ = 0, int FP8_ = 0, int AAUX_ = 0>
 struct GemmCfg {
+  static constexpr int AAUX = AAUX_;  // cache-policy bits of the A operand's LDS-DMA (2 = nt: streamed once)
   // FP8 = 1: the operands are e4m3 bytes, addressed as if they were bf16 rows of half the length (BK,
   // K and the operands' ld all count 2-byte units); only the fragment reads and the MFMA differ.
   static constexpr int FP8 = FP8_;
@@ -327,9 +328,14 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
 #endif
     if (half == 0) {
 #pragma unroll
-      for (int d = 0; d < C::A_DMA; ++d)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + A.k_off(kt, BK)),
-                                         (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024), 16, 0, 0);
+      for (int d = 0; d < C::A_DMA; ++d) {
+        if constexpr (C::AAUX == 2)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + A.k_off(kt, BK)),
+                                           (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024), 16, 0, 2);
+        else
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + A.k_off(kt, BK)),
+                                           (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024), 16, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int d = 0; d < C::W_DMA; ++d)

@@ -47,6 +47,7 @@ typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 1> SimCfg8Filter;
 // one (32 KB) - the premise operand streams from HBM, not from L2 like an encoder GEMM's weights
 typedef GemmCfg<256, 256, 32, 2, 2, 4, 1> SimCfgFilterK32;
 typedef GemmCfg<128, 64, 64, 2, 2, 3> SimCfgSampleK64;
+typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 0, 2> SimCfgFilterNt;      // experiment: premise stream with the nt policy
 constexpr int SIM_FILTER_META_BYTES = 12288;  // per-tile metadata behind the ring (EpiSimFilter::prologue)
 constexpr int SIM_FILTER_LIST_BYTES = 32768;  // per-wave survivor list (the ring, dead after the main loop)
 int g_scan_cfg = 0;   // 0: auto; 1: force 128-query tiles in the dense path
@@ -55,6 +56,7 @@ int g_scan_filter_cfg = 0;   // experiments: 0 = 256x256x64 2-stage, 1 = 256x256
 int g_scan_sample_cfg = 0;   // experiments: 0 = 128x64x32 6-stage, 1 = 128x64x64 3-stage
 int g_scan_stride = 0;       // experiments: > 0 overrides the sampling stride (power of two)
 int g_scan_no_epilogue = 0;  // timing only: the filter pass drops every score (main loop in isolation)
+int g_scan_same_block = 0;   // timing only: every workgroup reads premise block 1 (L2-resident operand)
 
 __device__ __forceinline__ uint64_t make_key(float score, int32_t id) {
   return ((uint64_t)f2ord(score) << 32) | (uint32_t)(~(uint32_t)id);
@@ -236,9 +238,11 @@ struct EpiSimFilter {
   uint64_t* cand;       // [B, cap]
   size_t cap;
   int32_t* count;       // [B * SIM_COUNT_STRIDE]
+  uint2* ovf_lists;     // [workgroups, 4 waves, 16384]: survivors beyond a wave's LDS list (rare)
   // per workgroup
   char* smem;
-  int meta_off;  // byte offset of the metadata behind the ring
+  int meta_off;    // byte offset of the metadata behind the ring
+  int list_bytes;  // per-wave survivor list (a slice of the dead ring)
   int p0, q0;    // first premise / query of this workgroup's tile
   int debug_drop_all;
 
@@ -292,41 +296,63 @@ struct EpiSimFilter {
     const float* s_es = reinterpret_cast<const float*>(meta + M_ES);
     const int pl0 = m_base - p0, ql0 = n_base - q0;  // this wave's first premise / query inside the tile
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint2* list = reinterpret_cast<uint2*>(smem + wave * SIM_FILTER_LIST_BYTES);
-    constexpr int LIST_CAP = SIM_FILTER_LIST_BYTES / 8;
+    uint2* list = reinterpret_cast<uint2*>(smem + wave * list_bytes);
+    const int LIST_CAP = list_bytes / 8;
     static_assert(FM * 32 <= 256 && FN * 32 <= 256, "row / column codes are 8 bits");
 
-    // survivors [0, cnt) of the wave's list -> predicate, exact key test, append; one survivor per lane
-    auto drain = [&](int cnt) {
-      for (int e = lane; e < cnt; e += 64) {
-        const uint2 en = list[e];
-        const float sc = __uint_as_float(en.x);
-        const int pl = pl0 + (int)(en.y >> 16), ql = ql0 + (int)(en.y & 0xffffu);
-        const int p = p0 + pl, q = q0 + ql;
-        bool ok = (p < N) && (q < B);
-        if (file_of && ok) {
-          const int32_t f = s_file[pl];
-          const uint32_t word = bits_t[(size_t)f * bits_words + (q >> 5)];
-          ok = ((word >> (q & 31)) & 1u) || (f == s_own[ql] && s_ek[pl] <= s_qk[ql]);
+    // survivors [0, cnt) of the wave's list -> predicate, exact key test, append.  Four survivors per lane and
+    // pass, in three phases (mask word loads, then the counter atomics, then the key stores) so that the four
+    // dependent global round trips of an entry overlap with those of the other three instead of adding up.
+    auto drain = [&](const uint2* src, int cnt) {
+      if (debug_drop_all & 4) return;
+      constexpr int U = 4;
+      for (int e0 = 0; e0 < cnt; e0 += 64 * U) {
+        float sc[U];
+        int pl[U], ql[U];
+        bool ok[U];
+        uint32_t word[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e = e0 + u * 64 + lane;
+          const uint2 en = src[min(e, cnt - 1)];
+          sc[u] = __uint_as_float(en.x);
+          pl[u] = pl0 + (int)(en.y >> 16);
+          ql[u] = ql0 + (int)(en.y & 0xffffu);
+          ok[u] = (e < cnt) && (p0 + pl[u] < N) && (q0 + ql[u] < B);
+          word[u] = 0xffffffffu;
+          if (file_of && ok[u]) word[u] = bits_t[(size_t)s_file[pl[u]] * bits_words + ((q0 + ql[u]) >> 5)];
         }
-        if (ok) {
-          const uint64_t key = make_key(sc, p + id_offset);
-          if (key > s_thr[ql]) {
-            const int pos = atomicAdd(&count[(size_t)q * SIM_COUNT_STRIDE], 1);
-            cand[(size_t)q * cap + pos] = key;  // cap = rows + k: cannot overflow
-          }
+        uint64_t key[U];
+        int pos[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int q = q0 + ql[u];
+          if (file_of && ok[u])
+            ok[u] = ((word[u] >> (q & 31)) & 1u) || (s_file[pl[u]] == s_own[ql[u]] && s_ek[pl[u]] <= s_qk[ql[u]]);
+          key[u] = make_key(sc[u], p0 + pl[u] + id_offset);
+          ok[u] = ok[u] && key[u] > s_thr[ql[u]];
+          pos[u] = 0;
+          if (ok[u]) pos[u] = atomicAdd(&count[(size_t)q * SIM_COUNT_STRIDE], 1);
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (ok[u]) cand[(size_t)(q0 + ql[u]) * cap + pos[u]] = key[u];  // cap = rows + k: cannot overflow
       }
     };
 
     float tauv[FN], qsv[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      tauv[j] = debug_drop_all ? INFINITY : s_tau[ql0 + j * 32 + cl];
+      tauv[j] = (debug_drop_all & 1) ? INFINITY : s_tau[ql0 + j * 32 + cl];
       qsv[j] = FP8 ? s_qs[ql0 + j * 32 + cl] : 1.f;
     }
     const uint32_t lane_code = ((uint32_t)(4 * hi) << 16) | (uint32_t)cl;
-    int cnt = 0;  // wave-uniform
+    // Compaction.  The LDS list holds LIST_CAP survivors; ~1-3 % of the 16384 scores of a wave tile are expected.
+    // When more survive (no bound: thr = 0, or a block of near-duplicates of a query) the excess goes to this wave's
+    // slice of a global overflow list (room for the whole tile, touched only in that case): straight-line code, the
+    // accumulators are only ever indexed statically, and the answer stays exact whatever the data.
+    uint2* ovf = ovf_lists + ((size_t)blockIdx.x * 4 + wave) * (size_t)(FM * FN * 1024);
+    int cnt = 0;  // wave-uniform: survivors seen so far
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       float esv[16];
@@ -340,10 +366,6 @@ struct EpiSimFilter {
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        if (cnt > LIST_CAP - 1024) {  // a fragment adds at most 1024 entries
-          drain(cnt);
-          cnt = 0;
-        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float sc = FP8 ? (acc[i][j][r] * qsv[j]) * esv[r] : acc[i][j][r];
@@ -352,15 +374,21 @@ struct EpiSimFilter {
           if (ball) {
             const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
-            if (surv)
-              list[pos] = make_uint2(__float_as_uint(sc),
-                                     lane_code + (((uint32_t)(i * 32 + (r & 3) + 8 * (r >> 2)) << 16) | (uint32_t)(j * 32)));
+            if (surv) {
+              const uint2 en = make_uint2(__float_as_uint(sc), lane_code + (((uint32_t)(i * 32 + (r & 3) + 8 * (r >> 2)) << 16) |
+                                                                            (uint32_t)(j * 32)));
+              if (pos < LIST_CAP)
+                list[pos] = en;
+              else
+                ovf[pos - LIST_CAP] = en;
+            }
             cnt += __popcll(ball);
           }
         }
       }
     }
-    drain(cnt);
+    drain(list, min(cnt, LIST_CAP));
+    if (cnt > LIST_CAP) drain(ovf, cnt - LIST_CAP);
   }
 };
 
@@ -368,13 +396,15 @@ template <class C>
 __global__ __launch_bounds__(C::THREADS) void sim_filter_kernel(GemmOperand Eop, GemmOperand Qop, int K, int tiles_q,
                                                                 int stride, EpiSimFilter<C::FP8> epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert(C::BM == SIM_PB && C::RING_BYTES >= C::NWAVES * SIM_FILTER_LIST_BYTES, "filter tile geometry");
+  static_assert(C::BM == SIM_PB && C::NWAVES == 4 && C::RING_BYTES / C::NWAVES >= 16384, "filter tile geometry");
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int qt = logical % tiles_q;
   const int fb = logical / tiles_q;
-  const int pb = fb + fb / (stride - 1) + 1;  // the fb-th block that is not a multiple of stride
+  int pb = fb + fb / (stride - 1) + 1;  // the fb-th block that is not a multiple of stride
+  if (epi.debug_drop_all & 2) pb = 1;
   epi.smem = smem;
   epi.meta_off = C::RING_BYTES;
+  epi.list_bytes = C::RING_BYTES / C::NWAVES;
   epi.p0 = pb * C::BM;
   epi.q0 = qt * C::BN;
   gemm_tile_pipe<C>(Eop, Qop, K, pb, qt, epi, smem);
@@ -557,7 +587,7 @@ struct SimPlan {
   int bm, tiles_q, tiles_p;  // dense-only: first-generation kernel, bm queries x 128 premises per tile
   size_t dense_ld;           // keys per query in the dense buffer
   size_t cap;                // candidate-list capacity per query: every row could pass, so it cannot overflow
-  size_t off_dense, off_cand, off_count, off_thr, off_tau, bytes;
+  size_t off_dense, off_cand, off_count, off_thr, off_tau, off_ovf, bytes;
 };
 
 // D2 = operand row length in 2-byte units
@@ -595,6 +625,8 @@ static SimPlan plan_sim(int B, int N, int D2, int k, int flags) {
   off += align_up((size_t)B * 8, 256);
   p.off_tau = off;
   off += align_up((size_t)B * 4, 256);
+  p.off_ovf = off;  // second-generation filter kernel: per-wave overflow lists (whole wave tile each)
+  if (!p.dense_only) off += (size_t)((B + 255) / 256) * p.filter_blocks * 4 * 16384 * 8;
   p.bytes = off;
   return p;
 }
@@ -764,10 +796,12 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
       ef.cand = cand;
       ef.cap = p.cap;
       ef.count = count;
+      ef.ovf_lists = (uint2*)(ws + p.off_ovf);
       ef.smem = nullptr;
       ef.meta_off = 0;
+      ef.list_bytes = 0;
       ef.p0 = ef.q0 = 0;
-      ef.debug_drop_all = g_scan_no_epilogue;
+      ef.debug_drop_all = g_scan_no_epilogue | (g_scan_same_block ? 2 : 0);
     };
     if (fp8) {
       EpiSimFilter<1> ef;
@@ -776,8 +810,9 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
     } else {
       EpiSimFilter<0> ef;
       fill(ef);
-      st = g_scan_filter_cfg == 1 ? launch_filter_cfg<SimCfgFilterK32>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
-                                  : launch_filter_cfg<SimCfgFilter>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+      st = g_scan_filter_cfg == 1   ? launch_filter_cfg<SimCfgFilterK32>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
+           : g_scan_filter_cfg == 3 ? launch_filter_cfg<SimCfgFilterNt>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
+                                    : launch_filter_cfg<SimCfgFilter>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
     }
   } else {
     epi.filter = 1;
