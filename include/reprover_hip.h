@@ -143,21 +143,7 @@ int32_t  rp_relative_position_bucket(int32_t relative_position, int32_t num_buck
  *   with key = (line_nb << 20) | column_nb.  Passing file_of == NULL disables the mask.
  * Ordering: (score descending, id ascending) — the reference's argsort leaves ties unspecified.
  * ------------------------------------------------------------------------------------------- */
-enum {
-  RP_TOPK_AUTO = 0,
-  RP_TOPK_DENSE = 1,     /* force the single-pass dense path */
-  RP_TOPK_E_BLOCKED = 2  /* E is in the blocked (panel) form written by rp_index_pack_blocked */
-};
-
-/* Blocked (panel) form of an embedding matrix, the layout the scan streams best: panels of 256 rows x 128 bytes,
- *   byte (r, b) of the matrix at ((r / 256) * (row_bytes / 128) + b / 128) * 32768 + (r % 256) * 128 + b % 128,
- * zero-padded to a whole number of 256-row blocks; row_bytes = D * elem_bytes must be a multiple of 128.
- * One K-slice of one row block is then one contiguous 32 KB run, read sequentially by the workgroup that owns the
- * block (row-major, the same slice touches 256 different DRAM rows).  No reference counterpart: the reference keeps
- * `corpus_embeddings` row-major (retrieval/model.py:190-194); the engine derives this copy from it. */
-size_t   rp_index_blocked_bytes(int64_t N, int32_t D, int32_t elem_bytes /* 2 = bf16, 1 = e4m3 */);
-RpStatus rp_index_pack_blocked(const void* E /* device [N, D] row-major */, int64_t N, int32_t D, int32_t elem_bytes,
-                               void* out /* device, rp_index_blocked_bytes */, void* stream);
+enum { RP_TOPK_AUTO = 0, RP_TOPK_DENSE = 1 /* force the single-pass dense path */ };
 
 size_t   rp_sim_topk_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t k, int32_t flags);
 

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libreprover_hip.so")
 
 RP_OK = 0
 RP_DT_F32, RP_DT_BF16 = 0, 1
-RP_TOPK_AUTO, RP_TOPK_DENSE, RP_TOPK_E_BLOCKED = 0, 1, 2
+RP_TOPK_AUTO, RP_TOPK_DENSE = 0, 1
 RP_EPI_STORE_BF16, RP_EPI_RESID_F32, RP_EPI_GEGLU_BF16 = 0, 1, 2
 ABI_VERSION = 1
 KERNEL_CLASSES = ["embed", "rmsnorm", "gemm_qkv", "attention", "gemm_o", "gemm_wi", "gemm_wo", "pool", "scan",
@@ -80,8 +80,6 @@ SIGNATURES = {
          C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
          C.c_size_t, C.c_void_p],
     ),
-    "rp_index_blocked_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
-    "rp_index_pack_blocked": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "rp_quantize_rows_e4m3": (
         C.c_int32,
         [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],

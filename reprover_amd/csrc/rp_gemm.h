@@ -88,29 +88,16 @@ struct GemmCfg {
 constexpr int EPI_ROW_BYTES = 144;
 constexpr int EPI_STAGE_BYTES = 64 * EPI_ROW_BYTES;  // 9216 B per wave
 
-// Row-major operand: [rows, ld], K-contiguous; tile rows beyond `rows` are clamped to rows-1.
-// Blocked operand (nkb > 0): the matrix is stored in panels of 256 rows x 64 two-byte units (128 B per row piece),
-//   element (r, c) at ((r / 256) * nkb + c / 64) * 16384 + (r % 256) * 64 + c % 64,    nkb = K / 64,
-// padded with zero rows to a whole number of panels (no clamping).  One K-slice of one 256-row block is then a
-// single contiguous 32 KB run in memory: a workgroup that streams its block from HBM reads sequentially instead of
-// touching 256 different DRAM rows per K-step (the index of the similarity scan is kept in this form).
-constexpr int PANEL_ROWS = 256, PANEL_K = 64, PANEL_ELEMS = PANEL_ROWS * PANEL_K;
+// Operand: [rows, ld] row-major, K-contiguous; tile rows beyond `rows` are clamped to rows-1.
+// (A panel-blocked form of the scan's premise operand - 256 rows x 128 B pieces, one K-slice of a row block = one
+// contiguous 32 KB run - was tried in round 2: identical timings to the bit, the DRAM access pattern is not what
+// bounds the scan; removed.)
 struct GemmOperand {
   const bf16_t* ptr;
-  int ld;    // elements (row-major form)
+  int ld;    // elements
   int rows;  // rows that may be read
-  int nkb;   // 0: row-major; > 0: blocked form with nkb K-panels per row block
-  // offset of (row r, 8-element chunk kc of K-tile 0)
-  __device__ __forceinline__ size_t row_off(int r, int kc) const {
-    if (nkb == 0) return (size_t)min(r, rows - 1) * ld + kc * 8;
-    return (size_t)(r >> 8) * nkb * PANEL_ELEMS + (r & 255) * PANEL_K + kc * 8;
-  }
-  // additional offset of K-tile kt (BK elements wide, BK divides 64)
-  __device__ __forceinline__ size_t k_off(int kt, int BK) const {
-    if (nkb == 0) return (size_t)kt * BK;
-    const int c = kt * BK;
-    return (size_t)(c >> 6) * PANEL_ELEMS + (c & 63);
-  }
+  __device__ __forceinline__ size_t row_off(int r, int kc) const { return (size_t)min(r, rows - 1) * ld + kc * 8; }
+  __device__ __forceinline__ size_t k_off(int kt, int BK) const { return (size_t)kt * BK; }
 };
 
 // An epilogue may declare `void prologue(char* extra_lds, int wave, int lane)`: gemm_tile_pipe calls it

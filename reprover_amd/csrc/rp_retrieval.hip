@@ -47,16 +47,16 @@ typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 1> SimCfg8Filter;
 // one (32 KB) - the premise operand streams from HBM, not from L2 like an encoder GEMM's weights
 typedef GemmCfg<256, 256, 32, 2, 2, 4, 1> SimCfgFilterK32;
 typedef GemmCfg<128, 64, 64, 2, 2, 3> SimCfgSampleK64;
-typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 0, 2> SimCfgFilterNt;      // experiment: premise stream with the nt policy
-constexpr int SIM_FILTER_META_BYTES = 12288;  // per-tile metadata behind the ring (EpiSimFilter::prologue)
-constexpr int SIM_FILTER_LIST_BYTES = 32768;  // per-wave survivor list (the ring, dead after the main loop)
+// default: the premise stream (read once, by one CU) carries the nt cache policy: -7 % filter time
+typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 0, 2> SimCfgFilterNt;
+constexpr int SIM_FILTER_META_BYTES = 3072;  // per-tile metadata behind the ring (EpiSimFilter::prologue)
 int g_scan_cfg = 0;   // 0: auto; 1: force 128-query tiles in the dense path
 int g_scan_impl = 0;  // 0: auto (pipelined filter kernel when the shape allows); 1: first-generation filter kernel
-int g_scan_filter_cfg = 0;   // experiments: 0 = 256x256x64 2-stage, 1 = 256x256x32 4-stage
-int g_scan_sample_cfg = 0;   // experiments: 0 = 128x64x32 6-stage, 1 = 128x64x64 3-stage
+int g_scan_impl_force_new = 0;  // experiments: second-generation filter for every batch size
+int g_scan_filter_cfg = 0;   // experiments: 0 = nt premise stream (default), 1 = 256x256x32 4-stage, 2 = default cache policy
+int g_scan_sample_cfg = 0;   // experiments: 0 = 128x64x64 3-stage when D % 64 == 0 (default), 1 = 128x64x32 6-stage
 int g_scan_stride = 0;       // experiments: > 0 overrides the sampling stride (power of two)
 int g_scan_no_epilogue = 0;  // timing only: the filter pass drops every score (main loop in isolation)
-int g_scan_same_block = 0;   // timing only: every workgroup reads premise block 1 (L2-resident operand)
 
 __device__ __forceinline__ uint64_t make_key(float score, int32_t id) {
   return ((uint64_t)f2ord(score) << 32) | (uint32_t)(~(uint32_t)id);
@@ -211,71 +211,51 @@ __global__ __launch_bounds__(C::THREADS) void sim_scan_kernel(GemmOperand Qop, G
 // Filter pass, second generation: premises are the MFMA row operand, queries the column operand.
 //   acc[i][j][r]  <->  premise m_base + 32 i + (r & 3) + 8 (r >> 2) + 4 hi,   query n_base + 32 j + (lane & 31)
 // so a lane holds, per column fragment j, ONE query: its lower bound tau (the float of the sampled k-th key)
-// lives in a register and the pre-test is a single v_cmp per score.  Survivors (~k * stride / N of the scores,
-// ~1 %) are first compacted, wave-ballot + mbcnt, no atomics, into a per-wave list in LDS (the operand ring is
-// dead by then), and only the list is run through the accessibility predicate, the exact 64-bit key test and the
-// per-query append - densely, one survivor per lane - instead of a divergent slow path per score.
-// Per-tile metadata (tau / thr / own_file / q_key of the 256 queries, file_of / end_key of the 256 premises)
-// rides into LDS behind the ring by LDS-DMA issued before the first operand DMA (prologue hook of gemm_tile_pipe).
+// lives in a register and the pre-test is a single v_cmp per score.
+//
+// No atomics, no cross-lane traffic: the 64 scores a lane holds for one query (4 row fragments x 16 registers)
+// have a PRIVATE run of 64 slots in global memory,
+//   slots[workgroup tile][query in tile (256)][entry (64)][part = 2 wave_row + hi (4)]   x  {score bits, 16 i + r}
+// (entry-major inside a query's 2 KB so that the FIRST entries of its four runs - all that is live in most runs -
+// share one 128-byte line for the reader),
+// and the lane appends its survivors (score >= tau: ~k * stride / (N * accessible fraction), 1-3 % of the scores)
+// with a private counter, written at the end to  scnt[query][filter block][part].  A run can hold every score of
+// its lane, so nothing can overflow whatever the data (no bound at all, near-duplicate blocks ...).  First
+// versions appended to one list per query with an atomic counter: 256 counters x ~1600 returning atomics each,
+// issued by all CUs in the same few microseconds of every round, cost more than the main loop's epilogue budget.
+// The accessibility predicate and the exact 64-bit key test move to gather_slots_kernel, which reads the runs of
+// ONE query per workgroup (the counts tell it how much of each run is live).
+// The bounds (and the e4m3 scales) of the tile ride into LDS behind the ring by LDS-DMA issued before the first
+// operand DMA (prologue hook of gemm_tile_pipe).
 // ------------------------------------------------------------------------------------------
+constexpr int SLOT_RUN = 64;                         // slots per (query, tile, part) = scores per lane and column fragment
+constexpr int SLOTS_PER_TILE = 256 * 4 * SLOT_RUN;   // uint2 entries per workgroup tile (512 KB)
+
 template <int FP8>
 struct EpiSimFilter {
-  // premise side (NULL file_of => no accessibility mask)
-  const int32_t* file_of;
-  const int64_t* end_key;
-  int N;
-  // query side
-  const uint32_t* bits_t;  // [F, bits_words]
-  int bits_words;
-  const int32_t* own_file;
-  const int64_t* q_key;
-  int B;
-  int id_offset;
+  int N, B;
   const float* q_scale;  // FP8: score = (acc * q_scale[query]) * e_scale[premise]
   const float* e_scale;
-  const uint64_t* thr;  // [B] sampled k-th key (0: fewer than k in the sample)
-  const float* tau;     // [B] its score (-inf when thr == 0)
-  uint64_t* cand;       // [B, cap]
-  size_t cap;
-  int32_t* count;       // [B * SIM_COUNT_STRIDE]
-  uint2* ovf_lists;     // [workgroups, 4 waves, 16384]: survivors beyond a wave's LDS list (rare)
+  const float* tau;      // [B] score of the sampled k-th key (-inf when the sample held fewer than k)
+  uint2* slots;          // [workgroup tiles][256][4][64]
+  int32_t* scnt;         // [tiles_q * 256][filter_blocks][4]
+  int filter_blocks;
   // per workgroup
   char* smem;
-  int meta_off;    // byte offset of the metadata behind the ring
-  int list_bytes;  // per-wave survivor list (a slice of the dead ring)
+  int meta_off;  // byte offset of the metadata behind the ring
   int p0, q0;    // first premise / query of this workgroup's tile
+  int wg_tile, fb;
   int debug_drop_all;
 
-  // metadata layout (bytes from meta_off)
-  static constexpr int M_TAU = 0, M_OWN = 1024, M_THR = 2048, M_QK = 4096, M_FILE = 6144, M_EK = 7168, M_QS = 9216,
-                       M_ES = 10240;
+  static constexpr int M_TAU = 0, M_QS = 1024, M_ES = 2048;  // metadata layout (bytes from meta_off)
 
   __device__ __forceinline__ void prologue(char* meta, int wave, int lane) {
     auto dma4 = [&](const void* g, char* dst) {
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)dst, 4, 0, 0);
     };
-    // 4-byte arrays: wave w brings entries [64 w, 64 w + 64); 8-byte arrays go as dwords [128 w, 128 w + 128)
-    const int e = wave * 64 + lane;
+    const int e = wave * 64 + lane;  // wave w brings entries [64 w, 64 w + 64)
     const int q = min(q0 + e, B - 1), p = min(p0 + e, N - 1);
     dma4(tau + q, meta + M_TAU + wave * 256);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int d = wave * 128 + i * 64 + lane;
-      dma4(reinterpret_cast<const uint32_t*>(thr) + 2 * (size_t)min(q0 + (d >> 1), B - 1) + (d & 1),
-           meta + M_THR + wave * 512 + i * 256);
-    }
-    if (file_of) {
-      dma4(own_file + q, meta + M_OWN + wave * 256);
-      dma4(file_of + p, meta + M_FILE + wave * 256);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int d = wave * 128 + i * 64 + lane;
-        dma4(reinterpret_cast<const uint32_t*>(q_key) + 2 * (size_t)min(q0 + (d >> 1), B - 1) + (d & 1),
-             meta + M_QK + wave * 512 + i * 256);
-        dma4(reinterpret_cast<const uint32_t*>(end_key) + 2 * (size_t)min(p0 + (d >> 1), N - 1) + (d & 1),
-             meta + M_EK + wave * 512 + i * 256);
-      }
-    }
     if constexpr (FP8 != 0) {
       dma4(q_scale + q, meta + M_QS + wave * 256);
       dma4(e_scale + p, meta + M_ES + wave * 256);
@@ -284,75 +264,26 @@ struct EpiSimFilter {
 
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* /*stage*/) {
+    static_assert(FM * 16 == SLOT_RUN, "a lane's scores for one query fill exactly one run");
     const int hi = lane >> 5, cl = lane & 31;
     const char* meta = smem + meta_off;
     const float* s_tau = reinterpret_cast<const float*>(meta + M_TAU);
-    const int32_t* s_own = reinterpret_cast<const int32_t*>(meta + M_OWN);
-    const uint64_t* s_thr = reinterpret_cast<const uint64_t*>(meta + M_THR);
-    const int64_t* s_qk = reinterpret_cast<const int64_t*>(meta + M_QK);
-    const int32_t* s_file = reinterpret_cast<const int32_t*>(meta + M_FILE);
-    const int64_t* s_ek = reinterpret_cast<const int64_t*>(meta + M_EK);
     const float* s_qs = reinterpret_cast<const float*>(meta + M_QS);
     const float* s_es = reinterpret_cast<const float*>(meta + M_ES);
     const int pl0 = m_base - p0, ql0 = n_base - q0;  // this wave's first premise / query inside the tile
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint2* list = reinterpret_cast<uint2*>(smem + wave * list_bytes);
-    const int LIST_CAP = list_bytes / 8;
-    static_assert(FM * 32 <= 256 && FN * 32 <= 256, "row / column codes are 8 bits");
-
-    // survivors [0, cnt) of the wave's list -> predicate, exact key test, append.  Four survivors per lane and
-    // pass, in three phases (mask word loads, then the counter atomics, then the key stores) so that the four
-    // dependent global round trips of an entry overlap with those of the other three instead of adding up.
-    auto drain = [&](const uint2* src, int cnt) {
-      if (debug_drop_all & 4) return;
-      constexpr int U = 4;
-      for (int e0 = 0; e0 < cnt; e0 += 64 * U) {
-        float sc[U];
-        int pl[U], ql[U];
-        bool ok[U];
-        uint32_t word[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int e = e0 + u * 64 + lane;
-          const uint2 en = src[min(e, cnt - 1)];
-          sc[u] = __uint_as_float(en.x);
-          pl[u] = pl0 + (int)(en.y >> 16);
-          ql[u] = ql0 + (int)(en.y & 0xffffu);
-          ok[u] = (e < cnt) && (p0 + pl[u] < N) && (q0 + ql[u] < B);
-          word[u] = 0xffffffffu;
-          if (file_of && ok[u]) word[u] = bits_t[(size_t)s_file[pl[u]] * bits_words + ((q0 + ql[u]) >> 5)];
-        }
-        uint64_t key[U];
-        int pos[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int q = q0 + ql[u];
-          if (file_of && ok[u])
-            ok[u] = ((word[u] >> (q & 31)) & 1u) || (s_file[pl[u]] == s_own[ql[u]] && s_ek[pl[u]] <= s_qk[ql[u]]);
-          key[u] = make_key(sc[u], p0 + pl[u] + id_offset);
-          ok[u] = ok[u] && key[u] > s_thr[ql[u]];
-          pos[u] = 0;
-          if (ok[u]) pos[u] = atomicAdd(&count[(size_t)q * SIM_COUNT_STRIDE], 1);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (ok[u]) cand[(size_t)(q0 + ql[u]) * cap + pos[u]] = key[u];  // cap = rows + k: cannot overflow
-      }
-    };
+    const int part = (pl0 >> 7) * 2 + hi;
 
     float tauv[FN], qsv[FN];
+    uint2* run_ptr[FN];
+    int n[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      tauv[j] = (debug_drop_all & 1) ? INFINITY : s_tau[ql0 + j * 32 + cl];
-      qsv[j] = FP8 ? s_qs[ql0 + j * 32 + cl] : 1.f;
+      const int ql = ql0 + j * 32 + cl;
+      tauv[j] = (debug_drop_all & 1) ? INFINITY : s_tau[ql];
+      qsv[j] = FP8 ? s_qs[ql] : 1.f;
+      run_ptr[j] = slots + ((size_t)wg_tile * 256 + ql) * (4 * SLOT_RUN) + part;
+      n[j] = 0;
     }
-    const uint32_t lane_code = ((uint32_t)(4 * hi) << 16) | (uint32_t)cl;
-    // Compaction.  The LDS list holds LIST_CAP survivors; ~1-3 % of the 16384 scores of a wave tile are expected.
-    // When more survive (no bound: thr = 0, or a block of near-duplicates of a query) the excess goes to this wave's
-    // slice of a global overflow list (room for the whole tile, touched only in that case): straight-line code, the
-    // accumulators are only ever indexed statically, and the answer stays exact whatever the data.
-    uint2* ovf = ovf_lists + ((size_t)blockIdx.x * 4 + wave) * (size_t)(FM * FN * 1024);
-    int cnt = 0;  // wave-uniform: survivors seen so far
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       float esv[16];
@@ -369,26 +300,16 @@ struct EpiSimFilter {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float sc = FP8 ? (acc[i][j][r] * qsv[j]) * esv[r] : acc[i][j][r];
-          const bool surv = sc >= tauv[j];
-          const unsigned long long ball = __ballot(surv);
-          if (ball) {
-            const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
-                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
-            if (surv) {
-              const uint2 en = make_uint2(__float_as_uint(sc), lane_code + (((uint32_t)(i * 32 + (r & 3) + 8 * (r >> 2)) << 16) |
-                                                                            (uint32_t)(j * 32)));
-              if (pos < LIST_CAP)
-                list[pos] = en;
-              else
-                ovf[pos - LIST_CAP] = en;
-            }
-            cnt += __popcll(ball);
+          if (sc >= tauv[j]) {
+            run_ptr[j][n[j]] = make_uint2(__float_as_uint(sc), (uint32_t)(i * 16 + r));
+            n[j] += 4;  // entry stride: the four parts of a query interleave
           }
         }
       }
     }
-    drain(list, min(cnt, LIST_CAP));
-    if (cnt > LIST_CAP) drain(ovf, cnt - LIST_CAP);
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+      scnt[((size_t)(q0 + ql0 + j * 32 + cl) * filter_blocks + fb) * 4 + part] = n[j] >> 2;
   }
 };
 
@@ -396,19 +317,44 @@ template <class C>
 __global__ __launch_bounds__(C::THREADS) void sim_filter_kernel(GemmOperand Eop, GemmOperand Qop, int K, int tiles_q,
                                                                 int stride, EpiSimFilter<C::FP8> epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert(C::BM == SIM_PB && C::NWAVES == 4 && C::RING_BYTES / C::NWAVES >= 16384, "filter tile geometry");
+  static_assert(C::BM == SIM_PB && C::BN == 256 && C::NWAVES == 4, "filter tile geometry");
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int qt = logical % tiles_q;
   const int fb = logical / tiles_q;
-  int pb = fb + fb / (stride - 1) + 1;  // the fb-th block that is not a multiple of stride
-  if (epi.debug_drop_all & 2) pb = 1;
+  const int pb = fb + fb / (stride - 1) + 1;  // the fb-th block that is not a multiple of stride
   epi.smem = smem;
   epi.meta_off = C::RING_BYTES;
-  epi.list_bytes = C::RING_BYTES / C::NWAVES;
   epi.p0 = pb * C::BM;
   epi.q0 = qt * C::BN;
+  epi.wg_tile = logical;
+  epi.fb = fb;
   gemm_tile_pipe<C>(Eop, Qop, K, pb, qt, epi, smem);
 }
+
+// ------------------------------------------------------------------------------------------
+// One workgroup per query: walk the query's runs (scnt says how many entries of each are live), apply the
+// accessibility predicate (common.py:280-289 in array form) and the exact key test against the sampled bound, and
+// append the passing keys behind the sample's own top-k in cand[q] (count[q] is updated).  The raw survivors are
+// first collected in LDS so that the dependent gathers of the predicate (file_of -> mask word) run entry-parallel,
+// four entries per thread in flight; the rare excess beyond the LDS list is handled entry by entry.
+// ------------------------------------------------------------------------------------------
+struct GatherArgs {
+  const uint2* slots;
+  const int32_t* scnt;
+  int filter_blocks, tiles_q, stride;
+  int N, B, id_offset;
+  const int32_t* file_of;  // NULL: no mask
+  const int64_t* end_key;
+  const uint32_t* bits_t;
+  int bits_words;
+  const int32_t* own_file;
+  const int64_t* q_key;
+  const uint64_t* thr;
+  uint64_t* cand;  // [B, cap]: entries [0, count) hold the sample's top keys on entry
+  size_t cap;
+  int32_t* count;  // [B * SIM_COUNT_STRIDE]
+  int debug;       // timing only: 8 = return at once, 16 = skip the entry loops of phase A, 32 = skip phase B
+};
 
 // ------------------------------------------------------------------------------------------
 // exact top-k of one query's key list: MSB radix select (8-bit digits) + bitonic sort.
@@ -434,47 +380,95 @@ struct SelectArgs {
   int32_t* out_count;  // [B]
 };
 
-__global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
-  __shared__ int hist[256];
-  __shared__ uint64_t sel[SIM_MAX_K];
-  __shared__ int s_digit, s_need, s_cnt, s_done;
-  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  int n = a.counts ? a.counts[(size_t)q * a.count_stride] : a.n_fixed;
-  const bool overflow = a.counts && n > a.cap;
-  if (n > a.cap && a.counts) n = a.cap;
-  const uint64_t* src = a.keys + (size_t)q * a.ld;
+constexpr int SELECT_LDS_KEYS = 8192;  // lists up to this size are staged in LDS once (64 KB) and every pass reads LDS
 
-  // number of real candidates
-  if (tid == 0) s_cnt = 0;
+// 1024 threads: every phase is a short latency-bound loop over the list (LDS read -> compare -> LDS atomic), and
+// with 256 threads (one wave per SIMD, nothing to hide the latency behind) a select took ~27 us whatever the batch.
+constexpr int SELECT_THREADS = 1024;
+
+struct SelectShared {
+  uint64_t staged[SELECT_LDS_KEYS];
+  uint64_t sel[SIM_MAX_K];
+  unsigned long long s_or[SELECT_THREADS / 64], s_and[SELECT_THREADS / 64];
+  int hist[256];
+  int s_digit, s_need, s_cnt, s_done;
+};
+
+// the key list of one query: in LDS when it fits, else in global memory
+struct KeySrc {
+  const uint64_t* g;
+  const uint64_t* l;
+  bool in_lds;
+  __device__ __forceinline__ uint64_t operator[](int i) const { return in_lds ? l[i] : g[i]; }
+};
+
+// Everything after the list is in place: exact top-k of src[0, n) -> the mode A / mode B outputs of query q.
+__device__ __forceinline__ void select_body(const SelectArgs& a, int q, const KeySrc src, int n, bool overflow,
+                                            SelectShared& sh) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  // number of real candidates, and the bits in which they differ at all: the radix passes start at the highest
+  // differing bit.  (Scores of one query share sign, exponent and often a few mantissa bits: byte-aligned passes
+  // from bit 63 spent their first rounds sending every key - and every 0 = "not a candidate" - to ONE histogram
+  // bin, thousands of LDS atomics on one address.)
+  if (tid == 0) sh.s_cnt = 0;
   __syncthreads();
   {
     int c = 0;
-    for (int i = tid; i < n; i += 256) c += (src[i] != 0ull);
+    unsigned long long vo = 0ull, va = ~0ull;
+    for (int i = tid; i < n; i += SELECT_THREADS) {
+      const uint64_t key = src[i];
+      if (key != 0ull) {
+        ++c;
+        vo |= key;
+        va &= key;
+      }
+    }
     c = (int)wave_sum((float)c);  // exact: c <= 2^24 per wave
-    if (lane == 0) atomicAdd(&s_cnt, c);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      vo |= __shfl_xor(vo, o, 64);
+      va &= __shfl_xor(va, o, 64);
+    }
+    if (lane == 0) {
+      atomicAdd(&sh.s_cnt, c);
+      sh.s_or[tid >> 6] = vo;
+      sh.s_and[tid >> 6] = va;
+    }
   }
   __syncthreads();
-  const int nvalid = s_cnt;
+  const int nvalid = sh.s_cnt;
   const int kk = min(a.k, nvalid);
+  unsigned long long all_or = 0ull, all_and = ~0ull;
+#pragma unroll
+  for (int w = 0; w < SELECT_THREADS / 64; ++w) {
+    all_or |= sh.s_or[w];
+    all_and &= sh.s_and[w];
+  }
   __syncthreads();
 
   uint64_t T = ~0ull;  // keys >= T are selected
   if (kk > 0) {
-    uint64_t prefix = 0;
+    const unsigned long long diff = all_or ^ all_and;
+    // keys agree above bit known_shift - 1; known_prefix = key >> known_shift of the bucket being refined
+    int known_shift = diff ? 64 - __builtin_clzll(diff) : 0;
+    uint64_t known_prefix = known_shift >= 64 ? 0ull : (all_and >> known_shift);
     int need = kk;
-    bool done = false;
-    for (int shift = 56; shift >= 0 && !done; shift -= 8) {
-      hist[tid] = 0;
+    bool done = known_shift == 0;  // a single distinct key
+    while (!done) {
+      const int new_shift = max(known_shift - 8, 0);
+      const int width = known_shift - new_shift;
+      const uint32_t dmask = (1u << width) - 1u;
+      if (tid < 256) sh.hist[tid] = 0;
       __syncthreads();
-      for (int i = tid; i < n; i += 256) {
+      for (int i = tid; i < n; i += SELECT_THREADS) {
         const uint64_t key = src[i];
-        const bool in = (shift == 56) ? true : ((key >> (shift + 8)) == prefix);
-        if (in) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
+        const bool in = key != 0ull && (known_shift >= 64 || (key >> known_shift) == known_prefix);
+        if (in) atomicAdd(&sh.hist[(int)((uint32_t)(key >> new_shift) & dmask)], 1);
       }
       __syncthreads();
       if (tid < 64) {  // wave 0: lane l owns digits 255-4l .. 252-4l (descending)
         const int d0 = 255 - 4 * lane;
-        const int h0 = hist[d0], h1 = hist[d0 - 1], h2 = hist[d0 - 2], h3 = hist[d0 - 3];
+        const int h0 = sh.hist[d0], h1 = sh.hist[d0 - 1], h2 = sh.hist[d0 - 2], h3 = sh.hist[d0 - 3];
         const int mine = h0 + h1 + h2 + h3;
         int incl = mine;
 #pragma unroll
@@ -495,46 +489,47 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
             }
             cum += hs[t];
           }
-          s_digit = d;
-          s_need = need - cum;          // how many to take inside the chosen bucket
-          s_done = (hsel == need - cum);  // whole bucket taken: no need to refine further
+          sh.s_digit = d;
+          sh.s_need = need - cum;          // how many to take inside the chosen bucket
+          sh.s_done = (hsel == need - cum);  // whole bucket taken: no need to refine further
         }
       }
       __syncthreads();
-      prefix = (prefix << 8) | (uint64_t)s_digit;
-      need = s_need;
-      done = s_done || shift == 0;
-      if (done) T = prefix << shift;
+      known_prefix = (known_prefix << width) | (uint64_t)sh.s_digit;
+      known_shift = new_shift;
+      need = sh.s_need;
+      done = sh.s_done || new_shift == 0;
       __syncthreads();
     }
+    T = known_shift >= 64 ? 0ull : (known_prefix << known_shift);
   }
 
   // collect the kk selected keys, pad to a power of two, sort descending
   int P = 1;
   while (P < kk) P <<= 1;
-  for (int i = tid; i < P; i += 256) sel[i] = 0ull;
-  if (tid == 0) s_cnt = 0;
+  for (int i = tid; i < P; i += SELECT_THREADS) sh.sel[i] = 0ull;
+  if (tid == 0) sh.s_cnt = 0;
   __syncthreads();
   if (kk > 0) {
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += SELECT_THREADS) {
       const uint64_t key = src[i];
       if (key >= T && key != 0ull) {
-        const int pos = atomicAdd(&s_cnt, 1);
-        if (pos < SIM_MAX_K) sel[pos] = key;
+        const int pos = atomicAdd(&sh.s_cnt, 1);
+        if (pos < SIM_MAX_K) sh.sel[pos] = key;
       }
     }
   }
   __syncthreads();
   for (int size = 2; size <= P; size <<= 1) {
     for (int strd = size >> 1; strd > 0; strd >>= 1) {
-      for (int i = tid; i < (P >> 1); i += 256) {
+      for (int i = tid; i < (P >> 1); i += SELECT_THREADS) {
         const int lo = ((i / strd) * strd * 2) + (i % strd);
         const int hi2 = lo + strd;
         const bool desc = ((lo & size) == 0);
-        const uint64_t x = sel[lo], y = sel[hi2];
+        const uint64_t x = sh.sel[lo], y = sh.sel[hi2];
         if ((x < y) == desc) {
-          sel[lo] = y;
-          sel[hi2] = x;
+          sh.sel[lo] = y;
+          sh.sel[hi2] = x;
         }
       }
       __syncthreads();
@@ -542,24 +537,189 @@ __global__ __launch_bounds__(256) void select_kernel(SelectArgs a) {
   }
 
   if (a.out_keys) {
-    for (int i = tid; i < kk; i += 256) a.out_keys[(size_t)q * a.out_ld + i] = sel[i];
+    for (int i = tid; i < kk; i += SELECT_THREADS) a.out_keys[(size_t)q * a.out_ld + i] = sh.sel[i];
     if (tid == 0) {
       a.out_cnt[(size_t)q * SIM_COUNT_STRIDE] = kk;
-      const uint64_t th = (kk == a.k) ? sel[kk - 1] : 0ull;
+      const uint64_t th = (kk == a.k) ? sh.sel[kk - 1] : 0ull;
       a.out_thr[q] = th;
       // keys > th have ordered(score) >= th.hi, i.e. score >= ord2f(th.hi)
       if (a.out_tau) a.out_tau[q] = th ? ord2f((uint32_t)(th >> 32)) : -INFINITY;
     }
   }
   if (a.out_scores) {
-    for (int i = tid; i < a.k; i += 256) {
+    for (int i = tid; i < a.k; i += SELECT_THREADS) {
       const bool v = i < kk;
-      const uint64_t key = v ? sel[i] : 0ull;
+      const uint64_t key = v ? sh.sel[i] : 0ull;
       a.out_scores[(size_t)q * a.k + i] = v ? ord2f((uint32_t)(key >> 32)) : -INFINITY;
       a.out_ids[(size_t)q * a.k + i] = v ? (int32_t)(~(uint32_t)key) : -1;
     }
     if (tid == 0) a.out_count[q] = overflow ? -1 : kk;
   }
+}
+
+__global__ __launch_bounds__(SELECT_THREADS) void select_kernel(SelectArgs a) {
+  __shared__ SelectShared sh;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  int n = a.counts ? a.counts[(size_t)q * a.count_stride] : a.n_fixed;
+  const bool overflow = a.counts && n > a.cap;
+  if (n > a.cap && a.counts) n = a.cap;
+  const uint64_t* gsrc = a.keys + (size_t)q * a.ld;
+  // The radix passes read the list up to ten times: from LDS when it fits (the sample's 8192 keys, the ~2k
+  // candidates of the final stage), from global memory otherwise (dense plans, adversarial candidate counts).
+  const bool in_lds = n <= SELECT_LDS_KEYS;
+  if (in_lds)
+    for (int i = tid; i < n; i += SELECT_THREADS) sh.staged[i] = gsrc[i];
+  __syncthreads();
+  select_body(a, q, KeySrc{gsrc, sh.staged, in_lds}, n, overflow, sh);
+}
+
+// ------------------------------------------------------------------------------------------
+// Final stage of the second-generation plan, one workgroup per query: walk the query's runs (scnt says how many
+// entries of each are live), apply the accessibility predicate (common.py:280-289 in array form) and the exact key
+// test against the sampled bound, put the passing keys behind the sample's own top-k, and select (select_body).
+// Latency is what this stage is made of (a few thousand scattered 8-byte reads per query), so every phase issues
+// its independent loads together: a block's four counts AND the first four entries of its four runs (one 128-byte
+// line) are requested at once - the line's address does not depend on the counts, and a run holds ~2 live entries
+// on average; positions in the raw list come from ONE block-wide prefix sum of the per-thread totals (a first
+// version took a wave-aggregated LDS atomic per entry round: 20 of its 37 us); the predicate's dependent gathers
+// run for all raw survivors of a thread level by level.
+// ------------------------------------------------------------------------------------------
+constexpr int GATHER_LDS_ENTRIES = 8192;
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// wave-aggregated append: one LDS atomic per wave, positions by mbcnt
+__device__ __forceinline__ int wave_append_pos(int* counter, bool want) {
+  const unsigned long long ball = __ballot(want);
+  int base = 0;
+  if (ball) {
+    const int lane = threadIdx.x & 63;
+    if (lane == (int)__builtin_ctzll(ball)) base = atomicAdd(counter, __popcll(ball));
+    base = __shfl(base, (int)__builtin_ctzll(ball), 64);
+  }
+  return base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
+}
+
+__global__ __launch_bounds__(SELECT_THREADS) void gather_select_kernel(GatherArgs a, SelectArgs sa) {
+  __shared__ SelectShared sh;
+  __shared__ uint2 raw[GATHER_LDS_ENTRIES];  // {score bits, premise row}
+  __shared__ int s_wave_tot[SELECT_THREADS / 64];
+  __shared__ int s_out;
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qt = q >> 8, qloc = q & 255;
+  const uint64_t thr = a.thr[q];
+  const int32_t own = a.file_of ? a.own_file[q] : -1;
+  const int64_t qk = a.file_of ? a.q_key[q] : 0;
+  uint64_t* out = a.cand + (size_t)q * a.cap;  // global copy of the key list (read back only when LDS is too small)
+  const int n_sample = a.count[(size_t)q * SIM_COUNT_STRIDE];
+  for (int i = tid; i < n_sample; i += SELECT_THREADS) sh.staged[i] = out[i];  // n_sample <= k <= SIM_MAX_K
+  if (tid == 0) s_out = n_sample;
+  auto accessible = [&](int32_t f, uint32_t word, int p) {
+    return ((word >> (q & 31)) & 1u) || (f == own && a.end_key[p] <= qk);
+  };
+  auto put_key = [&](uint64_t key, int pos) {
+    out[pos] = key;
+    if (pos < SELECT_LDS_KEYS) sh.staged[pos] = key;
+  };
+  // ---- phase A: runs -> raw list (one thread per filter block)
+  const i32x4* cnt4 = reinterpret_cast<const i32x4*>(a.scnt + (size_t)q * a.filter_blocks * 4);
+  int raw_base = 0;  // raw entries of earlier rounds of this loop (a query has more than 1024 filter blocks at 1M rows)
+  for (int fb0 = 0; fb0 < a.filter_blocks; fb0 += SELECT_THREADS) {
+    const int fb = fb0 + tid;
+    const int fbc = min(fb, a.filter_blocks - 1);
+    const uint2* base = a.slots + ((size_t)(fbc * a.tiles_q + qt) * 256 + qloc) * (4 * SLOT_RUN);
+    i32x4 n4 = cnt4[fbc];
+    if (fb >= a.filter_blocks || (a.debug & 16)) n4 = i32x4{0, 0, 0, 0};
+    uint4 line[8];  // entries e = 0..3 of parts 0..3: line[2 e + (part >> 1)] holds parts {0,1} / {2,3}
+#pragma unroll
+    for (int w = 0; w < 8; ++w) line[w] = reinterpret_cast<const uint4*>(base)[w];
+    const int row_pb = (fbc + fbc / (a.stride - 1) + 1) * SIM_PB;
+    // block-wide exclusive prefix sum of the per-thread entry totals
+    const int mine = n4[0] + n4[1] + n4[2] + n4[3];
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    __syncthreads();  // s_wave_tot free (previous round consumed)
+    if (lane == 63) s_wave_tot[wave] = incl;
+    __syncthreads();
+    int pos = raw_base + incl - mine;
+    int round_total = 0;
+#pragma unroll
+    for (int w = 0; w < SELECT_THREADS / 64; ++w) {
+      const int t = s_wave_tot[w];
+      if (w < wave) pos += t;
+      round_total += t;
+    }
+    raw_base += round_total;
+    auto emit = [&](uint2 en, int part) {
+      const int i = (int)(en.y >> 4), r = (int)(en.y & 15u);
+      const int p = row_pb + (part >> 1) * 128 + 4 * (part & 1) + i * 32 + (r & 3) + 8 * (r >> 2);
+      if (pos < GATHER_LDS_ENTRIES) {
+        raw[pos] = make_uint2(en.x, (uint32_t)p);
+      } else if (p < a.N) {  // beyond the LDS list (rare): straight through, one entry at a time
+        bool ok = true;
+        if (a.file_of) {
+          const int32_t f = a.file_of[p];
+          ok = accessible(f, a.bits_t[(size_t)f * a.bits_words + (q >> 5)], p);
+        }
+        const uint64_t key = make_key(__uint_as_float(en.x), p + a.id_offset);
+        if (ok && key > thr) put_key(key, atomicAdd(&s_out, 1));
+      }
+      ++pos;
+    };
+#pragma unroll
+    for (int e = 0; e < 4; ++e)  // from the registers (static indices)
+#pragma unroll
+      for (int part = 0; part < 4; ++part)
+        if (e < n4[part]) {
+          const uint4 v = line[2 * e + (part >> 1)];
+          emit((part & 1) ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y), part);
+        }
+    const int nmax = max(max(n4[0], n4[1]), max(n4[2], n4[3]));
+    for (int e = 4; e < nmax; ++e)
+#pragma unroll
+      for (int part = 0; part < 4; ++part)
+        if (e < n4[part]) emit(base[e * 4 + part], part);
+  }
+  __syncthreads();
+  // ---- phase B: entry-parallel predicate; every gather level of a thread's entries is issued before the next
+  const int nraw = (a.debug & 32) ? 0 : min(raw_base, GATHER_LDS_ENTRIES);
+  constexpr int U = 4;
+  for (int e0 = 0; e0 < nraw; e0 += U * SELECT_THREADS) {
+    uint2 en[U];
+    int32_t f[U];
+    uint32_t word[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * SELECT_THREADS + tid;
+      en[u] = raw[min(e, nraw - 1)];
+      live[u] = e < nraw && (int)en[u].y < a.N;  // padding rows of the last block never qualify
+      if (!live[u]) en[u].y = 0;
+      f[u] = a.file_of ? a.file_of[en[u].y] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) word[u] = a.file_of ? a.bits_t[(size_t)f[u] * a.bits_words + (q >> 5)] : 0xffffffffu;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bool ok = live[u];
+      if (a.file_of && ok) ok = accessible(f[u], word[u], (int)en[u].y);
+      const uint64_t key = make_key(__uint_as_float(en[u].x), (int32_t)en[u].y + a.id_offset);
+      ok = ok && key > thr;
+      const int pos = wave_append_pos(&s_out, ok);
+      if (ok) put_key(key, pos);
+    }
+  }
+  __syncthreads();
+  const int n = s_out;
+  select_body(sa, q, KeySrc{out, sh.staged, n <= SELECT_LDS_KEYS}, n, false, sh);
 }
 
 // (scores, ids, counts)[R, B, k] -> keys[B, R*k]
@@ -576,7 +736,7 @@ __global__ void merge_keys_kernel(const float* scores, const int32_t* ids, const
 
 static void launch_select(const SelectArgs& a, int B, hipStream_t stream) {
   ProfScope ps(stream, RP_K_SELECT);
-  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(SELECT_THREADS), 0, stream, a);
 }
 
 struct SimPlan {
@@ -587,7 +747,7 @@ struct SimPlan {
   int bm, tiles_q, tiles_p;  // dense-only: first-generation kernel, bm queries x 128 premises per tile
   size_t dense_ld;           // keys per query in the dense buffer
   size_t cap;                // candidate-list capacity per query: every row could pass, so it cannot overflow
-  size_t off_dense, off_cand, off_count, off_thr, off_tau, off_ovf, bytes;
+  size_t off_dense, off_cand, off_count, off_thr, off_tau, off_slots, off_scnt, bytes;
 };
 
 // D2 = operand row length in 2-byte units
@@ -609,7 +769,10 @@ static SimPlan plan_sim(int B, int N, int D2, int k, int flags) {
   // queries share it (the 8-GPU shape: 2048 queries x 16k rows would write and re-read 266 MB of keys)
   p.dense_only = (flags & RP_TOPK_DENSE) != 0 || p.blocks < 2 * stride ||
                  (N <= SIM_DENSE_MAX_N && (int64_t)B * N <= SIM_DENSE_MAX_KEYS);
-  p.new_filter = !p.dense_only && g_scan_impl == 0 && (D2 % 64 == 0);
+  // second-generation filter: needs whole 128-B operand rows per K-tile; its 256-query tile does the MFMA work of
+  // 256 queries whatever B is, so small batches (single-state queries) stay on the first-generation kernel, whose
+  // 128-query tiles are HBM-bound there (measured at B = 1: 142 vs 171 us per call)
+  p.new_filter = !p.dense_only && g_scan_impl == 0 && (D2 % 64 == 0) && (B > 128 || g_scan_impl_force_new);
   p.sample_blocks = p.dense_only ? 0 : (p.blocks + stride - 1) / stride;
   p.filter_blocks = p.dense_only ? 0 : p.blocks - p.sample_blocks;
   p.dense_ld = p.dense_only ? (size_t)p.tiles_p * 128 : (size_t)p.sample_blocks * SIM_PB;
@@ -625,8 +788,14 @@ static SimPlan plan_sim(int B, int N, int D2, int k, int flags) {
   off += align_up((size_t)B * 8, 256);
   p.off_tau = off;
   off += align_up((size_t)B * 4, 256);
-  p.off_ovf = off;  // second-generation filter kernel: per-wave overflow lists (whole wave tile each)
-  if (!p.dense_only) off += (size_t)((B + 255) / 256) * p.filter_blocks * 4 * 16384 * 8;
+  p.off_slots = off;  // second-generation filter kernel: private runs + their counts
+  p.off_scnt = off;
+  if (p.new_filter) {
+    const size_t wg_tiles = (size_t)((B + 255) / 256) * p.filter_blocks;
+    off += align_up(wg_tiles * SLOTS_PER_TILE * sizeof(uint2), 256);
+    p.off_scnt = off;
+    off += align_up(wg_tiles * 256 * 4 * sizeof(int32_t), 256);
+  }
   p.bytes = off;
   return p;
 }
@@ -699,11 +868,7 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   uint64_t* thr = (uint64_t*)(ws + p.off_thr);
   float* tau = (float*)(ws + p.off_tau);
 
-  GemmOperand qop{(const bf16_t*)Q, D2, B, 0}, eop{(const bf16_t*)E, D2, N, 0};
-  if (flags & RP_TOPK_E_BLOCKED) {
-    RP_REQUIRE(D2 % PANEL_K == 0, "blocked index: D=%d must be a multiple of %d", D, fp8 ? 128 : 64);
-    eop.nkb = D2 / PANEL_K;
-  }
+  GemmOperand qop{(const bf16_t*)Q, D2, B}, eop{(const bf16_t*)E, D2, N};
   EpiSim epi;
   epi.q_scale = q_scale;
   epi.e_scale = e_scale;
@@ -763,7 +928,7 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   // pass 0: dense keys of the sampled blocks (4 sub-tiles of 64 rows each), k best of the sample -> bound
   const int n_sub = p.sample_blocks * (SIM_PB / SimCfgSample::BN);
   st = fp8 ? launch_scan_cfg<SimCfg8Sample>(qop, eop, D2, n_sub, p.stride, epi, stream)
-       : (g_scan_sample_cfg == 1 && D2 % 64 == 0)
+       : (g_scan_sample_cfg == 0 && D2 % 64 == 0)
            ? launch_scan_cfg<SimCfgSampleK64>(qop, eop, D2, n_sub, p.stride, epi, stream)
            : launch_scan_cfg<SimCfgSample>(qop, eop, D2, n_sub, p.stride, epi, stream);
   if (st) return st;
@@ -780,28 +945,18 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   // pass 1: remaining blocks, keep only keys above each query's bound
   if (p.new_filter) {
     auto fill = [&](auto& ef) {
-      ef.file_of = file_of;
-      ef.end_key = end_key;
       ef.N = N;
-      ef.bits_t = file_bits_t;
-      ef.bits_words = (B + 31) / 32;
-      ef.own_file = own_file;
-      ef.q_key = q_key;
       ef.B = B;
-      ef.id_offset = id_offset;
       ef.q_scale = q_scale;
       ef.e_scale = e_scale;
-      ef.thr = thr;
       ef.tau = tau;
-      ef.cand = cand;
-      ef.cap = p.cap;
-      ef.count = count;
-      ef.ovf_lists = (uint2*)(ws + p.off_ovf);
+      ef.slots = (uint2*)(ws + p.off_slots);
+      ef.scnt = (int32_t*)(ws + p.off_scnt);
+      ef.filter_blocks = p.filter_blocks;
       ef.smem = nullptr;
       ef.meta_off = 0;
-      ef.list_bytes = 0;
-      ef.p0 = ef.q0 = 0;
-      ef.debug_drop_all = g_scan_no_epilogue | (g_scan_same_block ? 2 : 0);
+      ef.p0 = ef.q0 = ef.wg_tile = ef.fb = 0;
+      ef.debug_drop_all = g_scan_no_epilogue;
     };
     if (fp8) {
       EpiSimFilter<1> ef;
@@ -811,8 +966,8 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
       EpiSimFilter<0> ef;
       fill(ef);
       st = g_scan_filter_cfg == 1   ? launch_filter_cfg<SimCfgFilterK32>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
-           : g_scan_filter_cfg == 3 ? launch_filter_cfg<SimCfgFilterNt>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
-                                    : launch_filter_cfg<SimCfgFilter>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+           : g_scan_filter_cfg == 2 ? launch_filter_cfg<SimCfgFilter>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
+                                    : launch_filter_cfg<SimCfgFilterNt>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
     }
   } else {
     epi.filter = 1;
@@ -827,6 +982,28 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
                           : launch_scan_cfg<SimCfgQ128K32>(qop, eop, D2, n_t, p.stride, epi, stream);
   }
   if (st) return st;
+  GatherArgs ga;
+  if (p.new_filter) {
+    ga.slots = (const uint2*)(ws + p.off_slots);
+    ga.scnt = (const int32_t*)(ws + p.off_scnt);
+    ga.filter_blocks = p.filter_blocks;
+    ga.tiles_q = (B + 255) / 256;
+    ga.stride = p.stride;
+    ga.N = N;
+    ga.B = B;
+    ga.id_offset = id_offset;
+    ga.file_of = file_of;
+    ga.end_key = end_key;
+    ga.bits_t = file_bits_t;
+    ga.bits_words = (B + 31) / 32;
+    ga.own_file = own_file;
+    ga.q_key = q_key;
+    ga.thr = thr;
+    ga.cand = cand;
+    ga.cap = p.cap;
+    ga.count = count;
+    ga.debug = g_scan_no_epilogue;
+  }
   SelectArgs sb;
   sb.keys = cand;
   sb.ld = p.cap;
@@ -843,7 +1020,12 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   sb.out_scores = out_scores;
   sb.out_ids = out_ids;
   sb.out_count = out_count;
-  launch_select(sb, B, stream);
+  if (p.new_filter) {  // runs -> predicate -> key list -> select, one kernel
+    ProfScope ps(stream, RP_K_SELECT);
+    hipLaunchKernelGGL(gather_select_kernel, dim3(B), dim3(SELECT_THREADS), 0, stream, ga, sb);
+  } else {
+    launch_select(sb, B, stream);
+  }
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
@@ -928,45 +1110,6 @@ extern "C" RpStatus rp_quantize_rows_e4m3(const void* X, int32_t x_dtype, int64_
   else
     hipLaunchKernelGGL(quantize_rows_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)X, (int64_t)rows, D,
                        (uint8_t*)out_fp8, out_scale);
-  RP_CHECK_LAUNCH();
-  return RP_OK;
-}
-
-// ------------------------------------------------------------------------------------------
-// Blocked (panel) form of the index: see GemmOperand in rp_gemm.h.  units = 2-byte units per row.
-// ------------------------------------------------------------------------------------------
-namespace rp {
-__global__ __launch_bounds__(256) void pack_blocked_kernel(const uint4* __restrict__ src, int64_t rows, int units,
-                                                           uint4* __restrict__ dst, int64_t total_chunks) {
-  // one 16-B chunk (8 units) per thread; destination-linear so that the writes are the sequential side
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total_chunks) return;
-  const int nkb = units / PANEL_K;
-  const int kc = (int)(i & 7);                       // chunk inside the 128-B row piece
-  const int r = (int)((i >> 3) & (PANEL_ROWS - 1));  // row inside the panel
-  const int64_t panel = i >> 11;                     // 256 rows x 8 chunks per panel
-  const int kb = (int)(panel % nkb);
-  const int64_t row = (panel / nkb) * PANEL_ROWS + r;
-  uint4 v = make_uint4(0u, 0u, 0u, 0u);
-  if (row < rows) v = src[row * (units / 8) + kb * 8 + kc];
-  dst[i] = v;
-}
-}  // namespace rp
-
-extern "C" size_t rp_index_blocked_bytes(int64_t N, int32_t D, int32_t elem_bytes) {
-  if (N <= 0 || D <= 0 || (elem_bytes != 1 && elem_bytes != 2) || ((int64_t)D * elem_bytes) % 128) return 0;
-  return (size_t)((N + PANEL_ROWS - 1) / PANEL_ROWS) * PANEL_ROWS * D * elem_bytes;
-}
-
-extern "C" RpStatus rp_index_pack_blocked(const void* E, int64_t N, int32_t D, int32_t elem_bytes, void* out,
-                                          void* stream_) {
-  RP_REQUIRE(E && out && N > 0 && D > 0, "null / empty argument");
-  RP_REQUIRE((elem_bytes == 1 || elem_bytes == 2) && ((int64_t)D * elem_bytes) % 128 == 0,
-             "blocked index: rows must be whole 128-byte pieces (D=%d, %d-byte elements)", D, elem_bytes);
-  const int units = D * elem_bytes / 2;
-  const int64_t chunks = (int64_t)(rp_index_blocked_bytes(N, D, elem_bytes) / 16);
-  hipLaunchKernelGGL(pack_blocked_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
-                     (const uint4*)E, N, units, (uint4*)out, chunks);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

@@ -64,20 +64,6 @@ def sim_topk(Q, E, k, masks=None, id_offset=0, flags=0, N=None):
     return out_i, out_s, out_c
 
 
-def pack_blocked(E):
-    """Blocked (panel) form of a [N, D] bf16 / uint8 matrix via rp_index_pack_blocked (flat uint8 tensor)."""
-    lib = _lib.load()
-    E = E.contiguous()
-    eb = E.element_size()
-    nb = lib.rp_index_blocked_bytes(E.shape[0], E.shape[1], eb)
-    assert nb > 0
-    out = torch.empty(nb, dtype=torch.uint8, device=E.device)
-    _lib.check(lib.rp_index_pack_blocked(_lib.ptr(E), E.shape[0], E.shape[1], eb, _lib.ptr(out), _lib.current_stream()),
-               "rp_index_pack_blocked")
-    torch.cuda.synchronize()
-    return out
-
-
 def quantize_e4m3(X):
     """(codes uint8 [R, D], scale f32 [R]) device tensors via rp_quantize_rows_e4m3."""
     lib = _lib.load()

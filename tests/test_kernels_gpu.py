@@ -180,26 +180,6 @@ def test_sim_topk(gen, B, N, D, k, masked):
     # the dense single-pass path must give bit-identical answers
     ids2, sc2, cnt2 = hh.sim_topk(Q, E, k, dm, flags=_lib.RP_TOPK_DENSE)
     assert torch.equal(ids, ids2) and torch.equal(sc, sc2) and torch.equal(cnt, cnt2)
-    if D % 64 == 0:  # the blocked (panel) form of the index: same bytes in another order, identical answers
-        Eb = hh.pack_blocked(E)
-        for flags in (_lib.RP_TOPK_E_BLOCKED, _lib.RP_TOPK_E_BLOCKED | _lib.RP_TOPK_DENSE):
-            ids3, sc3, cnt3 = hh.sim_topk(Q, Eb, k, dm, flags=flags, N=N)
-            assert torch.equal(ids, ids3) and torch.equal(sc, sc3) and torch.equal(cnt, cnt3)
-
-
-def test_index_pack_blocked_layout(gen):
-    """rp_index_pack_blocked against the layout formula of include/reprover_hip.h (bit-exact byte shuffle)."""
-    for N, D, dt in ((1000, 128, torch.bfloat16), (513, 1472, torch.bfloat16), (300, 256, torch.uint8)):
-        X = torch.randint(0, 255, (N, D * (2 if dt == torch.bfloat16 else 1)), dtype=torch.uint8, device="cuda")
-        Xv = X.view(dt) if dt == torch.bfloat16 else X
-        got = hh.pack_blocked(Xv).cpu().numpy()
-        rb = X.shape[1]  # row bytes
-        blocks, nkb = (N + 255) // 256, rb // 128
-        want = np.zeros((blocks, nkb, 256, 128), dtype=np.uint8)
-        src = np.zeros((blocks * 256, rb), dtype=np.uint8)
-        src[:N] = X.cpu().numpy()
-        want[:] = src.reshape(blocks, 256, nkb, 128).transpose(0, 2, 1, 3)
-        assert np.array_equal(got, want.reshape(-1))
 
 
 def test_sim_topk_exact_ties_and_order(gen):
@@ -223,8 +203,9 @@ def test_sim_topk_sample_gives_no_bound(gen):
     """The adversarial case for the two-pass plan: every SAMPLED block (rows [256 j stride, +256)) is
     inaccessible, so the sample yields no bound (thr = 0) and every accessible score of the other blocks is a
     candidate - tens of thousands per query instead of ~k*stride.  The first-generation engine reported this as
-    out_count = -1 (list overflow, capacity 8192 + k); the list is now sized so that it cannot overflow, the
-    filter kernel drains its per-wave survivor list several times per tile, and the answer must stay exact."""
+    out_count = -1 (list overflow, capacity 8192 + k); now every lane of the filter kernel owns a run of slots that
+    can hold all of its scores and the candidate list has room for every row, so nothing can overflow and the answer
+    must stay exact."""
     rng = np.random.default_rng(31)
     B, N, D, k = 9, 70000, 128, 50
     E, Q = _rand_bf16(gen, N, D), _rand_bf16(gen, B, D)
@@ -252,9 +233,15 @@ def test_sim_topk_sample_gives_no_bound(gen):
     assert not acc[:, sampled].any() and acc[0].sum() > 8192 + k
     S = _scores(Q, E)
     dm = hh.masks_to_device((file_of, end_key, bits_t, own, qk), Q.device)
-    ids, sc, cnt = hh.sim_topk(Q, E, k, dm)
-    assert (cnt.cpu().numpy() >= 0).all(), "candidate-list overflow must not happen any more"
-    hh.check_topk_against_scores(ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy(), S, acc, k, tol=1e-4)
+    lib = _lib.load()
+    for force_new in (1, 0):  # both filter generations (batches <= 128 default to the first)
+        _lib.check(lib.rp_set_option(b"scan_force_new", force_new), "opt")
+        try:
+            ids, sc, cnt = hh.sim_topk(Q, E, k, dm)
+        finally:
+            _lib.check(lib.rp_set_option(b"scan_force_new", 0), "opt")
+        assert (cnt.cpu().numpy() >= 0).all(), "candidate-list overflow must not happen any more"
+        hh.check_topk_against_scores(ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy(), S, acc, k, tol=1e-4)
     ids2, sc2, cnt2 = hh.sim_topk(Q, E, k, dm, flags=_lib.RP_TOPK_DENSE)
     assert torch.equal(ids, ids2) and torch.equal(sc, sc2) and torch.equal(cnt, cnt2)
     # the sharded form of the same search (dist.hip_local_topk per rank + rp_topk_merge): a shard whose
@@ -269,7 +256,8 @@ def test_sim_topk_sample_gives_no_bound(gen):
     assert torch.equal(mi, ids) and torch.equal(ms, sc) and torch.equal(mc, cnt)
 
 
-@pytest.mark.parametrize("B,N,D,k", [(256, 50000, 1472, 100), (300, 33000, 64, 10), (1, 40000, 192, 100)])
+@pytest.mark.parametrize("B,N,D,k", [(256, 50000, 1472, 100), (300, 33000, 64, 10), (1, 40000, 192, 100),
+                                     (37, 70000, 128, 1000), (600, 20000, 256, 3)])
 def test_sim_topk_filter_generations_agree(gen, B, N, D, k):
     """scan_impl = 1 (first-generation filter kernel: queries as MFMA rows, per-score slow path) and the default
     (pipelined 256 x 256 tile, premises as MFMA rows, compacted survivors) must return identical tensors."""
@@ -278,12 +266,14 @@ def test_sim_topk_filter_generations_agree(gen, B, N, D, k):
     m, acc = hh.synth_masks(rng, N, B, F=max(2, N // 40))
     dm = hh.masks_to_device(m, Q.device)
     lib = _lib.load()
-    a = hh.sim_topk(Q, E, k, dm, id_offset=1000)
-    _lib.check(lib.rp_set_option(b"scan_impl", 1), "opt")
+    _lib.check(lib.rp_set_option(b"scan_force_new", 1), "opt")  # batches <= 128 default to the first generation
     try:
+        a = hh.sim_topk(Q, E, k, dm, id_offset=1000)
+        _lib.check(lib.rp_set_option(b"scan_impl", 1), "opt")
         b = hh.sim_topk(Q, E, k, dm, id_offset=1000)
     finally:
         _lib.check(lib.rp_set_option(b"scan_impl", 0), "opt")
+        _lib.check(lib.rp_set_option(b"scan_force_new", 0), "opt")
     for x, y in zip(a, b):
         assert torch.equal(x, y)
     hh.check_topk_against_scores(a[0].cpu().numpy() - 1000, a[1].cpu().numpy(), a[2].cpu().numpy(), _scores(Q, E), acc, k,

@@ -22,14 +22,7 @@ for lo in range(0, N, 100000):  # chunked: a 1M x 1536 fp32 temporary would be 6
     hi = min(N, lo + 100000)
     E[lo:hi] = torch.nn.functional.normalize(torch.randn(hi - lo, D, generator=g, device=dev), dim=1).to(torch.bfloat16)
 E8, es = hh.quantize_e4m3(E)
-def pack(X, eb):
-    nb = lib.rp_index_blocked_bytes(X.shape[0], X.shape[1], eb)
-    out = torch.empty(nb, dtype=torch.uint8, device=dev)
-    _lib.check(lib.rp_index_pack_blocked(X.data_ptr(), X.shape[0], X.shape[1], eb, out.data_ptr(), _lib.current_stream()), "pack")
-    return out
-blocked_modes = [int(c) for c in os.environ.get("BLOCKED", "0").split(",")]
-Eb = pack(E, 2) if 1 in blocked_modes else None
-E8b = pack(E8, 1) if (1 in blocked_modes and D % 128 == 0) else None
+blocked_modes = [0]
 rng = np.random.default_rng(0)
 for B in Bs:
     Q = torch.nn.functional.normalize(torch.randn(B, D, generator=g, device=dev), dim=1).to(torch.bfloat16)
@@ -40,8 +33,7 @@ for B in Bs:
         for flags in ((0, 1) if dense_too else (0,)):
             for cfg in [(c, i, cs, bl) for c in cfgs for i in (impls if not flags else [0]) for cs in (cases if not flags else [""]) for bl in blocked_modes]:
                 cfg, impl, case, bl = cfg
-                if bl and fp8 and E8b is None: continue
-                Ex, E8x, fl = (Eb if bl else E), (E8b if bl else E8), flags | (2 if bl else 0)
+                Ex, E8x, fl = E, E8, flags
                 _lib.check(lib.rp_set_option(b"scan_cfg", cfg), "opt")
                 _lib.check(lib.rp_set_option(b"scan_impl", impl), "opt")
                 for kv in filter(None, case.split(",")):
@@ -61,14 +53,16 @@ for B in Bs:
                                                    ws.data_ptr(), nb, _lib.current_stream()), "sim")
                 for _ in range(3): run()
                 torch.cuda.synchronize()
-                _lib.profile_enable(True)
                 it = 20
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(it): run()
                 e1.record(); torch.cuda.synchronize()
+                tot = e0.elapsed_time(e1) / it   # un-instrumented wall time per call
+                _lib.profile_enable(True)        # second loop: per-class split (event pairs around every launch)
+                for _ in range(it): run()
+                torch.cuda.synchronize()
                 prof = _lib.profile_read(); _lib.profile_enable(False)
-                tot = e0.elapsed_time(e1) / it
                 byts = N * D * (1 if fp8 else 2) + N * (16 if fp8 else 12)
                 scan_s = (prof['scan'][0] + prof['scan_sample'][0]) / it * 1e-3
                 print(f"B={B:4d} N={N} D={D} {'e4m3' if fp8 else 'bf16'} {'DENSE' if flags else 'AUTO '} scan_cfg={cfg} impl={impl}: total {tot*1e3:8.1f} us  "
