@@ -11,6 +11,13 @@ every rank encodes its own 256 states (weak scaling), query embeddings are all-g
 rank scans its shard for all N*256 queries, the per-shard top-k lists are all-gathered and each
 rank merges the lists of its own queries.  value = (N*256 queries) / max-over-ranks step time.
 
+The timed region is un-instrumented; a second pass of the same K steps with an event pair around every launch gives
+the per-kernel split the roofline objects are computed from.  Beside the headline value the line carries, at N = 1
+(SURVEY.md §8d): the same 256 queries through the PRODUCT API from strings (`product_api_qps`:
+RetrievalDataset-style collate -> PremiseRetriever.predict_step), premises/s at the fixed length tiers 128 / 512 /
+2048 and on the length mix, the wall time of a full 130,000-premise `reindex_corpus`, the wall latency of
+single-state `retrieve()` calls, and the CPU baseline (the oracle on the host cores, bounded sample).
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -84,35 +91,93 @@ def random_init_state_dict(cfg, device, seed):
     return sd
 
 
-def cpu_baseline(cfg, sd_dev, corpus_path, E_dev, state_texts, state_ctx, n_sample=16):
-    """The reference's CPU path as restated by the oracle (kind 'port'), timed on this host:
-    pad-to-longest batch encode (fp32) + Q@E.T + full argsort + per-query Python accessibility walk
-    (common.py:299-326) over the full 130k x 1472 fp32 matrix, on a sample of `n_sample` states."""
+def fast_text_corpus_records(n_files: int, n_premises: int, seed: int):
+    """The same DAG as fast_corpus_records, with premise code of the mathlib-like length mix (SURVEY.md §8d:
+    clip(round(LogNormal(ln 180, 0.9)), 8, 2048) tokens incl. the <a></a> mark-up and EOS) - the input of the
+    full re-index leg.  Vectorised: 130k strings from one random byte buffer."""
+    recs = fast_corpus_records(n_files, n_premises, seed)
+    rng = np.random.default_rng(seed + 5)
+    n = sum(len(r["premises"]) for r in recs)
+    lens = np.maximum(synth.synth_lengths(rng, n, "mix", lo=40, hi=2048) - 32, 8)  # room for name + mark-up + EOS
+    buf = rng.integers(32, 127, size=int(lens.sum()), dtype=np.uint8)
+    buf[buf == 60] = 32  # no '<': no tokenizer special by accident
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    i = 0
+    for r in recs:
+        for pr in r["premises"]:
+            body = buf[cu[i] : cu[i + 1]].tobytes().decode("ascii")
+            pr["code"] = "theorem " + pr["full_name"].split(".")[-1] + " : " + body
+            i += 1
+    return recs
+
+
+def cpu_baseline(cfg, sd_dev, corpus_path, E_dev, state_texts, state_ctx, n_encode=8, b_retrieve=64):
+    """The reference's CPU path as restated by the oracle (kind "port"), timed on this host: pad-to-longest batch
+    encode in fp32 at BOTH matmul precisions the reference can run at ("medium" = its own setting,
+    retrieval/model.py:26, and "highest"), and `get_nearest_premises` (Q @ E.T, full argsort, per-query Python
+    accessibility walk: common.py:299-326) over the full 130k x 1472 fp32 matrix at B = b_retrieve and B = 1.
+    A bounded sample of the step's workload (~30-40 s of CPU work), medians over the repeats."""
     from oracle import common_ref, t5_ref
 
     sd = {k: v.float().cpu() for k, v in sd_dev.items()}
     E = E_dev.float().cpu().numpy()
     ref_corpus = common_ref.CorpusRef(corpus_path)
-    texts = state_texts[:n_sample]
+    texts = state_texts[:n_encode]
     ctxs = [common_ref.ContextRef(c.path, c.theorem_full_name, common_ref.Pos(*c.theorem_pos), c.state)
-            for c in state_ctx[:n_sample]]
-    t0 = time.perf_counter()
-    q = t5_ref.encode_texts(cfg, sd, texts, 2048).numpy()
-    t1 = time.perf_counter()
-    ref_corpus.get_nearest_premises(E, ctxs, q, TOP_K)
-    t2 = time.perf_counter()
-    enc_s, ret_s = t1 - t0, t2 - t1
+            for c in state_ctx[:b_retrieve]]
+    enc_s = {}
+    q = None
+    for prec in ("medium", "highest"):
+        torch.set_float32_matmul_precision(prec)
+        t0 = time.perf_counter()
+        q = t5_ref.encode_texts(cfg, sd, texts, 2048).numpy()
+        enc_s[prec] = time.perf_counter() - t0
+    torch.set_float32_matmul_precision("highest")
+    rngq = np.random.default_rng(11)
+    Q = rngq.standard_normal((b_retrieve, E.shape[1])).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    Q[: len(q)] = q
+
+    def timed(fn, reps):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    ret_b = timed(lambda: ref_corpus.get_nearest_premises(E, ctxs, Q, TOP_K), 3)
+    ret_1 = timed(lambda: ref_corpus.get_nearest_premises(E, ctxs[:1], Q[:1], TOP_K), 5)
+    enc_q = n_encode / enc_s["medium"]
+    ret_q = b_retrieve / ret_b
     return {
-        "value": n_sample / (enc_s + ret_s),
+        "value": 1.0 / (1.0 / enc_q + 1.0 / ret_q),
         "unit": "queries/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": f"{n_sample} of the step's 256 states: oracle fp32 encode {enc_s:.2f}s + "
-                  f"get_nearest_premises on the full 130k x 1472 fp32 index {ret_s:.2f}s",
-        "encode_qps": n_sample / enc_s,
-        "retrieve_only_qps": n_sample / ret_s,
+        "sample": f"encode: {n_encode} of the step's 256 states, fp32, once per precision ({enc_s['medium']:.1f}s medium, "
+                  f"{enc_s['highest']:.1f}s highest); retrieve: get_nearest_premises on the full 130k x 1472 fp32 index, "
+                  f"B={b_retrieve} median of 3 ({ret_b:.2f}s), B=1 median of 5 ({ret_1 * 1e3:.0f}ms); value = encode(medium) "
+                  f"and retrieve(B={b_retrieve}) rates combined per query",
+        "encode_qps_medium": enc_q,
+        "encode_qps_highest": n_encode / enc_s["highest"],
+        "retrieve_only_qps": ret_q,
+        "retrieve_b1_latency_ms": ret_1 * 1e3,
         "cpu_model": _cpu_model(),
     }
+
+
+def kernel_source_hash() -> str:
+    """sha256 (16 hex digits) over the HIP sources: stamps profiles/pmc_traffic.json so that a counter-derived
+    traffic figure is only quoted for the kernels it was measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "reprover_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        with open(os.path.join(csrc, name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def _cpu_model():
@@ -132,6 +197,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--premise-sample", type=int, default=4096, help="premises in the encode-throughput leg")
+    ap.add_argument("--no-full-reindex", action="store_true", help="skip the 130,000-premise reindex_corpus leg (~20 s)")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the premise-encode and scan-only legs (used under rocprofv3 so that every launch of "
                          "the dominant kernel has the step's shape and the stats average is comparable)")
@@ -258,20 +324,26 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    _lib.profile_enable(True)
-    t0 = time.perf_counter()
+    t0 = time.perf_counter()  # ---- the timed region: exactly K steps, nothing but the hot path's own launches
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    prof = _lib.profile_read()
-    _lib.profile_enable(False)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # second pass, instrumented: an event pair around every launch (rp_profile_*) for the per-kernel split
+    _lib.profile_enable(True)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    if world > 1:
+        dist.barrier()
     counts_ok = bool(((f_c if world > 1 else out_c).cpu() == TOP_K).all())
     merged_ok = None
     if world > 1 and rank == 0:
@@ -371,6 +443,88 @@ def main():
         scan_only_qps = float(agg[1].item()) / world  # every rank scanned all queries on its shard
         scan_only_qps_fp8 = float(agg[2].item()) / world
 
+    # ---- N = 1 only: the product API from strings, length tiers, full re-index, single-state latency --------
+    product = tiers = reindex = b1 = None
+    if world == 1 and not args.headline_only:
+        from reprover_amd.retrieval.model import PremiseRetriever
+        from reprover_amd.tokenizer import ByT5Tokenizer
+
+        retr = PremiseRetriever(enc, max_seq_len=1024, num_retrieved=TOP_K)  # predict conf: max_seq_len 1024
+        retr.corpus, retr.corpus_embeddings, retr.embeddings_staled = corpus, E_full, False
+        tok = ByT5Tokenizer()
+
+        def predict_all():  # datamodule.py:130-144 collate + model.py:281-327 predict_step, eval batch size 64
+            retr.predict_step_outputs = []
+            for i in range(0, B_STATES, 64):
+                ctxs = all_ctx[i : i + 64]
+                t = tok([c.serialize() for c in ctxs], padding="longest", max_length=1024, truncation=True,
+                        return_tensors="pt")
+                b = {"context": ctxs, "context_ids": t.input_ids, "context_mask": t.attention_mask}
+                for key in ("url", "commit", "file_path", "full_name", "start", "tactic_idx", "all_pos_premises"):
+                    b[key] = [None] * len(ctxs)
+                retr.predict_step(b, 0)
+            return retr.predict_step_outputs
+
+        predict_all()
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            outs = predict_all()
+            ts.append(time.perf_counter() - t0)
+        product = {"qps": B_STATES / float(np.median(ts)), "ms_per_256_states": float(np.median(ts)) * 1e3,
+                   "path": "strings -> ByT5 tokenizer (padding=longest, max_length 1024) -> predict_step (rp_encode_padded "
+                           "+ Corpus.get_nearest_premises incl. mask packing, H2D/D2H, Premise mapping), 4 batches of 64",
+                   "n_outputs": len(outs), "premises_per_output": len(outs[0]["retrieved_premises"])}
+
+        tiers = {}
+        for L, n_p in ((128, 2048), (512, 512), (2048, 128)):  # fixed byte-length tiers incl. EOS
+            rngt = np.random.default_rng(synth.SEED + L)
+            tids, tcu = synth.synth_token_batch(rngt, np.full(n_p, L))
+            tout = torch.empty((n_p, D), dtype=torch.bfloat16, device=dev)
+            enc.encode_packed(tids, tcu, tout)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            enc.encode_packed(tids, tcu, tout)
+            torch.cuda.synchronize()
+            tdt = time.perf_counter() - t0
+            tiers[str(L)] = {"premises_per_s": n_p / tdt, "tokens_per_s": n_p * L / tdt, "premises": n_p}
+
+        lat = {}
+        for nbytes in (100, 300, 1000):  # the prover's call: one state per search node (tactic_generator.py:286-292)
+            rngl = np.random.default_rng(synth.SEED + nbytes)
+            st = synth.synth_state(rngl, nbytes)
+            c0 = all_ctx[0]
+            retr.retrieve(st, c0.path, c0.theorem_full_name, c0.theorem_pos, TOP_K)
+            ls = []
+            for _ in range(20):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                retr.retrieve(st, c0.path, c0.theorem_full_name, c0.theorem_pos, TOP_K)
+                ls.append(time.perf_counter() - t0)
+            lat[str(nbytes)] = float(np.median(ls)) * 1e3
+        b1 = {"retrieve_wall_ms_by_state_bytes": lat, "k": TOP_K,
+              "path": "PremiseRetriever.retrieve(): tokenise, encode, masked top-100 over the 130k index, D2H, Premise "
+                      "objects; median of 20 calls"}
+
+        if not args.no_full_reindex:
+            tpath = os.path.join(tmp, "corpus_text.jsonl")
+            synth.write_corpus_jsonl(tpath, fast_text_corpus_records(N_FILES, N_PREMISES, synth.SEED))
+            t0 = time.perf_counter()
+            r2 = PremiseRetriever(enc, max_seq_len=2048)
+            r2.load_corpus(tpath)
+            t_load = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            r2.reindex_corpus(batch_size=64)
+            torch.cuda.synchronize()
+            t_idx = time.perf_counter() - t0
+            n_tok = int(sum(min(len(pr.serialize().encode()) + 1, 2048) for pr in r2.corpus.all_premises[:2000]))
+            reindex = {"premises": len(r2.corpus), "reindex_corpus_s": t_idx, "premises_per_s": len(r2.corpus) / t_idx,
+                       "load_corpus_jsonl_s": t_load, "mean_tokens_per_premise_first_2000": n_tok / 2000.0,
+                       "path": "PremiseRetriever.reindex_corpus(64) from corpus.jsonl: serialize (regex) + tokenise on the "
+                               "host, packed varlen encode on the GPU; BASELINE configs[3] at N = 1"}
+            del r2
+
     result = {
         "metric": "retrieve QPS@top-100 (state encode + masked similarity top-k), ByT5-small, 130k-premise corpus",
         "value": qps,
@@ -396,6 +550,11 @@ def main():
         "premises_per_s_incl_host_tokenisation": prem_per_s_host,
         "premise_tokens_per_s": prem_tok_per_s,
         "premise_len_mix": "clip(round(LogNormal(ln 180, 0.9)), 8, 2048) tokens, %d premises/GPU" % args.premise_sample,
+        "premises_per_s_by_length_tier": tiers,
+        "product_api_qps": product["qps"] if product else None,
+        "product_api": product,
+        "reindex_130k": reindex,
+        "b1_latency_ms": b1,
         "scan_only_qps": scan_only_qps,
         "scan_only_qps_e4m3_index": scan_only_qps_fp8,
         "roofline": {
@@ -405,9 +564,13 @@ def main():
             "flops_per_launch": wi_flops, "avg_launch_ms": wi_ms / max(wi_n, 1), "launches": wi_n,
         },
         "roofline_scan": {
-            "kernel": "sim_scan_kernel (both passes of one rp_sim_topk)", "bound": "hbm", "achieved": scan_gbs,
-            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": scan_gbs / PEAK_HBM_GBS, "traffic": None,
+            "kernel": "sim_scan_kernel (sample pass) + sim_filter_kernel (filter pass) of one rp_sim_topk", "bound": "hbm",
+            "achieved": scan_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": scan_gbs / PEAK_HBM_GBS, "traffic": None,
             "bytes_per_step": scan_bytes, "ms_per_step": scan_ms / args.steps,
+            # MFMA utilisation of the similarity GEMM (north_star): 2 B N D flops over the same kernel time
+            "mfma_tflops": 2.0 * BQ * n_loc * D * args.steps / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0,
+            "mfma_frac": (2.0 * BQ * n_loc * D * args.steps / (scan_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if scan_ms > 0 else 0.0,
+            "select_ms_per_step": prof["select"][0] / args.steps,
         },
         "all_encoder_gemms_tflops": all_gemm_tf,
         "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
@@ -415,9 +578,13 @@ def main():
     traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(traffic_file):  # HBM-side bytes per launch from the rocprofv3 PMC passes of this command
         tj = json.load(open(traffic_file))
-        result["roofline"]["traffic"] = tj.get("gemm_wi_bytes_per_launch")
-        result["roofline"]["traffic_source"] = tj.get("source")
-        result["roofline_scan"]["traffic"] = tj.get("scan_bytes_per_step")
+        if tj.get("kernel_source_hash") == kernel_source_hash():  # measured on exactly these kernels
+            result["roofline"]["traffic"] = tj.get("gemm_wi_bytes_per_launch")
+            result["roofline"]["traffic_source"] = tj.get("source")
+            result["roofline_scan"]["traffic"] = tj.get("scan_bytes_per_step")
+        else:
+            result["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json was measured on other kernel sources "
+                                                    "(hash mismatch): traffic withheld; re-run tools/profile_round.sh")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, sd, corpus_path, E_full, all_txt, all_ctx)
     if rank == 0:

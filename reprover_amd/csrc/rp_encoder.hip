@@ -441,10 +441,18 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOpe
     const unsigned long long until = wall_clock64() + (unsigned long long)stagger_ticks * phase / 256u;  // 100 MHz
     while (wall_clock64() < until) __builtin_amdgcn_s_sleep(16);
   }
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  int nwg = gridDim.x;
+  if (t_dev) {
+    // rp_encode_padded: the grid covers an upper bound of the token count.  The live tiles are re-numbered over
+    // the first nwg workgroups so that they still spread over all 8 XCDs (skipping by tile index left the live
+    // token tiles - the first quarter of the logical range - on two XCDs: 3x slower).
+    tiles_n = (*t_dev + C::BN - 1) / C::BN;
+    nwg = tiles_m * tiles_n;
+    if ((int)blockIdx.x >= nwg) return;
+  }
+  const int logical = xcd_remap(blockIdx.x, nwg);
   int tm, tn;
   tile_coords(logical, tiles_n, tiles_m, group_m, tn, tm);  // token tiles grouped, feature tiles inside
-  if (t_dev && tn * C::BN >= *t_dev) return;  // rp_encode_padded: the grid covers an upper bound of the token count
   if constexpr (C::PIPE != 0)
     gemm_tile_pipe<C>(A, W, K, tm, tn, epi, smem);
   else

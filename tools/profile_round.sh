@@ -2,7 +2,7 @@
 # rocprofv3 evidence for the bench command: kernel-trace + stats (one run), then PMC passes
 # (separate runs, --kernel-trace only, as the guide prescribes).  Summaries -> gpurun_out/prof_*/
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
-R=${ROUND:-r01}
+R=${ROUND:-r02}
 timeout -k 5 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$R -o bench --output-format csv -- \
   python bench.py --steps 5 --warmup 2 --no-cpu-baseline --headline-only > gpurun_out/prof_$R.log 2>&1
 tail -1 gpurun_out/prof_$R.log | cut -c1-400
@@ -56,7 +56,11 @@ def get(kfrag, counter):
         if kfrag in r["kernel"] and r["counter"] == counter:
             return float(r["avg_per_launch"])
     return None
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB per launch) of 'python bench.py "
+import sys
+sys.path.insert(0, ".")
+import bench
+out = {"kernel_source_hash": bench.kernel_source_hash(),
+       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB per launch) of 'python bench.py "
                  "--headline-only'; read bytes = 2 x FETCH_SIZE x 1024 (gfx950 wide-read correction, "
                  "MI355X_MICROARCH.md HBM section), write bytes = WRITE_SIZE x 1024; Infinity-Cache hits are included",
        "round": R}
@@ -65,9 +69,11 @@ if f is not None and w is not None:
     out["gemm_wi_bytes_per_launch"] = 2 * f * 1024 + w * 1024
     out["gemm_wi_fetch_kib"], out["gemm_wi_write_kib"] = f, w
 fs, ws = get("sim_scan_kernel", "FETCH_SIZE"), get("sim_scan_kernel", "WRITE_SIZE")
-if fs is not None and ws is not None:
-    out["scan_bytes_per_step"] = 2 * (2 * fs * 1024 + ws * 1024)  # two launches (sample + filter pass) per step
-    out["scan_fetch_kib_per_launch"], out["scan_write_kib_per_launch"] = fs, ws
+ff, wf = get("sim_filter_kernel", "FETCH_SIZE"), get("sim_filter_kernel", "WRITE_SIZE")
+if None not in (fs, ws, ff, wf):  # one sample-pass launch + one filter-pass launch per step
+    out["scan_bytes_per_step"] = (2 * fs * 1024 + ws * 1024) + (2 * ff * 1024 + wf * 1024)
+    out["scan_sample_fetch_kib"], out["scan_sample_write_kib"] = fs, ws
+    out["scan_filter_fetch_kib"], out["scan_filter_write_kib"] = ff, wf
 json.dump(out, open(f"gpurun_out/profiles_{R}/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out)[:700])
 PY
