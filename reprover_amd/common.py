@@ -177,7 +177,9 @@ class Corpus:
 
     all_premises: List[Premise]
 
-    def __init__(self, jsonl_path: str) -> None:
+    def __init__(self, jsonl_path: str, _arrays: Optional[Dict[str, np.ndarray]] = None) -> None:
+        """``_arrays``: the array form persisted in a native index directory (``save_index``); when given,
+        the import closure and the per-premise arrays are taken from it instead of being rebuilt."""
         self._files: List[File] = []
         self._index: Dict[str, int] = {}
         direct: List[List[int]] = []
@@ -196,7 +198,26 @@ class Corpus:
                 self._files.append(f)
                 direct.append(deps)
                 self.all_premises.extend(f.premises)
-        self._build_arrays(direct)
+        if _arrays is not None:
+            self._adopt_arrays(_arrays)
+        else:
+            self._build_arrays(direct)
+
+    def _adopt_arrays(self, a: Dict[str, np.ndarray]) -> None:
+        F, N = len(self._files), len(self.all_premises)
+        self._reach = np.ascontiguousarray(a["reach"]).view(np.uint64).reshape(F, (F + 63) // 64)
+        self.file_of = np.ascontiguousarray(a["file_of"], dtype=np.int32)
+        self.end_key = np.ascontiguousarray(a["end_key"], dtype=np.int64)
+        self._file_start = np.ascontiguousarray(a["file_start"], dtype=np.int64)
+        if self.file_of.shape != (N,) or self.end_key.shape != (N,) or self._file_start.shape != (F + 1,):
+            raise ValueError("index arrays do not match corpus.jsonl (premise / file counts differ)")
+        self._dev = {}
+
+    def index_arrays(self) -> Dict[str, np.ndarray]:
+        """The array form to persist: transitive import closure (bit g of row f: f imports g), file index and
+        name-group end key of every premise, first premise of every file."""
+        return {"reach": self._reach.view(np.int64), "file_of": self.file_of, "end_key": self.end_key,
+                "file_start": self._file_start}
 
     # -- array form -----------------------------------------------------------------------------
     def _build_arrays(self, direct: List[List[int]]) -> None:
@@ -518,13 +539,18 @@ class IndexedCorpus:
 # drags in networkx and lean_dojo class identities.  The native form is a directory:
 #     corpus.jsonl            the corpus exactly as given (App. B.1), so every field survives
 #     embeddings.safetensors  "embeddings": [N, D] in the encoder's dtype (bf16: 383 MB at 130k x 1472)
-#     meta.json               {"format": 1, "n_premises": N, "d_model": D, "dtype": "..."}
+#     arrays.safetensors      what the GPU search consumes, precomputed: "reach" int64 [F, ceil(F/64)] (transitive
+#                             import closure as bit rows), "file_of" int32 [N], "end_key" int64 [N],
+#                             "file_start" int64 [F+1]  - loading never re-runs the closure
+#     fp8.safetensors         optional e4m3 form of the index: "codes" uint8 [N, D], "scale" f32 [N]
+#     meta.json               {"format": 2, "n_premises": N, "n_files": F, "d_model": D, "dtype": "...", "fp8": bool}
 # ``PremiseRetriever.load_corpus`` accepts a ``.jsonl``, a pickle, or such a directory.
 # ----------------------------------------------------------------------------------------------
-INDEX_FORMAT_VERSION = 1
+INDEX_FORMAT_VERSION = 2
 
 
-def save_index(dir_path: str, corpus_jsonl_path: str, embeddings: torch.Tensor) -> None:
+def save_index(dir_path: str, corpus_jsonl_path: str, embeddings: torch.Tensor, corpus: Optional[Corpus] = None,
+               fp8: Optional["Fp8Index"] = None) -> None:
     import os
     import shutil
 
@@ -534,26 +560,48 @@ def save_index(dir_path: str, corpus_jsonl_path: str, embeddings: torch.Tensor) 
     dst = os.path.join(dir_path, "corpus.jsonl")
     if os.path.abspath(corpus_jsonl_path) != os.path.abspath(dst):
         shutil.copyfile(corpus_jsonl_path, dst)
+    if corpus is None:
+        corpus = Corpus(dst)
     emb = embeddings.detach().cpu().contiguous()
+    assert emb.shape[0] == len(corpus)
     save_file({"embeddings": emb}, os.path.join(dir_path, "embeddings.safetensors"))
+    save_file({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in corpus.index_arrays().items()},
+              os.path.join(dir_path, "arrays.safetensors"))
+    if fp8 is not None:
+        assert len(fp8) == len(corpus)
+        save_file({"codes": fp8.codes.detach().cpu().contiguous(), "scale": fp8.scale.detach().cpu().contiguous()},
+                  os.path.join(dir_path, "fp8.safetensors"))
     with open(os.path.join(dir_path, "meta.json"), "w") as fh:
-        json.dump({"format": INDEX_FORMAT_VERSION, "n_premises": int(emb.shape[0]), "d_model": int(emb.shape[1]),
-                   "dtype": str(emb.dtype).replace("torch.", "")}, fh)
+        json.dump({"format": INDEX_FORMAT_VERSION, "n_premises": int(emb.shape[0]), "n_files": corpus.num_files,
+                   "d_model": int(emb.shape[1]), "dtype": str(emb.dtype).replace("torch.", ""), "fp8": fp8 is not None},
+                  fh)
 
 
-def load_index(dir_path: str) -> Tuple[Corpus, torch.Tensor]:
+def load_index(dir_path: str, with_fp8: bool = False):
+    """(corpus, embeddings) - or (corpus, embeddings, (codes, scale) | None) with ``with_fp8`` - from a native index
+    directory.  Format 2 carries the closure bit rows and the per-premise arrays, so nothing is rebuilt; a format-1
+    directory (round 1: embeddings + jsonl only) is still accepted and rebuilds them."""
     import os
 
     from safetensors.torch import load_file
 
     with open(os.path.join(dir_path, "meta.json")) as fh:
         meta = json.load(fh)
-    if meta.get("format") != INDEX_FORMAT_VERSION:
+    if meta.get("format") not in (1, INDEX_FORMAT_VERSION):
         raise ValueError(f"unsupported index format {meta.get('format')!r} in {dir_path}")
-    corpus = Corpus(os.path.join(dir_path, "corpus.jsonl"))
+    arrays = None
+    if meta["format"] >= 2:
+        arrays = {k: v.numpy() for k, v in load_file(os.path.join(dir_path, "arrays.safetensors")).items()}
+    corpus = Corpus(os.path.join(dir_path, "corpus.jsonl"), _arrays=arrays)
     emb = load_file(os.path.join(dir_path, "embeddings.safetensors"))["embeddings"]
     assert emb.shape == (meta["n_premises"], meta["d_model"]) and len(corpus) == meta["n_premises"]
-    return corpus, emb
+    if not with_fp8:
+        return corpus, emb
+    payload = None
+    if meta.get("fp8"):
+        t = load_file(os.path.join(dir_path, "fp8.safetensors"))
+        payload = (t["codes"], t["scale"])
+    return corpus, emb, payload
 
 
 def get_all_pos_premises(annot_tac, corpus: Corpus) -> List[Premise]:

@@ -68,7 +68,13 @@ def main(argv=None) -> None:
         model.reindex_corpus(batch_size=args.batch_size)
     if args.output_path.endswith(("/", ".rpidx")):
         # native index directory: bf16 embeddings as safetensors + the corpus jsonl (no pickle)
-        save_index(args.output_path, args.corpus_path, model.corpus_embeddings)
+        # + the closure bit rows / per-premise arrays the search consumes, and the e4m3 form when asked for
+        fp8 = None
+        if os.environ.get("RP_INDEX_FP8") == "1":
+            from ..common import Fp8Index
+
+            fp8 = Fp8Index.quantize(model.corpus_embeddings, device)
+        save_index(args.output_path, args.corpus_path, model.corpus_embeddings, corpus=model.corpus, fp8=fp8)
     else:  # the reference's format: pickled IndexedCorpus with fp32 CPU embeddings (index.py:37-40)
         with open(args.output_path, "wb") as oup:
             pickle.dump(IndexedCorpus(model.corpus, model.corpus_embeddings.to(torch.float32).cpu()), oup)

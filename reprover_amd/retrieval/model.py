@@ -100,8 +100,11 @@ class PremiseRetriever:
             return
         path = path_or_corpus
         if os.path.isdir(path):  # native index directory (common.save_index)
-            self.corpus, self.corpus_embeddings = load_index(path)
+            self.corpus, self.corpus_embeddings, fp8 = load_index(path, with_fp8=True)
             self.embeddings_staled = False
+            if fp8 is not None and self.index_dtype == "fp8":  # persisted e4m3 form: no re-quantisation
+                self._fp8_index = Fp8Index(fp8[0].to(self.device), fp8[1].to(self.device))
+                self._fp8_source = self.corpus_embeddings
             return
         if path.endswith(".jsonl"):
             self.corpus = Corpus(path)
@@ -241,8 +244,11 @@ class PremiseRetriever:
         context_emb = self.encode_texts([ctx.serialize()])
         if self.corpus_embeddings.device != context_emb.device or self.corpus_embeddings.dtype != torch.bfloat16:
             # a pickled index arrives as fp32 on the CPU (index.py:37-40): move + cast once
+            keep = self._fp8_index if self._fp8_source is self.corpus_embeddings else None  # e4m3 form from disk
             self._drop_derived()
             self.corpus_embeddings = self.corpus_embeddings.to(device=context_emb.device, dtype=torch.bfloat16)
+            if keep is not None:
+                self._fp8_index, self._fp8_source = keep, self.corpus_embeddings
         retrieved_premises, scores = self.corpus.get_nearest_premises(self._search_operand(), [ctx], context_emb, k)
         assert len(retrieved_premises) == len(scores) == 1
         return retrieved_premises[0], scores[0]

@@ -172,20 +172,46 @@ def test_product_does_not_import_the_oracle():
     assert uses and all(lo < u < lo + end for u in uses), "bench.py may use the oracle inside cpu_baseline() only"
 
 
-def test_native_index_roundtrip(g6):
-    """common.save_index / load_index: corpus and embeddings survive, dtype preserved, no pickle."""
+def test_native_index_roundtrip(g6, monkeypatch):
+    """common.save_index / load_index: corpus and embeddings survive, dtype preserved, no pickle; the closure bit
+    rows and the per-premise arrays are PERSISTED (format 2): load == rebuild bit for bit, without rebuilding."""
     from reprover_amd.common import load_index, save_index
 
     g, z, path = g6
     corpus = Corpus(path)
     emb = torch.randn(len(corpus), 64).to(torch.bfloat16)
     d = os.path.join(tempfile.mkdtemp(), "idx.rpidx")
-    save_index(d, path, emb)
-    assert sorted(os.listdir(d)) == ["corpus.jsonl", "embeddings.safetensors", "meta.json"]
+    save_index(d, path, emb, corpus=corpus)
+    assert sorted(os.listdir(d)) == ["arrays.safetensors", "corpus.jsonl", "embeddings.safetensors", "meta.json"]
+
+    def boom(self, direct):
+        raise AssertionError("load_index must not rebuild the import closure")
+
+    monkeypatch.setattr(Corpus, "_build_arrays", boom)
     c2, e2 = load_index(d)
+    monkeypatch.undo()
     assert torch.equal(e2, emb) and e2.dtype == torch.bfloat16
     assert [p.full_name for p in c2.all_premises] == [p.full_name for p in corpus.all_premises]
     assert np.array_equal(c2.file_of, corpus.file_of) and np.array_equal(c2.end_key, corpus.end_key)
+    assert np.array_equal(c2._reach, corpus._reach) and np.array_equal(c2._file_start, corpus._file_start)
+    for q in g["queries"][:6]:  # the loaded corpus answers accessibility exactly like the rebuilt one
+        pos = Pos(*q["pos"])
+        assert np.array_equal(c2.accessible_mask(q["path"], pos), corpus.accessible_mask(q["path"], pos))
+        assert c2.get_dependencies(q["path"]) == corpus.get_dependencies(q["path"])
+    # an e4m3 payload travels with the index when given (quantisation itself is a GPU test)
+    from reprover_amd.common import Fp8Index
+
+    fake = Fp8Index(torch.randint(0, 255, (len(corpus), 64), dtype=torch.uint8), torch.rand(len(corpus)))
+    save_index(d, path, emb, corpus=corpus, fp8=fake)
+    c3, e3, payload = load_index(d, with_fp8=True)
+    assert torch.equal(payload[0], fake.codes) and torch.equal(payload[1], fake.scale)
+    # a round-1 directory (format 1: no arrays file) still loads, by rebuilding
+    os.remove(os.path.join(d, "arrays.safetensors"))
+    os.remove(os.path.join(d, "fp8.safetensors"))
+    json.dump({"format": 1, "n_premises": len(corpus), "d_model": 64, "dtype": "bfloat16"},
+              open(os.path.join(d, "meta.json"), "w"))
+    c4, e4 = load_index(d)
+    assert np.array_equal(c4._reach, corpus._reach)
     json.dump({"format": 99}, open(os.path.join(d, "meta.json"), "w"))
     with pytest.raises(ValueError):
         load_index(d)
