@@ -201,6 +201,21 @@ RpStatus rp_topk_merge(const float* scores, const int32_t* ids, const int32_t* c
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Training forward, loss part: replaces retrieval/model.py:133-139
+ *   similarity = torch.mm(context_emb, all_premise_embs.t());  loss = F.mse_loss(similarity, label)
+ * (the embeddings come from rp_encode_padded / rp_encode_varlen with out_dtype RP_DT_F32).
+ *   context_emb    device f32 [B, D];  premise_embs device f32 [P, D]  (P = B * (1 + num_negatives))
+ *   label          device f32 [B, P]   (datamodule.py:160-175)
+ *   out_loss       device f32 [1]: mean over the B x P entries of (similarity - label)^2, summed in index order
+ *   out_similarity device f32 [B, P] or NULL
+ * Backward and the optimizer are not part of this library.
+ * ------------------------------------------------------------------------------------------- */
+size_t   rp_contrastive_mse_workspace_bytes(int32_t B, int32_t P);
+RpStatus rp_contrastive_mse(const float* context_emb, const float* premise_embs, const float* label,
+                            int32_t B, int32_t P, int32_t D, float* out_loss, float* out_similarity,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline
  * object).  While enabled, every kernel launch of the engine is bracketed by an event pair.
  * ------------------------------------------------------------------------------------------- */

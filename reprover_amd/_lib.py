@@ -96,6 +96,12 @@ SIGNATURES = {
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
          C.c_void_p, C.c_size_t, C.c_void_p],
     ),
+    "rp_contrastive_mse_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "rp_contrastive_mse": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+         C.c_size_t, C.c_void_p],
+    ),
     "rp_dbg_gemm": (
         C.c_int32,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],

@@ -1114,6 +1114,72 @@ extern "C" RpStatus rp_quantize_rows_e4m3(const void* X, int32_t x_dtype, int64_
   return RP_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Training forward, loss part (retrieval/model.py:116-140): similarity = context_emb @ all_premise_embs.T,
+// loss = F.mse_loss(similarity, label) = mean over all B x P entries of (similarity - label)^2.
+// B x P is small (batch x batch * (1 + negatives)): one wave per pair for the fp32 dot product, then ONE workgroup
+// sums the squared errors in index order - deterministic, no atomics.
+// ------------------------------------------------------------------------------------------
+namespace rp {
+__global__ __launch_bounds__(256) void pair_dots_kernel(const float* __restrict__ ctx, const float* __restrict__ prem,
+                                                        const float* __restrict__ label, int B, int P, int D,
+                                                        float* __restrict__ sim, float* __restrict__ err2) {
+  const int lane = threadIdx.x & 63;
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= B * P) return;
+  const int j = pair / P, k = pair % P;
+  const float4* a = reinterpret_cast<const float4*>(ctx + (size_t)j * D);
+  const float4* b = reinterpret_cast<const float4*>(prem + (size_t)k * D);
+  float acc = 0.f;
+  for (int c = lane; c < (D >> 2); c += 64) {
+    const float4 x = a[c], y = b[c];
+    acc = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, fmaf(x.w, y.w, acc))));
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    if (sim) sim[pair] = acc;
+    const float d = acc - label[pair];
+    err2[pair] = d * d;
+  }
+}
+
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  __shared__ float part[256];
+  const int per = (n + 255) / 256, lo = threadIdx.x * per, hi = min(lo + per, n);
+  float s = 0.f;
+  for (int i = lo; i < hi; ++i) s += v[i];  // contiguous chunk per thread, index order
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = part[0] / (float)n;
+}
+}  // namespace rp
+
+extern "C" size_t rp_contrastive_mse_workspace_bytes(int32_t B, int32_t P) {
+  if (B <= 0 || P <= 0) return 0;
+  return align_up((size_t)B * P * 4, 256);
+}
+
+extern "C" RpStatus rp_contrastive_mse(const float* context_emb, const float* premise_embs, const float* label, int32_t B,
+                                       int32_t P, int32_t D, float* out_loss, float* out_similarity, void* workspace,
+                                       size_t workspace_bytes, void* stream_) {
+  RP_REQUIRE(context_emb && premise_embs && label && out_loss, "null argument");
+  RP_REQUIRE(B > 0 && P > 0 && D > 0 && D % 4 == 0, "B=%d P=%d D=%d (D must be a multiple of 4)", B, P, D);
+  const size_t need = rp_contrastive_mse_workspace_bytes(B, P);
+  if (!workspace || workspace_bytes < need)
+    return fail(RP_E_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, need);
+  hipStream_t stream = (hipStream_t)stream_;
+  float* err2 = (float*)workspace;
+  hipLaunchKernelGGL(pair_dots_kernel, dim3((B * P + 3) / 4), dim3(256), 0, stream, context_emb, premise_embs, label, B,
+                     P, D, out_similarity, err2);
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, stream, (const float*)err2, B * P, out_loss);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
 extern "C" size_t rp_topk_merge_workspace_bytes(int32_t R, int32_t B, int32_t k) {
   if (R <= 0 || B <= 0 || k <= 0) return 0;
   return align_up((size_t)R * B * k * 8, 256);

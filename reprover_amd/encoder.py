@@ -174,8 +174,8 @@ class HipT5Encoder:
             b0 = b1
         return out
 
-    def encode_padded(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, defer_check: bool = False
-                      ) -> torch.Tensor:
+    def encode_padded(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, defer_check: bool = False,
+                      out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
         """Drop-in for ``_encode(input_ids, attention_mask)`` with right-padded [B, L] inputs: one
         ``rp_encode_padded`` launch sequence — lengths, cu_seqlens, id compaction and the right-padding check all
         happen on the device; no torch kernels, no host round trip.  The check's verdict arrives asynchronously:
@@ -188,9 +188,9 @@ class HipT5Encoder:
         assert mask.shape == (B, L)
         if B * L > self.max_tokens_per_pass:  # rare (huge padded batches): chunk the batch dimension
             step = max(1, self.max_tokens_per_pass // L)
-            return torch.cat([self.encode_padded(ids[i : i + step], mask[i : i + step], defer_check)
+            return torch.cat([self.encode_padded(ids[i : i + step], mask[i : i + step], defer_check, out_dtype)
                               for i in range(0, B, step)])
-        out = torch.empty((B, self.cfg["d_model"]), dtype=self.dtype, device=self.device)
+        out = torch.empty((B, self.cfg["d_model"]), dtype=out_dtype or self.dtype, device=self.device)
         meta = torch.empty(4, dtype=torch.int32, device=self.device)
         nbytes = self._lib.rp_encode_padded_workspace_bytes(self._handle, B, L)
         ws = self._workspace(nbytes)

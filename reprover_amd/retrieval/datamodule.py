@@ -1,8 +1,10 @@
 """Evaluation-side data loading of the retriever — the inference half of the reference's
 ``retrieval/datamodule.py`` (lean-dojo/ReProver): one example per traced tactic
 (``RetrievalDataset._load_data`` with ``is_train=False``, datamodule.py:44-90), context tokenisation
-in ``collate`` (:130-144), and the val / predict splits (:234-267).  Negative sampling and label
-matrices (training) are out of scope.
+in ``collate`` (:130-144), and the val / predict splits (:234-267).  Of the training half only the
+deterministic part is here: ``collate_train`` (the positive / negative tokenisation and the label matrix of
+datamodule.py:146-191), which feeds ``PremiseRetriever.forward``; the random negative sampling of
+``__getitem__`` (:95-128) is not.
 """
 from __future__ import annotations
 
@@ -71,6 +73,46 @@ class RetrievalDataset:
         """In-order, drop_last=False — what the reference's eval DataLoaders yield."""
         for i in range(0, len(self.data), batch_size):
             yield self.collate(self.data[i : i + batch_size])
+
+
+def label_matrix(examples: List[Example], num_negatives: int):
+    """``label[j, k] = 1`` iff column k's premise is one of example j's positive premises, columns = the batch's
+    positives followed by negative list 0, 1, ... (datamodule.py:160-175)."""
+    import torch
+
+    n = len(examples)
+    label = torch.zeros(n, n * (1 + num_negatives))
+    for j in range(n):
+        all_pos = examples[j]["all_pos_premises"]
+        for k in range(n * (1 + num_negatives)):
+            prem = examples[k]["pos_premise"] if k < n else examples[k % n]["neg_premises"][k // n - 1]
+            label[j, k] = float(prem in all_pos)
+    return label
+
+
+def collate_train(examples: List[Example], tokenizer, max_seq_len: int, num_negatives: int) -> Batch:
+    """The reference's ``collate`` with ``is_train=True`` (datamodule.py:130-198) for examples that already carry
+    ``pos_premise`` and ``neg_premises``: tokenised contexts / positives / negative lists + the label matrix."""
+    def tok(texts):
+        return tokenizer(texts, padding="longest", max_length=max_seq_len, truncation=True, return_tensors="pt")
+
+    context = [ex["context"] for ex in examples]
+    t = tok([c.serialize() for c in context])
+    batch: Batch = {"context": context, "context_ids": t.input_ids, "context_mask": t.attention_mask}
+    pos = [ex["pos_premise"] for ex in examples]
+    t = tok([p.serialize() for p in pos])
+    batch.update(pos_premise=pos, pos_premise_ids=t.input_ids, pos_premise_mask=t.attention_mask,
+                 label=label_matrix(examples, num_negatives), neg_premises=[], neg_premises_ids=[], neg_premises_mask=[])
+    for i in range(num_negatives):
+        neg = [ex["neg_premises"][i] for ex in examples]
+        t = tok([p.serialize() for p in neg])
+        batch["neg_premises"].append(neg)
+        batch["neg_premises_ids"].append(t.input_ids)
+        batch["neg_premises_mask"].append(t.attention_mask)
+    for k in examples[0].keys():
+        if k not in batch:
+            batch[k] = [ex[k] for ex in examples]
+    return batch
 
 
 class RetrievalDataModule:

@@ -4,7 +4,8 @@
 Same names, argument meaning and error behaviour as the reference for:
 ``load_hf`` (model.py:52-66), ``load_corpus`` (:68-85), ``embedding_size`` (:87-90), ``_encode``
 (:92-114), ``reindex_corpus`` (:183-210), ``retrieve`` (:338-375) and the predict hooks' bodies
-(:274-336).  The training half (``forward``, ``training_step``, optimizers) is out of scope.
+(:274-336), plus the FORWARD of the training loss (``forward``, :116-140).  Backward, ``training_step`` and the
+optimizers are out of scope (last in the ranking, forward first).
 
 What is different underneath: the encoder forward, pooling, similarity, masking and top-k all
 run in hand-written HIP kernels behind the C ABI of libreprover_hip.so; premises are encoded as
@@ -146,6 +147,43 @@ class PremiseRetriever:
     def _encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
         """Unit-norm feature vectors [B, D] for right-padded token batches."""
         return self.encoder.encode_padded(input_ids, attention_mask)
+
+    # -- training forward (model.py:116-140) --------------------------------------------------------
+    def forward(self, context_ids, context_mask, pos_premise_ids, pos_premise_mask, neg_premises_ids, neg_premises_mask,
+                label) -> torch.Tensor:
+        """The contrastive loss of the reference's ``forward``: encode the contexts, the positive premises and
+        every list of negatives (fp32 embeddings), ``similarity = context_emb @ all_premise_embs.T``,
+        ``loss = F.mse_loss(similarity, label)`` - all on the GPU through ``rp_encode_padded`` and
+        ``rp_contrastive_mse``; returns a 0-dim fp32 device tensor, ``self.last_similarity`` keeps the [B, P]
+        matrix.  Forward only: there are no backward kernels, so the tensor carries no graph."""
+        from .. import _lib
+        from ..common import _workspace
+
+        assert len(neg_premises_ids) == len(neg_premises_mask)
+        f32 = torch.float32
+        ctx = self.encoder.encode_padded(context_ids, context_mask, defer_check=True, out_dtype=f32)
+        prem = [self.encoder.encode_padded(pos_premise_ids, pos_premise_mask, defer_check=True, out_dtype=f32)]
+        for ids, mask in zip_strict(neg_premises_ids, neg_premises_mask):
+            prem.append(self.encoder.encode_padded(ids, mask, defer_check=True, out_dtype=f32))
+        all_prem = torch.cat(prem, dim=0).contiguous()
+        B, D = ctx.shape
+        P = all_prem.shape[0]
+        lab = label.to(device=self.device, dtype=f32).contiguous()
+        assert lab.shape == (B, P), f"label {tuple(lab.shape)} != ({B}, {P})"
+        loss = torch.empty((), dtype=f32, device=self.device)
+        sim = torch.empty((B, P), dtype=f32, device=self.device)
+        lib = _lib.load()
+        nbytes = lib.rp_contrastive_mse_workspace_bytes(B, P)
+        ws = _workspace(self.device, nbytes)
+        with torch.cuda.device(self.device):
+            _lib.check(lib.rp_contrastive_mse(_lib.ptr(ctx), _lib.ptr(all_prem), _lib.ptr(lab), B, P, D, loss.data_ptr(),
+                                              _lib.ptr(sim), _lib.ptr(ws), nbytes, _lib.current_stream()),
+                       "rp_contrastive_mse")
+        self.encoder.raise_pending()
+        self.last_similarity = sim
+        return loss
+
+    __call__ = forward
 
     def encode_texts(self, texts: List[str], out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Tokenise + encode without materialising padding (the packed form the engine consumes)."""

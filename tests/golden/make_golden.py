@@ -490,9 +490,78 @@ def g9_base_full_depth():
     print("g9 ok")
 
 
+# ----------------------------------------------------------------------------------------------
+def g10_train_forward():
+    """The training forward: the reference's own ``collate`` (is_train=True: tokenisation + label
+    matrix, datamodule.py:130-198) and ``forward`` (contrastive MSE, model.py:116-140) on a hand-built batch -
+    6 examples, 3 negatives each, one example's negative being another's positive, duplicates in all_pos."""
+    import importlib
+    from types import SimpleNamespace
+    from oracle import train_ref
+
+    dmod = importlib.import_module("retrieval.datamodule")
+    cfg = synth.t5_config("byt5-small")
+    cfg["num_layers"] = 4  # the loss logic is what this fixture pins; 4 layers keep the fp32 CPU run short
+    sd = synth.synth_state_dict(cfg, seed=10)
+    model = H.offline_retriever(rm, hf_cfg(cfg), sd, max_seq_len=512)
+    files = synth.synth_corpus_records(20, 300, seed=101, code_bytes=(30, 160))
+    td = tempfile.mkdtemp()
+    path = os.path.join(td, "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    corpus = common.Corpus(path)
+    prem = corpus.all_premises
+    where = {id(p): i for i, p in enumerate(prem)}
+    rng = np.random.default_rng(102)
+    n, nneg = 6, 3
+    pick = rng.choice(len(prem), size=n * (2 + nneg), replace=False)
+    examples = []
+    for j in range(n):
+        pos = prem[int(pick[j])]
+        extra = prem[int(pick[n + j])]
+        negs = [prem[int(pick[2 * n + j * nneg + i])] for i in range(nneg)]
+        state = synth.synth_state(rng, int(rng.integers(40, 220)))
+        examples.append({"context": common.Context(pos.path, f"thm{j}", H.Pos(500, 0), state), "pos_premise": pos,
+                         "all_pos_premises": [pos, extra], "neg_premises": negs})
+    examples[1]["neg_premises"][0] = examples[0]["pos_premise"]        # another example's positive as a negative
+    examples[2]["all_pos_premises"].append(examples[3]["pos_premise"])  # ... and as a further positive
+    examples[4]["all_pos_premises"].append(examples[5]["neg_premises"][2])
+    fake_self = SimpleNamespace(tokenizer=model.tokenizer, max_seq_len=512, num_negatives=nneg, is_train=True)
+    batch = dmod.RetrievalDataset.collate(fake_self, examples)
+    label = batch["label"]
+    with torch.no_grad():
+        loss = model(batch["context_ids"], batch["context_mask"], batch["pos_premise_ids"], batch["pos_premise_mask"],
+                     batch["neg_premises_ids"], batch["neg_premises_mask"], label)
+        ctx = model._encode(batch["context_ids"], batch["context_mask"])
+        allp = torch.cat([model._encode(batch["pos_premise_ids"], batch["pos_premise_mask"])] +
+                         [model._encode(i, m) for i, m in zip(batch["neg_premises_ids"], batch["neg_premises_mask"])])
+        sim = ctx @ allp.T
+    # the oracle restatement
+    o_label = train_ref.label_matrix([where[id(e["pos_premise"])] for e in examples],
+                                     [[where[id(p)] for p in e["neg_premises"]] for e in examples],
+                                     [[where[id(p)] for p in e["all_pos_premises"]] for e in examples])
+    assert np.array_equal(o_label, label.numpy()), "oracle label-matrix drift"
+    ctx_texts = [e["context"].serialize() for e in examples]
+    pos_texts = [e["pos_premise"].serialize() for e in examples]
+    neg_texts = [[e["neg_premises"][i].serialize() for e in examples] for i in range(nneg)]
+    o_loss, o_sim = train_ref.forward_loss(cfg, sd, ctx_texts, pos_texts, neg_texts, o_label, 512)
+    print(f"g10: reference loss {float(loss):.6f}; oracle {o_loss:.6f}; max|Δsim| {np.abs(o_sim - sim.numpy()).max():.2e}; "
+          f"label ones {int(label.sum())} of {label.numel()}")
+    assert abs(o_loss - float(loss)) < 1e-6 and np.abs(o_sim - sim.numpy()).max() < 2e-5
+    np.savez_compressed(
+        os.path.join(OUT, "g10_train_forward.npz"), context_texts=np.array(ctx_texts, dtype=object),
+        pos_texts=np.array(pos_texts, dtype=object), neg_texts=np.array(neg_texts, dtype=object),
+        pos_idx=np.array([where[id(e["pos_premise"])] for e in examples]),
+        neg_idx=np.array([[where[id(p)] for p in e["neg_premises"]] for e in examples]),
+        all_pos_idx=np.array([[where[id(p)] for p in e["all_pos_premises"]] + [-1] * (4 - len(e["all_pos_premises"]))
+                              for e in examples]),
+        label=label.numpy(), loss=np.float64(float(loss)), similarity=sim.numpy(), num_layers=np.int64(4),
+        weight_seed=np.int64(10), corpus_seed=np.int64(101), max_seq_len=np.int64(512))
+    print("g10 ok")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     torch.manual_seed(0)
     for name in which:
         {"g1": g1_tokenizer, "g2": g2_serialize, "g3": g3_buckets, "g4": g4_tiny, "g5": g5_small,
-         "g6": g6_nearest, "g7": g7_predict, "g8": g8_eval_data, "g9": g9_base_full_depth}[name]()
+         "g6": g6_nearest, "g7": g7_predict, "g8": g8_eval_data, "g9": g9_base_full_depth, "g10": g10_train_forward}[name]()

@@ -107,3 +107,20 @@ def test_format_augmented_state():
     out = common_ref.format_augmented_state(s, ["p1", "p22", "p333"], max_len=len(s.encode()) + 9)
     # p1\n\n = 4 bytes, p22\n\n = 5 bytes fit (9); p333 does not; later premises go in front
     assert out == "p22\n\np1\n\n" + s
+
+
+def test_g10_train_forward(golden_dir):
+    """oracle/train_ref.py (label matrix + contrastive-MSE forward) against the reference's own collate + forward."""
+    from oracle import train_ref
+
+    g = np.load(os.path.join(golden_dir, "g10_train_forward.npz"), allow_pickle=True)
+    all_pos = [[int(x) for x in row if x >= 0] for row in g["all_pos_idx"]]
+    label = train_ref.label_matrix(g["pos_idx"].tolist(), g["neg_idx"].tolist(), all_pos)
+    assert np.array_equal(label, g["label"])
+    cfg = synth.t5_config("byt5-small")
+    cfg["num_layers"] = int(g["num_layers"])
+    sd = synth.synth_state_dict(cfg, seed=int(g["weight_seed"]))
+    loss, sim = train_ref.forward_loss(cfg, sd, list(g["context_texts"]), list(g["pos_texts"]),
+                                       [list(r) for r in g["neg_texts"]], label, int(g["max_seq_len"]))
+    assert abs(loss - float(g["loss"])) < 1e-6
+    assert np.abs(sim - g["similarity"]).max() < 2e-5

@@ -1,0 +1,74 @@
+"""The training forward (forward only): host-side train collate (label matrix) on the CPU, and
+PremiseRetriever.forward - rp_encode_padded + rp_contrastive_mse - on the GPU, against fixture G10 (the reference's
+own collate + forward, HuggingFace fp32)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from reprover_amd import synth
+from reprover_amd.common import Context, Corpus, Pos
+from reprover_amd.retrieval.datamodule import collate_train, label_matrix
+from reprover_amd.tokenizer import ByT5Tokenizer
+
+
+@pytest.fixture(scope="module")
+def g10(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g10_train_forward.npz"), allow_pickle=True)
+    files = synth.synth_corpus_records(20, 300, seed=int(g["corpus_seed"]), code_bytes=(30, 160))
+    path = os.path.join(tempfile.mkdtemp(), "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    corpus = Corpus(path)
+    prem = corpus.all_premises
+    examples = []
+    for j in range(len(g["pos_idx"])):
+        pos = prem[int(g["pos_idx"][j])]
+        examples.append({"context": Context(pos.path, f"thm{j}", Pos(500, 0), str(g["context_texts"][j])),
+                         "pos_premise": pos, "neg_premises": [prem[int(i)] for i in g["neg_idx"][j]],
+                         "all_pos_premises": [prem[int(i)] for i in g["all_pos_idx"][j] if i >= 0]})
+    return g, examples
+
+
+def test_train_collate_matches_reference(g10):
+    g, examples = g10
+    nneg = g["neg_idx"].shape[1]
+    assert np.array_equal(label_matrix(examples, nneg).numpy(), g["label"])
+    b = collate_train(examples, ByT5Tokenizer(), int(g["max_seq_len"]), nneg)
+    assert [p.serialize() for p in b["pos_premise"]] == list(g["pos_texts"])  # byte-identical mark-up
+    assert [[p.serialize() for p in row] for row in b["neg_premises"]] == [list(r) for r in g["neg_texts"]]
+    assert len(b["neg_premises_ids"]) == nneg and b["label"].shape == (len(examples), len(examples) * (1 + nneg))
+    assert b["context_ids"].dtype == torch.int64 and b["context_ids"].shape == b["context_mask"].shape
+    lens = b["pos_premise_mask"].sum(1)
+    assert b["pos_premise_ids"].shape[1] == int(lens.max())  # padding="longest"
+
+
+@pytest.mark.gpu
+def test_forward_loss_matches_reference(g10):
+    from reprover_amd.retrieval.model import PremiseRetriever
+
+    g, examples = g10
+    cfg = synth.t5_config("byt5-small")
+    cfg["num_layers"] = int(g["num_layers"])
+    model = PremiseRetriever.from_state_dict(cfg, synth.synth_state_dict(cfg, seed=int(g["weight_seed"])),
+                                             int(g["max_seq_len"]), "cuda:0")
+    b = collate_train(examples, model.tokenizer, int(g["max_seq_len"]), g["neg_idx"].shape[1])
+    loss = model(b["context_ids"], b["context_mask"], b["pos_premise_ids"], b["pos_premise_mask"], b["neg_premises_ids"],
+                 b["neg_premises_mask"], b["label"])
+    assert loss.shape == () and loss.dtype == torch.float32 and loss.is_cuda
+    sim = model.last_similarity.cpu().numpy()
+    d_sim = np.abs(sim - g["similarity"]).max()
+    print(f"train forward: loss {float(loss):.6f} (reference {float(g['loss']):.6f}), max|Δsimilarity| {d_sim:.3e}")
+    # bf16-operand GEMMs, fp32 embeddings: similarities within the path's stated 1e-2, hence the mean squared error
+    assert d_sim <= 1e-2
+    assert abs(float(loss) - float(g["loss"])) <= 2e-3
+    assert sim.min() >= -1.0 - 1e-5 and sim.max() <= 1.0 + 1e-5  # the reference asserts [-1, 1] (model.py:138)
+    # the loss kernel alone, against torch on the engine's own embeddings
+    want = torch.nn.functional.mse_loss(model.last_similarity, b["label"].cuda().float())
+    assert abs(float(loss) - float(want)) < 1e-6
+    with pytest.raises(ValueError):  # a mask that is not right-padded is reported, as on the inference path
+        bad = b["context_mask"].clone()
+        bad[0, 0] = 0
+        model(b["context_ids"], bad, b["pos_premise_ids"], b["pos_premise_mask"], b["neg_premises_ids"],
+              b["neg_premises_mask"], b["label"])
