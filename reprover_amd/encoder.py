@@ -33,6 +33,8 @@ _LAYER_KEYS = {
 
 def _require_gpu(device) -> torch.device:
     device = torch.device(device)
+    if device.type == "cuda" and device.index is None and torch.cuda.is_available():
+        device = torch.device("cuda", torch.cuda.current_device())  # tensors report an explicit index
     if device.type != "cuda" or not torch.cuda.is_available():
         raise _lib.HipLibraryError(
             "the MI355X retrieval engine needs a HIP device; there is no CPU path "
@@ -192,8 +194,24 @@ class HipT5Encoder:
                               for i in range(0, B, step)])
         out = torch.empty((B, self.cfg["d_model"]), dtype=out_dtype or self.dtype, device=self.device)
         meta = torch.empty(4, dtype=torch.int32, device=self.device)
-        nbytes = self._lib.rp_encode_padded_workspace_bytes(self._handle, B, L)
-        ws = self._workspace(nbytes)
+        self.encode_padded_into(ids, mask, out, meta)
+        self._pending_meta.append(meta)
+        if not defer_check:
+            self.raise_pending()
+        return out
+
+    def padded_workspace_bytes(self, batch: int, padded_len: int) -> int:
+        return int(self._lib.rp_encode_padded_workspace_bytes(self._handle, batch, padded_len))
+
+    def encode_padded_into(self, ids: torch.Tensor, mask: torch.Tensor, out: torch.Tensor, meta: torch.Tensor,
+                           ws: Optional[torch.Tensor] = None) -> None:
+        """The bare ``rp_encode_padded`` launch sequence on caller-owned buffers (int64 device ids / mask [B, L],
+        out [B, d_model], meta int32 [4], optional workspace): allocation-free, so it can be captured in a hipGraph
+        (reprover_amd/single_query.py)."""
+        B, L = ids.shape
+        assert ids.dtype == torch.int64 and mask.dtype == torch.int64 and ids.is_contiguous() and mask.is_contiguous()
+        if ws is None:
+            ws = self._workspace(self.padded_workspace_bytes(B, L))
         out_dt = _lib.RP_DT_BF16 if out.dtype == torch.bfloat16 else _lib.RP_DT_F32
         with torch.cuda.device(self.device):
             _lib.check(
@@ -201,10 +219,6 @@ class HipT5Encoder:
                                            _lib.ptr(meta), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
                 "rp_encode_padded",
             )
-        self._pending_meta.append(meta)
-        if not defer_check:
-            self.raise_pending()
-        return out
 
     def raise_pending(self) -> None:
         """Read the verdicts of the ``encode_padded`` calls issued since the last check (synchronises)."""

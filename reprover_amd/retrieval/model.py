@@ -64,6 +64,10 @@ class PremiseRetriever:
         # under torch.distributed.run.
         self.shard_index_over_ranks = False
         self.index_shard = None
+        # Single-state retrieve() as one hipGraph replay (reprover_amd/single_query.py); set False to launch the
+        # kernels one by one as the batch paths do.
+        self.use_graphs = True
+        self._single_query = None
 
     # -- construction (model.py:52-66) --------------------------------------------------------------
     @classmethod
@@ -137,6 +141,8 @@ class PremiseRetriever:
 
         self._fp8_index = None
         self._fp8_source = None
+        if getattr(self, "_single_query", None) is not None:
+            self._single_query.clear()
         drop_cast_cache()
 
     @property
@@ -279,6 +285,14 @@ class PremiseRetriever:
         """Retrieve ``k`` premises from the corpus using ``state`` as the query."""
         self.reindex_corpus(batch_size=32)
         ctx = Context(file_name, theorem_full_name, theorem_pos, state)
+        if (self.use_graphs and self.index_dtype == "bf16" and self.corpus_embeddings.device == self.device
+                and self.corpus_embeddings.dtype == torch.bfloat16 and k <= 1024):
+            # the prover's hot call: one H2D copy, one graph replay (encode + masked top-k), one D2H copy
+            if self._single_query is None:
+                from ..single_query import SingleQueryCache
+
+                self._single_query = SingleQueryCache()
+            return self._single_query.retrieve(self, ctx, k)
         context_emb = self.encode_texts([ctx.serialize()])
         if self.corpus_embeddings.device != context_emb.device or self.corpus_embeddings.dtype != torch.bfloat16:
             # a pickled index arrives as fp32 on the CPU (index.py:37-40): move + cast once

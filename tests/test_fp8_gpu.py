@@ -199,7 +199,7 @@ def test_retriever_fp8_index_c5_slice():
     assert isinstance(idx, Fp8Index) and idx.shape == (len(corpus.all_premises), 1536)
     assert model.corpus_embeddings.dtype == torch.bfloat16  # what the reference exposes is untouched
     # oracle on the quantised operands
-    Qe = model.encode_texts([c.serialize() for c in ctxs])
+    Qe = torch.cat([model.encode_texts([c.serialize()]) for c in ctxs])  # one state per pass, as retrieve() encodes
     Q8, qs = fp8_ref.quantize_rows_e4m3(Qe.float().cpu().numpy())
     S = fp8_ref.scores_fp8(Q8, qs, idx.codes.cpu().numpy(), idx.scale.cpu().numpy())
     acc = np.stack([corpus.accessible_mask(c.path, c.theorem_pos) for c in ctxs])
@@ -222,7 +222,10 @@ def test_retriever_fp8_index_c5_slice():
         b[key] = [None] * len(ctxs)
     model.predict_step_outputs = []
     model.predict_step(b, 0)
-    assert [[where[id(p)] for p in r["retrieved_premises"]] for r in model.predict_step_outputs] == got_i.tolist()
+    # (the batch runs the per-tile schedule, single states the few-token one: ids agree under the gap rule)
+    batch_i = [[where[id(p)] for p in r["retrieved_premises"]] for r in model.predict_step_outputs]
+    checked, bad = hh.gap_rule_ids(batch_i, want_i.tolist(), want_s.tolist(), tol=4e-3)
+    assert bad == 0 and checked > 0
 
 
 def test_fp8_full_size_properties_1m_d1536():

@@ -132,7 +132,11 @@ def test_g7_predict_and_retrieve(g7):
     for j, single in enumerate(g["retrieve"]):
         c = ctxs[j]
         prem, sc = model.retrieve(c.state, c.path, c.theorem_full_name, c.theorem_pos, k)
-        assert [where[id(p)] for p in prem] == ids[j]
+        # one state alone runs the few-token schedule: same answer up to swaps between scores closer than the
+        # tolerance (the gap rule of every id comparison), scores within the stated bound of the golden ones
+        got = [where[id(p)] for p in prem]
+        checked1, bad1 = hh.gap_rule_ids([got], [single["ids"]], [single["scores"]], tol=1e-2)
+        assert bad1 == 0 and len(set(got) & set(ids[j])) >= k - 2
         assert np.abs(np.array(sc) - np.array(single["scores"])).max() <= max(1e-2, hf_err)
     # predictions.pickle round trip (model.py:329-336)
     d = tempfile.mkdtemp()
@@ -140,6 +144,42 @@ def test_g7_predict_and_retrieve(g7):
     back = pickle.load(open(os.path.join(d, "predictions.pickle"), "rb"))
     assert len(back) == len(ctxs) and back[3]["retrieved_premises"][0].full_name == \
         model.corpus.all_premises[ids[3][0]].full_name
+
+
+def test_retrieve_graph_replay_equals_launch_by_launch(g7):
+    """retrieve() as one hipGraph replay (single_query.py: padded encode + masked top-k on static buffers) must
+    return exactly what the launch-by-launch path returns - same premises, same scores - for states of every
+    length bucket, repeatedly (buffers are reused), and raise the reference's ValueError alike."""
+    g, z, model, _ = g7
+    rng = np.random.default_rng(5)
+    ctxs = [(q["path"], f"thm{j}", Pos(*q["pos"])) for j, q in enumerate(g["queries"][:6])]
+    states = [synth.synth_state(rng, n) for n in (9, 100, 127, 128, 300, 700, 1023, 1500)]
+    assert model.use_graphs
+    for rep in range(2):
+        for j, st in enumerate(states):
+            path, name, pos = ctxs[j % len(ctxs)]
+            model.use_graphs = True
+            a = model.retrieve(st, path, name, pos, 10)
+            model.use_graphs = False
+            b = model.retrieve(st, path, name, pos, 10)
+            model.use_graphs = True
+            assert [p.full_name for p in a[0]] == [p.full_name for p in b[0]] and a[1] == b[1], (rep, j)
+    assert model._single_query is not None and len(model._single_query._graphs) >= 3  # several buckets captured
+    first = model.corpus.files[0].path
+    with pytest.raises(ValueError):  # nothing is accessible from the first file's first line
+        model.retrieve(states[1], first, "t", Pos(0, 0), 10)
+    # a new embedding matrix invalidates the captured graphs (they hold raw pointers into the old one)
+    old = model.corpus_embeddings
+    model._drop_derived()
+    model.corpus_embeddings = old.flip(0).contiguous()
+    path, name, pos = ctxs[0]
+    a = model.retrieve(states[1], path, name, pos, 10)
+    model.use_graphs = False
+    b = model.retrieve(states[1], path, name, pos, 10)
+    model.use_graphs = True
+    assert [p.full_name for p in a[0]] == [p.full_name for p in b[0]] and a[1] == b[1]
+    model._drop_derived()
+    model.corpus_embeddings = old
 
 
 def test_indexed_corpus_pickle_roundtrip(g7):

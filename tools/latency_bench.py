@@ -8,7 +8,7 @@ from reprover_amd.retrieval.model import PremiseRetriever
 import importlib.util
 spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
 bench = importlib.util.module_from_spec(spec); sys.argv = ["x"]; spec.loader.exec_module(bench)
-dev = torch.device("cuda")
+dev = torch.device("cuda:0")
 cfg = synth.t5_config("byt5-small")
 sd = bench.random_init_state_dict(cfg, dev, 1)
 from reprover_amd.encoder import HipT5Encoder
@@ -25,7 +25,7 @@ lib = _lib.load()
 for sv in [int(x) for x in os.environ.get('SKINNY', '12').split(',')]:
   lib.rp_set_option(b'gemm_skinny_variant', sv)
   print('skinny variant', sv)
-  for nbytes in (100, 300, 1000):
+  for nbytes in [int(x) for x in os.environ.get('NBYTES', '100,300,1000').split(',')]:
       states = [synth.synth_state(rng, nbytes) for _ in range(30)]
       for s in states[:5]:
           model.retrieve(s, "M/F4000.lean", "t", Pos(30, 0), 100)
