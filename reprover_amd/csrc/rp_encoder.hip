@@ -891,11 +891,14 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const bf16_t* __restr
 // ------------------------------------------------------------------------------------------
 constexpr int POOL_CHUNK = 128;
 
+// NV = float4 per lane covering a row (ceil(D / 256)): 6 for d_model 1472 / 1536, 8 up to 2048.  Four token rows of a
+// wave are in flight before the first is consumed (the rows are independent streams: rs comes from rowscale).
+template <int NV>
 __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ rs,
                                                            const int32_t* __restrict__ cu,
                                                            float* __restrict__ partial, int D, int batch) {
-  __shared__ float red[4][RMS_MAX_V4 * 64 * 4];
+  __shared__ float red[4][NV * 64 * 4];
   const int b = find_sequence(cu, batch, blockIdx.x, POOL_CHUNK);  // work id = partial row (see above)
   if (b < 0) return;
   const int s0 = cu[b], len = cu[b + 1] - s0;
@@ -905,40 +908,49 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restri
   const int t1 = min(len, t0 + POOL_CHUNK);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = D >> 2;
-  float4 acc[RMS_MAX_V4];
+  float4 acc[NV];
 #pragma unroll
-  for (int i = 0; i < RMS_MAX_V4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  // rs[token] comes from the last residual epilogue's statistics (rowscale_kernel), so the rows are
-  // independent streams: two tokens' loads are in flight per wave before the first is consumed.
-  // Tokens are accumulated in index order per wave (w, w+4, ...), whatever the unrolling.
-  for (int t = t0 + wave; t < t1; t += 8) {
-    const bool two = t + 4 < t1;
-    const float4* src0 = reinterpret_cast<const float4*>(x + (size_t)(s0 + t) * D);
-    const float4* src1 = reinterpret_cast<const float4*>(x + (size_t)(s0 + (two ? t + 4 : t)) * D);
-    const float r0 = rs[s0 + t], r1 = two ? rs[s0 + t + 4] : 0.f;
-    float4 v0[RMS_MAX_V4], v1[RMS_MAX_V4];
+  for (int i = 0; i < NV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Tokens are accumulated in index order per wave (w, w+4, w+8, ...), whatever the unrolling.
+  constexpr int R = 4;  // rows in flight per wave
+  for (int t = t0 + wave; t < t1; t += 4 * R) {
+    float4 v[R][NV];
+    float r[R];
 #pragma unroll
-    for (int i = 0; i < RMS_MAX_V4; ++i) {
-      const int col = min(lane + 64 * i, nv - 1);  // clamped, unpredicated: keeps the loads in one block
-      v0[i] = src0[col];
-      v1[i] = src1[col];
+    for (int u = 0; u < R; ++u) {
+      const int tu = t + 4 * u;
+      const bool live = tu < t1;
+      const float4* src = reinterpret_cast<const float4*>(x + (size_t)(s0 + (live ? tu : t)) * D);
+      r[u] = live ? rs[s0 + tu] : 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[u][i] = src[min(lane + 64 * i, nv - 1)];  // clamped, unpredicated
     }
 #pragma unroll
-    for (int i = 0; i < RMS_MAX_V4; ++i) {
-      acc[i].x = fmaf(v1[i].x, r1, fmaf(v0[i].x, r0, acc[i].x));
-      acc[i].y = fmaf(v1[i].y, r1, fmaf(v0[i].y, r0, acc[i].y));
-      acc[i].z = fmaf(v1[i].z, r1, fmaf(v0[i].z, r0, acc[i].z));
-      acc[i].w = fmaf(v1[i].w, r1, fmaf(v0[i].w, r0, acc[i].w));
-    }
+    for (int u = 0; u < R; ++u)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        acc[i].x = fmaf(v[u][i].x, r[u], acc[i].x);
+        acc[i].y = fmaf(v[u][i].y, r[u], acc[i].y);
+        acc[i].z = fmaf(v[u][i].z, r[u], acc[i].z);
+        acc[i].w = fmaf(v[u][i].w, r[u], acc[i].w);
+      }
   }
 #pragma unroll
-  for (int i = 0; i < RMS_MAX_V4; ++i) {
+  for (int i = 0; i < NV; ++i) {
     int col = lane + 64 * i;
     if (col < nv) *reinterpret_cast<float4*>(&red[wave][col * 4]) = acc[i];
   }
   __syncthreads();
   float* dst = partial + (size_t)(s0 / POOL_CHUNK + b + c) * D;
   for (int col = threadIdx.x; col < D; col += 256) dst[col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+}
+
+static void launch_pool_partial(dim3 grid, hipStream_t stream, const float* x, const float* rs, const int32_t* cu,
+                                float* partial, int D, int batch) {
+  if (D <= 6 * 256)
+    hipLaunchKernelGGL(pool_partial_kernel<6>, grid, dim3(256), 0, stream, x, rs, cu, partial, D, batch);
+  else
+    hipLaunchKernelGGL(pool_partial_kernel<8>, grid, dim3(256), 0, stream, x, rs, cu, partial, D, batch);
 }
 
 __global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restrict__ partial,
@@ -1333,8 +1345,7 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
   launch_rowscale();  // final RMSNorm statistic
   {
     ProfScope ps(stream, RP_K_POOL);
-    hipLaunchKernelGGL(pool_partial_kernel, dim3(T / POOL_CHUNK + batch), dim3(256), 0, stream, w.x, w.rs, cu_seqlens,
-                       w.pool, D, batch);
+    launch_pool_partial(dim3(T / POOL_CHUNK + batch), stream, w.x, w.rs, cu_seqlens, w.pool, D, batch);
     hipLaunchKernelGGL(pool_finish_kernel, dim3(batch), dim3(256), 0, stream, w.pool, e->final_ln, cu_seqlens, out,
                        out_dtype == RP_DT_BF16 ? 1 : 0, D);
   }
@@ -1414,8 +1425,7 @@ static RpStatus encode_pass_small(RpEncoder* e, const int32_t* ids, const int32_
   }
   {
     ProfScope ps(stream, RP_K_POOL);
-    hipLaunchKernelGGL(pool_partial_kernel, dim3(T / POOL_CHUNK + batch), dim3(256), 0, stream, w.x, w.rs, cu_seqlens,
-                       w.pool, D, batch);
+    launch_pool_partial(dim3(T / POOL_CHUNK + batch), stream, w.x, w.rs, cu_seqlens, w.pool, D, batch);
     hipLaunchKernelGGL(pool_finish_kernel, dim3(batch), dim3(256), 0, stream, w.pool, e->final_ln, cu_seqlens, out,
                        out_dtype == RP_DT_BF16 ? 1 : 0, D);
   }
