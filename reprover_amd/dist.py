@@ -67,6 +67,12 @@ class IndexShard:
     def __len__(self) -> int:
         return self.hi - self.lo
 
+    def quantize(self) -> None:
+        """Derive the e4m3 form of this shard's rows (``PremiseRetriever(index_dtype="fp8")`` under sharding)."""
+        from .common import Fp8Index
+
+        self.fp8 = Fp8Index.quantize(self.embeddings, self.device)
+
 
 def reindex_shard(retriever, shard: IndexShard) -> None:
     """This rank's part of ``reindex_corpus`` (retrieval/model.py:183-210): encode premises
@@ -81,9 +87,13 @@ def reindex_shard(retriever, shard: IndexShard) -> None:
 
 
 def hip_local_topk(shard: IndexShard, batch_context: Sequence[Context], query_emb: torch.Tensor, k: int) -> TopK:
-    """Masked top-k of all queries against this rank's rows (global ids), on the GPU."""
+    """Masked top-k of all queries against this rank's rows (global ids), on the GPU.  ``shard.fp8`` (an
+    ``Fp8Index`` of the shard's rows, set by ``IndexShard.quantize``) switches the scan to the e4m3 form."""
     lib = _lib.load()
     dev = query_emb.device
+    fp8 = getattr(shard, "fp8", None)
+    if fp8 is not None:
+        return _hip_local_topk_fp8(shard, fp8, batch_context, query_emb, k)
     E = as_bf16_matrix(shard.embeddings, dev)
     Q = as_bf16_matrix(query_emb, dev)
     B, D = Q.shape
@@ -112,6 +122,36 @@ def hip_local_topk(shard: IndexShard, batch_context: Sequence[Context], query_em
     # merge (merge_keys treats a negative count as "no candidates").
     if bool((out_c < 0).any()):
         scan(_lib.RP_TOPK_DENSE)
+    return out_i, out_s, out_c
+
+
+def _hip_local_topk_fp8(shard: IndexShard, fp8, batch_context: Sequence[Context], query_emb: torch.Tensor, k: int) -> TopK:
+    from .common import Fp8Index
+
+    lib = _lib.load()
+    dev = query_emb.device
+    Q = Fp8Index.quantize(query_emb)
+    B, D = Q.shape
+    bits_t, own, qk = shard.corpus.query_masks(batch_context)
+    d_bits = torch.from_numpy(bits_t.view(np.int32)).to(dev)
+    d_own, d_qk = torch.from_numpy(own).to(dev), torch.from_numpy(qk).to(dev)
+    out_s = torch.empty((B, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((B, k), dtype=torch.int32, device=dev)
+    out_c = torch.empty((B,), dtype=torch.int32, device=dev)
+    for flags in (_lib.RP_TOPK_AUTO, _lib.RP_TOPK_DENSE):
+        nbytes = lib.rp_sim_topk_workspace_bytes(B, len(shard), D, k, flags)
+        ws = _workspace(dev, nbytes)
+        _lib.check(
+            lib.rp_sim_topk_fp8(
+                _lib.ptr(Q.codes), _lib.ptr(Q.scale), _lib.ptr(fp8.codes), _lib.ptr(fp8.scale), B, len(shard), D,
+                _lib.ptr(shard.file_of), _lib.ptr(shard.end_key), _lib.ptr(d_bits), shard.corpus.num_files, _lib.ptr(d_own),
+                _lib.ptr(d_qk), shard.lo, k, flags, _lib.ptr(out_s), _lib.ptr(out_i), _lib.ptr(out_c), _lib.ptr(ws),
+                nbytes, _lib.current_stream(),
+            ),
+            "rp_sim_topk_fp8",
+        )
+        if not bool((out_c < 0).any()):  # -1 = candidate overflow (reserved by the ABI): redo densely
+            break
     return out_i, out_s, out_c
 
 

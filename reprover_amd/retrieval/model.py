@@ -72,7 +72,11 @@ class PremiseRetriever:
     # -- construction (model.py:52-66) --------------------------------------------------------------
     @classmethod
     def load_hf(cls, ckpt_path: str, max_seq_len: int, device, dtype=None) -> "PremiseRetriever":
-        """``dtype`` None → bf16, the reference's own choice on a capable GPU (model.py:59-64)."""
+        """``dtype`` None → bf16, the reference's own choice on a capable GPU (model.py:59-64).  ``dtype`` selects
+        the dtype of the embeddings handed back (``corpus_embeddings``, ``_encode``); the arithmetic is the same for
+        both values - bf16 MFMA operands, fp32 accumulation / residual stream / statistics - where the reference
+        with ``dtype=float32`` would also multiply in fp32.  ``retrieve`` / ``num_retrieved`` accept k <= 1024 (the
+        final selection sorts in LDS); the reference accepts any k."""
         return cls(ckpt_path, 0.0, 0, max_seq_len, 100, device=device, dtype=dtype or torch.bfloat16)
 
     @classmethod
@@ -232,6 +236,8 @@ class PremiseRetriever:
             bounds = rdist.shard_bounds(rdist.premise_token_counts(corpus, self.max_seq_len), dist.get_world_size())
             self.index_shard = rdist.IndexShard(corpus, bounds, dist.get_rank(), self.device)
             rdist.reindex_shard(self, self.index_shard)
+            if self.index_dtype == "fp8":
+                self.index_shard.quantize()  # the sharded search then scans the e4m3 form, like the single-GPU one
             return
         self.reindex_corpus(eval_batch_size)
 
