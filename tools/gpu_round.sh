@@ -6,7 +6,8 @@ mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
 KEXPR="${KEXPR:-}"
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt
-for f in test_kernels_gpu test_fp8_gpu test_encoder_gpu test_edge_cases_gpu test_retriever_gpu test_cli_gpu; do
+: > gpurun_out/pytest.log
+for f in test_kernels_gpu test_fp8_gpu test_encoder_gpu test_edge_cases_gpu test_retriever_gpu test_cli_gpu test_train_forward; do
   echo "=== $f" | tee -a gpurun_out/pytest.log
   if [ -n "$KEXPR" ]; then
     timeout 1200 python -m pytest tests/$f.py -m gpu -q --tb=short -s -k "$KEXPR" 2>&1 | tail -150 | tee -a gpurun_out/pytest.log
@@ -14,6 +15,8 @@ for f in test_kernels_gpu test_fp8_gpu test_encoder_gpu test_edge_cases_gpu test
     timeout 1200 python -m pytest tests/$f.py -m gpu -q --tb=short -s 2>&1 | tail -150 | tee -a gpurun_out/pytest.log
   fi
 done
+echo "=== all at once (the driver's command)" | tee -a gpurun_out/pytest.log
+timeout 1800 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -5 | tee -a gpurun_out/pytest.log
 echo "=== smoke" | tee -a gpurun_out/pytest.log
 timeout 600 python __graft_entry__.py smoke 2>&1 | tail -20 | tee gpurun_out/smoke.log
 echo "=== bench" 
