@@ -20,6 +20,11 @@ for name, N, K, epi in shapes:
         continue
     A = (torch.randn(M, K, generator=g, device=dev)).to(torch.bfloat16)
     W = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.bfloat16)
+    fill = os.environ.get("FILL", "random")  # DVFS check: the same kernel on zero / sign-constant operands
+    if fill == "zero":
+        A.zero_(); W.zero_()
+    elif fill == "abs":
+        A = A.abs(); W = W.abs()
     CH = M if M <= 4096 else 256
     ref = A[:CH].float() @ W.float().T
     if epi == _lib.RP_EPI_RESID_F32:
