@@ -245,8 +245,10 @@ RpStatus rp_dbg_gemm(const void* A, const void* W, void* out, int32_t M, int32_t
 RpStatus rp_dbg_gemm_fused(const void* A, const void* W, void* out, int32_t M, int32_t N, int32_t K,
                            int32_t n_valid, int32_t epilogue, const float* ssp_in, int32_t np_in, float inv_d,
                            float eps, void* xb_out, float* ssp_out, int32_t np_out, void* stream);
-RpStatus rp_dbg_rmsnorm(const float* x, const float* w, void* out_bf16, int32_t rows, int32_t D,
-                        float eps, void* stream);
+/* The T5 RMSNorm statistic as the product computes it (there is no separate normalisation pass): rs[row] =
+ * rsqrt(sum_p ssp[p, row] * inv_d + eps) from the slot-major partial sums of squares the residual epilogues emit. */
+RpStatus rp_dbg_rowscale(const float* ssp /* [np, rows] */, float* rs /* [rows] */, int32_t rows, int32_t np,
+                         float inv_d, float eps, void* stream);
 RpStatus rp_dbg_attention(const void* qkv_bf16, const int32_t* cu_seqlens, const float* bias_tab,
                           void* out_bf16, int32_t batch, int32_t max_len, int32_t num_heads,
                           int32_t rows_total, void* stream);

@@ -171,48 +171,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ 
   if (rs_out && lane == 0) rs_out[row] = rsqrtf(ss / (float)D + eps);  // few-token schedule: no rowscale launch
 }
 
-// ------------------------------------------------------------------------------------------
-// K2: T5 RMSNorm  h = w * x * rsqrt(mean(x^2) + eps)  (HF:59-72), fp32 in, bf16 out.
-//   One wave per row; the row (<= 8 float4 per lane, D <= 2048) stays in registers between the
-//   reduction and the scaled store, so x is read exactly once.
-// ------------------------------------------------------------------------------------------
-constexpr int RMS_MAX_V4 = 8;
-
-__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x,
-                                                      const float* __restrict__ w,
-                                                      bf16_t* __restrict__ h, int rows, int D,
-                                                      float eps) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const float4* src = reinterpret_cast<const float4*>(x + (size_t)row * D);
-  const int nv = D >> 2;
-  float4 v[RMS_MAX_V4];
-  float ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < RMS_MAX_V4; ++i) {
-    int c = lane + 64 * i;
-    if (c < nv) {
-      v[i] = src[c];
-      ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
-    }
-  }
-  ss = wave_sum(ss);
-  const float rs = rsqrtf(ss / (float)D + eps);
-  const float4* w4 = reinterpret_cast<const float4*>(w);
-  uint2* dst = reinterpret_cast<uint2*>(h + (size_t)row * D);
-#pragma unroll
-  for (int i = 0; i < RMS_MAX_V4; ++i) {
-    int c = lane + 64 * i;
-    if (c < nv) {
-      float4 g = w4[c];
-      uint2 o;
-      o.x = pack_bf2(v[i].x * rs * g.x, v[i].y * rs * g.y);
-      o.y = pack_bf2(v[i].z * rs * g.z, v[i].w * rs * g.w);
-      dst[c] = o;
-    }
-  }
-}
+constexpr int RMS_MAX_V4 = 8;  // a row is at most 8 float4 per lane of a wave: d_model <= 2048
 
 // ------------------------------------------------------------------------------------------
 // K3/K6/K7/K8: GEMM epilogues
@@ -662,10 +621,9 @@ constexpr int ATT_TAB_MAX = 1024;  // max table entries (2*max_distance+1)
 //     with tools/probes/tr_probe.hip); 4 rows x 64 B = one 256-B bank row: conflict-free;
 //   * K is staged with the GEMM's XOR swizzle (slot ^= (row >> 1) & 7 on the DMA source address);
 //   * waves whose 32 queries lie past the sequence end only help with the DMA;
-//   * work list without a prefix-sum pass: query block q of sequence b is workgroup
-//     cu[b] / 128 + b + q (strictly increasing in b, at most T/128 + B ids in all), and a workgroup
-//     finds its b with two block-wide counting rounds over cu.  A (max_len/128) x B grid would launch
-//     ~6 empty workgroups per useful one on the benchmark's length mix.
+//   * one workgroup per entry of the pass's work list (attention_worklist_kernel below: 128-query blocks, longest
+//     sequence first; at most T/128 + B entries).  A (max_len/128) x B grid would launch ~6 empty workgroups per
+//     useful one on the benchmark's length mix.
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) short v4s16;
 constexpr int AT2_K_BYTES = 64 * 128, AT2_V_BYTES = 64 * 128, AT2_STAGE = AT2_K_BYTES + AT2_V_BYTES;
@@ -685,22 +643,50 @@ __device__ __forceinline__ int find_sequence(const int32_t* __restrict__ cu, int
   return first + n2 - 1;
 }
 
+// Work list of one encoder pass, built once and used by all layers: entry = {first token of the sequence, its length,
+// first query of the block, 0}, one per 128-query block, ordered by DESCENDING key count (buckets of 64 keys, longest
+// first; inside a bucket by sequence, then block).  A block's cost grows with its sequence's length (32 key tiles at
+// 2048 tokens against 1-2 for a short state), and the grid is a few rounds deep: dispatched in corpus order, a long
+// sequence met late kept a handful of CUs busy long after everything else had finished; longest-first closes that
+// tail.  It also replaces the two block-wide counting rounds every workgroup of every layer spent finding its sequence.
+// Entries beyond the live count have length 0.  One workgroup of 64 threads, thread k owns bucket k.
+constexpr int ATT_BUCKETS = 64;
+__global__ __launch_bounds__(64) void attention_worklist_kernel(const int32_t* __restrict__ cu, int batch,
+                                                                int4* __restrict__ work, int n_slots) {
+  __shared__ int s_cnt[ATT_BUCKETS];
+  const int k = threadIdx.x;  // bucket k holds sequences of (k, k+1] * 64 keys; bucket 63 everything longer
+  auto bucket_of = [](int len) { return min((len - 1) >> 6, ATT_BUCKETS - 1); };
+  int mine = 0;
+  for (int b = 0; b < batch; ++b) {
+    const int len = cu[b + 1] - cu[b];
+    if (len > 0 && bucket_of(len) == k) mine += (len + ATT_Q - 1) / ATT_Q;
+  }
+  s_cnt[k] = mine;
+  __syncthreads();
+  int pos = 0;  // blocks of all longer buckets come first
+  for (int j = ATT_BUCKETS - 1; j > k; --j) pos += s_cnt[j];
+  for (int b = 0; b < batch; ++b) {
+    const int s0 = cu[b], len = cu[b + 1] - s0;
+    if (len > 0 && bucket_of(len) == k)
+      for (int q0 = 0; q0 < len; q0 += ATT_Q) work[pos++] = make_int4(s0, len, q0, 0);
+  }
+  if (k == 0) {  // k = 0 is the last bucket: pos is the live count
+    for (int i = pos; i < n_slots; ++i) work[i] = make_int4(0, 0, 0, 0);
+  }
+}
+
 __global__ __launch_bounds__(256, 4) void attention_kernel(const bf16_t* __restrict__ qkv,
-                                                         const int32_t* __restrict__ cu,
+                                                         const int4* __restrict__ work,
                                                          const float* __restrict__ bias_tab,
-                                                        bf16_t* __restrict__ out, int H, int maxd,
-                                                        int batch) {
+                                                        bf16_t* __restrict__ out, int H, int maxd) {
   __shared__ __attribute__((aligned(16))) char smem[2 * AT2_STAGE + ATT_TAB_MAX * 4];
   float* tab = reinterpret_cast<float*>(smem + 2 * AT2_STAGE);
 
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, cl = lane & 31;
-  const int g = blockIdx.x, h = blockIdx.y;
-  const int b = find_sequence(cu, batch, g, ATT_Q);
-  if (b < 0) return;
-  const int s0 = cu[b];
-  const int len = cu[b + 1] - s0;
-  const int q0 = (g - (s0 / ATT_Q + b)) * ATT_Q;
-  if (q0 >= len) return;
+  const int h = blockIdx.y;
+  const int4 wk = work[blockIdx.x];
+  const int s0 = wk.x, len = wk.y, q0 = wk.z;
+  if (len == 0) return;
 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int inner = H * 64, ld = 3 * inner;
@@ -1234,6 +1220,7 @@ struct Workspace {
   float* ssp;   // [Tp, ceil(D/64)] per-row partial sums of squares of x
   float* rs;    // [Tp] rsqrt(mean(x^2) + eps)
   float* pool;  // [Tp / 128 + batch, D] partial column sums of the pooling pass
+  int4* work;   // [Tp / 128 + batch] attention work list of the pass (attention_worklist_kernel)
   float* part;  // few-token schedule: split-K partial tiles [S, rows, features] (NULL otherwise)
   size_t part_floats;
   size_t bytes;
@@ -1271,6 +1258,7 @@ Workspace carve(const RpEncoder* e, int T, int batch, char* base) {
   w.att = (bf16_t*)take(Tp * inner * 2);
   w.ff = (bf16_t*)take(Tp * F * 2);
   w.pool = (float*)take((Tp / POOL_CHUNK + (size_t)batch + 1) * D * 4);
+  w.work = (int4*)take((Tp / ATT_Q + (size_t)batch + 1) * sizeof(int4));
   w.part = nullptr;
   w.part_floats = 0;
   if (small_schedule(T)) {
@@ -1316,7 +1304,8 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
                        Tp, D, c.vocab_size, t_dev, (float*)nullptr, 0.f);
   }
   RP_CHECK_LAUNCH();
-  const dim3 att_grid(T / ATT_Q + batch, H);  // upper bound of the work ids (see attention_kernel)
+  const dim3 att_grid(T / ATT_Q + batch, H);  // upper bound of the number of 128-query blocks
+  hipLaunchKernelGGL(attention_worklist_kernel, dim3(1), dim3(64), 0, stream, cu_seqlens, batch, w.work, (int)att_grid.x);
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerPacked& L = e->layers[i];
     // attention sub-layer: qkv = rs * (xb Wqkv'^T)  ->  attention  ->  x += att Wo^T  (+ xb, ssp refreshed)
@@ -1326,8 +1315,8 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
       return st;
     {
       ProfScope ps(stream, RP_K_ATTENTION);
-      hipLaunchKernelGGL(attention_kernel, att_grid, dim3(256), 0, stream, w.qkv,
-                         cu_seqlens, e->bias_tab, w.att, H, e->maxd, batch);
+      hipLaunchKernelGGL(attention_kernel, att_grid, dim3(256), 0, stream, w.qkv, (const int4*)w.work, e->bias_tab, w.att,
+                         H, e->maxd);
     }
     if ((st = launch_gemm(w.att, inner, Tp, L.wo, inner, D, inner, EpiResidF32{w.x, D, D, w.xb, w.ssp, np, Tp}, stream,
                           RP_K_GEMM_O, tv, t_dev)))
@@ -1386,6 +1375,7 @@ static RpStatus encode_pass_small(RpEncoder* e, const int32_t* ids, const int32_
                        Tp, D, c.vocab_size, t_dev, w.rs, eps);
   }
   const dim3 att_grid(T / ATT_Q + batch, H);
+  hipLaunchKernelGGL(attention_worklist_kernel, dim3(1), dim3(64), 0, stream, cu_seqlens, batch, w.work, (int)att_grid.x);
   int S, ld;
   size_t stride;
   for (int i = 0; i < c.num_layers; ++i) {
@@ -1399,8 +1389,8 @@ static RpStatus encode_pass_small(RpEncoder* e, const int32_t* ids, const int32_
     }
     {
       ProfScope ps(stream, RP_K_ATTENTION);
-      hipLaunchKernelGGL(attention_kernel, att_grid, dim3(256), 0, stream, w.qkv, cu_seqlens, e->bias_tab, w.att, H,
-                         e->maxd, batch);
+      hipLaunchKernelGGL(attention_kernel, att_grid, dim3(256), 0, stream, w.qkv, (const int4*)w.work, e->bias_tab, w.att,
+                         H, e->maxd);
     }
     project(w.att, inner, L.wo, D, inner, RP_K_GEMM_O, S, ld, stride);
     {
@@ -1635,11 +1625,11 @@ extern "C" RpStatus rp_dbg_gemm_fused(const void* A, const void* W, void* out, i
   return fail(RP_E_INVALID, "unknown epilogue %d", epilogue);
 }
 
-extern "C" RpStatus rp_dbg_rmsnorm(const float* x, const float* w, void* out_bf16, int32_t rows, int32_t D,
-                                   float eps, void* stream_) {
-  RP_REQUIRE(D % 4 == 0 && D <= RMS_MAX_V4 * 256, "D=%d", D);
-  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream_, x, w,
-                     (bf16_t*)out_bf16, rows, D, eps);
+extern "C" RpStatus rp_dbg_rowscale(const float* ssp, float* rs, int32_t rows, int32_t np, float inv_d, float eps,
+                                    void* stream_) {
+  RP_REQUIRE(ssp && rs && rows > 0 && np > 0 && np <= 32, "rows=%d np=%d", rows, np);
+  hipLaunchKernelGGL(rowscale_kernel, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream_, ssp, rs, rows, np, inv_d,
+                     eps);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
@@ -1648,10 +1638,16 @@ extern "C" RpStatus rp_dbg_attention(const void* qkv, const int32_t* cu, const f
                                      int32_t batch, int32_t max_len, int32_t H, int32_t rows_total, void* stream_) {
   const int maxd = 128;
   (void)max_len;
+  hipStream_t stream = (hipStream_t)stream_;
   const dim3 grid(rows_total / ATT_Q + batch, H);  // rows_total >= the packed token count
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)qkv, cu, bias_tab,
-                     (bf16_t*)out, H, maxd, batch);
-  RP_CHECK_LAUNCH();
+  int4* work = nullptr;  // test entry only: a stream-ordered scratch allocation is fine here
+  RP_HIP(hipMallocAsync((void**)&work, (size_t)grid.x * sizeof(int4), stream));
+  hipLaunchKernelGGL(attention_worklist_kernel, dim3(1), dim3(64), 0, stream, cu, batch, work, (int)grid.x);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, stream, (const bf16_t*)qkv, (const int4*)work, bias_tab,
+                     (bf16_t*)out, H, maxd);
+  const hipError_t le = hipGetLastError();
+  (void)hipFreeAsync(work, stream);
+  if (le != hipSuccess) return rp::fail(RP_E_HIP, "attention launch failed: %s", hipGetErrorString(le));
   return RP_OK;
 }
 

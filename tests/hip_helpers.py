@@ -20,13 +20,15 @@ def gemm(A, W, n_valid, epilogue, out):
     return out
 
 
-def rmsnorm(x, w, eps=1e-6):
+def rowscale(ssp, inv_d, eps=1e-6):
+    """rs [rows] from slot-major partial sums of squares ssp [np, rows] (rowscale_kernel, as the encoder runs it)."""
     lib = _lib.load()
-    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    _lib.check(lib.rp_dbg_rmsnorm(_lib.ptr(x), _lib.ptr(w), _lib.ptr(out), x.shape[0], x.shape[1], eps,
-                                  _lib.current_stream()), "rp_dbg_rmsnorm")
+    np_, rows = ssp.shape
+    rs = torch.empty(rows, dtype=torch.float32, device=ssp.device)
+    _lib.check(lib.rp_dbg_rowscale(_lib.ptr(ssp), _lib.ptr(rs), rows, np_, inv_d, eps, _lib.current_stream()),
+               "rp_dbg_rowscale")
     torch.cuda.synchronize()
-    return out
+    return rs
 
 
 def attention(qkv, cu, tab, H):
