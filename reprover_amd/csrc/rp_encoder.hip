@@ -621,27 +621,12 @@ constexpr int ATT_TAB_MAX = 1024;  // max table entries (2*max_distance+1)
 //     with tools/probes/tr_probe.hip); 4 rows x 64 B = one 256-B bank row: conflict-free;
 //   * K is staged with the GEMM's XOR swizzle (slot ^= (row >> 1) & 7 on the DMA source address);
 //   * waves whose 32 queries lie past the sequence end only help with the DMA;
-//   * one workgroup per entry of the pass's work list (attention_worklist_kernel below: 128-query blocks, longest
+//   * one workgroup per entry of the pass's work list (worklist_kernel below: 128-query blocks, longest
 //     sequence first; at most T/128 + B entries).  A (max_len/128) x B grid would launch ~6 empty workgroups per
 //     useful one on the benchmark's length mix.
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) short v4s16;
 constexpr int AT2_K_BYTES = 64 * 128, AT2_V_BYTES = 64 * 128, AT2_STAGE = AT2_K_BYTES + AT2_V_BYTES;
-
-// Which sequence owns work id g of a "cu[b] / chunk + b + index" numbering (increasing in b)?  Two
-// block-wide counting rounds over cu: every stride-th sequence, then inside the stride that was hit.
-// Returns -1 (uniformly) for an id below the first sequence's base; 256 threads.
-__device__ __forceinline__ int find_sequence(const int32_t* __restrict__ cu, int batch, int g, int chunk) {
-  const int tid = threadIdx.x;
-  const int stride = (batch + 255) / 256;
-  int c = tid * stride;
-  const int n1 = __syncthreads_count(c < batch && cu[min(c, batch - 1)] / chunk + c <= g);
-  if (n1 == 0) return -1;
-  const int first = (n1 - 1) * stride;
-  c = first + tid;
-  const int n2 = __syncthreads_count(tid < stride && c < batch && cu[min(c, batch - 1)] / chunk + c <= g);
-  return first + n2 - 1;
-}
 
 // Work list of one encoder pass, built once and used by all layers: entry = {first token of the sequence, its length,
 // first query of the block, 0}, one per 128-query block, ordered by DESCENDING key count (buckets of 64 keys, longest
@@ -649,30 +634,49 @@ __device__ __forceinline__ int find_sequence(const int32_t* __restrict__ cu, int
 // 2048 tokens against 1-2 for a short state), and the grid is a few rounds deep: dispatched in corpus order, a long
 // sequence met late kept a handful of CUs busy long after everything else had finished; longest-first closes that
 // tail.  It also replaces the two block-wide counting rounds every workgroup of every layer spent finding its sequence.
-// Entries beyond the live count have length 0.  One workgroup of 64 threads, thread k owns bucket k.
+// Entries beyond the live count have length 0.  One workgroup; a counting sort over 64 length buckets in LDS.
 constexpr int ATT_BUCKETS = 64;
-__global__ __launch_bounds__(64) void attention_worklist_kernel(const int32_t* __restrict__ cu, int batch,
-                                                                int4* __restrict__ work, int n_slots) {
-  __shared__ int s_cnt[ATT_BUCKETS];
-  const int k = threadIdx.x;  // bucket k holds sequences of (k, k+1] * 64 keys; bucket 63 everything longer
+constexpr int POOL_CHUNK = 64;  // tokens per workgroup of the pooling pass (see pool_kernel)
+// The same launch lays out the pooling pass's list: chunk c of sequence b is entry cu[b] / 64 + b + c = {first token,
+// length, c, b} (strictly increasing in b, at most T/64 + B entries; a gap entry has length 0).
+__global__ __launch_bounds__(1024) void worklist_kernel(const int32_t* __restrict__ cu, int batch,
+                                                        int4* __restrict__ work, int n_slots,
+                                                        int4* __restrict__ pwork, int n_pslots) {
+  __shared__ int s_cnt[ATT_BUCKETS], s_pos[ATT_BUCKETS], s_live;
+  const int tid = threadIdx.x;
+  // bucket k holds sequences of (k, k+1] * 64 keys; the last one everything longer
   auto bucket_of = [](int len) { return min((len - 1) >> 6, ATT_BUCKETS - 1); };
-  int mine = 0;
-  for (int b = 0; b < batch; ++b) {
-    const int len = cu[b + 1] - cu[b];
-    if (len > 0 && bucket_of(len) == k) mine += (len + ATT_Q - 1) / ATT_Q;
-  }
-  s_cnt[k] = mine;
+  if (tid < ATT_BUCKETS) s_cnt[tid] = 0;
   __syncthreads();
-  int pos = 0;  // blocks of all longer buckets come first
-  for (int j = ATT_BUCKETS - 1; j > k; --j) pos += s_cnt[j];
-  for (int b = 0; b < batch; ++b) {
-    const int s0 = cu[b], len = cu[b + 1] - s0;
-    if (len > 0 && bucket_of(len) == k)
-      for (int q0 = 0; q0 < len; q0 += ATT_Q) work[pos++] = make_int4(s0, len, q0, 0);
+  for (int b = tid; b < batch; b += 1024) {
+    const int len = cu[b + 1] - cu[b];
+    if (len > 0) atomicAdd(&s_cnt[bucket_of(len)], (len + ATT_Q - 1) / ATT_Q);
   }
-  if (k == 0) {  // k = 0 is the last bucket: pos is the live count
-    for (int i = pos; i < n_slots; ++i) work[i] = make_int4(0, 0, 0, 0);
+  __syncthreads();
+  if (tid < ATT_BUCKETS) {  // blocks of all longer buckets come first
+    int pos = 0;
+    for (int j = ATT_BUCKETS - 1; j > tid; --j) pos += s_cnt[j];
+    s_pos[tid] = pos;
+    if (tid == 0) s_live = pos + s_cnt[0];
   }
+  __syncthreads();
+  // the order INSIDE a bucket is whatever the atomics give: every block's result is independent of its position
+  for (int b = tid; b < batch; b += 1024) {
+    const int s0 = cu[b], s1 = cu[b + 1], len = s1 - s0;
+    const int pbase = s0 / POOL_CHUNK + b;
+    const int pnext = (b + 1 < batch) ? s1 / POOL_CHUNK + b + 1 : n_pslots;
+    int c = 0;
+    for (; c * POOL_CHUNK < len; ++c) pwork[pbase + c] = make_int4(s0, len, c, b);
+    for (int i = pbase + c; i < pnext; ++i) pwork[i] = make_int4(0, 0, 0, 0);
+    if (b == 0)
+      for (int i = 0; i < pbase; ++i) pwork[i] = make_int4(0, 0, 0, 0);  // cu[0] is 0 in every caller; kept general
+    if (len <= 0) continue;
+    int pos = atomicAdd(&s_pos[bucket_of(len)], (len + ATT_Q - 1) / ATT_Q);
+    for (int q0 = 0; q0 < len; q0 += ATT_Q) work[pos++] = make_int4(s0, len, q0, 0);
+  }
+  for (int i = s_live + tid; i < n_slots; i += 1024) work[i] = make_int4(0, 0, 0, 0);
+  if (batch == 0)
+    for (int i = tid; i < n_pslots; i += 1024) pwork[i] = make_int4(0, 0, 0, 0);
 }
 
 __global__ __launch_bounds__(256, 4) void attention_kernel(const bf16_t* __restrict__ qkv,
@@ -868,29 +872,32 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const bf16_t* __restr
 // K2(final)+K9+K10: final RMSNorm, masked mean over the sequence's tokens, L2 normalise.
 //   mean_t(w * x_t * rs_t) = w * mean_t(x_t * rs_t); e / max(||e||, 1e-12)  (model.py:108-114)
 //   Two deterministic passes (no atomics, so results are bit-reproducible whatever the batch):
-//   pool_partial_kernel: one workgroup per 128-token chunk of a sequence; wave w takes tokens
-//     w, w+4, ...; rs_t from the last residual epilogue's statistics (as for every other RMSNorm);
-//     per-lane partial column sums of x_t * rs_t in registers, combined through LDS,
-//     written to partial[chunk_base(b) + c][D]   (chunk_base(b) = cu[b] / 128 + b);
-//   pool_finish_kernel: one workgroup per sequence sums its chunks in order, applies w / len and
-//     the L2 normalisation.
+//   pool_partial_kernel: one workgroup per 64-token chunk of a sequence (the pass's list, worklist_kernel); wave w
+//     takes tokens w, w+4, ...; rs_t from the last residual epilogue's statistics (as for every other RMSNorm);
+//     per-lane partial column sums of x_t * rs_t in registers, combined through LDS, written to
+//     partial[chunk_base(b) + c][D]   (chunk_base(b) = cu[b] / 64 + b);
+//   pool_finish_kernel: one workgroup per sequence sums its chunks in order, applies w / len and the L2
+//     normalisation.
+//   64-token chunks because the chunks are unequal (the benchmark's sequences are 16..2048 tokens, most of them
+//   short): with 128-token chunks every workgroup of the pass was resident at once, nothing was left to balance the
+//   CUs that drew three full chunks against those that drew three stubs, and the pass ran at the pace of the former
+//   (51 % of the HBM peak for a plain streaming read).
+//   (Tried: the finish done by whichever workgroup arrives last at a per-sequence counter, one launch instead of
+//   two.  The device-scope release fence that makes the other chunks' sums visible across XCDs writes back the whole
+//   L2, which at this point holds the last layer's residual stream: 0.13 -> 0.45 ms per pass.)
 // ------------------------------------------------------------------------------------------
-constexpr int POOL_CHUNK = 128;
 
 // NV = float4 per lane covering a row (ceil(D / 256)): 6 for d_model 1472 / 1536, 8 up to 2048.  Four token rows of a
 // wave are in flight before the first is consumed (the rows are independent streams: rs comes from rowscale).
 template <int NV>
-__global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restrict__ x,
-                                                           const float* __restrict__ rs,
-                                                           const int32_t* __restrict__ cu,
-                                                           float* __restrict__ partial, int D, int batch) {
+__global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restrict__ x, const float* __restrict__ rs,
+                                                           const int4* __restrict__ pwork,
+                                                           float* __restrict__ partial, int D) {
   __shared__ float red[4][NV * 64 * 4];
-  const int b = find_sequence(cu, batch, blockIdx.x, POOL_CHUNK);  // work id = partial row (see above)
-  if (b < 0) return;
-  const int s0 = cu[b], len = cu[b + 1] - s0;
-  const int c = blockIdx.x - (s0 / POOL_CHUNK + b);
+  const int4 wk = pwork[blockIdx.x];
+  const int s0 = wk.x, len = wk.y, c = wk.z, b = wk.w;
+  if (len == 0) return;
   const int t0 = c * POOL_CHUNK;
-  if (t0 >= len) return;
   const int t1 = min(len, t0 + POOL_CHUNK);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = D >> 2;
@@ -931,12 +938,12 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restri
   for (int col = threadIdx.x; col < D; col += 256) dst[col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
 
-static void launch_pool_partial(dim3 grid, hipStream_t stream, const float* x, const float* rs, const int32_t* cu,
-                                float* partial, int D, int batch) {
+static void launch_pool_partial(dim3 grid, hipStream_t stream, const float* x, const float* rs, const int4* pwork,
+                                float* partial, int D) {
   if (D <= 6 * 256)
-    hipLaunchKernelGGL(pool_partial_kernel<6>, grid, dim3(256), 0, stream, x, rs, cu, partial, D, batch);
+    hipLaunchKernelGGL(pool_partial_kernel<6>, grid, dim3(256), 0, stream, x, rs, pwork, partial, D);
   else
-    hipLaunchKernelGGL(pool_partial_kernel<8>, grid, dim3(256), 0, stream, x, rs, cu, partial, D, batch);
+    hipLaunchKernelGGL(pool_partial_kernel<8>, grid, dim3(256), 0, stream, x, rs, pwork, partial, D);
 }
 
 __global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restrict__ partial,
@@ -1220,7 +1227,8 @@ struct Workspace {
   float* ssp;   // [Tp, ceil(D/64)] per-row partial sums of squares of x
   float* rs;    // [Tp] rsqrt(mean(x^2) + eps)
   float* pool;  // [Tp / 128 + batch, D] partial column sums of the pooling pass
-  int4* work;   // [Tp / 128 + batch] attention work list of the pass (attention_worklist_kernel)
+  int4* work;   // [Tp / 128 + batch] attention work list of the pass (worklist_kernel)
+  int4* pwork;  // [Tp / 64 + batch] pooling work list
   float* part;  // few-token schedule: split-K partial tiles [S, rows, features] (NULL otherwise)
   size_t part_floats;
   size_t bytes;
@@ -1259,6 +1267,7 @@ Workspace carve(const RpEncoder* e, int T, int batch, char* base) {
   w.ff = (bf16_t*)take(Tp * F * 2);
   w.pool = (float*)take((Tp / POOL_CHUNK + (size_t)batch + 1) * D * 4);
   w.work = (int4*)take((Tp / ATT_Q + (size_t)batch + 1) * sizeof(int4));
+  w.pwork = (int4*)take((Tp / POOL_CHUNK + (size_t)batch + 1) * sizeof(int4));
   w.part = nullptr;
   w.part_floats = 0;
   if (small_schedule(T)) {
@@ -1305,7 +1314,8 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
   }
   RP_CHECK_LAUNCH();
   const dim3 att_grid(T / ATT_Q + batch, H);  // upper bound of the number of 128-query blocks
-  hipLaunchKernelGGL(attention_worklist_kernel, dim3(1), dim3(64), 0, stream, cu_seqlens, batch, w.work, (int)att_grid.x);
+  hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu_seqlens, batch, w.work, (int)att_grid.x, w.pwork,
+                     T / POOL_CHUNK + batch);
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerPacked& L = e->layers[i];
     // attention sub-layer: qkv = rs * (xb Wqkv'^T)  ->  attention  ->  x += att Wo^T  (+ xb, ssp refreshed)
@@ -1334,7 +1344,7 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
   launch_rowscale();  // final RMSNorm statistic
   {
     ProfScope ps(stream, RP_K_POOL);
-    launch_pool_partial(dim3(T / POOL_CHUNK + batch), stream, w.x, w.rs, cu_seqlens, w.pool, D, batch);
+    launch_pool_partial(dim3(T / POOL_CHUNK + batch), stream, w.x, w.rs, (const int4*)w.pwork, w.pool, D);
     hipLaunchKernelGGL(pool_finish_kernel, dim3(batch), dim3(256), 0, stream, w.pool, e->final_ln, cu_seqlens, out,
                        out_dtype == RP_DT_BF16 ? 1 : 0, D);
   }
@@ -1375,7 +1385,8 @@ static RpStatus encode_pass_small(RpEncoder* e, const int32_t* ids, const int32_
                        Tp, D, c.vocab_size, t_dev, w.rs, eps);
   }
   const dim3 att_grid(T / ATT_Q + batch, H);
-  hipLaunchKernelGGL(attention_worklist_kernel, dim3(1), dim3(64), 0, stream, cu_seqlens, batch, w.work, (int)att_grid.x);
+  hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu_seqlens, batch, w.work, (int)att_grid.x, w.pwork,
+                     T / POOL_CHUNK + batch);
   int S, ld;
   size_t stride;
   for (int i = 0; i < c.num_layers; ++i) {
@@ -1415,7 +1426,7 @@ static RpStatus encode_pass_small(RpEncoder* e, const int32_t* ids, const int32_
   }
   {
     ProfScope ps(stream, RP_K_POOL);
-    launch_pool_partial(dim3(T / POOL_CHUNK + batch), stream, w.x, w.rs, cu_seqlens, w.pool, D, batch);
+    launch_pool_partial(dim3(T / POOL_CHUNK + batch), stream, w.x, w.rs, (const int4*)w.pwork, w.pool, D);
     hipLaunchKernelGGL(pool_finish_kernel, dim3(batch), dim3(256), 0, stream, w.pool, e->final_ln, cu_seqlens, out,
                        out_dtype == RP_DT_BF16 ? 1 : 0, D);
   }
@@ -1640,9 +1651,11 @@ extern "C" RpStatus rp_dbg_attention(const void* qkv, const int32_t* cu, const f
   (void)max_len;
   hipStream_t stream = (hipStream_t)stream_;
   const dim3 grid(rows_total / ATT_Q + batch, H);  // rows_total >= the packed token count
-  int4* work = nullptr;  // test entry only: a stream-ordered scratch allocation is fine here
-  RP_HIP(hipMallocAsync((void**)&work, (size_t)grid.x * sizeof(int4), stream));
-  hipLaunchKernelGGL(attention_worklist_kernel, dim3(1), dim3(64), 0, stream, cu, batch, work, (int)grid.x);
+  // test entry only: a stream-ordered scratch allocation is fine here (attention list | pooling list)
+  const int n_p = rows_total / POOL_CHUNK + batch;
+  int4* work = nullptr;
+  RP_HIP(hipMallocAsync((void**)&work, ((size_t)grid.x + n_p) * sizeof(int4), stream));
+  hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu, batch, work, (int)grid.x, work + grid.x, n_p);
   hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, stream, (const bf16_t*)qkv, (const int4*)work, bias_tab,
                      (bf16_t*)out, H, maxd);
   const hipError_t le = hipGetLastError();

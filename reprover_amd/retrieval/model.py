@@ -58,6 +58,7 @@ class PremiseRetriever:
         self.index_dtype = index_dtype
         self._fp8_index: Optional[Fp8Index] = None
         self._fp8_source: Optional[torch.Tensor] = None  # the tensor object the e4m3 copy was derived from
+        self._attached = False  # corpus_embeddings is another process's memory (attach_index): never written here
         # Multi-GPU predict (BASELINE.json configs[2]; the reference replicates the whole index per rank):
         # when set, ``on_predict_start`` encodes only this rank's row shard and ``predict_step`` merges the
         # per-rank top-k lists through one all-gather (reprover_amd/dist.py).  Set by retrieval/main.py
@@ -81,9 +82,9 @@ class PremiseRetriever:
 
     @classmethod
     def from_state_dict(cls, cfg: Dict, state_dict: Dict[str, torch.Tensor], max_seq_len: int, device,
-                        dtype: torch.dtype = torch.bfloat16) -> "PremiseRetriever":
+                        dtype: torch.dtype = torch.bfloat16, index_dtype: str = "bf16") -> "PremiseRetriever":
         """Build from an in-memory HF-keyed state dict (synthetic weights; no checkpoint on disk)."""
-        return cls(HipT5Encoder(cfg, state_dict, device, dtype), 0.0, 0, max_seq_len, 100)
+        return cls(HipT5Encoder(cfg, state_dict, device, dtype), 0.0, 0, max_seq_len, 100, index_dtype=index_dtype)
 
     @property
     def device(self) -> torch.device:
@@ -102,6 +103,7 @@ class PremiseRetriever:
         stale), a pickled ``IndexedCorpus`` with pre-computed embeddings, or a native index
         directory written by ``common.save_index`` / ``index.py --output-path <dir>/``."""
         self._drop_derived()
+        self._attached = False
         if isinstance(path_or_corpus, Corpus):
             self.corpus = path_or_corpus
             self.corpus_embeddings = None
@@ -138,6 +140,40 @@ class PremiseRetriever:
             self._fp8_index = Fp8Index.quantize(self.corpus_embeddings, self.device)
             self._fp8_source = self.corpus_embeddings
         return self._fp8_index
+
+    # ---- one index per GPU, shared by the worker processes on it (reprover_amd/shared_index.py) -------------
+    def share_index(self):
+        """Owner side: a picklable handle to this retriever's device-resident index (bf16 matrix, mask arrays and,
+        when ``index_dtype`` is e4m3, the codes and scales).  Keep this retriever alive while workers use it."""
+        from ..shared_index import export_index
+
+        assert self.corpus is not None and self.corpus_embeddings is not None and not self.embeddings_staled
+        if self.corpus_embeddings.device != self.device or self.corpus_embeddings.dtype != torch.bfloat16:
+            self._drop_derived()
+            self.corpus_embeddings = self.corpus_embeddings.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        fp8 = self._search_operand() if self.index_dtype != "bf16" else None
+        return export_index(self.corpus_embeddings, self.corpus, fp8)
+
+    def attach_index(self, handle, corpus: Union[str, Corpus]) -> None:
+        """Worker side: use the owner's index in place (no copy).  ``corpus`` is this process's own host-side corpus
+        (a ``Corpus`` or the path of the same ``corpus.jsonl`` / index directory): premise objects live on the host."""
+        from ..shared_index import attach_index
+
+        if isinstance(corpus, Corpus):
+            self.corpus = corpus
+        else:
+            self.load_corpus(corpus)
+        self._drop_derived()
+        t = attach_index(handle)
+        assert handle.n_premises == len(self.corpus), "the handle belongs to a different corpus"
+        assert t["embeddings"].device == self.device, "attach on the GPU the owner exported from"
+        self.corpus_embeddings = t["embeddings"]
+        self.corpus._dev[str(self.device)] = (t["file_of"], t["end_key"])
+        if handle.has_fp8:
+            self._fp8_index = Fp8Index(t["fp8_codes"], t["fp8_scale"])
+            self._fp8_source = self.corpus_embeddings
+        self.embeddings_staled = False
+        self._attached = True
 
     def _drop_derived(self) -> None:
         """Forget every copy derived from ``corpus_embeddings`` (e4m3 index, cached bf16 cast)."""
@@ -212,6 +248,9 @@ class PremiseRetriever:
         reference."""
         if not self.embeddings_staled:
             return
+        if self._attached:
+            raise RuntimeError("this retriever searches an index owned by another process (attach_index); "
+                               "re-index in the owner")
         N = len(self.corpus.all_premises)
         self._drop_derived()
         self.corpus_embeddings = torch.zeros(N, self.embedding_size, dtype=self.encoder.dtype, device=self.device)
