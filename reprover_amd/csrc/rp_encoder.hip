@@ -687,8 +687,10 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const bf16_t* __restr
   float* tab = reinterpret_cast<float*>(smem + 2 * AT2_STAGE);
 
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, cl = lane & 31;
-  const int h = blockIdx.y;
-  const int4 wk = work[blockIdx.x];
+  // heads vary fastest in dispatch order: the six workgroups that read the six 128-byte pieces of the same qkv rows
+  // (a 2304-byte row holds every head's q, k and v) run at the same time, so DRAM sees whole rows, not pieces
+  const int h = blockIdx.x;
+  const int4 wk = work[blockIdx.y];
   const int s0 = wk.x, len = wk.y, q0 = wk.z;
   if (len == 0) return;
 
@@ -1313,8 +1315,8 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
                        Tp, D, c.vocab_size, t_dev, (float*)nullptr, 0.f);
   }
   RP_CHECK_LAUNCH();
-  const dim3 att_grid(T / ATT_Q + batch, H);  // upper bound of the number of 128-query blocks
-  hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu_seqlens, batch, w.work, (int)att_grid.x, w.pwork,
+  const dim3 att_grid(H, T / ATT_Q + batch);  // upper bound of the number of 128-query blocks
+  hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu_seqlens, batch, w.work, (int)att_grid.y, w.pwork,
                      T / POOL_CHUNK + batch);
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerPacked& L = e->layers[i];
@@ -1384,8 +1386,8 @@ static RpStatus encode_pass_small(RpEncoder* e, const int32_t* ids, const int32_
     hipLaunchKernelGGL(embed_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.x, w.xb, w.ssp, np, T,
                        Tp, D, c.vocab_size, t_dev, w.rs, eps);
   }
-  const dim3 att_grid(T / ATT_Q + batch, H);
-  hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu_seqlens, batch, w.work, (int)att_grid.x, w.pwork,
+  const dim3 att_grid(H, T / ATT_Q + batch);
+  hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu_seqlens, batch, w.work, (int)att_grid.y, w.pwork,
                      T / POOL_CHUNK + batch);
   int S, ld;
   size_t stride;
@@ -1650,12 +1652,12 @@ extern "C" RpStatus rp_dbg_attention(const void* qkv, const int32_t* cu, const f
   const int maxd = 128;
   (void)max_len;
   hipStream_t stream = (hipStream_t)stream_;
-  const dim3 grid(rows_total / ATT_Q + batch, H);  // rows_total >= the packed token count
+  const dim3 grid(H, rows_total / ATT_Q + batch);  // rows_total >= the packed token count
   // test entry only: a stream-ordered scratch allocation is fine here (attention list | pooling list)
   const int n_p = rows_total / POOL_CHUNK + batch;
   int4* work = nullptr;
-  RP_HIP(hipMallocAsync((void**)&work, ((size_t)grid.x + n_p) * sizeof(int4), stream));
-  hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu, batch, work, (int)grid.x, work + grid.x, n_p);
+  RP_HIP(hipMallocAsync((void**)&work, ((size_t)grid.y + n_p) * sizeof(int4), stream));
+  hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu, batch, work, (int)grid.y, work + grid.y, n_p);
   hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, stream, (const bf16_t*)qkv, (const int4*)work, bias_tab,
                      (bf16_t*)out, H, maxd);
   const hipError_t le = hipGetLastError();
