@@ -232,16 +232,19 @@ RpStatus rp_profile_read(int32_t kernel_class, double* total_ms, int64_t* launch
  * Kernel-level entry points used by the parity tests (tests/test_kernels_gpu.py) to check each
  * HIP kernel against the oracle in isolation.  Same conventions as above.
  * ------------------------------------------------------------------------------------------- */
-enum { RP_EPI_STORE_BF16 = 0, RP_EPI_RESID_F32 = 1, RP_EPI_GEGLU_BF16 = 2 };
+enum { RP_EPI_STORE_BF16 = 0, RP_EPI_RESID = 1, RP_EPI_GEGLU_BF16 = 2 };
 /* C = A[M,K] (bf16) x W[N,K]^T (bf16); M, N multiples of 128 (N may exceed n_valid: only the
  * first n_valid columns are written), K multiple of 32.
- *   STORE_BF16: out bf16 [M, n_valid]           RESID_F32: out f32 [M, n_valid] += C
+ *   STORE_BF16: out bf16 [M, n_valid]
+ *   RESID:      out = the residual stream's two bf16 planes [2, M, n_valid] (hi = bf16(x), lo = bf16(x - hi));
+ *               x += C, re-split (n_valid multiple of 8)
  *   GEGLU_BF16: W rows interleaved 32 gate / 32 up; out bf16 [M, n_valid/2] = gelu_new(g)*u  */
 RpStatus rp_dbg_gemm(const void* A, const void* W, void* out, int32_t M, int32_t N, int32_t K,
                      int32_t n_valid, int32_t epilogue, void* stream);
 /* The same GEMM with the fused T5-RMSNorm pieces (rp_encoder.hip "RMSNorm folded into the GEMMs"):
  *   STORE / GEGLU: accumulators are scaled by rs[row] = rsqrt(sum_p ssp_in[p, row] * inv_d + eps), ssp slot-major [np, M] (ssp_in NULL = 1);
- *   RESID: additionally writes xb_out = bf16(out) and ssp_out[p, row] = sum of out^2 over features [64p, 64p+64). */
+ *   RESID: additionally writes ssp_out[p, row] = sum of x^2 over features [64p, 64p+64) (x as stored: hi + lo); xb_out is
+ *          unused (the hi plane IS the next projection's operand) and may be NULL. */
 RpStatus rp_dbg_gemm_fused(const void* A, const void* W, void* out, int32_t M, int32_t N, int32_t K,
                            int32_t n_valid, int32_t epilogue, const float* ssp_in, int32_t np_in, float inv_d,
                            float eps, void* xb_out, float* ssp_out, int32_t np_out, void* stream);

@@ -131,14 +131,35 @@ __global__ void to_f32_kernel(float* dst, const void* src, int n) {
 }
 
 // ------------------------------------------------------------------------------------------
+// The residual stream x lives in HBM as TWO bf16 planes: hi = bf16(x) and lo = bf16(x - hi), x = hi + lo to 2^-18
+// relative (16 mantissa bits).  hi IS the A operand of the next projection, so a residual update reads 4 B and writes
+// 4 B per element where an fp32 stream with a separate bf16 copy read 4 and wrote 6: the two residual epilogues and the
+// embedding move 20 % fewer bytes, and the chip read-modify-writes the two planes 29 % faster than the fp32 + bf16 form
+// (tools/probes/rmw_probe.hip: 0.168 vs 0.238 ms for [70144, 1472] in 256 x 256 tiles).  The GEMM operands are
+// bf16-rounded either way; the 2^-18 bound per update is far below that rounding (2^-9).
+// ------------------------------------------------------------------------------------------
+// one updated element pair: (hi + lo) + d, re-split; ss accumulates the squares of the values as stored
+__device__ __forceinline__ void hilo_update2(uint32_t h2, uint32_t l2, float d0, float d1, uint32_t& oh, uint32_t& ol,
+                                             float& ss) {
+  const float v0 = (__uint_as_float(h2 << 16) + __uint_as_float(l2 << 16)) + d0;
+  const float v1 = (__uint_as_float(h2 & 0xffff0000u) + __uint_as_float(l2 & 0xffff0000u)) + d1;
+  oh = pack_bf2(v0, v1);
+  const float h0 = __uint_as_float(oh << 16), h1 = __uint_as_float(oh & 0xffff0000u);
+  ol = pack_bf2(v0 - h0, v1 - h1);
+  const float x0 = h0 + __uint_as_float(ol << 16), x1 = h1 + __uint_as_float(ol & 0xffff0000u);
+  // explicit fma chain: the same rounding sequence for every token, wherever it sits in the batch
+  ss = __fmaf_rn(x1, x1, __fmaf_rn(x0, x0, ss));
+}
+
+// ------------------------------------------------------------------------------------------
 // K1: byte-token embedding gather  x[t] = embed[ids[t]]   (HF:678); the table (vocab x D fp32,
-//   2.3 MB for ByT5-small) is L2-resident.  Also emits the bf16 copy of x (the A operand of the first
+//   2.3 MB for ByT5-small) is L2-resident.  Emits the two planes of x (hi = the A operand of the first
 //   projection) and the row's sum of squares (RMSNorm statistic, applied in that GEMM's epilogue).
 //   rows >= T (tile padding) get token 0 so every workspace row stays finite.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ ids,
                                                     const float* __restrict__ table,
-                                                    float* __restrict__ x, bf16_t* __restrict__ xb,
+                                                    bf16_t* __restrict__ xhi, bf16_t* __restrict__ xlo,
                                                     float* __restrict__ ssp, int np, int T, int Tp, int D,
                                                     int vocab, const int32_t* __restrict__ t_dev,
                                                     float* __restrict__ rs_out, float eps) {
@@ -153,20 +174,21 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ 
   int id = (row < T) ? ids[row] : 0;
   id = min(max(id, 0), vocab - 1);
   const float4* src = reinterpret_cast<const float4*>(table + (size_t)id * D);
-  float4* dst = reinterpret_cast<float4*>(x + (size_t)row * D);
-  uint2* dstb = reinterpret_cast<uint2*>(xb + (size_t)row * D);
+  uint4* dh = reinterpret_cast<uint4*>(xhi + (size_t)row * D);
+  uint4* dl = reinterpret_cast<uint4*>(xlo + (size_t)row * D);
   float ss = 0.f;
-  for (int c = lane; c < (D >> 2); c += 64) {
-    const float4 v = src[c];
-    dst[c] = v;
-    uint2 o;
-    o.x = pack_bf2(v.x, v.y);
-    o.y = pack_bf2(v.z, v.w);
-    dstb[c] = o;
-    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  for (int c = lane; c < (D >> 3); c += 64) {  // 8 features per lane and step
+    const float4 a = src[2 * c], b = src[2 * c + 1];
+    uint4 oh, ol;
+    hilo_update2(0u, 0u, a.x, a.y, oh.x, ol.x, ss);
+    hilo_update2(0u, 0u, a.z, a.w, oh.y, ol.y, ss);
+    hilo_update2(0u, 0u, b.x, b.y, oh.z, ol.z, ss);
+    hilo_update2(0u, 0u, b.z, b.w, oh.w, ol.w, ss);
+    dh[c] = oh;
+    dl[c] = ol;
   }
   ss = wave_sum(ss);
-  // sum-of-squares partials of the row (see EpiResidF32): slot 0 carries the whole row here
+  // sum-of-squares partials of the row (see EpiResid): slot 0 carries the whole row here
   for (int p = lane; p < np; p += 64) ssp[(size_t)p * Tp + row] = (p == 0) ? ss : 0.f;
   if (rs_out && lane == 0) rs_out[row] = rsqrtf(ss / (float)D + eps);  // few-token schedule: no rowscale launch
 }
@@ -260,10 +282,10 @@ struct EpiStoreBf16 {  // out[token, feature] = bf16(acc * rs[token])
   }
 };
 
-struct EpiResidF32 {  // x[token, feature] += acc  (residual stream, fp32) [+ xb = bf16(x), + ssp partials]
-  float* __restrict__ x;
-  int ldx, n_valid;
-  bf16_t* __restrict__ xb;   // optional: bf16 copy of the updated rows (same leading dimension)
+struct EpiResid {  // x[token, feature] += acc on the two planes of the residual stream (+ ssp partials)
+  bf16_t* __restrict__ xhi;  // bf16(x): also the next projection's A operand
+  bf16_t* __restrict__ xlo;  // bf16(x - hi)
+  int ldx, n_valid;          // n_valid % 8 == 0
   float* __restrict__ ssp;   // optional: [np, ssp_ld] partial sums of squares, slot = feature / 64; slot-major so
                              // that a workgroup's statistics land in whole cache lines (token-major they were
                              // 16-B fragments of lines shared with workgroups on other XCDs)
@@ -272,10 +294,9 @@ struct EpiResidF32 {  // x[token, feature] += acc  (residual stream, fp32) [+ xb
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
     static_assert(FM % 2 == 0, "one statistic slot per 64 features (two row fragments)");
     const int hi = lane >> 5, cl = lane & 31;
-    // Blocks of 64 features x 32 tokens.  16 lanes x 16 B cover one token's 64 features = 256
-    // contiguous bytes of its x row (4 tokens per wave-instruction): read-modify-write in 256-B row
-    // segments streams at ~4.5 TB/s on this chip, in 128-B segments at ~3 (tools/probes/rmw_probe.hip).
-    const int sub = lane & 15, rr = lane >> 4;
+    // Blocks of 64 features x 32 tokens.  8 lanes x 16 B cover one token's 64 features = 128 contiguous bytes of
+    // its row on EACH plane (8 tokens per wave-instruction).
+    const int sub = lane & 7, rr = lane >> 3;
     constexpr int RB = 272;  // staging row: 64 floats + 16 B pad (32 rows = 8704 B <= EPI_STAGE_BYTES)
     constexpr int NB = (FM / 2) * FN;
     // The read-modify-write of x is latency-bound unless many loads are in flight: the old values of
@@ -284,20 +305,23 @@ struct EpiResidF32 {  // x[token, feature] += acc  (residual stream, fp32) [+ xb
     // make hipcc drain vmcnt to 0 around it, which serialises the whole epilogue.
     // (wave tiles of 128 x 128 keep their accumulators in AGPRs and have the VGPRs for 3 blocks ahead)
     constexpr int DEPTH = (FM * FN >= 16) ? 4 : 2;
-    float4 xin[DEPTH][8];
+    uint4 xh[DEPTH][4], xl[DEPTH][4];
     auto fetch = [&](int b, int p) {
       const int q = b / FN, j = b % FN;
-      const int f = min(m_base + q * 64 + sub * 4, n_valid - 4);
+      const int f = min(m_base + q * 64 + sub * 8, n_valid - 8);
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
-        xin[p][c] = *reinterpret_cast<const float4*>(x + (size_t)(n_base + j * 32 + c * 4 + rr) * ldx + f);
+      for (int c = 0; c < 4; ++c) {
+        const size_t off = (size_t)(n_base + j * 32 + c * 8 + rr) * ldx + f;
+        xh[p][c] = *reinterpret_cast<const uint4*>(xhi + off);
+        xl[p][c] = *reinterpret_cast<const uint4*>(xlo + off);
+      }
     };
 #pragma unroll
     for (int b = 0; b < DEPTH - 1 && b < NB; ++b) fetch(b, b);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const int q = b / FN, j = b % FN;
-      const int f = m_base + q * 64 + sub * 4;
+      const int f = m_base + q * 64 + sub * 8;
       const int slot = (m_base >> 6) + q;
       if (b + DEPTH - 1 < NB) fetch(b + DEPTH - 1, (b + DEPTH - 1) % DEPTH);
 #pragma unroll
@@ -308,33 +332,26 @@ struct EpiResidF32 {  // x[token, feature] += acc  (residual stream, fp32) [+ xb
               make_float4(acc[2 * q + i][j][4 * g], acc[2 * q + i][j][4 * g + 1], acc[2 * q + i][j][4 * g + 2],
                           acc[2 * q + i][j][4 * g + 3]);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int t = c * 4 + rr;
-        const float4 d = *reinterpret_cast<const float4*>(stage + t * RB + sub * 16);
+      for (int c = 0; c < 4; ++c) {
+        const int t = c * 8 + rr;
+        const float4 d0 = *reinterpret_cast<const float4*>(stage + t * RB + sub * 32);
+        const float4 d1 = *reinterpret_cast<const float4*>(stage + t * RB + sub * 32 + 16);
         float ss = 0.f;
         if (f < n_valid) {
           const size_t off = (size_t)(n_base + j * 32 + t) * ldx + f;
-          float4 v = xin[b % DEPTH][c];
-          v.x += d.x;
-          v.y += d.y;
-          v.z += d.z;
-          v.w += d.w;
-          *reinterpret_cast<float4*>(x + off) = v;
-          if (xb) {
-            uint2 o;
-            o.x = pack_bf2(v.x, v.y);
-            o.y = pack_bf2(v.z, v.w);
-            *reinterpret_cast<uint2*>(xb + off) = o;
-          }
-          // explicit fma chain + fixed shuffle tree: the same rounding sequence for every token,
-          // wherever it sits in the batch
-          ss = __fmaf_rn(v.w, v.w, __fmaf_rn(v.z, v.z, __fmaf_rn(v.y, v.y, v.x * v.x)));
+          const uint4 h = xh[b % DEPTH][c], l = xl[b % DEPTH][c];
+          uint4 oh, ol;
+          hilo_update2(h.x, l.x, d0.x, d0.y, oh.x, ol.x, ss);
+          hilo_update2(h.y, l.y, d0.z, d0.w, oh.y, ol.y, ss);
+          hilo_update2(h.z, l.z, d1.x, d1.y, oh.z, ol.z, ss);
+          hilo_update2(h.w, l.w, d1.z, d1.w, oh.w, ol.w, ss);
+          *reinterpret_cast<uint4*>(xhi + off) = oh;
+          *reinterpret_cast<uint4*>(xlo + off) = ol;
         }
-        if (ssp) {
+        if (ssp) {  // fixed shuffle tree over the 8 lanes of the token's 64 features
           ss += __shfl_xor(ss, 1, 64);
           ss += __shfl_xor(ss, 2, 64);
           ss += __shfl_xor(ss, 4, 64);
-          ss += __shfl_xor(ss, 8, 64);
           if (sub == 0 && slot < np) ssp[(size_t)slot * ssp_ld + n_base + j * 32 + t] = ss;
         }
       }
@@ -532,7 +549,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int part_ld,
                                                             size_t part_split_stride, int S, int n_valid,
                                                             const float* __restrict__ rs_in, bf16_t* __restrict__ out_bf,
-                                                            int ldo, float* __restrict__ x, bf16_t* __restrict__ xb, int ldx,
+                                                            int ldo, bf16_t* __restrict__ xhi, bf16_t* __restrict__ xlo, int ldx,
                                                             float* __restrict__ rs_out, float inv_d, float eps,
                                                             const int32_t* __restrict__ t_dev) {
   __shared__ float red[4];
@@ -579,14 +596,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     float ss = 0.f;
     for (int f = tid * 4; f < n_valid; f += 1024) {
       const float4 a = total4(f);
-      float4 v = *reinterpret_cast<const float4*>(x + (size_t)t * ldx + f);
-      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-      *reinterpret_cast<float4*>(x + (size_t)t * ldx + f) = v;
-      uint2 o;
-      o.x = pack_bf2(v.x, v.y);
-      o.y = pack_bf2(v.z, v.w);
-      *reinterpret_cast<uint2*>(xb + (size_t)t * ldx + f) = o;
-      ss = __fmaf_rn(v.w, v.w, __fmaf_rn(v.z, v.z, __fmaf_rn(v.y, v.y, __fmaf_rn(v.x, v.x, ss))));
+      const size_t off = (size_t)t * ldx + f;
+      const uint2 h = *reinterpret_cast<const uint2*>(xhi + off), l = *reinterpret_cast<const uint2*>(xlo + off);
+      uint2 oh, ol;
+      hilo_update2(h.x, l.x, a.x, a.y, oh.x, ol.x, ss);
+      hilo_update2(h.y, l.y, a.z, a.w, oh.y, ol.y, ss);
+      *reinterpret_cast<uint2*>(xhi + off) = oh;
+      *reinterpret_cast<uint2*>(xlo + off) = ol;
     }
     ss = wave_sum(ss);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
@@ -636,9 +652,9 @@ constexpr int AT2_K_BYTES = 64 * 128, AT2_V_BYTES = 64 * 128, AT2_STAGE = AT2_K_
 // tail.  It also replaces the two block-wide counting rounds every workgroup of every layer spent finding its sequence.
 // Entries beyond the live count have length 0.  One workgroup; a counting sort over 64 length buckets in LDS.
 constexpr int ATT_BUCKETS = 64;
-constexpr int POOL_CHUNK = 64;  // tokens per workgroup of the pooling pass (see pool_kernel)
-// The same launch lays out the pooling pass's list: chunk c of sequence b is entry cu[b] / 64 + b + c = {first token,
-// length, c, b} (strictly increasing in b, at most T/64 + B entries; a gap entry has length 0).
+constexpr int POOL_CHUNK = 128;  // tokens per workgroup of the pooling pass (pool_partial_kernel)
+// The same launch lays out the pooling pass's list: chunk c of sequence b is entry cu[b] / 128 + b + c = {first token,
+// length, c, b} (strictly increasing in b, at most T/128 + B entries; a gap entry has length 0).
 __global__ __launch_bounds__(1024) void worklist_kernel(const int32_t* __restrict__ cu, int batch,
                                                         int4* __restrict__ work, int n_slots,
                                                         int4* __restrict__ pwork, int n_pslots) {
@@ -874,78 +890,92 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const bf16_t* __restr
 // K2(final)+K9+K10: final RMSNorm, masked mean over the sequence's tokens, L2 normalise.
 //   mean_t(w * x_t * rs_t) = w * mean_t(x_t * rs_t); e / max(||e||, 1e-12)  (model.py:108-114)
 //   Two deterministic passes (no atomics, so results are bit-reproducible whatever the batch):
-//   pool_partial_kernel: one workgroup per 64-token chunk of a sequence (the pass's list, worklist_kernel); wave w
+//   pool_partial_kernel: one workgroup per 128-token chunk of a sequence (the pass's list, worklist_kernel); wave w
 //     takes tokens w, w+4, ...; rs_t from the last residual epilogue's statistics (as for every other RMSNorm);
 //     per-lane partial column sums of x_t * rs_t in registers, combined through LDS, written to
-//     partial[chunk_base(b) + c][D]   (chunk_base(b) = cu[b] / 64 + b);
+//     partial[chunk_base(b) + c][D]   (chunk_base(b) = cu[b] / 128 + b);
 //   pool_finish_kernel: one workgroup per sequence sums its chunks in order, applies w / len and the L2
 //     normalisation.
-//   64-token chunks because the chunks are unequal (the benchmark's sequences are 16..2048 tokens, most of them
-//   short): with 128-token chunks every workgroup of the pass was resident at once, nothing was left to balance the
-//   CUs that drew three full chunks against those that drew three stubs, and the pass ran at the pace of the former
-//   (51 % of the HBM peak for a plain streaming read).
-//   (Tried: the finish done by whichever workgroup arrives last at a per-sequence counter, one launch instead of
-//   two.  The device-scope release fence that makes the other chunks' sums visible across XCDs writes back the whole
-//   L2, which at this point holds the last layer's residual stream: 0.13 -> 0.45 ms per pass.)
+//   Tried, both without gain: 64-token chunks (twice the workgroups, to balance the unequal chunks of the length mix
+//   over the CUs: 0.129 -> 0.137 ms per pass); the finish done by whichever workgroup arrives last at a per-sequence
+//   counter (one launch instead of two: the device-scope release fence that makes the other chunks' sums visible
+//   across XCDs costs ~2 us per workgroup, serialised per XCD: 0.13 -> 0.45 ms per pass).
 // ------------------------------------------------------------------------------------------
 
-// NV = float4 per lane covering a row (ceil(D / 256)): 6 for d_model 1472 / 1536, 8 up to 2048.  Four token rows of a
-// wave are in flight before the first is consumed (the rows are independent streams: rs comes from rowscale).
+// NV = 16-byte pieces (8 features) per lane and plane covering a row (ceil(D / 512)): 3 for d_model 1472 / 1536,
+// 4 up to 2048.  Four token rows of a wave are in flight before the first is consumed (the rows are independent
+// streams: rs comes from rowscale).
 template <int NV>
-__global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restrict__ x, const float* __restrict__ rs,
+__global__ __launch_bounds__(256) void pool_partial_kernel(const bf16_t* __restrict__ xhi, const bf16_t* __restrict__ xlo,
+                                                           const float* __restrict__ rs,
                                                            const int4* __restrict__ pwork,
                                                            float* __restrict__ partial, int D) {
-  __shared__ float red[4][NV * 64 * 4];
+  __shared__ float red[4][NV * 64 * 8];
   const int4 wk = pwork[blockIdx.x];
   const int s0 = wk.x, len = wk.y, c = wk.z, b = wk.w;
   if (len == 0) return;
   const int t0 = c * POOL_CHUNK;
   const int t1 = min(len, t0 + POOL_CHUNK);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nv = D >> 2;
-  float4 acc[NV];
+  const int nv = D >> 3;
+  float acc[NV][8];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
   // Tokens are accumulated in index order per wave (w, w+4, w+8, ...), whatever the unrolling.
   constexpr int R = 4;  // rows in flight per wave
   for (int t = t0 + wave; t < t1; t += 4 * R) {
-    float4 v[R][NV];
+    uint4 vh[R][NV], vl[R][NV];
     float r[R];
 #pragma unroll
     for (int u = 0; u < R; ++u) {
       const int tu = t + 4 * u;
       const bool live = tu < t1;
-      const float4* src = reinterpret_cast<const float4*>(x + (size_t)(s0 + (live ? tu : t)) * D);
+      const size_t row = (size_t)(s0 + (live ? tu : t)) * D;
+      const uint4* sh = reinterpret_cast<const uint4*>(xhi + row);
+      const uint4* sl = reinterpret_cast<const uint4*>(xlo + row);
       r[u] = live ? rs[s0 + tu] : 0.f;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) v[u][i] = src[min(lane + 64 * i, nv - 1)];  // clamped, unpredicated
+      for (int i = 0; i < NV; ++i) {  // clamped, unpredicated
+        vh[u][i] = sh[min(lane + 64 * i, nv - 1)];
+        vl[u][i] = sl[min(lane + 64 * i, nv - 1)];
+      }
     }
 #pragma unroll
     for (int u = 0; u < R; ++u)
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
-        acc[i].x = fmaf(v[u][i].x, r[u], acc[i].x);
-        acc[i].y = fmaf(v[u][i].y, r[u], acc[i].y);
-        acc[i].z = fmaf(v[u][i].z, r[u], acc[i].z);
-        acc[i].w = fmaf(v[u][i].w, r[u], acc[i].w);
+        const uint32_t h[4] = {vh[u][i].x, vh[u][i].y, vh[u][i].z, vh[u][i].w};
+        const uint32_t l[4] = {vl[u][i].x, vl[u][i].y, vl[u][i].z, vl[u][i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x0 = __uint_as_float(h[e] << 16) + __uint_as_float(l[e] << 16);
+          const float x1 = __uint_as_float(h[e] & 0xffff0000u) + __uint_as_float(l[e] & 0xffff0000u);
+          acc[i][2 * e] = fmaf(x0, r[u], acc[i][2 * e]);
+          acc[i][2 * e + 1] = fmaf(x1, r[u], acc[i][2 * e + 1]);
+        }
       }
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    int col = lane + 64 * i;
-    if (col < nv) *reinterpret_cast<float4*>(&red[wave][col * 4]) = acc[i];
+    const int col = lane + 64 * i;
+    if (col < nv) {
+      *reinterpret_cast<float4*>(&red[wave][col * 8]) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+      *reinterpret_cast<float4*>(&red[wave][col * 8 + 4]) = make_float4(acc[i][4], acc[i][5], acc[i][6], acc[i][7]);
+    }
   }
   __syncthreads();
   float* dst = partial + (size_t)(s0 / POOL_CHUNK + b + c) * D;
   for (int col = threadIdx.x; col < D; col += 256) dst[col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
 
-static void launch_pool_partial(dim3 grid, hipStream_t stream, const float* x, const float* rs, const int4* pwork,
-                                float* partial, int D) {
-  if (D <= 6 * 256)
-    hipLaunchKernelGGL(pool_partial_kernel<6>, grid, dim3(256), 0, stream, x, rs, pwork, partial, D);
+static void launch_pool_partial(dim3 grid, hipStream_t stream, const bf16_t* xhi, const bf16_t* xlo, const float* rs,
+                                const int4* pwork, float* partial, int D) {
+  if (D <= 3 * 512)
+    hipLaunchKernelGGL(pool_partial_kernel<3>, grid, dim3(256), 0, stream, xhi, xlo, rs, pwork, partial, D);
   else
-    hipLaunchKernelGGL(pool_partial_kernel<8>, grid, dim3(256), 0, stream, x, rs, pwork, partial, D);
+    hipLaunchKernelGGL(pool_partial_kernel<4>, grid, dim3(256), 0, stream, xhi, xlo, rs, pwork, partial, D);
 }
 
 __global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restrict__ partial,
@@ -1224,13 +1254,13 @@ extern "C" void rp_encoder_destroy(RpEncoder* e) {
 
 namespace {
 struct Workspace {
-  float* x;
-  bf16_t *xb, *qkv, *att, *ff;  // xb = bf16 copy of x (A operand of the QKV / FFN-in GEMMs)
+  bf16_t *xb, *xlo;  // the residual stream's two planes: xb = bf16(x) (A operand of the QKV / FFN-in GEMMs), xlo = x - xb
+  bf16_t *qkv, *att, *ff;
   float* ssp;   // [Tp, ceil(D/64)] per-row partial sums of squares of x
   float* rs;    // [Tp] rsqrt(mean(x^2) + eps)
   float* pool;  // [Tp / 128 + batch, D] partial column sums of the pooling pass
   int4* work;   // [Tp / 128 + batch] attention work list of the pass (worklist_kernel)
-  int4* pwork;  // [Tp / 64 + batch] pooling work list
+  int4* pwork;  // [Tp / 128 + batch] pooling work list
   float* part;  // few-token schedule: split-K partial tiles [S, rows, features] (NULL otherwise)
   size_t part_floats;
   size_t bytes;
@@ -1260,8 +1290,8 @@ Workspace carve(const RpEncoder* e, int T, int batch, char* base) {
     off += align_up(bytes, 256);
     return p;
   };
-  w.x = (float*)take(Tp * D * 4);
   w.xb = (bf16_t*)take(Tp * D * 2);
+  w.xlo = (bf16_t*)take(Tp * D * 2);
   w.ssp = (float*)take(Tp * ((D + 63) / 64) * 4);
   w.rs = (float*)take(Tp * 4);
   w.qkv = (bf16_t*)take(Tp * 3 * inner * 2);
@@ -1311,7 +1341,7 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
   };
   {
     ProfScope ps(stream, RP_K_EMBED);
-    hipLaunchKernelGGL(embed_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.x, w.xb, w.ssp, np, T,
+    hipLaunchKernelGGL(embed_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.xb, w.xlo, w.ssp, np, T,
                        Tp, D, c.vocab_size, t_dev, (float*)nullptr, 0.f);
   }
   RP_CHECK_LAUNCH();
@@ -1330,7 +1360,7 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
       hipLaunchKernelGGL(attention_kernel, att_grid, dim3(256), 0, stream, w.qkv, (const int4*)w.work, e->bias_tab, w.att,
                          H, e->maxd);
     }
-    if ((st = launch_gemm(w.att, inner, Tp, L.wo, inner, D, inner, EpiResidF32{w.x, D, D, w.xb, w.ssp, np, Tp}, stream,
+    if ((st = launch_gemm(w.att, inner, Tp, L.wo, inner, D, inner, EpiResid{w.xb, w.xlo, D, D, w.ssp, np, Tp}, stream,
                           RP_K_GEMM_O, tv, t_dev)))
       return st;
     if (g_debug_skip_ffn) continue;
@@ -1339,14 +1369,14 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
     if ((st = launch_gemm(w.xb, D, Tp, L.wi, D, 2 * F, D, EpiGegluBf16{w.ff, F, 2 * F, rs}, stream, RP_K_GEMM_WI, tv,
                           t_dev)))
       return st;
-    if ((st = launch_gemm(w.ff, F, Tp, L.wo2, F, D, F, EpiResidF32{w.x, D, D, w.xb, w.ssp, np, Tp}, stream,
+    if ((st = launch_gemm(w.ff, F, Tp, L.wo2, F, D, F, EpiResid{w.xb, w.xlo, D, D, w.ssp, np, Tp}, stream,
                           RP_K_GEMM_WO, tv, t_dev)))
       return st;
   }
   launch_rowscale();  // final RMSNorm statistic
   {
     ProfScope ps(stream, RP_K_POOL);
-    launch_pool_partial(dim3(T / POOL_CHUNK + batch), stream, w.x, w.rs, (const int4*)w.pwork, w.pool, D);
+    launch_pool_partial(dim3(T / POOL_CHUNK + batch), stream, w.xb, w.xlo, w.rs, (const int4*)w.pwork, w.pool, D);
     hipLaunchKernelGGL(pool_finish_kernel, dim3(batch), dim3(256), 0, stream, w.pool, e->final_ln, cu_seqlens, out,
                        out_dtype == RP_DT_BF16 ? 1 : 0, D);
   }
@@ -1383,7 +1413,7 @@ static RpStatus encode_pass_small(RpEncoder* e, const int32_t* ids, const int32_
   };
   {
     ProfScope ps(stream, RP_K_EMBED);
-    hipLaunchKernelGGL(embed_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.x, w.xb, w.ssp, np, T,
+    hipLaunchKernelGGL(embed_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.xb, w.xlo, w.ssp, np, T,
                        Tp, D, c.vocab_size, t_dev, w.rs, eps);
   }
   const dim3 att_grid(H, T / ATT_Q + batch);
@@ -1397,7 +1427,7 @@ static RpStatus encode_pass_small(RpEncoder* e, const int32_t* ids, const int32_
     {
       ProfScope ps(stream, RP_K_GEMM_QKV);
       hipLaunchKernelGGL(splitk_reduce_kernel<RED_STORE>, dim3(rows), dim3(256), 0, stream, (const float*)w.part, ld,
-                         stride, S, 3 * inner, (const float*)w.rs, w.qkv, 3 * inner, (float*)nullptr, (bf16_t*)nullptr, 0,
+                         stride, S, 3 * inner, (const float*)w.rs, w.qkv, 3 * inner, (bf16_t*)nullptr, (bf16_t*)nullptr, 0,
                          (float*)nullptr, 0.f, 0.f, t_dev);
     }
     {
@@ -1409,26 +1439,26 @@ static RpStatus encode_pass_small(RpEncoder* e, const int32_t* ids, const int32_
     {
       ProfScope ps(stream, RP_K_GEMM_O);
       hipLaunchKernelGGL(splitk_reduce_kernel<RED_RESID>, dim3(rows), dim3(256), 0, stream, (const float*)w.part, ld,
-                         stride, S, D, (const float*)nullptr, (bf16_t*)nullptr, 0, w.x, w.xb, D, w.rs, inv_d, eps, t_dev);
+                         stride, S, D, (const float*)nullptr, (bf16_t*)nullptr, 0, w.xb, w.xlo, D, w.rs, inv_d, eps, t_dev);
     }
     if (g_debug_skip_ffn) continue;
     project(w.xb, D, L.wi, 2 * F, D, RP_K_GEMM_WI, S, ld, stride);
     {
       ProfScope ps(stream, RP_K_GEMM_WI);
       hipLaunchKernelGGL(splitk_reduce_kernel<RED_GEGLU>, dim3(rows), dim3(256), 0, stream, (const float*)w.part, ld,
-                         stride, S, 2 * F, (const float*)w.rs, w.ff, F, (float*)nullptr, (bf16_t*)nullptr, 0,
+                         stride, S, 2 * F, (const float*)w.rs, w.ff, F, (bf16_t*)nullptr, (bf16_t*)nullptr, 0,
                          (float*)nullptr, 0.f, 0.f, t_dev);
     }
     project(w.ff, F, L.wo2, D, F, RP_K_GEMM_WO, S, ld, stride);
     {
       ProfScope ps(stream, RP_K_GEMM_WO);
       hipLaunchKernelGGL(splitk_reduce_kernel<RED_RESID>, dim3(rows), dim3(256), 0, stream, (const float*)w.part, ld,
-                         stride, S, D, (const float*)nullptr, (bf16_t*)nullptr, 0, w.x, w.xb, D, w.rs, inv_d, eps, t_dev);
+                         stride, S, D, (const float*)nullptr, (bf16_t*)nullptr, 0, w.xb, w.xlo, D, w.rs, inv_d, eps, t_dev);
     }
   }
   {
     ProfScope ps(stream, RP_K_POOL);
-    launch_pool_partial(dim3(T / POOL_CHUNK + batch), stream, w.x, w.rs, (const int4*)w.pwork, w.pool, D);
+    launch_pool_partial(dim3(T / POOL_CHUNK + batch), stream, w.xb, w.xlo, w.rs, (const int4*)w.pwork, w.pool, D);
     hipLaunchKernelGGL(pool_finish_kernel, dim3(batch), dim3(256), 0, stream, w.pool, e->final_ln, cu_seqlens, out,
                        out_dtype == RP_DT_BF16 ? 1 : 0, D);
   }
@@ -1593,8 +1623,11 @@ extern "C" RpStatus rp_dbg_gemm(const void* A, const void* W, void* out, int32_t
     case RP_EPI_STORE_BF16:
       return launch_gemm(a, K, M, w, K, N, K, EpiStoreBf16{(bf16_t*)out, n_valid, n_valid, RowScale{nullptr}}, stream,
                          RP_K_GEMM_QKV);
-    case RP_EPI_RESID_F32:
-      return launch_gemm(a, K, M, w, K, N, K, EpiResidF32{(float*)out, n_valid, n_valid, nullptr, nullptr, 0, 0}, stream, RP_K_GEMM_WO);
+    case RP_EPI_RESID:  // out = the two planes of the residual stream, [2, M, n_valid] bf16 (hi, then lo)
+      RP_REQUIRE(n_valid % 8 == 0, "n_valid=%d", n_valid);
+      return launch_gemm(a, K, M, w, K, N, K,
+                         EpiResid{(bf16_t*)out, (bf16_t*)out + (size_t)M * n_valid, n_valid, n_valid, nullptr, 0, 0}, stream,
+                         RP_K_GEMM_WO);
     case RP_EPI_GEGLU_BF16:
       return launch_gemm(a, K, M, w, K, N, K, EpiGegluBf16{(bf16_t*)out, n_valid / 2, n_valid, RowScale{nullptr}}, stream,
                          RP_K_GEMM_WI);
@@ -1628,8 +1661,10 @@ extern "C" RpStatus rp_dbg_gemm_fused(const void* A, const void* W, void* out, i
   switch (epilogue) {
     case RP_EPI_STORE_BF16:
       return launch_gemm(a, K, M, w, K, N, K, EpiStoreBf16{(bf16_t*)out, n_valid, n_valid, rs}, stream, RP_K_GEMM_QKV);
-    case RP_EPI_RESID_F32:
-      return launch_gemm(a, K, M, w, K, N, K, EpiResidF32{(float*)out, n_valid, n_valid, (bf16_t*)xb_out, ssp_out, np_out, M},
+    case RP_EPI_RESID:  // out = [2, M, n_valid] bf16 planes (hi, lo); xb_out unused (hi is the operand copy)
+      RP_REQUIRE(n_valid % 8 == 0, "n_valid=%d", n_valid);
+      return launch_gemm(a, K, M, w, K, N, K,
+                         EpiResid{(bf16_t*)out, (bf16_t*)out + (size_t)M * n_valid, n_valid, n_valid, ssp_out, np_out, M},
                          stream, RP_K_GEMM_WO);
     case RP_EPI_GEGLU_BF16:
       return launch_gemm(a, K, M, w, K, N, K, EpiGegluBf16{(bf16_t*)out, n_valid / 2, n_valid, rs}, stream,

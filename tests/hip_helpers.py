@@ -10,13 +10,29 @@ def dev():
     return torch.device("cuda:0")
 
 
+def split_planes(x):
+    """fp32 [M, N] -> the residual stream's two bf16 planes [2, M, N]: hi = bf16(x), lo = bf16(x - hi)."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo]).contiguous()
+
+
+def merge_planes(planes):
+    return planes[0].float() + planes[1].float()
+
+
 def gemm(A, W, n_valid, epilogue, out):
+    """``out``: the epilogue's output; for RP_EPI_RESID an fp32 [M, n_valid] matrix that is updated in place THROUGH
+    the engine's two-plane form of the residual stream (split before the call, merged after it)."""
     lib = _lib.load()
     M, K = A.shape
     N = W.shape[0]
-    _lib.check(lib.rp_dbg_gemm(_lib.ptr(A), _lib.ptr(W), _lib.ptr(out), M, N, K, n_valid, epilogue,
+    target = split_planes(out) if epilogue == _lib.RP_EPI_RESID else out
+    _lib.check(lib.rp_dbg_gemm(_lib.ptr(A), _lib.ptr(W), _lib.ptr(target), M, N, K, n_valid, epilogue,
                                _lib.current_stream()), "rp_dbg_gemm")
     torch.cuda.synchronize()
+    if epilogue == _lib.RP_EPI_RESID:
+        out.copy_(merge_planes(target))
     return out
 
 

@@ -48,13 +48,24 @@ def test_gemm_detects_transposes_with_structured_operands(gen):
     assert torch.equal(out.float(), A @ W.T)
 
 
-def test_gemm_residual_f32(gen):
+def test_gemm_residual_two_planes(gen):
+    """x += A W^T on the residual stream's two bf16 planes (hi = bf16(x), lo = bf16(x - hi)): the update must be the
+    fp32 sum to 2^-17 relative (one re-split), and hi must be the bf16 rounding of the result."""
     M, N, K = 256, 1472, 384
     A, W = _rand_bf16(gen, M, K), _rand_bf16(gen, N, K, scale=K ** -0.5)
     x = torch.randn(M, N, generator=gen, device="cuda")
-    ref = x + A.float() @ W.float().T
-    hh.gemm(A, W, N, _lib.RP_EPI_RESID_F32, x)
-    assert (x - ref).abs().max().item() < 2e-4
+    planes = hh.split_planes(x)
+    x0 = hh.merge_planes(planes)
+    assert (x0 - x).abs().max().item() <= 2 ** -17 * x.abs().max().item()
+    ref = x0 + A.float() @ W.float().T
+    lib = _lib.load()
+    _lib.check(lib.rp_dbg_gemm(A.data_ptr(), W.data_ptr(), planes.data_ptr(), M, N, K, N, _lib.RP_EPI_RESID,
+                               _lib.current_stream()), "rp_dbg_gemm")
+    torch.cuda.synchronize()
+    got = hh.merge_planes(planes)
+    assert (got - ref).abs().max().item() < 2e-4
+    assert torch.equal(planes[0], got.to(torch.bfloat16)), "hi must be the bf16 rounding of the updated x"
+    assert (planes[1].float().abs() <= 2 ** -8 * planes[0].float().abs() + 1e-30).all(), "lo is a rounding remainder"
 
 
 def test_gemm_geglu(gen):
@@ -325,7 +336,7 @@ def test_shard_merge_equals_single_shot(gen):
 @pytest.mark.parametrize("variant", [20, 26, 12, 0, 9])
 @pytest.mark.parametrize("M", [256, 768])
 def test_gemm_fused_rmsnorm_pieces_all_variants(gen, variant, M):
-    """Residual epilogue with its bf16 copy + per-64-feature sums of squares, and the row-scaled
+    """Residual epilogue on the two planes + per-64-feature sums of squares, and the row-scaled
     store / GEGLU epilogues, for every tile configuration (the auto small-M switch disabled)."""
     lib = _lib.load()
     N, K = 1472, 384
@@ -334,16 +345,16 @@ def test_gemm_fused_rmsnorm_pieces_all_variants(gen, variant, M):
     _lib.check(lib.rp_set_option(b"gemm_variant_all", variant), "opt")
     try:
         A, W = _rand_bf16(gen, M, K), _rand_bf16(gen, N, K, scale=K ** -0.5)
-        x0 = torch.randn(M, N, generator=gen, device="cuda")
-        x = x0.clone()
-        xb = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        planes = hh.split_planes(torch.randn(M, N, generator=gen, device="cuda"))
+        x0 = hh.merge_planes(planes)
         ssp = torch.full((np_, M), float("nan"), device="cuda")  # slot-major
-        _lib.check(lib.rp_dbg_gemm_fused(A.data_ptr(), W.data_ptr(), x.data_ptr(), M, N, K, N, _lib.RP_EPI_RESID_F32, None,
-                                         0, 0.0, 0.0, xb.data_ptr(), ssp.data_ptr(), np_, _lib.current_stream()), "fused")
+        _lib.check(lib.rp_dbg_gemm_fused(A.data_ptr(), W.data_ptr(), planes.data_ptr(), M, N, K, N, _lib.RP_EPI_RESID, None,
+                                         0, 0.0, 0.0, None, ssp.data_ptr(), np_, _lib.current_stream()), "fused")
         torch.cuda.synchronize()
+        x, xb = hh.merge_planes(planes), planes[0]
         ref = x0 + A.float() @ W.float().T
         assert (x - ref).abs().max().item() < 2e-4
-        assert torch.equal(xb, x.to(torch.bfloat16)), "xb must be the bf16 rounding of the updated x"
+        assert torch.equal(xb, x.to(torch.bfloat16)), "hi (the next GEMM's operand) must be the bf16 rounding of x"
         want = (x.double() ** 2).view(M, np_, 64).sum(-1).float().T
         assert not torch.isnan(ssp).any(), "a sum-of-squares slot was never written"
         assert (ssp - want).abs().max().item() <= 1e-4 * want.abs().max().item()

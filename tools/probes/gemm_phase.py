@@ -21,25 +21,24 @@ lib.rp_probe_read_phase_ts.argtypes = [C.c_void_p, C.c_int]
 lib.rp_probe_read_handover_ts.argtypes = [C.c_void_p]
 dev = torch.device("cuda")
 M = int(os.environ.get("M", 65536))
-shapes = {"wi": (7168, 1472, _lib.RP_EPI_GEGLU_BF16), "wo": (1472, 3584, _lib.RP_EPI_RESID_F32),
-          "o": (1472, 384, _lib.RP_EPI_RESID_F32),
+shapes = {"wi": (7168, 1472, _lib.RP_EPI_GEGLU_BF16), "wo": (1472, 3584, _lib.RP_EPI_RESID),
+          "o": (1472, 384, _lib.RP_EPI_RESID),
           "qkv": (1152, 1472, _lib.RP_EPI_STORE_BF16)}
 for name in os.environ.get("ONLY", "wi,wo").split(","):
     N, K, epi = shapes[name]
     A = torch.randn(M, K, device=dev).to(torch.bfloat16)
     W = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
-    out = (torch.zeros(M, N, device=dev) if epi == _lib.RP_EPI_RESID_F32 else
+    out = (torch.zeros(2, M, N, dtype=torch.bfloat16, device=dev) if epi == _lib.RP_EPI_RESID else
            torch.empty(M, N // 2 if epi == _lib.RP_EPI_GEGLU_BF16 else N, dtype=torch.bfloat16, device=dev))
     for v in [int(x) for x in os.environ.get("VARIANTS", "6,20").split(",")]:
         _lib.check(lib.rp_set_option(b"gemm_variant_all", v), "opt")
-        fused = epi == _lib.RP_EPI_RESID_F32
+        fused = epi == _lib.RP_EPI_RESID
         np_ = (N + 63) // 64
-        xb = torch.empty(M, N, dtype=torch.bfloat16, device=dev) if fused else None
         ssp = torch.empty(np_, M, device=dev) if fused else None
         for _ in range(12):
             if fused:
                 _lib.check(lib.rp_dbg_gemm_fused(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, N, epi, None, 0, 0.0,
-                                                 0.0, xb.data_ptr(), ssp.data_ptr(), np_, _lib.current_stream()), "gemm")
+                                                 0.0, None, ssp.data_ptr(), np_, _lib.current_stream()), "gemm")
             else:
                 _lib.check(lib.rp_dbg_gemm(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, N, epi, _lib.current_stream()), "gemm")
         torch.cuda.synchronize()

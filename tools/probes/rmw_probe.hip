@@ -40,6 +40,48 @@ __global__ __launch_bounds__(256) void rmw(float* __restrict__ x, uint16_t* __re
   }
 }
 
+// The same update on a residual stream kept as two bf16 planes (hi = bf16(x), lo = bf16(x - hi)): 8 bytes per element
+// instead of 10, hi is the next GEMM's operand.  SEG_LANES lanes x 16 B (8 bf16) cover one row segment of a plane.
+template <int SEG_LANES>
+__global__ __launch_bounds__(256) void rmw_hilo(uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int T, int D,
+                                                int tile_tok, int tile_feat, int tiles_f) {
+  const int tf = blockIdx.x % tiles_f, tt = blockIdx.x / tiles_f;
+  const int f0 = tf * tile_feat, t0 = tt * tile_tok;
+  const int lane_in = threadIdx.x % SEG_LANES, row_in = threadIdx.x / SEG_LANES;
+  constexpr int ROWS = 256 / SEG_LANES;
+  for (int fc = 0; fc < tile_feat; fc += SEG_LANES * 8) {
+    const int f = f0 + fc + lane_in * 8;
+    uint4 vh[8], vl[8];
+    for (int tb = 0; tb < tile_tok; tb += ROWS * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + tb + u * ROWS + row_in;
+        const bool ok = t < T && f < D;
+        vh[u] = ok ? *reinterpret_cast<const uint4*>(hi + (size_t)t * D + f) : make_uint4(0, 0, 0, 0);
+        vl[u] = ok ? *reinterpret_cast<const uint4*>(lo + (size_t)t * D + f) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + tb + u * ROWS + row_in;
+        if (t < T && f < D) {
+          const uint32_t h[4] = {vh[u].x, vh[u].y, vh[u].z, vh[u].w}, l[4] = {vl[u].x, vl[u].y, vl[u].z, vl[u].w};
+          uint32_t oh[4], ol[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float a = __uint_as_float(h[e] << 16) + __uint_as_float(l[e] << 16) + 1.f;
+            float b = __uint_as_float(h[e] & 0xffff0000u) + __uint_as_float(l[e] & 0xffff0000u) + 1.f;
+            const uint32_t ah = __float_as_uint(a) & 0xffff0000u, bh = __float_as_uint(b) & 0xffff0000u;
+            oh[e] = (ah >> 16) | bh;
+            ol[e] = (__float_as_uint(a - __uint_as_float(ah)) >> 16) | (__float_as_uint(b - __uint_as_float(bh)) & 0xffff0000u);
+          }
+          *reinterpret_cast<uint4*>(hi + (size_t)t * D + f) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
+          *reinterpret_cast<uint4*>(lo + (size_t)t * D + f) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+        }
+      }
+    }
+  }
+}
+
 int main() {
   const int T = 70144, D = 1472;
   float* x; uint16_t* xb;
@@ -64,5 +106,24 @@ int main() {
   run("256-B row segments", rmw<16>, 256, 256);
   run("512-B row segments", rmw<32>, 256, 256);
   run("512-B segments, full rows", rmw<32>, 64, 1472);
+  {
+    uint16_t* lo; hipMalloc(&lo, (size_t)T * D * 2); hipMemset(lo, 0, (size_t)T * D * 2);
+    const double b8 = (double)T * D * 8.0;
+    auto run2 = [&](const char* name, auto kern, int tile_tok, int tile_feat) {
+      const int tiles_f = (D + tile_feat - 1) / tile_feat, tiles_t = (T + tile_tok - 1) / tile_tok;
+      for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(tiles_f * tiles_t), dim3(256), 0, 0, xb, lo, T, D, tile_tok, tile_feat, tiles_f);
+      hipEventRecord(e0);
+      const int it = 10;
+      for (int i = 0; i < it; ++i) hipLaunchKernelGGL(kern, dim3(tiles_f * tiles_t), dim3(256), 0, 0, xb, lo, T, D, tile_tok, tile_feat, tiles_f);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1); ms /= it;
+      printf("%-34s tile %3d tok x %4d feat: %.3f ms  %.2f TB/s (8 B per element; fp32 form at this time: %.2f TB/s-equivalent)\n", name, tile_tok,
+             tile_feat, ms, b8 / ms / 1e9, bytes / ms / 1e9);
+    };
+    run2("hi/lo planes, 128-B segments", rmw_hilo<8>, 256, 256);
+    run2("hi/lo planes, 256-B segments", rmw_hilo<16>, 256, 256);
+    run2("hi/lo planes, 256-B segments", rmw_hilo<16>, 128, 128);
+    run2("hi/lo planes, full rows", rmw_hilo<32>, 64, 1472);
+  }
   return 0;
 }
