@@ -68,7 +68,7 @@ def test_gemm_residual_two_planes(gen):
     # to bf16(hi + lo) except where lo's own rounding lands the sum exactly on a tie)
     hi = planes[0].float()
     assert ((got - hi).abs() <= 2 ** -8 * hi.abs() + 1e-30).all(), "lo must be a rounding remainder of hi"
-    assert (planes[0] != got.to(torch.bfloat16)).float().mean().item() < 1e-3
+    assert (planes[0] != got.to(torch.bfloat16)).float().mean().item() < 1e-2
 
 
 def test_gemm_geglu(gen):
@@ -359,7 +359,7 @@ def test_gemm_fused_rmsnorm_pieces_all_variants(gen, variant, M):
         assert (x - ref).abs().max().item() < 2e-4
         # hi (the next GEMM's operand) is the bf16 rounding of x up to ties created by lo's own rounding
         assert ((x - xb.float()).abs() <= 2 ** -8 * xb.float().abs() + 1e-30).all()
-        assert (xb != x.to(torch.bfloat16)).float().mean().item() < 1e-3
+        assert (xb != x.to(torch.bfloat16)).float().mean().item() < 1e-2
         want = (x.double() ** 2).view(M, np_, 64).sum(-1).float().T
         assert not torch.isnan(ssp).any(), "a sum-of-squares slot was never written"
         assert (ssp - want).abs().max().item() <= 1e-4 * want.abs().max().item()
