@@ -39,6 +39,8 @@ static int g_gemm_variant_qkv = 26;  // QKV
 static int g_gemm_variant_wo = 26;   // FFN-out (+ residual)
 static int g_gemm_variant_o = 0;     // attention output (+ residual)
 static int g_small_t = 1;  // few-token split-K schedule (rp_set_option("small_t_schedule", 0): per-tile K loops)
+static int g_small_t_max = 512;  // passes of at most this many tokens take it (rp_set_option("small_t_max", n)):
+                                 // 300-byte state 1.92 -> 1.68 ms at 512; no gain from 1024 up (tools/latency_bench.py)
 static int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 static int g_gemm_skinny = 1;
 static int g_gemm_skinny_variant = 12;
@@ -1094,6 +1096,11 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     g_small_t = value != 0;
     return RP_OK;
   }
+  if (!strcmp(name, "small_t_max")) {
+    RP_REQUIRE(value >= 0 && value <= 4096, "small_t_max=%d", value);
+    g_small_t_max = value;
+    return RP_OK;
+  }
   if (!strcmp(name, "gemm_skinny")) {
     g_gemm_skinny = value != 0;
     return RP_OK;
@@ -1267,8 +1274,7 @@ struct Workspace {
 };
 
 // ---- few-token (split-K) schedule: sizing shared by carve() and the launcher
-constexpr int SMALL_T_MAX = 256;
-inline bool small_schedule(int T) { return g_small_t && T <= SMALL_T_MAX; }
+inline bool small_schedule(int T) { return g_small_t && T <= g_small_t_max; }
 // Splits of one projection: enough for ~one workgroup per CU at one token tile, at least four 32-wide K-steps per
 // split.  A function of the projection's shape ONLY: an embedding must not depend on how many other tokens share
 // the pass (or on the padded length of a captured graph), so neither S nor the K ranges may depend on T.

@@ -47,6 +47,7 @@ typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 1> SimCfg8Filter;
 // one (32 KB) - the premise operand streams from HBM, not from L2 like an encoder GEMM's weights
 typedef GemmCfg<256, 256, 32, 2, 2, 4, 1> SimCfgFilterK32;
 typedef GemmCfg<128, 64, 64, 2, 2, 3> SimCfgSampleK64;
+typedef GemmCfg<128, 64, 64, 2, 2, 6> SimCfgSampleK64x6;  // experiment: five 24-KB slices in flight per CU
 // default: the premise stream (read once, by one CU) carries the nt cache policy: -7 % filter time
 typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 0, 2> SimCfgFilterNt;
 constexpr int SIM_FILTER_META_BYTES = 3072;  // per-tile metadata behind the ring (EpiSimFilter::prologue)
@@ -89,6 +90,7 @@ struct EpiSim {
   char* smem;          // GEMM LDS, free once the main loop is done
   int tile_q0;         // first query of this workgroup's tile (set per workgroup)
   int bm;              // queries per workgroup tile
+  int debug_skip;      // timing only: 64 = the dense (sample) pass writes nothing
 
   // Accessibility predicate + key of one score.  imported/own exactly as common.py:280-289.
   __device__ __forceinline__ bool accessible(uint32_t word, int bit, int32_t f, int64_t ek, int32_t own,
@@ -99,6 +101,7 @@ struct EpiSim {
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* /*stage*/) {
     const int hi = lane >> 5, cl = lane & 31;
+    if (!filter && (debug_skip & 64)) return;
     // stage the tile's queries: own_file / q_key / threshold key / float lower bound of the threshold
     int32_t* s_own = reinterpret_cast<int32_t*>(smem);                  // [bm]
     float* s_tau = reinterpret_cast<float*>(smem + 1024);               // [bm]
@@ -892,6 +895,7 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   epi.smem = nullptr;
   epi.tile_q0 = 0;
   epi.bm = p.bm;
+  epi.debug_skip = g_scan_no_epilogue;
 
   RpStatus st;
   SelectArgs sa;
@@ -928,6 +932,8 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   // pass 0: dense keys of the sampled blocks (4 sub-tiles of 64 rows each), k best of the sample -> bound
   const int n_sub = p.sample_blocks * (SIM_PB / SimCfgSample::BN);
   st = fp8 ? launch_scan_cfg<SimCfg8Sample>(qop, eop, D2, n_sub, p.stride, epi, stream)
+       : (g_scan_sample_cfg == 2 && D2 % 64 == 0)
+           ? launch_scan_cfg<SimCfgSampleK64x6>(qop, eop, D2, n_sub, p.stride, epi, stream)
        : (g_scan_sample_cfg == 0 && D2 % 64 == 0)
            ? launch_scan_cfg<SimCfgSampleK64>(qop, eop, D2, n_sub, p.stride, epi, stream)
            : launch_scan_cfg<SimCfgSample>(qop, eop, D2, n_sub, p.stride, epi, stream);

@@ -22,9 +22,10 @@ model.corpus_embeddings = torch.nn.functional.normalize(torch.randn(N, 1472, gen
 model.embeddings_staled = False
 rng = np.random.default_rng(0)
 lib = _lib.load()
-for sv in [int(x) for x in os.environ.get('SKINNY', '12').split(',')]:
-  lib.rp_set_option(b'gemm_skinny_variant', sv)
-  print('skinny variant', sv)
+for sv in [int(x) for x in os.environ.get('SMALL_T_MAX', '256').split(',')]:
+  lib.rp_set_option(b'small_t_max', sv)
+  model._single_query = None  # captured graphs hold the schedule they were captured with
+  print('small_t_max', sv)
   for nbytes in [int(x) for x in os.environ.get('NBYTES', '100,300,1000').split(',')]:
       states = [synth.synth_state(rng, nbytes) for _ in range(30)]
       for s in states[:5]:
