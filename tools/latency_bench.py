@@ -22,10 +22,10 @@ model.corpus_embeddings = torch.nn.functional.normalize(torch.randn(N, 1472, gen
 model.embeddings_staled = False
 rng = np.random.default_rng(0)
 lib = _lib.load()
-for sv in [int(x) for x in os.environ.get('SMALL_T_MAX', '256').split(',')]:
-  lib.rp_set_option(b'small_t_max', sv)
+for sv in [int(x) for x in os.environ.get('SMALL_T_GEMM', '1').split(',')]:
+  lib.rp_set_option(b'small_t_gemm', sv)
   model._single_query = None  # captured graphs hold the schedule they were captured with
-  print('small_t_max', sv)
+  print('small_t_gemm', sv, '(1 = weights streamed to registers in fragment order, 0 = LDS ring)')
   for nbytes in [int(x) for x in os.environ.get('NBYTES', '100,300,1000').split(',')]:
       states = [synth.synth_state(rng, nbytes) for _ in range(30)]
       for s in states[:5]:
