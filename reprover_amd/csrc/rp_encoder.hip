@@ -39,7 +39,6 @@ static int g_gemm_variant_qkv = 26;  // QKV
 static int g_gemm_variant_wo = 26;   // FFN-out (+ residual)
 static int g_gemm_variant_o = 0;     // attention output (+ residual)
 static int g_small_t = 1;  // few-token split-K schedule (rp_set_option("small_t_schedule", 0): per-tile K loops)
-static int g_small_t_gemm = 1;  // few-token projections: 1 = weights streamed to registers in fragment order, 0 = LDS ring
 static int g_small_t_max = 512;  // passes of at most this many tokens take it (rp_set_option("small_t_max", n)):
                                  // 300-byte state 1.92 -> 1.68 ms at 512; no gain from 1024 up (tools/latency_bench.py)
 static int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
@@ -615,103 +614,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------
-// Few tokens, second generation of the projection: the weights go HBM -> REGISTERS, in MFMA-fragment order.
-//   With one state in the pass a projection is a pure weight stream (3-21 MB, a few hundred KFLOP per byte of nothing),
-//   and what bounds it is the number of weight bytes a CU keeps in flight.  The LDS-ring kernel above stages 64 weight
-//   rows x 32 K per step = 4 KB, six steps ahead: 24 KB in flight per CU, ~12 GB/s per CU whatever the layout in HBM.
-//   Here every weight matrix has a second copy laid out as [32-row block][16-wide K step][lane][8 bf16] - exactly the
-//   A operand of v_mfma_f32_32x32x16_bf16, 1 KB contiguous per wave and step - so a wave's whole K range is ONE
-//   contiguous stream that it requests with plain 16-byte global loads, eight steps (8 KB) ahead per wave, straight
-//   into the registers the MFMA reads.  Only the activations (the B operand, shared by the four waves) go through LDS:
-//   the workgroup's K slice of its 128 tokens is copied in once.
-//   grid = groups of four 32-row blocks x token tiles x S splits; partial tiles go to the same part[s][token][feature]
-//   array and the same row-wise reduce kernels as the first generation.
-// ------------------------------------------------------------------------------------------
-constexpr int FRAG_TOK = 128;   // tokens per workgroup tile
-constexpr int FRAG_DEPTH = 8;   // weight steps in flight per wave
-constexpr int FRAG_NMAX = 32;   // 16-wide K steps per split at most: the activation slice is 128 x (32 n + 16) bytes of LDS
-inline int frag_lds_bytes(int n) { return FRAG_TOK * (n * 32 + 16); }
-
-// dst[((fb * nk16 + ks) * 64 + lane) * 8 + e] = src[fb * 32 + (lane & 31)][ks * 16 + (lane >> 5) * 8 + e]
-__global__ __launch_bounds__(256) void pack_frag_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
-                                                        int n_rows, int K) {
-  const int nk16 = K / 16;
-  const size_t chunk = (size_t)blockIdx.x * 256 + threadIdx.x;  // one 16-byte chunk each
-  if (chunk >= (size_t)n_rows / 32 * nk16 * 64) return;
-  const int lane = (int)(chunk & 63);
-  const size_t step = chunk >> 6;
-  const int ks = (int)(step % nk16), fb = (int)(step / nk16);
-  const bf16_t* from = src + (size_t)(fb * 32 + (lane & 31)) * K + ks * 16 + (lane >> 5) * 8;
-  *reinterpret_cast<uint4*>(dst + chunk * 8) = *reinterpret_cast<const uint4*>(from);
-}
-
-__global__ __launch_bounds__(256) void gemm_frag_splitk_kernel(const bf16_t* __restrict__ Wf, const bf16_t* __restrict__ A,
-                                                               int lda, int nk16, int nfb, int groups_f, int S,
-                                                               float* __restrict__ part, int part_ld,
-                                                               size_t part_split_stride,
-                                                               const int32_t* __restrict__ t_dev) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tile = blockIdx.x / S, s = blockIdx.x - tile * S;
-  const int gf = tile % groups_f, tn = tile / groups_f;
-  if (t_dev && tn * FRAG_TOK >= *t_dev) return;
-  const int k0 = (int)((long long)nk16 * s / S), k1 = (int)((long long)nk16 * (s + 1) / S);
-  const int n = k1 - k0;
-  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, cl = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fb = gf * 4 + wave;
-  const bool live = fb < nfb;  // wave-uniform: the last group of a matrix may hold fewer than four blocks
-  // this wave's weight stream: steps k0 .. k1 of block fb, 64 chunks of 16 bytes per step
-  const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(Wf) + ((size_t)min(fb, nfb - 1) * nk16 + k0) * 64 + lane;
-  bf16x8 wf[FRAG_DEPTH];
-#pragma unroll
-  for (int d = 0; d < FRAG_DEPTH; ++d) wf[d] = wsrc[(size_t)min(d, n - 1) * 64];
-  // activation slice -> LDS: rows of n x 32 bytes (+16 pad: consecutive tokens land 4 banks apart)
-  const int row_bytes = n * 32 + 16;
-  {
-    const int r0 = tid >> 4, q0 = tid & 15;
-    const bf16_t* arow = A + (size_t)(tn * FRAG_TOK) * lda + (size_t)k0 * 16;
-#pragma unroll
-    for (int rp = 0; rp < FRAG_TOK / 16; ++rp) {
-      const int r = rp * 16 + r0;
-      for (int q = q0; q < 2 * n; q += 16)
-        *reinterpret_cast<uint4*>(smem + r * row_bytes + q * 16) =
-            *reinterpret_cast<const uint4*>(arow + (size_t)r * lda + q * 8);
-    }
-  }
-  __syncthreads();
-  f32x16 acc[FRAG_TOK / 32];
-#pragma unroll
-  for (int j = 0; j < FRAG_TOK / 32; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  if (live) {
-    const char* bbase = smem + cl * row_bytes + hi * 16;
-    for (int ks0 = 0; ks0 < n; ks0 += FRAG_DEPTH) {
-#pragma unroll
-      for (int d = 0; d < FRAG_DEPTH; ++d) {
-        const int ks = ks0 + d;
-        if (ks < n) {
-          const bf16x8 w = wf[d];
-          if (ks + FRAG_DEPTH < n) wf[d] = wsrc[(size_t)(ks + FRAG_DEPTH) * 64];
-#pragma unroll
-          for (int j = 0; j < FRAG_TOK / 32; ++j) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(bbase + (j * 32) * row_bytes + ks * 32);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, b, acc[j], 0, 0, 0);
-          }
-        }
-      }
-    }
-    float* dst = part + (size_t)s * part_split_stride + (size_t)(tn * FRAG_TOK + cl) * part_ld + fb * 32 + 4 * hi;
-#pragma unroll
-    for (int j = 0; j < FRAG_TOK / 32; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(dst + (size_t)(j * 32) * part_ld + 8 * g) =
-            make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // K4+K5: T5 self-attention, flash-style, varlen.
 //   scores = q·k (NO 1/sqrt(d) scaling, HF:197) + bias[h, clamp(j-i, -128, 128)]; keys >= len are
 //   excluded (HF uses finfo.min via where(mask, bias, min): identical result whenever a row has
@@ -1124,8 +1026,6 @@ struct LayerPacked {
   bf16_t* wo;    // [D, inner]
   bf16_t* wi;    // [2F, D] gate/up interleaved by 32
   bf16_t* wo2;   // [D, F]
-  // the same four matrices in MFMA-fragment order for the few-token schedule (see gemm_frag_splitk_kernel)
-  bf16_t *wqkv_f, *wo_f, *wi_f, *wo2_f;
 };
 
 }  // namespace rp
@@ -1194,10 +1094,6 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   }
   if (!strcmp(name, "small_t_schedule")) {
     g_small_t = value != 0;
-    return RP_OK;
-  }
-  if (!strcmp(name, "small_t_gemm")) {
-    g_small_t_gemm = value != 0;
     return RP_OK;
   }
   if (!strcmp(name, "small_t_max")) {
@@ -1312,16 +1208,6 @@ static RpStatus pack_all(RpEncoder* e, const RpT5Weights* w) {
     hipLaunchKernelGGL((pack_rows_kernel<T>), dim3(D), dim3(256), 0, 0, L.wo2, s.wo, nullptr, nullptr, D, F, 0,
                        (int)PACK_COPY, (const float*)nullptr);
     RP_CHECK_LAUNCH();
-    // fragment-order copies for the few-token schedule
-    struct { bf16_t* src; bf16_t** dst; int rows, K; } fr[4] = {
-        {L.wqkv, &L.wqkv_f, 3 * inner, D}, {L.wo, &L.wo_f, D, inner}, {L.wi, &L.wi_f, 2 * F, D}, {L.wo2, &L.wo2_f, D, F}};
-    for (auto& f : fr) {
-      if ((st = alloc((size_t)f.rows * f.K * 2, (void**)f.dst))) return st;
-      const size_t chunks = (size_t)f.rows * f.K / 8;
-      hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, 0, f.src, *f.dst, f.rows,
-                         f.K);
-    }
-    RP_CHECK_LAUNCH();
   }
   // relative-position bias -> [H, 2*maxd+1] table (host; the raw table is tiny)
   const int nbk = c.rel_num_buckets, H = c.num_heads, maxd = e->maxd, ntab = 2 * maxd + 1;
@@ -1348,7 +1234,7 @@ extern "C" RpStatus rp_encoder_create(const RpT5Config* cfg, const RpT5Weights* 
                                       RpEncoder** out) {
   RP_REQUIRE(cfg && weights && out, "null argument");
   if (cfg->d_kv != 64) return fail(RP_E_UNSUPPORTED, "d_kv=%d: kernels implement d_kv=64", cfg->d_kv);
-  if (cfg->d_model % 32 || cfg->d_model > RMS_MAX_V4 * 256 || cfg->d_ff % 32 || (cfg->num_heads * cfg->d_kv) % 32)
+  if (cfg->d_model % 32 || cfg->d_model > RMS_MAX_V4 * 256 || cfg->d_ff % 32)
     return fail(RP_E_UNSUPPORTED, "d_model=%d (multiple of 32, <= %d) / d_ff=%d (multiple of 32) unsupported",
                 cfg->d_model, RMS_MAX_V4 * 256, cfg->d_ff);
   if (2 * cfg->rel_max_distance + 1 > ATT_TAB_MAX)
@@ -1397,18 +1283,8 @@ inline int splitk_S(int n_features, int K) {
   const int by_wgs = 256 / tiles_f, by_k = std::max(1, K / 32 / 4);  // never more workgroups than CUs: one round
   return std::max(1, std::min(by_wgs, by_k));
 }
-// The fragment-order kernel: groups of 128 features; enough splits for ~one workgroup per CU, at least eight 16-wide
-// K steps per split, at most 16 splits (the partial tiles are traffic too), never more than FRAG_NMAX steps per split.
-inline int frag_S(int n_features, int K) {
-  const int groups_f = (n_features / 32 + 3) / 4, nk16 = K / 16;
-  const int by_wgs = std::max(1, 256 / groups_f), by_k = std::max(1, nk16 / 8);
-  const int need = (nk16 + FRAG_NMAX - 1) / FRAG_NMAX;
-  return std::max(need, std::min(16, std::min(by_wgs, by_k)));
-}
-inline size_t splitk_floats(int n_features, int T, int K) {  // either generation fits
-  const size_t rows = align_up((size_t)T, 128);
-  return std::max((size_t)splitk_S(n_features, K) * rows * align_up((size_t)n_features, 64),
-                  (size_t)frag_S(n_features, K) * rows * align_up((size_t)n_features, 128));
+inline size_t splitk_floats(int n_features, int T, int K) {
+  return (size_t)splitk_S(n_features, K) * align_up((size_t)T, 128) * align_up((size_t)n_features, 64);
 }
 Workspace carve(const RpEncoder* e, int T, int batch, char* base) {
   const size_t Tp = align_up((size_t)T, GEMM_M_ALIGN);
@@ -1530,28 +1406,14 @@ static RpStatus encode_pass_small(RpEncoder* e, const int32_t* ids, const int32_
   RP_HIP(attr.ensure((const void*)gemm_splitk_kernel, C::LDS_BYTES));
   RP_REQUIRE(w.part != nullptr, "workspace was sized without the few-token schedule");
   // partial tiles of  out[t, f] = sum_k act[t, k] W[f, k]  ->  part[s][t][f]
-  static LdsAttrOnce attr_frag;
-  RP_HIP(attr_frag.ensure((const void*)gemm_frag_splitk_kernel, frag_lds_bytes(FRAG_NMAX)));
-  const bool frag = g_small_t_gemm != 0;
-  auto project = [&](const bf16_t* act, int lda, const bf16_t* W, const bf16_t* Wf, int n_features, int K,
-                     int prof_class, int& S, int& ld, size_t& stride) {
-    const int tiles_t = rows / 128;
-    ProfScope ps(stream, prof_class);
-    if (frag) {
-      S = frag_S(n_features, K);
-      const int nfb = n_features / 32, groups_f = (nfb + 3) / 4, nk16 = K / 16;
-      ld = groups_f * 128;
-      stride = (size_t)rows * ld;
-      const int n_max = (nk16 + S - 1) / S;
-      hipLaunchKernelGGL(gemm_frag_splitk_kernel, dim3(groups_f * tiles_t * S), dim3(256), frag_lds_bytes(n_max), stream, Wf,
-                         act, lda, nk16, nfb, groups_f, S, w.part, ld, stride, t_dev);
-      return;
-    }
+  auto project = [&](const bf16_t* act, int lda, const bf16_t* W, int n_features, int K, int prof_class, int& S,
+                     int& ld, size_t& stride) {
     S = splitk_S(n_features, K);
-    const int tiles_f = (n_features + 63) / 64;
+    const int tiles_f = (n_features + 63) / 64, tiles_t = rows / 128;
     ld = tiles_f * 64;
     stride = (size_t)rows * ld;
     GemmOperand wop{W, K, n_features}, aop{act, lda, Tp};
+    ProfScope ps(stream, prof_class);
     hipLaunchKernelGGL(gemm_splitk_kernel, dim3(tiles_f * tiles_t * S), dim3(C::THREADS), C::LDS_BYTES, stream, wop, aop,
                        K, tiles_f, tiles_t, S, w.part, ld, stride, t_dev);
   };
@@ -1567,7 +1429,7 @@ static RpStatus encode_pass_small(RpEncoder* e, const int32_t* ids, const int32_
   size_t stride;
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerPacked& L = e->layers[i];
-    project(w.xb, D, L.wqkv, L.wqkv_f, 3 * inner, D, RP_K_GEMM_QKV, S, ld, stride);
+    project(w.xb, D, L.wqkv, 3 * inner, D, RP_K_GEMM_QKV, S, ld, stride);
     {
       ProfScope ps(stream, RP_K_GEMM_QKV);
       hipLaunchKernelGGL(splitk_reduce_kernel<RED_STORE>, dim3(rows), dim3(256), 0, stream, (const float*)w.part, ld,
@@ -1579,21 +1441,21 @@ static RpStatus encode_pass_small(RpEncoder* e, const int32_t* ids, const int32_
       hipLaunchKernelGGL(attention_kernel, att_grid, dim3(256), 0, stream, w.qkv, (const int4*)w.work, e->bias_tab, w.att,
                          H, e->maxd);
     }
-    project(w.att, inner, L.wo, L.wo_f, D, inner, RP_K_GEMM_O, S, ld, stride);
+    project(w.att, inner, L.wo, D, inner, RP_K_GEMM_O, S, ld, stride);
     {
       ProfScope ps(stream, RP_K_GEMM_O);
       hipLaunchKernelGGL(splitk_reduce_kernel<RED_RESID>, dim3(rows), dim3(256), 0, stream, (const float*)w.part, ld,
                          stride, S, D, (const float*)nullptr, (bf16_t*)nullptr, 0, w.xb, w.xlo, D, w.rs, inv_d, eps, t_dev);
     }
     if (g_debug_skip_ffn) continue;
-    project(w.xb, D, L.wi, L.wi_f, 2 * F, D, RP_K_GEMM_WI, S, ld, stride);
+    project(w.xb, D, L.wi, 2 * F, D, RP_K_GEMM_WI, S, ld, stride);
     {
       ProfScope ps(stream, RP_K_GEMM_WI);
       hipLaunchKernelGGL(splitk_reduce_kernel<RED_GEGLU>, dim3(rows), dim3(256), 0, stream, (const float*)w.part, ld,
                          stride, S, 2 * F, (const float*)w.rs, w.ff, F, (bf16_t*)nullptr, (bf16_t*)nullptr, 0,
                          (float*)nullptr, 0.f, 0.f, t_dev);
     }
-    project(w.ff, F, L.wo2, L.wo2_f, D, F, RP_K_GEMM_WO, S, ld, stride);
+    project(w.ff, F, L.wo2, D, F, RP_K_GEMM_WO, S, ld, stride);
     {
       ProfScope ps(stream, RP_K_GEMM_WO);
       hipLaunchKernelGGL(splitk_reduce_kernel<RED_RESID>, dim3(rows), dim3(256), 0, stream, (const float*)w.part, ld,

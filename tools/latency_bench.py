@@ -22,10 +22,12 @@ model.corpus_embeddings = torch.nn.functional.normalize(torch.randn(N, 1472, gen
 model.embeddings_staled = False
 rng = np.random.default_rng(0)
 lib = _lib.load()
-for sv in [int(x) for x in os.environ.get('SMALL_T_GEMM', '1').split(',')]:
-  lib.rp_set_option(b'small_t_gemm', sv)
+if os.environ.get('EAGER') == '1':
+    model.use_graphs = False  # launch by launch: the per-class event pairs see every kernel
+for sv in [int(x) for x in os.environ.get('SMALL_T_MAX', '512').split(',')]:
+  lib.rp_set_option(b'small_t_max', sv)
   model._single_query = None  # captured graphs hold the schedule they were captured with
-  print('small_t_gemm', sv, '(1 = weights streamed to registers in fragment order, 0 = LDS ring)')
+  print('small_t_max', sv)
   for nbytes in [int(x) for x in os.environ.get('NBYTES', '100,300,1000').split(',')]:
       states = [synth.synth_state(rng, nbytes) for _ in range(30)]
       for s in states[:5]:
@@ -40,9 +42,9 @@ for sv in [int(x) for x in os.environ.get('SMALL_T_GEMM', '1').split(',')]:
           model.retrieve(s, "M/F4000.lean", "t", Pos(30, 0), 100)
       prof = _lib.profile_read(); _lib.profile_enable(False)
       gpu_ms = sum(v[0] for v in prof.values()) / 25
-      top = sorted(prof.items(), key=lambda kv: -kv[1][0])[:6]
+      top = sorted(prof.items(), key=lambda kv: -kv[1][0])[:9]
       print(f"state {nbytes:5d} B: retrieve() {dt*1e3:7.3f} ms wall; GPU kernels {gpu_ms:6.3f} ms; " +
-            ", ".join(f"{k} {v[0]/25*1e3:.0f}us" for k, v in top), flush=True)
+            ", ".join(f"{k} {v[0]/25*1e3:.0f}us/{v[1]//25}" for k, v in top), flush=True)
 if os.environ.get("CPROFILE") == "1":
     import cProfile, pstats
     states = [synth.synth_state(rng, 100) for _ in range(200)]
