@@ -9,6 +9,8 @@ variants = [int(v) for v in os.environ.get("VARIANTS", "26,20,9,0").split(",")]
 groups = [int(v) for v in os.environ.get("GROUP_M", "8").split(",")]
 staggers = [int(v) for v in os.environ.get("STAGGER", "0").split(",")]  # gemm_stagger_us_* values (first-round spread)
 OPT = {"wi": b"gemm_stagger_us_wi", "wo": b"gemm_stagger_us_wo", "qk": b"gemm_stagger_us_qkv", "o ": b"gemm_stagger_us_o"}
+if os.environ.get("SKINNY") is not None:  # 0: the variant asked for is the variant run, whatever the token count
+    _lib.check(lib.rp_set_option(b"gemm_skinny", int(os.environ["SKINNY"])), "opt")
 dev = torch.device("cuda")
 g = torch.Generator(device=dev); g.manual_seed(0)
 only = os.environ.get('ONLY')
