@@ -39,8 +39,9 @@ static int g_gemm_variant_qkv = 26;  // QKV
 static int g_gemm_variant_wo = 26;   // FFN-out (+ residual)
 static int g_gemm_variant_o = 0;     // attention output (+ residual)
 static int g_small_t = 1;  // few-token split-K schedule (rp_set_option("small_t_schedule", 0): per-tile K loops)
-static int g_small_t_max = 512;  // passes of at most this many tokens take it (rp_set_option("small_t_max", n)):
-                                 // 300-byte state 1.92 -> 1.68 ms at 512; no gain from 1024 up (tools/latency_bench.py)
+static int g_small_t_max = 128;  // passes of at most this many tokens take it (rp_set_option("small_t_max", n)).
+                                 // From 129 tokens up the per-tile schedule with 64 x 128 tiles is as fast or faster
+                                 // (tools/latency_bench.py: 200-byte state 1.39 vs 1.42 ms, 300-byte 1.41 vs 1.68 ms).
 static int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 static int g_gemm_skinny = 1;
 static int g_gemm_skinny_variant = 12;

@@ -60,7 +60,7 @@ def test_padded_entry_point_equals_packed_and_ignores_padding(tiny, golden_dir):
     mask2 = torch.nn.functional.pad(mask, (0, 77))
     assert torch.equal(tiny._encode(ids2.cuda(), mask2.cuda()), packed)
     # each text alone == inside the batch, and order does not matter.  Bitwise-level agreement
-    # holds inside one launch schedule; a text alone (<= 512 tokens) takes the few-token split-K schedule, whose fp32
+    # holds inside one launch schedule; a text alone (<= 128 tokens) takes the few-token split-K schedule, whose fp32
     # partial sums associate differently from the per-tile K loop of a big pass: there the agreement is one bf16
     # rounding of an intermediate (stated bound 4e-3 on unit-norm rows), never a different answer.
     from reprover_amd import _lib
@@ -147,7 +147,7 @@ def test_bf16_output_and_chunked_passes_agree(small, golden_dir):
         small.encoder.max_tokens_per_pass = old
         _lib.check(lib.rp_set_option(b"small_t_schedule", 1), "opt")
     assert (chunked_same - ref).abs().max().item() < 1e-6
-    assert (chunked - ref).abs().max().item() < 4e-3  # passes of <= 512 tokens take the split-K schedule
+    assert (chunked - ref).abs().max().item() < 4e-3  # passes of <= 128 tokens take the split-K schedule
     out_bf = torch.empty(ref.shape, dtype=torch.bfloat16, device=ref.device)
     ids, cu = small.tokenizer.packed(texts, small.max_seq_len)
     small.encoder.encode_packed(ids, cu, out_bf)
