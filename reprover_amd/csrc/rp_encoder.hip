@@ -481,35 +481,36 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
   // Few tokens (the prover's single-state query): the 256 x 256 tiling would leave
   // most CUs idle and each workgroup latency-bound on its K loop.  Switch to 64-feature tiles with a
   // 7-deep LDS ring so every workgroup streams its weight slab with ~6 K-steps of DMA in flight.
-  // Measured per launch at 1024 / 2048 tokens (tools/gemm_bench.py, SKINNY=0 FUSED=1; us):
-  //            64x128 (15)   64x256 (12)   128x128 (0)   256x256 (26)
-  //   FFN-out    31 /  60      47 /  52      41 /  46      76 /  78
-  //   QKV        14 /  26      20 /  21      17 /  19      29 /  32
-  //   attn-out    9 /  15      12 /  14      11 /  13      18 /  20
-  //   FFN-in     52 /  92      44 /  85      33 /  64      35 /  41
+  // Measured per launch (tools/gemm_bench.py, SKINNY=0 FUSED=1; us) at 256 / 512 / 1024 / 2048 tokens:
+  //            64x128x64 (16)    64x128x32 (15)    64x256x32 (12)   128x128x32 (0)    256x256x64 (26)
+  //   FFN-out  27/28/30/ -       29/30/32/60        - / - /47/52    39/41/42/46        - / - /76/78
+  //   QKV      12/13/13/ -       14/14/15/26        - / - /20/21    17/17/18/19        - / - /29/32
+  //   attn-out  8/ 8/ 9/ -        8/ 9/ 9/15        - / - /12/14    11/11/12/13        - / - /18/20
+  //   FFN-in   14/25/47/ -       15/29/53/92        - / - /44/85    19/20/34/64        - / - /35/41
+  // (FFN-out stays ~28 us from 256 to 1024 tokens: 23 feature tiles, each workgroup walking 459 KB of weights.)
   if (g_gemm_skinny && m256) {
     const int tv = (tokens_valid > 0 && tokens_valid < M) ? tokens_valid : M;
-    if (((n_rows_w + 255) / 256) * (M / 256) < 96) {
-      if (g_gemm_skinny_variant != 12) v = g_gemm_skinny_variant;  // forced by a test
-      else if (prof_class == RP_K_GEMM_WI) v = 0;
-      else v = (tv <= 1024) ? 15 : 0;
-    } else if (prof_class == RP_K_GEMM_WI && tv <= 1024) {
-      v = 0;
-    }
+    const bool few_tiles = ((n_rows_w + 255) / 256) * (M / 256) < 96;
+    if (few_tiles && g_gemm_skinny_variant != 12) v = g_gemm_skinny_variant;  // forced by a test
+    else if (prof_class == RP_K_GEMM_WI) v = (tv <= 256) ? 16 : (few_tiles || tv <= 1024) ? 0 : v;
+    else if (few_tiles) v = (tv <= 1024) ? 16 : 0;
   }
   if ((v == 20 || v == 26) && !k64) v = 9;  // 64-wide K tiles need K % 64 == 0
+  if (v == 16 && !k64) v = 15;
   if (v >= 5 && !m256) v = 0;
   // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages[, pipelined]>:
   //   20 / 26  pipelined 256 x 256 x 64, 4 / 8 waves     (the encoder's big GEMMs)
   //   9        plain 256 x 256 x 32, 3 stages             (K % 64 != 0)
   //   0        plain 128 x 128 x 32, 3 stages, 2 blocks/CU (attention-out; token counts not a multiple of 256)
-  //   12 / 15  64 x 256 / 64 x 128 x 32, 7 stages         (up to ~1024 tokens: single-state queries; 12 only on request)
+  //   16 / 15  64 x 128 x 64, 4 stages / x 32, 7 stages   (up to ~1024 tokens: single-state queries)
+  //   12       64 x 256 x 32, 7 stages                    (on request only)
   switch (v) {
     case 20: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
     case 26: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
     case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
     case 12: return launch_gemm_cfg<GemmCfg<64, 256, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
     case 15: return launch_gemm_cfg<GemmCfg<64, 128, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
+    case 16: return launch_gemm_cfg<GemmCfg<64, 128, 64, 1, 4, 4>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
     default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
   }
 }
