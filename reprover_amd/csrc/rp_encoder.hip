@@ -1509,9 +1509,12 @@ extern "C" RpStatus rp_encode_varlen(RpEncoder* e, const int32_t* ids, const int
 // bound B * L of the token count and skips, on the device, what lies beyond the real count.
 // ------------------------------------------------------------------------------------------
 namespace rp {
-// lens[b] = number of non-zero mask entries; the row is right-padded iff that equals (last non-zero index + 1)
+// lens[b] = number of non-zero mask entries; the row is right-padded iff that equals (last non-zero index + 1).
+// A row that is not right-padded, or empty, is reported as -(count + 1): padded_scan_kernel turns that into meta[2].
+// (No memset node: meta is written by plain stores only.  hipMemsetAsync on a 4-byte-aligned address inside a captured
+// graph left 0x54545454 in one of the four words on replay - the low byte of the destination address.)
 __global__ __launch_bounds__(256) void padded_lens_kernel(const int64_t* __restrict__ mask, int L,
-                                                          int32_t* __restrict__ lens, int32_t* __restrict__ meta) {
+                                                          int32_t* __restrict__ lens) {
   __shared__ int s_cnt[4], s_last[4];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t* row = mask + (size_t)b * L;
@@ -1534,23 +1537,28 @@ __global__ __launch_bounds__(256) void padded_lens_kernel(const int64_t* __restr
   if (threadIdx.x == 0) {
     cnt = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
-    lens[b] = cnt;
-    if (cnt != last || cnt == 0) atomicOr(&meta[2], 1);  // not right-padded, or an empty sequence
+    lens[b] = (cnt != last || cnt == 0) ? -(cnt + 1) : cnt;  // not right-padded, or an empty sequence
   }
 }
 
-// cu[0] = 0, cu[b + 1] = sum of lens[0..b]; meta[0] = total, meta[1] = longest.  One workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) void padded_scan_kernel(const int32_t* __restrict__ lens, int B,
+// cu[0] = 0, cu[b + 1] = sum of lens[0..b]; meta = {total, longest, any row rejected, 0}.  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void padded_scan_kernel(const int32_t* __restrict__ lens_in, int B,
                                                            int32_t* __restrict__ cu, int32_t* __restrict__ meta) {
   __shared__ int s_part[1024];
   const int tid = threadIdx.x;
   const int per = (B + 1023) / 1024;
   const int lo = min(tid * per, B), hi = min(lo + per, B);
-  int sum = 0, mx = 0;
+  auto len_of = [&](int i) {  // a rejected row keeps its count (the pass still runs; the caller raises afterwards)
+    const int v = lens_in[i];
+    return v < 0 ? -v - 1 : v;
+  };
+  int sum = 0, mx = 0, bad = 0;
   for (int i = lo; i < hi; ++i) {
-    sum += lens[i];
-    mx = max(mx, lens[i]);
+    bad |= lens_in[i] < 0;
+    sum += len_of(i);
+    mx = max(mx, len_of(i));
   }
+  const int any_bad = __syncthreads_or(bad);
   s_part[tid] = sum;
   __syncthreads();
   for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan of the per-thread sums
@@ -1563,7 +1571,7 @@ __global__ __launch_bounds__(1024) void padded_scan_kernel(const int32_t* __rest
   const int total = s_part[1023];
   if (tid == 0) cu[0] = 0;
   for (int i = lo; i < hi; ++i) {
-    run += lens[i];
+    run += len_of(i);
     cu[i + 1] = run;
   }
   __syncthreads();  // everyone has read its prefix and the total: s_part is reused for the maximum
@@ -1576,6 +1584,8 @@ __global__ __launch_bounds__(1024) void padded_scan_kernel(const int32_t* __rest
   if (tid == 0) {
     meta[0] = total;
     meta[1] = s_part[0];
+    meta[2] = any_bad ? 1 : 0;
+    meta[3] = 0;
   }
 }
 
@@ -1624,8 +1634,7 @@ extern "C" RpStatus rp_encode_padded(RpEncoder* e, const int64_t* input_ids, con
   Workspace w = carve(e, T_max, batch, workspace ? (char*)workspace + pp.bytes : nullptr);
   if (!workspace || workspace_bytes < pp.bytes + w.bytes)
     return fail(RP_E_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, pp.bytes + w.bytes);
-  RP_HIP(hipMemsetAsync(meta, 0, 4 * sizeof(int32_t), stream));
-  hipLaunchKernelGGL(padded_lens_kernel, dim3(batch), dim3(256), 0, stream, attention_mask, padded_len, pp.lens, meta);
+  hipLaunchKernelGGL(padded_lens_kernel, dim3(batch), dim3(256), 0, stream, attention_mask, padded_len, pp.lens);
   hipLaunchKernelGGL(padded_scan_kernel, dim3(1), dim3(1024), 0, stream, pp.lens, batch, pp.cu, meta);
   hipLaunchKernelGGL(padded_pack_kernel, dim3((padded_len + 255) / 256, batch), dim3(256), 0, stream, input_ids, pp.cu,
                      padded_len, pp.packed);

@@ -53,17 +53,18 @@ class SingleQueryGraph:
         self.d_qk = dv[2 * L * 8 : 2 * L * 8 + 8].view(torch.int64)
         self.d_own = dv[2 * L * 8 + 8 : 2 * L * 8 + 12].view(torch.int32)
         self.d_bits = dv[2 * L * 8 + 16 :].view(torch.int32).view(F, 1)
-        # ---- output block: f32 scores [k], int32 ids [k], int32 count, int32 meta [4]
-        self._n_out = 8 * k + 4 + 16
+        # ---- output block: int32 meta [4] (16-byte aligned), f32 scores [k], int32 ids [k], int32 count
+        self._n_out = 16 + 8 * k + 4
         self.d_out = torch.zeros(self._n_out, dtype=torch.uint8, device=dev)
         self.h_out = torch.zeros(self._n_out, dtype=torch.uint8).pin_memory()
-        self.d_scores = self.d_out[: 4 * k].view(torch.float32).view(1, k)
-        self.d_topk = self.d_out[4 * k : 8 * k].view(torch.int32).view(1, k)
-        self.d_count = self.d_out[8 * k : 8 * k + 4].view(torch.int32)
-        self.d_meta = self.d_out[8 * k + 4 :].view(torch.int32)
+        self.d_meta = self.d_out[:16].view(torch.int32)
+        self.d_scores = self.d_out[16 : 16 + 4 * k].view(torch.float32).view(1, k)
+        self.d_topk = self.d_out[16 + 4 * k : 16 + 8 * k].view(torch.int32).view(1, k)
+        self.d_count = self.d_out[16 + 8 * k :].view(torch.int32)
         ho = self.h_out.numpy()
-        self.h_scores, self.h_topk = ho[: 4 * k].view(np.float32), ho[4 * k : 8 * k].view(np.int32)
-        self.h_count, self.h_meta = ho[8 * k : 8 * k + 4].view(np.int32), ho[8 * k + 4 :].view(np.int32)
+        self.h_meta = ho[:16].view(np.int32)
+        self.h_scores, self.h_topk = ho[16 : 16 + 4 * k].view(np.float32), ho[16 + 4 * k : 16 + 8 * k].view(np.int32)
+        self.h_count = ho[16 + 8 * k :].view(np.int32)
         # ---- scratch owned by the graph (the captured nodes hold raw pointers)
         self.q = torch.zeros((1, D), dtype=torch.bfloat16, device=dev)
         self.ws_enc = torch.empty(encoder.padded_workspace_bytes(1, L), dtype=torch.uint8, device=dev)
@@ -108,8 +109,8 @@ class SingleQueryGraph:
         self.graph.replay()
         self.h_out.copy_(self.d_out, non_blocking=True)
         torch.cuda.current_stream(self.E.device).synchronize()
-        if self.h_meta[2] != 0:
-            raise ValueError("empty state")
+        if self.h_meta[2] != 0:  # the device-side check of rp_encode_padded (cannot fire for a tokenised state)
+            raise ValueError(f"rp_encode_padded rejected the state: meta={self.h_meta.tolist()} for {n} tokens")
         return self.h_topk.copy(), self.h_scores.copy(), int(self.h_count[0])
 
 

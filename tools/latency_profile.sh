@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel durations of single-state retrieve() calls (graph replay).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
-for g in ${CASES:-512}; do
+for g in ${CASES:--1}; do
   timeout -k 5 300 rocprofv3 --kernel-trace --stats -d gpurun_out/lat_prof_$g -o lat --output-format csv -- \
     env SMALL_T_MAX=$g NBYTES=${NBYTES:-100} python tools/latency_bench.py > gpurun_out/lat_prof_$g.log 2>&1
   python - <<PY
