@@ -223,6 +223,23 @@ struct RowScale {
   const float* rs;  // [tokens] or NULL (no scaling); produced by rowscale_kernel from the ssp partials
   __device__ __forceinline__ float get(int token) const { return rs ? rs[token] : 1.f; }
 };
+// Passes of at most ~1000 tokens (a single proof state) skip the rowscale launches - there a launch costs more than
+// its work - and the consuming epilogue sums the slots itself, in the same index order (the same bits).  A separate
+// type, instantiated for the small tile configurations only: the big tiles' register allocation stays as it was.
+struct RowScaleFromSlots {
+  const float* ssp;  // [np, ld] slot-major partial sums of squares
+  int np, ld;
+  float inv_d, eps;
+  __device__ __forceinline__ float get(int token) const {
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = (i < np) ? ssp[(size_t)i * ld + token] : 0.f;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += v[i];
+    return rsqrtf(s * inv_d + eps);
+  }
+};
 
 // rs[token] = rsqrt(sum_p ssp[p][token] / D + eps), slots summed in index order
 __global__ __launch_bounds__(64) void rowscale_kernel(const float* __restrict__ ssp, float* __restrict__ rs, int rows,
@@ -238,10 +255,11 @@ __global__ __launch_bounds__(64) void rowscale_kernel(const float* __restrict__ 
   rs[t] = rsqrtf(s * inv_d + eps);
 }
 
-struct EpiStoreBf16 {  // out[token, feature] = bf16(acc * rs[token])
+template <class RS>
+struct EpiStoreBf16T {  // out[token, feature] = bf16(acc * rs[token])
   bf16_t* out;
   int ldo, n_valid;  // n_valid = number of real output features (multiple of 8)
-  RowScale rs;
+  RS rs;
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
     const int hi = lane >> 5, cl = lane & 31;
@@ -362,10 +380,11 @@ struct EpiResid {  // x[token, feature] += acc on the two planes of the residual
   }
 };
 
-struct EpiGegluBf16 {  // W rows interleaved 32 gate / 32 up: even row-fragments gate, odd up
+template <class RS>
+struct EpiGegluBf16T {  // W rows interleaved 32 gate / 32 up: even row-fragments gate, odd up
   bf16_t* out;         // [tokens, n_valid/2]
   int ldo, n_valid;    // n_valid counts interleaved rows (= 2 * d_ff)
-  RowScale rs;
+  RS rs;
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
     static_assert(FM % 2 == 0, "gate/up fragment pairs");
@@ -410,6 +429,10 @@ struct EpiGegluBf16 {  // W rows interleaved 32 gate / 32 up: even row-fragments
     }
   }
 };
+typedef EpiStoreBf16T<RowScale> EpiStoreBf16;
+typedef EpiGegluBf16T<RowScale> EpiGegluBf16;
+typedef EpiStoreBf16T<RowScaleFromSlots> EpiStoreBf16Slots;
+typedef EpiGegluBf16T<RowScaleFromSlots> EpiGegluBf16Slots;
 
 template <class C, class Epi>
 __global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOperand W, int K, int tiles_m,
@@ -466,13 +489,8 @@ static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hi
 // rows of the activation workspace are padded to this so every variant tiles the tokens exactly
 constexpr int GEMM_M_ALIGN = 256;
 
-template <class Epi>
-// tokens_valid = real token count of the pass (0: all M rows): lets the small-token configurations skip tiles
-// that hold only padding rows
-static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, int ldw, int n_rows_w,
-                            int K, Epi epi, hipStream_t stream, int prof_class, int tokens_valid = 0,
-                            const int32_t* t_dev = nullptr) {
-  GemmOperand a{A, lda, M}, w{W, ldw, n_rows_w};
+// Which tile configuration a projection runs with.  tokens_valid = real token count of the pass (0: all M rows).
+static int pick_gemm_variant(int prof_class, int M, int n_rows_w, int K, int tokens_valid) {
   int v = prof_class == RP_K_GEMM_O     ? g_gemm_variant_o
           : prof_class == RP_K_GEMM_WO  ? g_gemm_variant_wo
           : prof_class == RP_K_GEMM_QKV ? g_gemm_variant_qkv
@@ -480,7 +498,7 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
   const bool k64 = (K % 64 == 0), m256 = (M % 256 == 0);
   // Few tokens (the prover's single-state query): the 256 x 256 tiling would leave
   // most CUs idle and each workgroup latency-bound on its K loop.  Switch to 64-feature tiles with a
-  // 7-deep LDS ring so every workgroup streams its weight slab with ~6 K-steps of DMA in flight.
+  // deep LDS ring so every workgroup streams its weight slab with several K-steps of DMA in flight.
   // Measured per launch (tools/gemm_bench.py, SKINNY=0 FUSED=1; us) at 256 / 512 / 1024 / 2048 tokens:
   //            64x128x64 (16)    64x128x32 (15)    64x256x32 (12)   128x128x32 (0)    256x256x64 (26)
   //   FFN-out  27/28/30/ -       29/30/32/60        - / - /47/52    39/41/42/46        - / - /76/78
@@ -498,17 +516,35 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
   if ((v == 20 || v == 26) && !k64) v = 9;  // 64-wide K tiles need K % 64 == 0
   if (v == 16 && !k64) v = 15;
   if (v >= 5 && !m256) v = 0;
-  // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages[, pipelined]>:
-  //   20 / 26  pipelined 256 x 256 x 64, 4 / 8 waves     (the encoder's big GEMMs)
-  //   9        plain 256 x 256 x 32, 3 stages             (K % 64 != 0)
-  //   0        plain 128 x 128 x 32, 3 stages, 2 blocks/CU (attention-out; token counts not a multiple of 256)
-  //   16 / 15  64 x 128 x 64, 4 stages / x 32, 7 stages   (up to ~1024 tokens: single-state queries)
-  //   12       64 x 256 x 32, 7 stages                    (on request only)
+  return v;
+}
+inline bool small_variant(int v) { return v == 0 || v == 15 || v == 16; }
+
+// GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages[, pipelined]>:
+//   20 / 26  pipelined 256 x 256 x 64, 4 / 8 waves     (the encoder's big GEMMs)
+//   9        plain 256 x 256 x 32, 3 stages             (K % 64 != 0)
+//   0        plain 128 x 128 x 32, 3 stages, 2 blocks/CU (attention-out; token counts not a multiple of 256)
+//   16 / 15  64 x 128 x 64, 4 stages / x 32, 7 stages   (up to ~1024 tokens: single-state queries)
+//   12       64 x 256 x 32, 7 stages                    (on request only)
+// SMALL_ONLY: the epilogue type exists for the small configurations only (pick_gemm_variant said so).
+template <bool SMALL_ONLY = false, class Epi>
+static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, int ldw, int n_rows_w,
+                            int K, Epi epi, hipStream_t stream, int prof_class, int tokens_valid = 0,
+                            const int32_t* t_dev = nullptr) {
+  GemmOperand a{A, lda, M}, w{W, ldw, n_rows_w};
+  const int v = pick_gemm_variant(prof_class, M, n_rows_w, K, tokens_valid);
+  if constexpr (!SMALL_ONLY) {
+    switch (v) {
+      case 20: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
+      case 26: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
+      case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
+      case 12: return launch_gemm_cfg<GemmCfg<64, 256, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
+      default: break;
+    }
+  } else {
+    RP_REQUIRE(small_variant(v), "tile configuration %d has no fused row-scale form", v);
+  }
   switch (v) {
-    case 20: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-    case 26: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-    case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-    case 12: return launch_gemm_cfg<GemmCfg<64, 256, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
     case 15: return launch_gemm_cfg<GemmCfg<64, 128, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
     case 16: return launch_gemm_cfg<GemmCfg<64, 128, 64, 1, 4, 4>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
     default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
@@ -1355,8 +1391,14 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
   RpStatus st;
 
   const int np = (D + 63) / 64;
+  // When both row-scaled projections run small tiles (passes of up to ~1000 tokens) their epilogues reduce the
+  // statistic themselves (RowScaleFromSlots): two launches fewer per layer.
+  const bool fused_rs = small_variant(pick_gemm_variant(RP_K_GEMM_QKV, Tp, 3 * inner, D, tv)) &&
+                        small_variant(pick_gemm_variant(RP_K_GEMM_WI, Tp, 2 * F, D, tv));
   const RowScale rs{w.rs};
-  auto launch_rowscale = [&]() {
+  const RowScaleFromSlots rs_slots{w.ssp, np, Tp, 1.f / (float)D, c.layer_norm_eps};
+  auto launch_rowscale = [&](bool needed_anyway = false) {
+    if (fused_rs && !needed_anyway) return;
     ProfScope ps(stream, RP_K_RMSNORM);
     hipLaunchKernelGGL(rowscale_kernel, dim3((Tp + 63) / 64), dim3(64), 0, stream, w.ssp, w.rs, Tp, np,
                        1.f / (float)D, c.layer_norm_eps);
@@ -1374,9 +1416,11 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
     const LayerPacked& L = e->layers[i];
     // attention sub-layer: qkv = rs * (xb Wqkv'^T)  ->  attention  ->  x += att Wo^T  (+ xb, ssp refreshed)
     launch_rowscale();
-    if ((st = launch_gemm(w.xb, D, Tp, L.wqkv, D, 3 * inner, D, EpiStoreBf16{w.qkv, 3 * inner, 3 * inner, rs}, stream,
-                          RP_K_GEMM_QKV, tv, t_dev)))
-      return st;
+    st = fused_rs ? launch_gemm<true>(w.xb, D, Tp, L.wqkv, D, 3 * inner, D,
+                                      EpiStoreBf16Slots{w.qkv, 3 * inner, 3 * inner, rs_slots}, stream, RP_K_GEMM_QKV, tv, t_dev)
+                  : launch_gemm(w.xb, D, Tp, L.wqkv, D, 3 * inner, D, EpiStoreBf16{w.qkv, 3 * inner, 3 * inner, rs}, stream,
+                                RP_K_GEMM_QKV, tv, t_dev);
+    if (st) return st;
     {
       ProfScope ps(stream, RP_K_ATTENTION);
       hipLaunchKernelGGL(attention_kernel, att_grid, dim3(256), 0, stream, w.qkv, (const int4*)w.work, e->bias_tab, w.att,
@@ -1388,14 +1432,16 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
     if (g_debug_skip_ffn) continue;
     launch_rowscale();
     // feed-forward sub-layer: ff = gelu(rs * g) * (rs * u)  ->  x += ff Wo2^T  (+ xb, ssp refreshed)
-    if ((st = launch_gemm(w.xb, D, Tp, L.wi, D, 2 * F, D, EpiGegluBf16{w.ff, F, 2 * F, rs}, stream, RP_K_GEMM_WI, tv,
-                          t_dev)))
-      return st;
+    st = fused_rs ? launch_gemm<true>(w.xb, D, Tp, L.wi, D, 2 * F, D, EpiGegluBf16Slots{w.ff, F, 2 * F, rs_slots}, stream,
+                                      RP_K_GEMM_WI, tv, t_dev)
+                  : launch_gemm(w.xb, D, Tp, L.wi, D, 2 * F, D, EpiGegluBf16{w.ff, F, 2 * F, rs}, stream, RP_K_GEMM_WI, tv,
+                                t_dev);
+    if (st) return st;
     if ((st = launch_gemm(w.ff, F, Tp, L.wo2, F, D, F, EpiResid{w.xb, w.xlo, D, D, w.ssp, np, Tp}, stream,
                           RP_K_GEMM_WO, tv, t_dev)))
       return st;
   }
-  launch_rowscale();  // final RMSNorm statistic
+  launch_rowscale(true);  // final RMSNorm statistic (the pooling pass reads rs per token row)
   {
     ProfScope ps(stream, RP_K_POOL);
     launch_pool_partial(dim3(T / POOL_CHUNK + batch), stream, w.xb, w.xlo, w.rs, (const int4*)w.pwork, w.pool, D);
