@@ -38,10 +38,6 @@ static int g_gemm_variant = 20;      // FFN-in (wi_0|wi_1 + gated GELU)
 static int g_gemm_variant_qkv = 26;  // QKV
 static int g_gemm_variant_wo = 26;   // FFN-out (+ residual)
 static int g_gemm_variant_o = 0;     // attention output (+ residual)
-static int g_small_t = 1;  // few-token split-K schedule (rp_set_option("small_t_schedule", 0): per-tile K loops)
-static int g_small_t_max = 128;  // passes of at most this many tokens take it (rp_set_option("small_t_max", n)).
-                                 // From 129 tokens up the per-tile schedule with 64 x 128 tiles is as fast or faster
-                                 // (tools/latency_bench.py: 200-byte state 1.39 vs 1.42 ms, 300-byte 1.41 vs 1.68 ms).
 static int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 static int g_gemm_skinny = 1;
 static int g_gemm_skinny_variant = 12;
@@ -164,8 +160,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ 
                                                     const float* __restrict__ table,
                                                     bf16_t* __restrict__ xhi, bf16_t* __restrict__ xlo,
                                                     float* __restrict__ ssp, int np, int T, int Tp, int D,
-                                                    int vocab, const int32_t* __restrict__ t_dev,
-                                                    float* __restrict__ rs_out, float eps) {
+                                                    int vocab, const int32_t* __restrict__ t_dev) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   int rows = Tp;  // Tp stays the leading dimension of the slot-major statistics
@@ -193,7 +188,6 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ 
   ss = wave_sum(ss);
   // sum-of-squares partials of the row (see EpiResid): slot 0 carries the whole row here
   for (int p = lane; p < np; p += 64) ssp[(size_t)p * Tp + row] = (p == 0) ? ss : 0.f;
-  if (rs_out && lane == 0) rs_out[row] = rsqrtf(ss / (float)D + eps);  // few-token schedule: no rowscale launch
 }
 
 constexpr int RMS_MAX_V4 = 8;  // a row is at most 8 float4 per lane of a wave: d_model <= 2048
@@ -548,120 +542,6 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
     case 15: return launch_gemm_cfg<GemmCfg<64, 128, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
     case 16: return launch_gemm_cfg<GemmCfg<64, 128, 64, 1, 4, 4>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
     default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Few tokens (a single proof state: the prover's retrieve()).  With T <= a few hundred tokens a
-// projection has 18-112 workgroups of 64 features, each walking its whole K range alone: 23 workgroups x 459 KB of
-// FFN-out weights took 38 us per launch, ~12 GB/s per CU, 1.4 ms per state.  Here the K range is SPLIT over S
-// workgroups per tile (deterministically: every split writes its fp32 partial tile, nobody accumulates in place),
-// and ONE row-wise kernel per projection sums the S partials in index order and applies the epilogue - scaled bf16
-// store, gated GELU, or residual add which then also yields the row's RMSNorm scale directly (a workgroup owns the
-// whole row), so the rowscale launches disappear from this schedule.
-// ------------------------------------------------------------------------------------------
-typedef GemmCfg<64, 128, 32, 1, 4, 7> GemmCfgSplitK;
-
-struct EpiPartialF32 {  // part[token, feature] = acc   (feature-contiguous rows of ld floats)
-  float* part;
-  int ld;
-  template <int FM, int FN>
-  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* /*stage*/) {
-    const int hi = lane >> 5, cl = lane & 31;
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(part + (size_t)(n_base + j * 32 + cl) * ld + m_base + i * 32 + 8 * g + 4 * hi) =
-              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-  }
-};
-
-// grid = tiles_f x tiles_t x S; split s takes the 32-wide K-steps [nk s / S, nk (s + 1) / S)
-__global__ __launch_bounds__(GemmCfgSplitK::THREADS) void gemm_splitk_kernel(GemmOperand A, GemmOperand W, int K, int tiles_m,
-                                                                             int tiles_n, int S, float* part,
-                                                                             int part_ld, size_t part_split_stride,
-                                                                             const int32_t* __restrict__ t_dev) {
-  using C = GemmCfgSplitK;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tile = blockIdx.x / S, s = blockIdx.x - tile * S;
-  const int tm = tile % tiles_m, tn = tile / tiles_m;
-  if (t_dev && tn * C::BN >= *t_dev) return;
-  const int nk = K / C::BK;
-  const int k0 = (int)((long long)nk * s / S), k1 = (int)((long long)nk * (s + 1) / S);
-  A.ptr += (size_t)k0 * C::BK;
-  W.ptr += (size_t)k0 * C::BK;
-  EpiPartialF32 epi{part + (size_t)s * part_split_stride, part_ld};
-  gemm_tile<C>(A, W, (k1 - k0) * C::BK, tm, tn, epi, smem);
-}
-
-// one workgroup (256 threads) per token row
-enum { RED_STORE = 0, RED_GEGLU = 1, RED_RESID = 2 };
-template <int MODE>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int part_ld,
-                                                            size_t part_split_stride, int S, int n_valid,
-                                                            const float* __restrict__ rs_in, bf16_t* __restrict__ out_bf,
-                                                            int ldo, bf16_t* __restrict__ xhi, bf16_t* __restrict__ xlo, int ldx,
-                                                            float* __restrict__ rs_out, float inv_d, float eps,
-                                                            const int32_t* __restrict__ t_dev) {
-  __shared__ float red[4];
-  const int t = blockIdx.x, tid = threadIdx.x;
-  if (t_dev && t >= ((*t_dev + 127) & ~127)) return;  // rows of token tiles that were skipped hold no partials
-  const float* p0 = part + (size_t)t * part_ld;
-  auto total4 = [&](int f) {  // sum of the S partials of features f .. f+3, in split order
-    // four loads in flight per step (the adds stay in split order: the sum is the same for every S-aligned chunking)
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s0 = 0; s0 < S; s0 += 4) {
-      float4 b[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        b[u] = *reinterpret_cast<const float4*>(p0 + (size_t)min(s0 + u, S - 1) * part_split_stride + f);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (s0 + u < S) {
-          a.x += b[u].x; a.y += b[u].y; a.z += b[u].z; a.w += b[u].w;
-        }
-    }
-    return a;
-  };
-  if constexpr (MODE == RED_STORE) {
-    const float sc = rs_in[t];
-    for (int f = tid * 4; f < n_valid; f += 1024) {
-      const float4 a = total4(f);
-      uint2 o;
-      o.x = pack_bf2(a.x * sc, a.y * sc);
-      o.y = pack_bf2(a.z * sc, a.w * sc);
-      *reinterpret_cast<uint2*>(out_bf + (size_t)t * ldo + f) = o;
-    }
-  } else if constexpr (MODE == RED_GEGLU) {
-    // rows interleaved 32 gate / 32 up: output c of block b = c / 32 comes from rows 64 b + c % 32 and + 32
-    const float sc = rs_in[t];
-    for (int c = tid * 4; c < n_valid / 2; c += 1024) {
-      const int g0 = 64 * (c >> 5) + (c & 31);
-      const float4 g = total4(g0), u = total4(g0 + 32);
-      uint2 o;
-      o.x = pack_bf2(gelu_new(g.x * sc) * (u.x * sc), gelu_new(g.y * sc) * (u.y * sc));
-      o.y = pack_bf2(gelu_new(g.z * sc) * (u.z * sc), gelu_new(g.w * sc) * (u.w * sc));
-      *reinterpret_cast<uint2*>(out_bf + (size_t)t * ldo + c) = o;
-    }
-  } else {
-    float ss = 0.f;
-    for (int f = tid * 4; f < n_valid; f += 1024) {
-      const float4 a = total4(f);
-      const size_t off = (size_t)t * ldx + f;
-      const uint2 h = *reinterpret_cast<const uint2*>(xhi + off), l = *reinterpret_cast<const uint2*>(xlo + off);
-      uint2 oh, ol;
-      hilo_update2(h.x, l.x, a.x, a.y, oh.x, ol.x, ss);
-      hilo_update2(h.y, l.y, a.z, a.w, oh.y, ol.y, ss);
-      *reinterpret_cast<uint2*>(xhi + off) = oh;
-      *reinterpret_cast<uint2*>(xlo + off) = ol;
-    }
-    ss = wave_sum(ss);
-    if ((tid & 63) == 0) red[tid >> 6] = ss;
-    __syncthreads();
-    if (tid == 0) rs_out[t] = rsqrtf(((red[0] + red[1]) + (red[2] + red[3])) * inv_d + eps);
   }
 }
 
@@ -1144,15 +1024,6 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     g_gemm_skinny_variant = value;
     return RP_OK;
   }
-  if (!strcmp(name, "small_t_schedule")) {
-    g_small_t = value != 0;
-    return RP_OK;
-  }
-  if (!strcmp(name, "small_t_max")) {
-    RP_REQUIRE(value >= 0 && value <= 4096, "small_t_max=%d", value);
-    g_small_t_max = value;
-    return RP_OK;
-  }
   if (!strcmp(name, "gemm_skinny")) {
     g_gemm_skinny = value != 0;
     return RP_OK;
@@ -1320,24 +1191,9 @@ struct Workspace {
   float* pool;  // [Tp / 128 + batch, D] partial column sums of the pooling pass
   int4* work;   // [Tp / 128 + batch] attention work list of the pass (worklist_kernel)
   int4* pwork;  // [Tp / 128 + batch] pooling work list
-  float* part;  // few-token schedule: split-K partial tiles [S, rows, features] (NULL otherwise)
-  size_t part_floats;
   size_t bytes;
 };
 
-// ---- few-token (split-K) schedule: sizing shared by carve() and the launcher
-inline bool small_schedule(int T) { return g_small_t && T <= g_small_t_max; }
-// Splits of one projection: enough for ~one workgroup per CU at one token tile, at least four 32-wide K-steps per
-// split.  A function of the projection's shape ONLY: an embedding must not depend on how many other tokens share
-// the pass (or on the padded length of a captured graph), so neither S nor the K ranges may depend on T.
-inline int splitk_S(int n_features, int K) {
-  const int tiles_f = (n_features + 63) / 64;
-  const int by_wgs = 256 / tiles_f, by_k = std::max(1, K / 32 / 4);  // never more workgroups than CUs: one round
-  return std::max(1, std::min(by_wgs, by_k));
-}
-inline size_t splitk_floats(int n_features, int T, int K) {
-  return (size_t)splitk_S(n_features, K) * align_up((size_t)T, 128) * align_up((size_t)n_features, 64);
-}
 Workspace carve(const RpEncoder* e, int T, int batch, char* base) {
   const size_t Tp = align_up((size_t)T, GEMM_M_ALIGN);
   const size_t D = e->cfg.d_model, F = e->cfg.d_ff, inner = e->inner;
@@ -1358,13 +1214,6 @@ Workspace carve(const RpEncoder* e, int T, int batch, char* base) {
   w.pool = (float*)take((Tp / POOL_CHUNK + (size_t)batch + 1) * D * 4);
   w.work = (int4*)take((Tp / ATT_Q + (size_t)batch + 1) * sizeof(int4));
   w.pwork = (int4*)take((Tp / POOL_CHUNK + (size_t)batch + 1) * sizeof(int4));
-  w.part = nullptr;
-  w.part_floats = 0;
-  if (small_schedule(T)) {
-    w.part_floats = std::max(std::max(splitk_floats(3 * (int)inner, T, (int)D), splitk_floats((int)D, T, (int)inner)),
-                             std::max(splitk_floats(2 * (int)F, T, (int)D), splitk_floats((int)D, T, (int)F)));
-    w.part = (float*)take(w.part_floats * 4);
-  }
   w.bytes = off;
   return w;
 }
@@ -1375,15 +1224,10 @@ extern "C" size_t rp_encoder_workspace_bytes(const RpEncoder* enc, int32_t total
   return carve(enc, total_tokens, batch, nullptr).bytes;
 }
 
-static RpStatus encode_pass_small(RpEncoder* e, const int32_t* ids, const int32_t* cu_seqlens, int32_t batch, int32_t T,
-                                  const int32_t* t_dev, void* out, int32_t out_dtype, const Workspace& w,
-                                  hipStream_t stream);
-
 // The launch sequence of one encoder pass.  T / batch size the grids; when t_dev is given (rp_encode_padded) the
 // real token count is known on the device only: T is then an upper bound, kernels skip the rows beyond *t_dev.
 static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_seqlens, int32_t batch, int32_t T,
                             const int32_t* t_dev, void* out, int32_t out_dtype, const Workspace& w, hipStream_t stream) {
-  if (small_schedule(T)) return encode_pass_small(e, ids, cu_seqlens, batch, T, t_dev, out, out_dtype, w, stream);
   const RpT5Config& c = e->cfg;
   const int D = c.d_model, F = c.d_ff, inner = e->inner, H = c.num_heads;
   const int Tp = (int)align_up((size_t)T, GEMM_M_ALIGN);
@@ -1406,7 +1250,7 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
   {
     ProfScope ps(stream, RP_K_EMBED);
     hipLaunchKernelGGL(embed_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.xb, w.xlo, w.ssp, np, T,
-                       Tp, D, c.vocab_size, t_dev, (float*)nullptr, 0.f);
+                       Tp, D, c.vocab_size, t_dev);
   }
   RP_CHECK_LAUNCH();
   const dim3 att_grid(H, T / ATT_Q + batch);  // upper bound of the number of 128-query blocks
@@ -1442,88 +1286,6 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
       return st;
   }
   launch_rowscale(true);  // final RMSNorm statistic (the pooling pass reads rs per token row)
-  {
-    ProfScope ps(stream, RP_K_POOL);
-    launch_pool_partial(dim3(T / POOL_CHUNK + batch), stream, w.xb, w.xlo, w.rs, (const int4*)w.pwork, w.pool, D);
-    hipLaunchKernelGGL(pool_finish_kernel, dim3(batch), dim3(256), 0, stream, w.pool, e->final_ln, cu_seqlens, out,
-                       out_dtype == RP_DT_BF16 ? 1 : 0, D);
-  }
-  RP_CHECK_LAUNCH();
-  return RP_OK;
-}
-
-// The few-token schedule (see gemm_splitk_kernel): 9 launches per layer, none of them a per-tile K loop, no
-// rowscale launches (the residual reduce owns whole rows and emits rs itself).
-static RpStatus encode_pass_small(RpEncoder* e, const int32_t* ids, const int32_t* cu_seqlens, int32_t batch, int32_t T,
-                                  const int32_t* t_dev, void* out, int32_t out_dtype, const Workspace& w,
-                                  hipStream_t stream) {
-  using C = GemmCfgSplitK;
-  const RpT5Config& c = e->cfg;
-  const int D = c.d_model, F = c.d_ff, inner = e->inner, H = c.num_heads;
-  const int Tp = (int)align_up((size_t)T, GEMM_M_ALIGN);
-  const int rows = (int)align_up((size_t)T, 128);
-  const int np = (D + 63) / 64;
-  const float inv_d = 1.f / (float)D, eps = c.layer_norm_eps;
-  static LdsAttrOnce attr;
-  RP_HIP(attr.ensure((const void*)gemm_splitk_kernel, C::LDS_BYTES));
-  RP_REQUIRE(w.part != nullptr, "workspace was sized without the few-token schedule");
-  // partial tiles of  out[t, f] = sum_k act[t, k] W[f, k]  ->  part[s][t][f]
-  auto project = [&](const bf16_t* act, int lda, const bf16_t* W, int n_features, int K, int prof_class, int& S,
-                     int& ld, size_t& stride) {
-    S = splitk_S(n_features, K);
-    const int tiles_f = (n_features + 63) / 64, tiles_t = rows / 128;
-    ld = tiles_f * 64;
-    stride = (size_t)rows * ld;
-    GemmOperand wop{W, K, n_features}, aop{act, lda, Tp};
-    ProfScope ps(stream, prof_class);
-    hipLaunchKernelGGL(gemm_splitk_kernel, dim3(tiles_f * tiles_t * S), dim3(C::THREADS), C::LDS_BYTES, stream, wop, aop,
-                       K, tiles_f, tiles_t, S, w.part, ld, stride, t_dev);
-  };
-  {
-    ProfScope ps(stream, RP_K_EMBED);
-    hipLaunchKernelGGL(embed_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.xb, w.xlo, w.ssp, np, T,
-                       Tp, D, c.vocab_size, t_dev, w.rs, eps);
-  }
-  const dim3 att_grid(H, T / ATT_Q + batch);
-  hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu_seqlens, batch, w.work, (int)att_grid.y, w.pwork,
-                     T / POOL_CHUNK + batch);
-  int S, ld;
-  size_t stride;
-  for (int i = 0; i < c.num_layers; ++i) {
-    const LayerPacked& L = e->layers[i];
-    project(w.xb, D, L.wqkv, 3 * inner, D, RP_K_GEMM_QKV, S, ld, stride);
-    {
-      ProfScope ps(stream, RP_K_GEMM_QKV);
-      hipLaunchKernelGGL(splitk_reduce_kernel<RED_STORE>, dim3(rows), dim3(256), 0, stream, (const float*)w.part, ld,
-                         stride, S, 3 * inner, (const float*)w.rs, w.qkv, 3 * inner, (bf16_t*)nullptr, (bf16_t*)nullptr, 0,
-                         (float*)nullptr, 0.f, 0.f, t_dev);
-    }
-    {
-      ProfScope ps(stream, RP_K_ATTENTION);
-      hipLaunchKernelGGL(attention_kernel, att_grid, dim3(256), 0, stream, w.qkv, (const int4*)w.work, e->bias_tab, w.att,
-                         H, e->maxd);
-    }
-    project(w.att, inner, L.wo, D, inner, RP_K_GEMM_O, S, ld, stride);
-    {
-      ProfScope ps(stream, RP_K_GEMM_O);
-      hipLaunchKernelGGL(splitk_reduce_kernel<RED_RESID>, dim3(rows), dim3(256), 0, stream, (const float*)w.part, ld,
-                         stride, S, D, (const float*)nullptr, (bf16_t*)nullptr, 0, w.xb, w.xlo, D, w.rs, inv_d, eps, t_dev);
-    }
-    if (g_debug_skip_ffn) continue;
-    project(w.xb, D, L.wi, 2 * F, D, RP_K_GEMM_WI, S, ld, stride);
-    {
-      ProfScope ps(stream, RP_K_GEMM_WI);
-      hipLaunchKernelGGL(splitk_reduce_kernel<RED_GEGLU>, dim3(rows), dim3(256), 0, stream, (const float*)w.part, ld,
-                         stride, S, 2 * F, (const float*)w.rs, w.ff, F, (bf16_t*)nullptr, (bf16_t*)nullptr, 0,
-                         (float*)nullptr, 0.f, 0.f, t_dev);
-    }
-    project(w.ff, F, L.wo2, D, F, RP_K_GEMM_WO, S, ld, stride);
-    {
-      ProfScope ps(stream, RP_K_GEMM_WO);
-      hipLaunchKernelGGL(splitk_reduce_kernel<RED_RESID>, dim3(rows), dim3(256), 0, stream, (const float*)w.part, ld,
-                         stride, S, D, (const float*)nullptr, (bf16_t*)nullptr, 0, w.xb, w.xlo, D, w.rs, inv_d, eps, t_dev);
-    }
-  }
   {
     ProfScope ps(stream, RP_K_POOL);
     launch_pool_partial(dim3(T / POOL_CHUNK + batch), stream, w.xb, w.xlo, w.rs, (const int4*)w.pwork, w.pool, D);

@@ -59,23 +59,11 @@ def test_padded_entry_point_equals_packed_and_ignores_padding(tiny, golden_dir):
     ids2 = torch.nn.functional.pad(ids, (0, 77))
     mask2 = torch.nn.functional.pad(mask, (0, 77))
     assert torch.equal(tiny._encode(ids2.cuda(), mask2.cuda()), packed)
-    # each text alone == inside the batch, and order does not matter.  Bitwise-level agreement
-    # holds inside one launch schedule; a text alone (<= 128 tokens) takes the few-token split-K schedule, whose fp32
-    # partial sums associate differently from the per-tile K loop of a big pass: there the agreement is one bf16
-    # rounding of an intermediate (stated bound 4e-3 on unit-norm rows), never a different answer.
-    from reprover_amd import _lib
-
-    lib = _lib.load()
+    # each text alone == inside the batch, and order does not matter: every output element is one
+    # K-ascending chain of MFMA steps whatever the tile configuration the pass size selects, statistics and pooling
+    # are per row / per sequence
     solo = torch.cat([tiny.encode_texts([t]) for t in texts])
-    assert (solo - packed).abs().max().item() < 4e-3
-    assert torch.nn.functional.cosine_similarity(solo, packed, dim=1).min().item() > 0.9999
-    _lib.check(lib.rp_set_option(b"small_t_schedule", 0), "opt")
-    try:
-        solo_same = torch.cat([tiny.encode_texts([t]) for t in texts])
-    finally:
-        _lib.check(lib.rp_set_option(b"small_t_schedule", 1), "opt")
-    assert (solo_same - packed).abs().max().item() < 1e-6
-    # within the few-token schedule itself a row does not depend on its neighbours either
+    assert (solo - packed).abs().max().item() < 1e-6
     pair = tiny.encode_texts([texts[1], texts[3]])
     assert torch.equal(pair[0], solo[1]) and torch.equal(pair[1], solo[3])
     perm = np.random.default_rng(0).permutation(len(texts))
@@ -135,19 +123,12 @@ def test_bf16_output_and_chunked_passes_agree(small, golden_dir):
     texts = list(g["texts"])[:10]
     ref = small.encode_texts(texts)
     old = small.encoder.max_tokens_per_pass
-    from reprover_amd import _lib
-
-    lib = _lib.load()
     try:
-        small.encoder.max_tokens_per_pass = 700  # forces several rp_encode_varlen passes
+        small.encoder.max_tokens_per_pass = 700  # forces several rp_encode_varlen passes (other tile configurations)
         chunked = small.encode_texts(texts)
-        _lib.check(lib.rp_set_option(b"small_t_schedule", 0), "opt")
-        chunked_same = small.encode_texts(texts)  # every pass on the per-tile schedule, like the one-pass reference
     finally:
         small.encoder.max_tokens_per_pass = old
-        _lib.check(lib.rp_set_option(b"small_t_schedule", 1), "opt")
-    assert (chunked_same - ref).abs().max().item() < 1e-6
-    assert (chunked - ref).abs().max().item() < 4e-3  # passes of <= 128 tokens take the split-K schedule
+    assert (chunked - ref).abs().max().item() < 1e-6
     out_bf = torch.empty(ref.shape, dtype=torch.bfloat16, device=ref.device)
     ids, cu = small.tokenizer.packed(texts, small.max_seq_len)
     small.encoder.encode_packed(ids, cu, out_bf)

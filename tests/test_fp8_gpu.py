@@ -222,7 +222,7 @@ def test_retriever_fp8_index_c5_slice():
         b[key] = [None] * len(ctxs)
     model.predict_step_outputs = []
     model.predict_step(b, 0)
-    # (the batch runs the per-tile schedule, single states the few-token one: ids agree under the gap rule)
+    # (ids agree under the gap rule)
     batch_i = [[where[id(p)] for p in r["retrieved_premises"]] for r in model.predict_step_outputs]
     checked, bad = hh.gap_rule_ids(batch_i, want_i.tolist(), want_s.tolist(), tol=4e-3)
     assert bad == 0 and checked > 0

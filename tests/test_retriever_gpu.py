@@ -132,8 +132,8 @@ def test_g7_predict_and_retrieve(g7):
     for j, single in enumerate(g["retrieve"]):
         c = ctxs[j]
         prem, sc = model.retrieve(c.state, c.path, c.theorem_full_name, c.theorem_pos, k)
-        # one state alone runs the few-token schedule: same answer up to swaps between scores closer than the
-        # tolerance (the gap rule of every id comparison), scores within the stated bound of the golden ones
+        # one state alone: the same answer as inside the batch up to swaps between scores closer than the tolerance
+        # (the gap rule of every id comparison), scores within the stated bound of the golden ones
         got = [where[id(p)] for p in prem]
         checked1, bad1 = hh.gap_rule_ids([got], [single["ids"]], [single["scores"]], tol=1e-2)
         assert bad1 == 0 and len(set(got) & set(ids[j])) >= k - 2

@@ -24,11 +24,7 @@ rng = np.random.default_rng(0)
 lib = _lib.load()
 if os.environ.get('EAGER') == '1':
     model.use_graphs = False  # launch by launch: the per-class event pairs see every kernel
-for sv in [int(x) for x in os.environ.get('SMALL_T_MAX', '-1').split(',')]:
-  if sv >= 0:
-      lib.rp_set_option(b'small_t_max', sv)
-  model._single_query = None  # captured graphs hold the schedule they were captured with
-  print('small_t_max', sv if sv >= 0 else '(library default)')
+for _ in range(int(os.environ.get('REPEAT', '1'))):
   for nbytes in [int(x) for x in os.environ.get('NBYTES', '100,300,1000').split(',')]:
       states = [synth.synth_state(rng, nbytes) for _ in range(30)]
       for s in states[:5]:
