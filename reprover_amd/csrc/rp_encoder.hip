@@ -38,6 +38,7 @@ static int g_gemm_variant = 20;      // FFN-in (wi_0|wi_1 + gated GELU)
 static int g_gemm_variant_qkv = 26;  // QKV
 static int g_gemm_variant_wo = 26;   // FFN-out (+ residual)
 static int g_gemm_variant_o = 0;     // attention output (+ residual)
+static int g_gemm_tail_split = 1;  // big passes: last partial round of 256 x 256 tiles as one round of 128 x 128 tiles
 static int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 static int g_gemm_skinny = 1;
 static int g_gemm_skinny_variant = 12;
@@ -524,9 +525,9 @@ inline bool small_variant(int v) { return v == 0 || v == 15 || v == 16; }
 template <bool SMALL_ONLY = false, class Epi>
 static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, int ldw, int n_rows_w,
                             int K, Epi epi, hipStream_t stream, int prof_class, int tokens_valid = 0,
-                            const int32_t* t_dev = nullptr) {
+                            const int32_t* t_dev = nullptr, int force_variant = -1) {
   GemmOperand a{A, lda, M}, w{W, ldw, n_rows_w};
-  const int v = pick_gemm_variant(prof_class, M, n_rows_w, K, tokens_valid);
+  const int v = force_variant >= 0 ? force_variant : pick_gemm_variant(prof_class, M, n_rows_w, K, tokens_valid);
   if constexpr (!SMALL_ONLY) {
     switch (v) {
       case 20: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
@@ -1024,6 +1025,10 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     g_gemm_skinny_variant = value;
     return RP_OK;
   }
+  if (!strcmp(name, "gemm_tail_split")) {
+    g_gemm_tail_split = value != 0;
+    return RP_OK;
+  }
   if (!strcmp(name, "gemm_skinny")) {
     g_gemm_skinny = value != 0;
     return RP_OK;
@@ -1241,6 +1246,36 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
                         small_variant(pick_gemm_variant(RP_K_GEMM_WI, Tp, 2 * F, D, tv));
   const RowScale rs{w.rs};
   const RowScaleFromSlots rs_slots{w.ssp, np, Tp, 1.f / (float)D, c.layer_norm_eps};
+  // Tail of a big launch.  1644 tiles of 256 x 256 on 256 CUs are 6.42 rounds: the seventh runs 108 tiles while 148
+  // CUs idle (FFN-out, 70 k tokens; QKV: 5.35 rounds).  The token rows that make whole rounds go to the big tiles;
+  // the rest (18 token tiles here) runs as ONE round of 128 x 128 tiles, two workgroups per CU, which takes about
+  // half a big tile's time.  Same K-ascending chains per output element: not a bit changes.
+  static int n_cus = 0;
+  if (n_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cus = prop.multiProcessorCount;
+    if (n_cus <= 0) n_cus = 256;
+  }
+  auto main_rows = [&](int prof_class, int n_features, int K) -> int {
+    if (!g_gemm_tail_split || t_dev) return Tp;  // (token count known on the device only: one launch)
+    const int v = pick_gemm_variant(prof_class, Tp, n_features, K, tv);
+    if (v != 20 && v != 26) return Tp;
+    const int tiles_f = (n_features + 255) / 256, tiles_t = Tp / 256;
+    int g = tiles_f, b = n_cus;  // gcd
+    while (b) {
+      const int t = g % b;
+      g = b;
+      b = t;
+    }
+    const int unit = n_cus / g;  // token tiles per whole number of rounds
+    const int t1 = tiles_t / unit * unit, rest = tiles_t - t1;
+    if (t1 == 0 || rest == 0) return Tp;
+    if (rest * tiles_f > (7 * n_cus) / 10) return Tp;                      // the last round is nearly full anyway
+    if (rest * 2 * ((n_features + 127) / 128) > 2 * n_cus) return Tp;      // the small tiles would not fit one round
+    return t1 * 256;
+  };
+  const int qkv_main = main_rows(RP_K_GEMM_QKV, 3 * inner, D), wo_main = main_rows(RP_K_GEMM_WO, D, F);
   auto launch_rowscale = [&](bool needed_anyway = false) {
     if (fused_rs && !needed_anyway) return;
     ProfScope ps(stream, RP_K_RMSNORM);
@@ -1260,10 +1295,21 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
     const LayerPacked& L = e->layers[i];
     // attention sub-layer: qkv = rs * (xb Wqkv'^T)  ->  attention  ->  x += att Wo^T  (+ xb, ssp refreshed)
     launch_rowscale();
-    st = fused_rs ? launch_gemm<true>(w.xb, D, Tp, L.wqkv, D, 3 * inner, D,
-                                      EpiStoreBf16Slots{w.qkv, 3 * inner, 3 * inner, rs_slots}, stream, RP_K_GEMM_QKV, tv, t_dev)
-                  : launch_gemm(w.xb, D, Tp, L.wqkv, D, 3 * inner, D, EpiStoreBf16{w.qkv, 3 * inner, 3 * inner, rs}, stream,
-                                RP_K_GEMM_QKV, tv, t_dev);
+    if (fused_rs) {
+      st = launch_gemm<true>(w.xb, D, Tp, L.wqkv, D, 3 * inner, D, EpiStoreBf16Slots{w.qkv, 3 * inner, 3 * inner, rs_slots},
+                             stream, RP_K_GEMM_QKV, tv, t_dev);
+    } else if (qkv_main < Tp) {
+      const int r1 = qkv_main;
+      st = launch_gemm(w.xb, D, r1, L.wqkv, D, 3 * inner, D, EpiStoreBf16{w.qkv, 3 * inner, 3 * inner, rs}, stream,
+                       RP_K_GEMM_QKV);
+      if (st) return st;
+      st = launch_gemm(w.xb + (size_t)r1 * D, D, Tp - r1, L.wqkv, D, 3 * inner, D,
+                       EpiStoreBf16{w.qkv + (size_t)r1 * 3 * inner, 3 * inner, 3 * inner, RowScale{w.rs + r1}}, stream,
+                       RP_K_GEMM_QKV, std::max(1, tv - r1), nullptr, 0);
+    } else {
+      st = launch_gemm(w.xb, D, Tp, L.wqkv, D, 3 * inner, D, EpiStoreBf16{w.qkv, 3 * inner, 3 * inner, rs}, stream,
+                       RP_K_GEMM_QKV, tv, t_dev);
+    }
     if (st) return st;
     {
       ProfScope ps(stream, RP_K_ATTENTION);
@@ -1281,9 +1327,18 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
                   : launch_gemm(w.xb, D, Tp, L.wi, D, 2 * F, D, EpiGegluBf16{w.ff, F, 2 * F, rs}, stream, RP_K_GEMM_WI, tv,
                                 t_dev);
     if (st) return st;
-    if ((st = launch_gemm(w.ff, F, Tp, L.wo2, F, D, F, EpiResid{w.xb, w.xlo, D, D, w.ssp, np, Tp}, stream,
-                          RP_K_GEMM_WO, tv, t_dev)))
-      return st;
+    if (wo_main < Tp) {
+      const int r1 = wo_main;
+      st = launch_gemm(w.ff, F, r1, L.wo2, F, D, F, EpiResid{w.xb, w.xlo, D, D, w.ssp, np, Tp}, stream, RP_K_GEMM_WO);
+      if (st) return st;
+      st = launch_gemm(w.ff + (size_t)r1 * F, F, Tp - r1, L.wo2, F, D, F,
+                       EpiResid{w.xb + (size_t)r1 * D, w.xlo + (size_t)r1 * D, D, D, w.ssp + r1, np, Tp}, stream,
+                       RP_K_GEMM_WO, std::max(1, tv - r1), nullptr, 0);
+    } else {
+      st = launch_gemm(w.ff, F, Tp, L.wo2, F, D, F, EpiResid{w.xb, w.xlo, D, D, w.ssp, np, Tp}, stream, RP_K_GEMM_WO, tv,
+                       t_dev);
+    }
+    if (st) return st;
   }
   launch_rowscale(true);  // final RMSNorm statistic (the pooling pass reads rs per token row)
   {
