@@ -1246,10 +1246,11 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
                         small_variant(pick_gemm_variant(RP_K_GEMM_WI, Tp, 2 * F, D, tv));
   const RowScale rs{w.rs};
   const RowScaleFromSlots rs_slots{w.ssp, np, Tp, 1.f / (float)D, c.layer_norm_eps};
-  // Tail of a big launch.  1644 tiles of 256 x 256 on 256 CUs are 6.42 rounds: the seventh runs 108 tiles while 148
-  // CUs idle (FFN-out, 70 k tokens; QKV: 5.35 rounds).  The token rows that make whole rounds go to the big tiles;
-  // the rest (18 token tiles here) runs as ONE round of 128 x 128 tiles, two workgroups per CU, which takes about
-  // half a big tile's time.  Same K-ascending chains per output element: not a bit changes.
+  // Tail of the FFN-out launch.  1644 tiles of 256 x 256 on 256 CUs are 6.42 rounds: the seventh runs 108 tiles
+  // while 148 CUs idle (70 k tokens).  The token rows that make whole rounds go to the big tiles; the rest (18 token
+  // tiles here) runs as ONE round of 128 x 128 tiles, two workgroups per CU.  Same K-ascending chains per output
+  // element: not a bit changes.  Measured 9.28 -> 9.04 ms per step; the same split of the QKV projection (5.35
+  // rounds) gained nothing (3.11 -> 3.14 ms: its short K loop leaves the tail round cheap already).
   static int n_cus = 0;
   if (n_cus == 0) {
     int dev = 0;
@@ -1275,7 +1276,7 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
     if (rest * 2 * ((n_features + 127) / 128) > 2 * n_cus) return Tp;      // the small tiles would not fit one round
     return t1 * 256;
   };
-  const int qkv_main = main_rows(RP_K_GEMM_QKV, 3 * inner, D), wo_main = main_rows(RP_K_GEMM_WO, D, F);
+  const int wo_main = main_rows(RP_K_GEMM_WO, D, F);
   auto launch_rowscale = [&](bool needed_anyway = false) {
     if (fused_rs && !needed_anyway) return;
     ProfScope ps(stream, RP_K_RMSNORM);
@@ -1295,21 +1296,10 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
     const LayerPacked& L = e->layers[i];
     // attention sub-layer: qkv = rs * (xb Wqkv'^T)  ->  attention  ->  x += att Wo^T  (+ xb, ssp refreshed)
     launch_rowscale();
-    if (fused_rs) {
-      st = launch_gemm<true>(w.xb, D, Tp, L.wqkv, D, 3 * inner, D, EpiStoreBf16Slots{w.qkv, 3 * inner, 3 * inner, rs_slots},
-                             stream, RP_K_GEMM_QKV, tv, t_dev);
-    } else if (qkv_main < Tp) {
-      const int r1 = qkv_main;
-      st = launch_gemm(w.xb, D, r1, L.wqkv, D, 3 * inner, D, EpiStoreBf16{w.qkv, 3 * inner, 3 * inner, rs}, stream,
-                       RP_K_GEMM_QKV);
-      if (st) return st;
-      st = launch_gemm(w.xb + (size_t)r1 * D, D, Tp - r1, L.wqkv, D, 3 * inner, D,
-                       EpiStoreBf16{w.qkv + (size_t)r1 * 3 * inner, 3 * inner, 3 * inner, RowScale{w.rs + r1}}, stream,
-                       RP_K_GEMM_QKV, std::max(1, tv - r1), nullptr, 0);
-    } else {
-      st = launch_gemm(w.xb, D, Tp, L.wqkv, D, 3 * inner, D, EpiStoreBf16{w.qkv, 3 * inner, 3 * inner, rs}, stream,
-                       RP_K_GEMM_QKV, tv, t_dev);
-    }
+    st = fused_rs ? launch_gemm<true>(w.xb, D, Tp, L.wqkv, D, 3 * inner, D,
+                                      EpiStoreBf16Slots{w.qkv, 3 * inner, 3 * inner, rs_slots}, stream, RP_K_GEMM_QKV, tv, t_dev)
+                  : launch_gemm(w.xb, D, Tp, L.wqkv, D, 3 * inner, D, EpiStoreBf16{w.qkv, 3 * inner, 3 * inner, rs}, stream,
+                                RP_K_GEMM_QKV, tv, t_dev);
     if (st) return st;
     {
       ProfScope ps(stream, RP_K_ATTENTION);
