@@ -1251,12 +1251,12 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
   // tiles here) runs as ONE round of 128 x 128 tiles, two workgroups per CU.  Same K-ascending chains per output
   // element: not a bit changes.  Measured 9.28 -> 9.04 ms per step; the same split of the QKV projection (5.35
   // rounds) gained nothing (3.11 -> 3.14 ms: its short K loop leaves the tail round cheap already).
-  static int n_cus = 0;
-  if (n_cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cus = prop.multiProcessorCount;
-    if (n_cus <= 0) n_cus = 256;
+  int n_cus = 256;
+  {
+    int dev = 0, v = 0;  // an attribute query, not the (slow) property struct: this runs once per pass
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      n_cus = v;
   }
   auto main_rows = [&](int prof_class, int n_features, int K) -> int {
     if (!g_gemm_tail_split || t_dev) return Tp;  // (token count known on the device only: one launch)
