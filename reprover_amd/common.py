@@ -380,9 +380,7 @@ class Corpus:
         assert N == len(self.all_premises) and E.shape[1] == D
         bits_t, own, qk = self.query_masks(batch_context)
         file_of, end_key = self._device_arrays(dev)
-        d_bits = torch.from_numpy(bits_t.view(np.int32)).to(dev)
-        d_own = torch.from_numpy(own).to(dev)
-        d_qk = torch.from_numpy(qk).to(dev)
+        d_bits, d_own, d_qk = _upload_query_masks(bits_t, own, qk, dev)
         out_s = torch.empty((B, k), dtype=torch.float32, device=dev)
         out_i = torch.empty((B, k), dtype=torch.int32, device=dev)
         out_c = torch.empty((B,), dtype=torch.int32, device=dev)
@@ -410,6 +408,28 @@ class Corpus:
         )
         return out_i, out_s, out_c
 
+    def launch_nearest_premises(
+        self,
+        premise_embeddings: "torch.Tensor | Fp8Index",
+        batch_context: Sequence[Context],
+        batch_context_emb: torch.Tensor,
+        k: int,
+        also_copy: Sequence[torch.Tensor] = (),
+    ) -> "PendingSearch":
+        """First half of ``get_nearest_premises``: everything up to and including the asynchronous copy of the result
+        to pinned host memory is enqueued; nothing waits.  ``finish()`` of the returned object is the second half.
+        ``also_copy``: small device tensors (the encoder's verdict words) to bring along: ``.extra_host`` after finish."""
+        ids, scores, counts = self.nearest_premise_ids(premise_embeddings, batch_context, batch_context_emb, k)
+        B = len(batch_context)
+        host = _pinned_result_buffers(B, k)
+        host[0].copy_(ids, non_blocking=True)
+        host[1].copy_(scores, non_blocking=True)
+        host[2].copy_(counts, non_blocking=True)
+        extra = [torch.empty(t.shape, dtype=t.dtype).pin_memory().copy_(t, non_blocking=True) for t in also_copy]
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(batch_context_emb.device))
+        return PendingSearch(self, premise_embeddings, list(batch_context), batch_context_emb, k, host, done, extra)
+
     def get_nearest_premises(
         self,
         premise_embeddings: torch.Tensor,
@@ -420,19 +440,80 @@ class Corpus:
         """Batch nearest-neighbour search restricted to accessible premises (common.py:299-326).
         Raises ``ValueError`` when a query has fewer than ``k`` accessible premises, as the
         reference does (common.py:323-324)."""
-        ids, scores, counts = self.nearest_premise_ids(premise_embeddings, batch_context, batch_context_emb, k)
-        counts_h = counts.cpu()
-        if bool((counts_h < 0).any()):  # candidate-list overflow: redo with the dense pass
-            ids, scores, counts = self.nearest_premise_ids(
-                premise_embeddings, batch_context, batch_context_emb, k, dense=True
-            )
-            counts_h = counts.cpu()
-        if bool((counts_h < k).any()):
-            raise ValueError
-        ids_h = ids.cpu().tolist()
-        scores_h = scores.cpu().tolist()
-        prem = self.all_premises
-        return [[prem[i] for i in row] for row in ids_h], scores_h
+        return self.launch_nearest_premises(premise_embeddings, batch_context, batch_context_emb, k).finish()
+
+
+_staging: Dict[int, List[list]] = {}  # nbytes -> [[pinned uint8 buffer, event of its last upload], ...], used in turn
+
+
+def _upload_query_masks(bits_t: np.ndarray, own: np.ndarray, qk: np.ndarray, dev: torch.device):
+    """(file_bits_t int32 [F, W], own_file int32 [B], q_key int64 [B]) on the device through ONE asynchronous copy
+    from pinned staging memory.  (Three ``.to(device)`` calls from pageable memory block the host until the stream
+    reaches them - i.e. until the encode launched just before has finished.)"""
+    B = own.shape[0]
+    n_qk, n_own, n_bits = 8 * B, 4 * B, bits_t.size * 4
+    off_own, off_bits = n_qk, n_qk + ((n_own + 15) // 16) * 16
+    total = off_bits + n_bits
+    ring = _staging.setdefault(total, [])
+    if len(ring) < 3:
+        ring.append([torch.empty(total, dtype=torch.uint8).pin_memory(), None])
+        slot = ring[-1]
+    else:
+        slot = ring.pop(0)
+        ring.append(slot)
+        slot[1].synchronize()  # its previous upload (three searches ago) has long completed
+    h = slot[0].numpy()
+    h[:n_qk].view(np.int64)[:] = qk
+    h[off_own : off_own + n_own].view(np.int32)[:] = own
+    h[off_bits:].view(np.uint32)[:] = bits_t.reshape(-1)
+    d = torch.empty(total, dtype=torch.uint8, device=dev)
+    d.copy_(slot[0], non_blocking=True)
+    slot[1] = torch.cuda.Event()
+    slot[1].record(torch.cuda.current_stream(dev))
+    return (d[off_bits:].view(torch.int32).view(bits_t.shape), d[off_own : off_own + n_own].view(torch.int32),
+            d[:n_qk].view(torch.int64))
+
+
+_pinned_pool: Dict[Tuple[int, int], List[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]] = {}
+
+
+def _pinned_result_buffers(B: int, k: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(ids int32 [B,k], scores f32 [B,k], counts int32 [B]) in pinned host memory, from a small pool per shape
+    (page-locking costs more than the copy); a set goes back to the pool when its search has been finished."""
+    pool = _pinned_pool.setdefault((B, k), [])
+    if pool:
+        return pool.pop()
+    return (torch.empty((B, k), dtype=torch.int32).pin_memory(), torch.empty((B, k), dtype=torch.float32).pin_memory(),
+            torch.empty((B,), dtype=torch.int32).pin_memory())
+
+
+class PendingSearch:
+    """A launched nearest-premise search whose result is on its way to the host (``Corpus.launch_nearest_premises``)."""
+
+    def __init__(self, corpus, premise_embeddings, batch_context, batch_context_emb, k, host, done, extra_host=()):
+        self.corpus, self.premise_embeddings, self.batch_context = corpus, premise_embeddings, batch_context
+        self.batch_context_emb, self.k, self.host, self.done = batch_context_emb, k, host, done
+        self.extra_host = list(extra_host)
+
+    def finish(self) -> Tuple[List[List[Premise]], List[List[float]]]:
+        """Wait for the copy, map ids to ``Premise`` objects; ``ValueError`` as the reference (common.py:323-324)."""
+        self.done.synchronize()
+        ids_h, scores_h, counts_h = self.host
+        k = self.k
+        try:
+            if bool((counts_h < 0).any()):  # candidate-list overflow (reserved by the ABI): redo with the dense pass
+                ids, scores, counts = self.corpus.nearest_premise_ids(
+                    self.premise_embeddings, self.batch_context, self.batch_context_emb, k, dense=True
+                )
+                ids_h, scores_h, counts_h = ids.cpu(), scores.cpu(), counts.cpu()
+            if bool((counts_h < k).any()):
+                raise ValueError
+            ids_l, scores_l = ids_h.tolist(), scores_h.tolist()
+        finally:
+            _pinned_pool.setdefault((len(self.batch_context), k), []).append(self.host)
+            self.batch_context_emb = None
+        prem = self.corpus.all_premises
+        return [[prem[i] for i in row] for row in ids_l], scores_l
 
 
 @dataclass

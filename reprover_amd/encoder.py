@@ -220,6 +220,18 @@ class HipT5Encoder:
                 "rp_encode_padded",
             )
 
+    def take_pending(self) -> list:
+        """Hand the unread verdict words (device int32 [4] each) to a caller that brings them to the host itself
+        (``PremiseRetriever.predict_step`` copies them along with the search result); check with ``check_verdict``."""
+        metas, self._pending_meta = self._pending_meta, []
+        return metas
+
+    @staticmethod
+    def check_verdict(meta_host) -> None:
+        if int(meta_host[2]) != 0:
+            raise ValueError("attention_mask must be right-padded (1s then 0s) with at least one token per row, "
+                             "as the tokenizer produces")
+
     def raise_pending(self) -> None:
         """Read the verdicts of the ``encode_padded`` calls issued since the last check (synchronises)."""
         metas, self._pending_meta = self._pending_meta, []

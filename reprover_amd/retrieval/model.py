@@ -50,7 +50,8 @@ class PremiseRetriever:
         self.corpus: Optional[Corpus] = None
         self.corpus_embeddings: Optional[torch.Tensor] = None
         self.embeddings_staled = True
-        self.predict_step_outputs: List[Dict[str, Any]] = []
+        self._predict_outputs: List[Dict[str, Any]] = []
+        self._predict_pending = None  # (batch, PendingSearch) of the last predict_step, finished lazily
         # "bf16": search the embedding matrix as it is (the reference's behaviour).  "fp8": search an
         # e4m3 copy with per-row scales (BASELINE.json configs[4]); ``corpus_embeddings`` stays what the
         # reference exposes, the quantised copy is derived from it lazily.
@@ -280,27 +281,61 @@ class PremiseRetriever:
             return
         self.reindex_corpus(eval_batch_size)
 
+    # ``predict_step_outputs`` (model.py:274, 314-327) - the reference's attribute.  Here the last batch's records
+    # are completed lazily: reading the attribute (or the next predict_step, or on_predict_epoch_end) finishes them.
+    @property
+    def predict_step_outputs(self) -> List[Dict[str, Any]]:
+        self._finish_pending_predict()
+        return self._predict_outputs
+
+    @predict_step_outputs.setter
+    def predict_step_outputs(self, value: List[Dict[str, Any]]) -> None:
+        self._predict_pending = None
+        self._predict_outputs = value
+
     def predict_step(self, batch: Dict[str, Any], _=None) -> None:
-        # launch-only encode (mask -> lengths -> packed ids on the device); its right-padding verdict is read at
-        # the synchronisation the search needs anyway
+        """model.py:281-327.  One batch deep software pipeline: this call enqueues its own GPU work (encode, masked
+        top-k, copy to pinned memory) and only then completes the PREVIOUS batch's records, so the host-side mapping
+        of batch i - and whatever the caller does between calls: collating batch i+1 - overlaps the GPU work of
+        batch i+1.  Consequence: a ``ValueError`` (fewer than k accessible premises; a mask that is not right-padded)
+        surfaces one call later than in the reference, at the latest when the outputs are read or the epoch ends."""
+        # launch-only encode (mask -> lengths -> packed ids on the device)
         context_emb = self.encoder.encode_padded(batch["context_ids"], batch["context_mask"], defer_check=True)
-        if self.index_shard is not None:  # every rank holds the batch; the index is row-sharded
+        if self.index_shard is not None:  # every rank holds the batch; the index is row-sharded (synchronous)
             from ..dist import sharded_get_nearest_premises
 
+            self._finish_pending_predict()
             retrieved_premises, scores = sharded_get_nearest_premises(
                 self.index_shard, batch["context"], context_emb, self.num_retrieved
             )
-        else:
-            assert not self.embeddings_staled
-            retrieved_premises, scores = self.corpus.get_nearest_premises(
-                self._search_operand(), batch["context"], context_emb, self.num_retrieved
-            )
-        self.encoder.raise_pending()
+            self.encoder.raise_pending()
+            self._append_predictions(batch, retrieved_premises, scores)
+            return
+        assert not self.embeddings_staled
+        launched = self.corpus.launch_nearest_premises(
+            self._search_operand(), batch["context"], context_emb, self.num_retrieved,
+            also_copy=self.encoder.take_pending(),  # the encode's right-padding verdict travels with the result
+        )
+        previous, self._predict_pending = self._predict_pending, (batch, launched)
+        self._finish_pending_predict(previous)
+
+    def _finish_pending_predict(self, pending="current") -> None:
+        if pending == "current":
+            pending, self._predict_pending = self._predict_pending, None
+        if pending is None:
+            return
+        batch, launched = pending
+        retrieved_premises, scores = launched.finish()
+        for verdict in launched.extra_host:
+            self.encoder.check_verdict(verdict)
+        self._append_predictions(batch, retrieved_premises, scores)
+
+    def _append_predictions(self, batch: Dict[str, Any], retrieved_premises, scores) -> None:
         for url, commit, file_path, full_name, start, tactic_idx, ctx, pos_premises, premises, s in zip_strict(
             batch["url"], batch["commit"], batch["file_path"], batch["full_name"], batch["start"],
             batch["tactic_idx"], batch["context"], batch["all_pos_premises"], retrieved_premises, scores,
         ):
-            self.predict_step_outputs.append(
+            self._predict_outputs.append(
                 {
                     "url": url,
                     "commit": commit,
@@ -319,7 +354,7 @@ class PremiseRetriever:
         if log_dir is not None:
             path = os.path.join(log_dir, "predictions.pickle")
             with open(path, "wb") as oup:
-                pickle.dump(self.predict_step_outputs, oup)
+                pickle.dump(self.predict_step_outputs, oup)  # (reading the attribute completes the last batch)
         self.predict_step_outputs.clear()
 
     # -- single query (model.py:338-375) ------------------------------------------------------------
