@@ -146,6 +146,49 @@ def test_g7_predict_and_retrieve(g7):
         model.corpus.all_premises[ids[3][0]].full_name
 
 
+def test_predict_step_pipeline_order_and_late_errors(g7):
+    """predict_step completes batch i-1 after launching batch i: records must come out in call order, identical to a
+    run that reads the outputs after every call (no overlap), and the reference's ValueError (common.py:323-324)
+    must still surface - at the latest when the outputs are read."""
+    g, z, model, _ = g7
+    k = g["k"]
+    model.num_retrieved = k
+    ctxs = [Context(q["path"], f"thm{j}", Pos(*q["pos"]), q["state"]) for j, q in enumerate(g["queries"][:24])]
+
+    def make_batch(batch):
+        tok = model.tokenizer([c.serialize() for c in batch], padding="longest", max_length=g["max_seq_len"],
+                              truncation=True, return_tensors="pt")
+        b = {"context": batch, "context_ids": tok.input_ids, "context_mask": tok.attention_mask}
+        for key in ("url", "commit", "file_path", "full_name", "start", "tactic_idx", "all_pos_premises"):
+            b[key] = [None] * len(batch)
+        b["tactic_idx"] = list(range(len(batch)))
+        return b
+
+    batches = [make_batch(ctxs[i : i + 8]) for i in range(0, 24, 8)]
+    model.predict_step_outputs = []
+    for b in batches:  # pipelined: nothing is read between the calls
+        model.predict_step(b, 0)
+    piped = model.predict_step_outputs
+    model.predict_step_outputs = []
+    stepwise = []
+    for b in batches:  # every call followed by a read: batch i is complete before batch i+1 is launched
+        model.predict_step(b, 0)
+        stepwise = list(model.predict_step_outputs)
+    assert len(piped) == len(stepwise) == 24
+    for a, b in zip(piped, stepwise):
+        assert a["context"] is b["context"] and a["scores"] == b["scores"]
+        assert [p.full_name for p in a["retrieved_premises"]] == [p.full_name for p in b["retrieved_premises"]]
+    # fewer than k accessible premises: nothing accessible from the first file's first line
+    first = model.corpus.files[0].path
+    bad = make_batch([Context(first, "t", Pos(0, 0), "x ⊢ y")])
+    model.predict_step_outputs = []
+    model.predict_step(batches[0], 0)
+    model.predict_step(bad, 0)  # launches; completes batches[0]
+    with pytest.raises(ValueError):
+        model.predict_step_outputs  # completing the bad batch raises
+    model.predict_step_outputs = []
+
+
 def test_retrieve_graph_replay_equals_launch_by_launch(g7):
     """retrieve() as one hipGraph replay (single_query.py: padded encode + masked top-k on static buffers) must
     return exactly what the launch-by-launch path returns - same premises, same scores - for states of every
