@@ -152,7 +152,9 @@ def _attention_ref(qkv, cu, tab, H):
     return out
 
 
-@pytest.mark.parametrize("lens", [[1, 5, 64, 65, 127, 128, 129, 200, 300], [700], [2048, 33]])
+@pytest.mark.parametrize("lens", [[1, 5, 64, 65, 127, 128, 129, 200, 300], [700], [2048, 33],
+                                  # more sequences than the work-list kernel has threads, every short-length bucket
+                                  [int(x) for x in np.random.default_rng(1).integers(1, 150, 1300)]])
 def test_attention(gen, lens):
     H = 2
     T = sum(lens)
