@@ -47,7 +47,6 @@ typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 1> SimCfg8Filter;
 // one (32 KB) - the premise operand streams from HBM, not from L2 like an encoder GEMM's weights
 typedef GemmCfg<256, 256, 32, 2, 2, 4, 1> SimCfgFilterK32;
 typedef GemmCfg<128, 64, 64, 2, 2, 3> SimCfgSampleK64;
-typedef GemmCfg<128, 64, 64, 2, 2, 6> SimCfgSampleK64x6;  // experiment: five 24-KB slices in flight per CU
 // default: the premise stream (read once, by one CU) carries the nt cache policy: -7 % filter time
 typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 0, 2> SimCfgFilterNt;
 constexpr int SIM_FILTER_META_BYTES = 3072;  // per-tile metadata behind the ring (EpiSimFilter::prologue)
@@ -56,6 +55,7 @@ int g_scan_impl = 0;  // 0: auto (pipelined filter kernel when the shape allows)
 int g_scan_impl_force_new = 0;  // experiments: second-generation filter for every batch size
 int g_scan_filter_cfg = 0;   // experiments: 0 = nt premise stream (default), 1 = 256x256x32 4-stage, 2 = default cache policy
 int g_scan_sample_cfg = 0;   // experiments: 0 = 128x64x64 3-stage when D % 64 == 0 (default), 1 = 128x64x32 6-stage
+                             // (a 6-stage 64-wide ring - five slices in flight - measured the same 23.5 us: not the depth)
 int g_scan_stride = 0;       // experiments: > 0 overrides the sampling stride (power of two)
 int g_scan_no_epilogue = 0;  // timing only: the filter pass drops every score (main loop in isolation)
 
@@ -932,8 +932,6 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   // pass 0: dense keys of the sampled blocks (4 sub-tiles of 64 rows each), k best of the sample -> bound
   const int n_sub = p.sample_blocks * (SIM_PB / SimCfgSample::BN);
   st = fp8 ? launch_scan_cfg<SimCfg8Sample>(qop, eop, D2, n_sub, p.stride, epi, stream)
-       : (g_scan_sample_cfg == 2 && D2 % 64 == 0)
-           ? launch_scan_cfg<SimCfgSampleK64x6>(qop, eop, D2, n_sub, p.stride, epi, stream)
        : (g_scan_sample_cfg == 0 && D2 % 64 == 0)
            ? launch_scan_cfg<SimCfgSampleK64>(qop, eop, D2, n_sub, p.stride, epi, stream)
            : launch_scan_cfg<SimCfgSample>(qop, eop, D2, n_sub, p.stride, epi, stream);
