@@ -500,28 +500,25 @@ static int pick_gemm_variant(int prof_class, int M, int n_rows_w, int K, int tok
   //   QKV      12/13/13/ -       14/14/15/26        - / - /20/21    17/17/18/19        - / - /29/32
   //   attn-out  8/ 8/ 9/ -        8/ 9/ 9/15        - / - /12/14    11/11/12/13        - / - /18/20
   //   FFN-in   14/25/47/ -       15/29/53/92        - / - /44/85    19/20/34/64        - / - /35/41
-  //   FFN-in with 128x128x64, 2 stages, two workgroups per CU (1):  54 at 2048 tokens against 63 for (0)
   // (FFN-out stays ~28 us from 256 to 1024 tokens: 23 feature tiles, each workgroup walking 459 KB of weights.)
   if (g_gemm_skinny && m256) {
     const int tv = (tokens_valid > 0 && tokens_valid < M) ? tokens_valid : M;
     const bool few_tiles = ((n_rows_w + 255) / 256) * (M / 256) < 96;
     if (few_tiles && g_gemm_skinny_variant != 12) v = g_gemm_skinny_variant;  // forced by a test
-    else if (prof_class == RP_K_GEMM_WI) v = (tv <= 256) ? 16 : (few_tiles || tv <= 1024) ? 1 : v;
+    else if (prof_class == RP_K_GEMM_WI) v = (tv <= 256) ? 16 : (few_tiles || tv <= 1024) ? 0 : v;
     else if (few_tiles) v = (tv <= 1024) ? 16 : 0;
   }
   if ((v == 20 || v == 26) && !k64) v = 9;  // 64-wide K tiles need K % 64 == 0
   if (v == 16 && !k64) v = 15;
-  if (v == 1 && !k64) v = 0;
   if (v >= 5 && !m256) v = 0;
   return v;
 }
-inline bool small_variant(int v) { return v == 0 || v == 1 || v == 15 || v == 16; }
+inline bool small_variant(int v) { return v == 0 || v == 15 || v == 16; }
 
 // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages[, pipelined]>:
 //   20 / 26  pipelined 256 x 256 x 64, 4 / 8 waves     (the encoder's big GEMMs)
 //   9        plain 256 x 256 x 32, 3 stages             (K % 64 != 0)
 //   0        plain 128 x 128 x 32, 3 stages, 2 blocks/CU (attention-out; token counts not a multiple of 256)
-//   1        plain 128 x 128 x 64, 2 stages, 2 blocks/CU (FFN-in of passes of 257-1024 tokens)
 //   16 / 15  64 x 128 x 64, 4 stages / x 32, 7 stages   (up to ~1024 tokens: single-state queries)
 //   12       64 x 256 x 32, 7 stages                    (on request only)
 // SMALL_ONLY: the epilogue type exists for the small configurations only (pick_gemm_variant said so).
@@ -545,7 +542,6 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
   switch (v) {
     case 15: return launch_gemm_cfg<GemmCfg<64, 128, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
     case 16: return launch_gemm_cfg<GemmCfg<64, 128, 64, 1, 4, 4>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-    case 1: return launch_gemm_cfg<GemmCfg<128, 128, 64, 2, 2, 2>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
     default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
   }
 }
