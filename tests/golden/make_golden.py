@@ -559,9 +559,112 @@ def g10_train_forward():
     print("g10 ok")
 
 
+def g11_train_backward():
+    """The training step: ``loss.backward()`` through the reference's ``forward`` (model.py:116-140) on
+    its own collated batch, then two optimizer steps as ``get_optimizers`` configures them outside DeepSpeed
+    (common.py:395-398: torch.optim.AdamW(lr) + get_constant_schedule_with_warmup).  Tiny geometry (2 layers, d_model
+    128) so that every gradient fits in a fixture; dropout off (eval mode): T5's dropout is stochastic."""
+    import importlib
+    from types import SimpleNamespace
+
+    from transformers import get_constant_schedule_with_warmup
+
+    from oracle import train_ref
+
+    dmod = importlib.import_module("retrieval.datamodule")
+    cfg = synth.t5_config("tiny")
+    sd = synth.synth_state_dict(cfg, seed=11)
+    model = H.offline_retriever(rm, hf_cfg(cfg), sd, max_seq_len=256)
+    model.eval()
+    files = synth.synth_corpus_records(12, 120, seed=111, code_bytes=(20, 90))
+    td = tempfile.mkdtemp()
+    path = os.path.join(td, "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    corpus = common.Corpus(path)
+    prem = corpus.all_premises
+    where = {id(p): i for i, p in enumerate(prem)}
+    rng = np.random.default_rng(112)
+    n, nneg = 4, 2
+    pick = rng.choice(len(prem), size=n * (2 + nneg), replace=False)
+    examples = []
+    for j in range(n):
+        pos = prem[int(pick[j])]
+        extra = prem[int(pick[n + j])]
+        negs = [prem[int(pick[2 * n + j * nneg + i])] for i in range(nneg)]
+        state = synth.synth_state(rng, int(rng.integers(30, 120)))
+        examples.append({"context": common.Context(pos.path, f"thm{j}", H.Pos(500, 0), state), "pos_premise": pos,
+                         "all_pos_premises": [pos, extra], "neg_premises": negs})
+    examples[1]["neg_premises"][0] = examples[0]["pos_premise"]
+    fake_self = SimpleNamespace(tokenizer=model.tokenizer, max_seq_len=256, num_negatives=nneg, is_train=True)
+    batch = dmod.RetrievalDataset.collate(fake_self, examples)
+    label = batch["label"]
+    lr, warmup = 1e-3, 1
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=lr)
+    sched = get_constant_schedule_with_warmup(opt, warmup)
+    names = {id(p): k for k, p in model.named_parameters()}
+
+    def strip(k):  # PremiseRetriever.encoder.<HF name>
+        assert k.startswith("encoder."), k
+        return k[len("encoder."):]
+
+    def step():
+        opt.zero_grad()
+        loss = model(batch["context_ids"], batch["context_mask"], batch["pos_premise_ids"], batch["pos_premise_mask"],
+                     batch["neg_premises_ids"], batch["neg_premises_mask"], label)
+        loss.backward()
+        grads = {strip(names[id(p)]): p.grad.detach().clone().numpy() for p in params}
+        opt.step()
+        sched.step()
+        return float(loss.detach()), grads
+
+    loss0, grads0 = step()  # learning rate 0 (warm-up): parameters unchanged, moments updated
+    loss1, grads1 = step()  # learning rate lr
+    loss2, _ = step()
+    after = {strip(k): p.detach().clone().numpy() for k, p in model.named_parameters()}
+    # ---- the oracle restatement against the reference, here and now
+    ctx_texts = [e["context"].serialize() for e in examples]
+    pos_texts = [e["pos_premise"].serialize() for e in examples]
+    neg_texts = [[e["neg_premises"][i].serialize() for e in examples] for i in range(nneg)]
+    o_label = train_ref.label_matrix([where[id(e["pos_premise"])] for e in examples],
+                                     [[where[id(p)] for p in e["neg_premises"]] for e in examples],
+                                     [[where[id(p)] for p in e["all_pos_premises"]] for e in examples])
+    assert np.array_equal(o_label, label.numpy())
+    o_loss, o_grads = train_ref.forward_backward(cfg, sd, ctx_texts, pos_texts, neg_texts, o_label, 256)
+    assert set(o_grads) == set(grads0), (sorted(set(o_grads) ^ set(grads0)))
+    worst = max(np.abs(o_grads[k] - grads0[k]).max() / (np.abs(grads0[k]).max() + 1e-12) for k in grads0)
+    print(f"g11: loss {loss0:.6f} (oracle {o_loss:.6f}); worst relative gradient difference oracle vs reference {worst:.2e}; "
+          f"losses over the three steps {loss0:.6f} {loss1:.6f} {loss2:.6f}")
+    assert abs(o_loss - loss0) < 1e-6 and worst < 2e-4
+    # AdamW restatement: three steps from the reference's gradients of steps 0, 1 (step 2's are not stored: the
+    # parameters after the SECOND effective update are what the fixture pins) - replay steps 0..1 and compare with the
+    # reference's parameters before its third update... simpler and sufficient: replay all three with recomputed grads
+    P = {k: v.numpy().astype(np.float32).copy() for k, v in sd.items() if k != train_ref.TIED}
+    M = {k: np.zeros_like(v, dtype=np.float64) for k, v in P.items()}
+    V = {k: np.zeros_like(v, dtype=np.float64) for k, v in P.items()}
+    for t in range(3):
+        _, g = train_ref.forward_backward(cfg, {k: torch.from_numpy(v) for k, v in P.items()}, ctx_texts, pos_texts,
+                                          neg_texts, o_label, 256)
+        for k in P:
+            P[k], M[k], V[k] = train_ref.adamw_step(P[k], g[k], M[k], V[k], t + 1, lr * train_ref.warmup_factor(t, warmup))
+    worst_p = max(np.abs(P[k] - after[k]).max() for k in P)
+    print(f"g11: max |parameter difference| after three optimizer steps, oracle vs reference: {worst_p:.2e}")
+    assert worst_p < 5e-6
+    out = {"loss": np.float64(loss0), "losses": np.array([loss0, loss1, loss2]), "label": label.numpy(),
+           "context_texts": np.array(ctx_texts, dtype=object), "pos_texts": np.array(pos_texts, dtype=object),
+           "neg_texts": np.array(neg_texts, dtype=object), "weight_seed": np.int64(11), "max_seq_len": np.int64(256),
+           "lr": np.float64(lr), "warmup_steps": np.int64(warmup)}
+    for k, v in grads0.items():
+        out["grad/" + k] = v.astype(np.float32)
+    for k, v in after.items():
+        out["after3/" + k] = v.astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "g11_train_backward.npz"), **out)
+    print("g11 ok")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     torch.manual_seed(0)
     for name in which:
         {"g1": g1_tokenizer, "g2": g2_serialize, "g3": g3_buckets, "g4": g4_tiny, "g5": g5_small,
-         "g6": g6_nearest, "g7": g7_predict, "g8": g8_eval_data, "g9": g9_base_full_depth, "g10": g10_train_forward}[name]()
+         "g6": g6_nearest, "g7": g7_predict, "g8": g8_eval_data, "g9": g9_base_full_depth, "g10": g10_train_forward, "g11": g11_train_backward}[name]()

@@ -124,3 +124,39 @@ def test_g10_train_forward(golden_dir):
                                        [list(r) for r in g["neg_texts"]], label, int(g["max_seq_len"]))
     assert abs(loss - float(g["loss"])) < 1e-6
     assert np.abs(sim - g["similarity"]).max() < 2e-5
+
+
+def test_g11_train_backward_and_adamw(golden_dir):
+    """oracle/train_ref.py (autograd over the forward restatement; AdamW + constant-with-warmup schedule) against the
+    reference's own ``loss.backward()`` and three optimizer steps (common.py:381-405 outside DeepSpeed)."""
+    import torch
+
+    from oracle import train_ref
+
+    g = np.load(os.path.join(golden_dir, "g11_train_backward.npz"), allow_pickle=True)
+    cfg = synth.t5_config("tiny")
+    sd = synth.synth_state_dict(cfg, seed=int(g["weight_seed"]))
+    texts = (list(g["context_texts"]), list(g["pos_texts"]), [list(r) for r in g["neg_texts"]])
+    L = int(g["max_seq_len"])
+    loss, grads = train_ref.forward_backward(cfg, sd, *texts, g["label"], L)
+    assert abs(loss - float(g["loss"])) < 1e-6
+    gold = {k[len("grad/"):]: g[k] for k in g.files if k.startswith("grad/")}
+    assert set(gold) == set(grads) and train_ref.TIED not in gold  # the tied embedding is one parameter
+    for k, want in gold.items():
+        assert np.abs(grads[k] - want).max() <= 1e-5 * np.abs(want).max() + 1e-9, k
+    assert np.abs(gold["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"]).max() > 0  # bias table trained
+    # three optimizer steps on the same batch (step 0 at learning rate 0: warm-up), parameters after the third
+    lr, warmup = float(g["lr"]), int(g["warmup_steps"])
+    assert [train_ref.warmup_factor(t, warmup) for t in range(3)] == [0.0, 1.0, 1.0]
+    P = {k: v.numpy().astype(np.float32).copy() for k, v in sd.items() if k != train_ref.TIED}
+    M = {k: np.zeros(v.shape) for k, v in P.items()}
+    V = {k: np.zeros(v.shape) for k, v in P.items()}
+    losses = []
+    for t in range(3):
+        l, gr = train_ref.forward_backward(cfg, {k: torch.from_numpy(v) for k, v in P.items()}, *texts, g["label"], L)
+        losses.append(l)
+        for k in P:
+            P[k], M[k], V[k] = train_ref.adamw_step(P[k], gr[k], M[k], V[k], t + 1, lr * train_ref.warmup_factor(t, warmup))
+    assert np.abs(np.array(losses) - g["losses"]).max() < 2e-6 and losses[2] < losses[0]
+    for k in P:
+        assert np.abs(P[k] - g["after3/" + k]).max() < 5e-6, k
