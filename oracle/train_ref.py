@@ -66,7 +66,7 @@ def forward_backward(cfg: Dict, sd: Dict[str, torch.Tensor], context_texts: List
         loss = torch.nn.functional.mse_loss(sim, torch.from_numpy(np.asarray(label, dtype=np.float32)))
     loss.backward()
     grads = {k: (w.grad if w.grad is not None else torch.zeros_like(w)).detach().numpy() for k, w in W.items()}
-    return float(loss), grads
+    return float(loss.detach()), grads
 
 
 def warmup_factor(step_index: int, warmup_steps: int) -> float:
