@@ -208,12 +208,24 @@ RpStatus rp_topk_merge(const float* scores, const int32_t* ids, const int32_t* c
  *   label          device f32 [B, P]   (datamodule.py:160-175)
  *   out_loss       device f32 [1]: mean over the B x P entries of (similarity - label)^2, summed in index order
  *   out_similarity device f32 [B, P] or NULL
- * Backward and the optimizer are not part of this library.
+ * The encoder's backward is not part of this library; the two ends of the training step around it are:
  * ------------------------------------------------------------------------------------------- */
 size_t   rp_contrastive_mse_workspace_bytes(int32_t B, int32_t P);
 RpStatus rp_contrastive_mse(const float* context_emb, const float* premise_embs, const float* label,
                             int32_t B, int32_t P, int32_t D, float* out_loss, float* out_similarity,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* Backward of that loss (what autograd does behind retrieval/model.py:137-139): with S = out_similarity of the forward,
+ * dS = 2 (S - label) / (B P);  d_context_emb [B, D] = dS premise_embs;  d_premise_embs [P, D] = dS^T context_emb. */
+RpStatus rp_contrastive_mse_backward(const float* context_emb, const float* premise_embs, const float* similarity,
+                                     const float* label, int32_t B, int32_t P, int32_t D, float* d_context_emb,
+                                     float* d_premise_embs, void* stream);
+/* One torch.optim.AdamW update (/root/reference/common.py:395: `torch.optim.AdamW(parameters, lr=lr)`; decoupled
+ * weight decay, bias-corrected moments) of n fp32 parameters, in place:  param, exp_avg, exp_avg_sq device f32 [n],
+ * 16-byte aligned;  step = 1, 2, ...;  lr = base rate x the schedule's factor for this step
+ * (get_constant_schedule_with_warmup: min(1, (step - 1) / warmup_steps)).  torch defaults: betas (0.9, 0.999),
+ * eps 1e-8, weight_decay 1e-2. */
+RpStatus rp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline

@@ -102,6 +102,16 @@ SIGNATURES = {
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
          C.c_size_t, C.c_void_p],
     ),
+    "rp_contrastive_mse_backward": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+         C.c_void_p],
+    ),
+    "rp_adamw_step": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
+         C.c_float, C.c_void_p],
+    ),
     "rp_dbg_gemm": (
         C.c_int32,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],

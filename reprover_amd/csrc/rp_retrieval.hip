@@ -15,6 +15,7 @@
 //     tiles and appends only keys above the bound to a per-query candidate list (expected size
 //     ~ k * stride).  A final radix-select + bitonic sort over <= cap candidates yields the
 //     sorted top-k.  Small shards (N <= 16384) and RP_TOPK_DENSE take the single dense pass.
+#include <cmath>
 #include "rp_gemm.h"
 
 namespace rp {
@@ -1180,6 +1181,96 @@ extern "C" RpStatus rp_contrastive_mse(const float* context_emb, const float* pr
   hipLaunchKernelGGL(pair_dots_kernel, dim3((B * P + 3) / 4), dim3(256), 0, stream, context_emb, premise_embs, label, B,
                      P, D, out_similarity, err2);
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, stream, (const float*)err2, B * P, out_loss);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// First pieces of the training step behind the forward (oracle: oracle/train_ref.py, fixture G11).
+//   * rp_contrastive_mse_backward: loss = mean((C P^T - label)^2)  =>  dS = 2 (S - label) / (B P),
+//     dC = dS P, dP = dS^T C.  One workgroup per output row, the other index walked in order (deterministic).
+//   * rp_adamw_step: torch.optim.AdamW's update (common.py:395 `torch.optim.AdamW(parameters, lr=lr)`), in place on
+//     fp32 parameters and moments; 28 bytes per parameter, HBM-bound.
+// The encoder's own backward is not built.
+// ------------------------------------------------------------------------------------------
+namespace rp {
+__global__ __launch_bounds__(256) void mse_backward_kernel(const float* __restrict__ ctx, const float* __restrict__ prem,
+                                                           const float* __restrict__ sim, const float* __restrict__ label,
+                                                           int B, int P, int D, float* __restrict__ d_ctx,
+                                                           float* __restrict__ d_prem) {
+  const int row = blockIdx.x;  // [0, B): a context row; [B, B + P): a premise row
+  const float scale = 2.f / ((float)B * (float)P);
+  const bool is_ctx = row < B;
+  const int r = is_ctx ? row : row - B;
+  const int n_other = is_ctx ? P : B;
+  const float* other = is_ctx ? prem : ctx;
+  float* dst = (is_ctx ? d_ctx : d_prem) + (size_t)r * D;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float acc = 0.f;
+    for (int o = 0; o < n_other; ++o) {
+      const int j = is_ctx ? r : o, k = is_ctx ? o : r;
+      const float ds = (sim[(size_t)j * P + k] - label[(size_t)j * P + k]) * scale;
+      acc = fmaf(ds, other[(size_t)o * D + c], acc);
+    }
+    dst[c] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, size_t n4, size_t n,
+                                                    float decay, float beta1, float beta2, float step_size,
+                                                    float inv_sqrt_bc2, float eps) {
+  auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+    pp *= decay;                              // param.mul_(1 - lr * weight_decay)
+    mm = fmaf(gg - mm, 1.f - beta1, mm);      // exp_avg.lerp_(grad, 1 - beta1)
+    vv = fmaf(gg * gg, 1.f - beta2, vv * beta2);
+    const float denom = fmaf(sqrtf(vv), inv_sqrt_bc2, eps);
+    pp -= step_size * (mm / denom);
+  };
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    upd(pp.x, gg.x, mm.x, vv.x);
+    upd(pp.y, gg.y, mm.y, vv.y);
+    upd(pp.z, gg.z, mm.z, vv.z);
+    upd(pp.w, gg.w, mm.w, vv.w);
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n4 * 4)) {  // tail of fewer than four elements
+    const size_t i = n4 * 4 + threadIdx.x;
+    upd(p[i], g[i], m[i], v[i]);
+  }
+}
+}  // namespace rp
+
+extern "C" RpStatus rp_contrastive_mse_backward(const float* context_emb, const float* premise_embs,
+                                                const float* similarity, const float* label, int32_t B, int32_t P,
+                                                int32_t D, float* d_context_emb, float* d_premise_embs, void* stream_) {
+  RP_REQUIRE(context_emb && premise_embs && similarity && label && d_context_emb && d_premise_embs, "null argument");
+  RP_REQUIRE(B > 0 && P > 0 && D > 0, "B=%d P=%d D=%d", B, P, D);
+  hipLaunchKernelGGL(mse_backward_kernel, dim3(B + P), dim3(256), 0, (hipStream_t)stream_, context_emb, premise_embs,
+                     similarity, label, B, P, D, d_context_emb, d_premise_embs);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" RpStatus rp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                  void* stream_) {
+  RP_REQUIRE(param && grad && exp_avg && exp_avg_sq, "null argument");
+  RP_REQUIRE(n > 0 && step >= 1 && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "n=%lld step=%d",
+             (long long)n, step);
+  RP_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+             "16-byte aligned arrays");
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  const size_t n4 = (size_t)n / 4;
+  const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>((n4 + 255) / 256, 1), 256 * 16);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, param, grad, exp_avg, exp_avg_sq, n4,
+                     (size_t)n, 1.f - lr * weight_decay, beta1, beta2, (float)((double)lr / bc1),
+                     (float)(1.0 / std::sqrt(bc2)), eps);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

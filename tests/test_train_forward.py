@@ -72,3 +72,60 @@ def test_forward_loss_matches_reference(g10):
         bad[0, 0] = 0
         model(b["context_ids"], bad, b["pos_premise_ids"], b["pos_premise_mask"], b["neg_premises_ids"],
               b["neg_premises_mask"], b["label"])
+
+
+@pytest.mark.gpu
+def test_loss_backward_and_adamw_kernels():
+    """The two ends of the training step around the encoder: rp_contrastive_mse_backward against torch autograd on
+    the same fp32 operands, rp_adamw_step against the oracle's AdamW (itself pinned to the reference's optimizer by
+    G11) and against torch.optim.AdamW, incl. the warm-up step at learning rate 0 and a length that is not a
+    multiple of four; achieved HBM rate of the update on 64 M parameters."""
+    from oracle import train_ref
+    from reprover_amd import train
+
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(7)
+    B, P, D = 6, 24, 1472
+    C = torch.nn.functional.normalize(torch.randn(B, D, generator=gen, device="cuda"), dim=1).requires_grad_(True)
+    Pm = torch.nn.functional.normalize(torch.randn(P, D, generator=gen, device="cuda"), dim=1).requires_grad_(True)
+    label = (torch.rand(B, P, generator=gen, device="cuda") < 0.2).float()
+    S = C @ Pm.T
+    torch.nn.functional.mse_loss(S, label).backward()
+    d_ctx, d_prem = train.contrastive_mse_backward(C.detach(), Pm.detach(), S.detach(), label)
+    assert (d_ctx - C.grad).abs().max().item() < 1e-7 and (d_prem - Pm.grad).abs().max().item() < 1e-7
+
+    n = 100_003
+    p0 = torch.randn(n, generator=gen, device="cuda")
+    grads = [torch.randn(n, generator=gen, device="cuda") * 0.1 for _ in range(3)]
+    p = p0.clone()
+    opt = train.AdamW([p], lr=1e-3, warmup_steps=1)
+    ref_p = torch.nn.Parameter(p0.clone())
+    ref_opt = torch.optim.AdamW([ref_p], lr=1e-3)
+    sched = torch.optim.lr_scheduler.LambdaLR(ref_opt, lambda s: train_ref.warmup_factor(s, 1))
+    po, m, v = p0.cpu().numpy(), np.zeros(n), np.zeros(n)
+    for t, g in enumerate(grads):
+        opt.step([g])
+        ref_p.grad = g.clone()
+        ref_opt.step()
+        sched.step()
+        po, m, v = train_ref.adamw_step(po, g.cpu().numpy(), m, v, t + 1, 1e-3 * train_ref.warmup_factor(t, 1))
+        if t == 0:
+            assert torch.equal(p, p0), "the warm-up step has learning rate 0"
+    torch.cuda.synchronize()
+    assert np.abs(p.cpu().numpy() - po).max() < 2e-6  # the oracle (float64 inside)
+    assert (p - ref_p.detach()).abs().max().item() < 2e-6  # torch's own kernel
+    assert (opt.exp_avg[0].cpu().numpy() - m).__abs__().max() < 1e-6
+
+    n = 64 << 20
+    big = [torch.zeros(n, device="cuda") for _ in range(4)]
+    big[1].fill_(0.01)
+    o2 = train.AdamW([big[0]], lr=1e-3)
+    o2.step([big[1]])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        o2.step([big[1]])
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print(f"rp_adamw_step on {n >> 20} M parameters: {ms:.3f} ms = {28.0 * n / ms / 1e9:.2f} TB/s of 8 (28 B per parameter)")
