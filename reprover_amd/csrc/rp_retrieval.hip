@@ -1228,16 +1228,29 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     pp -= step_size * (mm / denom);
   };
   const size_t stride = (size_t)gridDim.x * 256;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-    float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
-    const float4 gg = reinterpret_cast<const float4*>(g)[i];
-    upd(pp.x, gg.x, mm.x, vv.x);
-    upd(pp.y, gg.y, mm.y, vv.y);
-    upd(pp.z, gg.z, mm.z, vv.z);
-    upd(pp.w, gg.w, mm.w, vv.w);
-    reinterpret_cast<float4*>(p)[i] = pp;
-    reinterpret_cast<float4*>(m)[i] = mm;
-    reinterpret_cast<float4*>(v)[i] = vv;
+  constexpr int U = 2;  // two 16-byte pieces of each of the four arrays in flight per thread
+  for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += U * stride) {
+    float4 pp[U], mm[U], vv[U], gg[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = min(i0 + u * stride, n4 - 1);
+      pp[u] = reinterpret_cast<float4*>(p)[i];
+      mm[u] = reinterpret_cast<float4*>(m)[i];
+      vv[u] = reinterpret_cast<float4*>(v)[i];
+      gg[u] = reinterpret_cast<const float4*>(g)[i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + u * stride;
+      if (i >= n4) break;
+      upd(pp[u].x, gg[u].x, mm[u].x, vv[u].x);
+      upd(pp[u].y, gg[u].y, mm[u].y, vv[u].y);
+      upd(pp[u].z, gg[u].z, mm[u].z, vv[u].z);
+      upd(pp[u].w, gg[u].w, mm[u].w, vv[u].w);
+      reinterpret_cast<float4*>(p)[i] = pp[u];
+      reinterpret_cast<float4*>(m)[i] = mm[u];
+      reinterpret_cast<float4*>(v)[i] = vv[u];
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n4 * 4)) {  // tail of fewer than four elements
     const size_t i = n4 * 4 + threadIdx.x;
@@ -1267,7 +1280,7 @@ extern "C" RpStatus rp_adamw_step(float* param, const float* grad, float* exp_av
              "16-byte aligned arrays");
   const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
   const size_t n4 = (size_t)n / 4;
-  const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>((n4 + 255) / 256, 1), 256 * 16);
+  const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>((n4 + 511) / 512, 1), 256 * 32);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, param, grad, exp_avg, exp_avg_sq, n4,
                      (size_t)n, 1.f - lr * weight_decay, beta1, beta2, (float)((double)lr / bc1),
                      (float)(1.0 / std::sqrt(bc2)), eps);
