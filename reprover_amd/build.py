@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libreprover_hip.so")
 SOURCES = ["rp_encoder.hip", "rp_retrieval.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+COMPILE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc() -> str:
@@ -40,13 +40,27 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     tmp = f"{LIB_PATH}.{os.getpid()}.tmp"  # per-process: concurrent builders (one per rank) must not share it
-    cmd = [_hipcc(), *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", tmp]
+    objs = [os.path.join(LIB_DIR, f"{os.path.splitext(s)[0]}.{os.getpid()}.o") for s in SOURCES]
+    # one translation unit per process, side by side (a cold build is bound by the slowest unit, not their sum)
+    cmds = [[_hipcc(), *COMPILE_FLAGS, "-c", os.path.join(CSRC, s), "-o", o] for s, o in zip(SOURCES, objs)]
     if verbose:
-        print(" ".join(cmd), flush=True)
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        sys.stderr.write(res.stdout + res.stderr)
-        raise RuntimeError("hipcc failed building libreprover_hip.so")
+        for c in cmds:
+            print(" ".join(c), flush=True)
+    procs = [subprocess.Popen(c, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for c in cmds]
+    outs = [p.communicate()[0] for p in procs]
+    try:
+        if any(p.returncode != 0 for p in procs):
+            sys.stderr.write("".join(outs))
+            raise RuntimeError("hipcc failed building libreprover_hip.so")
+        link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp]
+        res = subprocess.run(link, capture_output=True, text=True)
+        if res.returncode != 0:
+            sys.stderr.write(res.stdout + res.stderr)
+            raise RuntimeError("hipcc failed linking libreprover_hip.so")
+    finally:
+        for o in objs:
+            if os.path.exists(o):
+                os.remove(o)
     os.replace(tmp, LIB_PATH)
     return LIB_PATH
 

@@ -5,19 +5,16 @@
 // attention :281-369, RMSNorm :50-72, gated-GELU FFN :97-123).  Exact math: SURVEY.md App. A.
 //
 // Data layout in HBM for a pass over T packed tokens (Tp = T rounded up to 256):
-//   x    f32  [Tp, D]        residual stream (kept fp32; HF-bf16 keeps it bf16)
-//   h    bf16 [Tp, D]        RMSNorm output = GEMM A operand
+//   xb   bf16 [Tp, D]        hi plane of the residual stream, bf16(x): also the A operand of the QKV / FFN-in GEMMs
+//   xlo  bf16 [Tp, D]        lo plane, bf16(x - xb): x = xb + xlo to 2^-18 relative (HF-bf16 keeps 8 mantissa bits)
+//   ssp  f32  [D/64, Tp]     slot-major partial sums of squares of x (RMSNorm statistic; the norm weight is folded
+//   rs   f32  [Tp]           into the consuming weights, rs = rsqrt(mean x^2 + eps) multiplies in their epilogues)
 //   qkv  bf16 [Tp, 3*H*64]   fused projection output, [q | k | v], head-major inside each
 //   att  bf16 [Tp, H*64]     attention output
 //   ff   bf16 [Tp, F]        gelu_new(wi_0 h) * (wi_1 h)
 // Sequences are packed back to back (varlen): no padded token is ever computed except the
-// <128 rows that round the last GEMM tile.
-#include <math.h>
-#include <string.h>
-
-#include <vector>
-
-#include "rp_gemm.h"
+// < 256 rows that round the last GEMM tile.  Device code: rp_encoder_kernels.h (shared with rp_train.hip).
+#include "rp_encoder_kernels.h"
 
 namespace rp {
 
@@ -27,25 +24,25 @@ thread_local std::string g_last_error;
 // options
 // ------------------------------------------------------------------------------------------
 extern int g_scan_cfg, g_scan_impl, g_scan_filter_cfg, g_scan_sample_cfg, g_scan_stride, g_scan_no_epilogue, g_scan_impl_force_new;
-static int g_gemm_group_m = 8;
+int g_gemm_group_m = 8;
 // Tile configuration per encoder GEMM (see launch_gemm()), measured at 65536 tokens (tools/gemm_bench.py,
 // profiles/).  20 / 26 = the software-pipelined 256 x 256 x 64 tile with 4 / 8 waves: the same main
 // loop; 8 waves finish the heavier epilogues (bf16 store of 1152 features, fp32 residual
 // read-modify-write) sooner, 4 waves win by a hair on the gated-GELU GEMM.  The K = H*64
 // attention-output projection is bound by the read-modify-write of x whatever the tiling: two small
 // blocks per CU overlap one block's epilogue with the other's main loop.
-static int g_gemm_variant = 20;      // FFN-in (wi_0|wi_1 + gated GELU)
-static int g_gemm_variant_qkv = 26;  // QKV
-static int g_gemm_variant_wo = 26;   // FFN-out (+ residual)
-static int g_gemm_variant_o = 0;     // attention output (+ residual)
-static int g_gemm_tail_split = 1;  // big passes: last partial round of 256 x 256 tiles as one round of 128 x 128 tiles
-static int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
-static int g_gemm_skinny = 1;
-static int g_gemm_skinny_variant = 12;
+int g_gemm_variant = 20;      // FFN-in (wi_0|wi_1 + gated GELU)
+int g_gemm_variant_qkv = 26;  // QKV
+int g_gemm_variant_wo = 26;   // FFN-out (+ residual)
+int g_gemm_variant_o = 0;     // attention output (+ residual)
+int g_gemm_tail_split = 1;  // big passes: last partial round of 256 x 256 tiles as one round of 128 x 128 tiles
+int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
+int g_gemm_skinny = 1;
+int g_gemm_skinny_variant = 12;
 // Experiment knob: spread the first round of workgroups of the big GEMMs over this many microseconds (0 = off).
 // All 256 CUs otherwise reach their epilogues at the same moment, round after round (tiles take equal time), and
 // the epilogue traffic arrives in bursts.  Indexed by kernel class (RP_K_GEMM_*).
-static int g_gemm_stagger_us[RP_K_COUNT] = {};
+int g_gemm_stagger_us[RP_K_COUNT] = {};
 
 // ------------------------------------------------------------------------------------------
 // per-kernel event timing
@@ -79,900 +76,8 @@ void prof_end(hipStream_t stream) {
   (void)hipEventRecord(g_prof_recs.back().b, stream);
 }
 
-// ------------------------------------------------------------------------------------------
-// weight packing (create time only)
-// ------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ float load_as_f32(const void* p, size_t i);
-template <>
-__device__ __forceinline__ float load_as_f32<float>(const void* p, size_t i) {
-  return reinterpret_cast<const float*>(p)[i];
-}
-template <>
-__device__ __forceinline__ float load_as_f32<bf16_t>(const void* p, size_t i) {
-  return bf2f(reinterpret_cast<const bf16_t*>(p)[i]);
-}
-
-enum PackMode { PACK_CONCAT3 = 0, PACK_GEGLU = 1, PACK_COPY = 2 };
-
-// dst bf16 [rows_dst, cols]; source row mapping by mode:
-//   CONCAT3: rows [0,n) from s0, [n,2n) from s1, [2n,3n) from s2      (fused q|k|v)
-//   GEGLU  : 64-row blocks: 32 rows of s0 (gate, wi_0) then 32 rows of s1 (up, wi_1)
-//   COPY   : row r from s0
-//   colscale (optional, fp32 [cols]): every row is multiplied column-wise before rounding — used to
-//   fold the T5 RMSNorm weight into the projection that consumes the normalised activations.
-template <typename T>
-__global__ void pack_rows_kernel(bf16_t* dst, const void* s0, const void* s1, const void* s2,
-                                 int rows_dst, int cols, int n, int mode, const float* colscale) {
-  const int r = blockIdx.x;
-  const void* src;
-  int sr;
-  if (mode == PACK_CONCAT3) {
-    src = (r < n) ? s0 : (r < 2 * n ? s1 : s2);
-    sr = r % n;
-  } else if (mode == PACK_GEGLU) {
-    src = ((r >> 5) & 1) ? s1 : s0;
-    sr = (r >> 6) * 32 + (r & 31);
-  } else {
-    src = s0;
-    sr = r;
-  }
-  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
-    float v = load_as_f32<T>(src, (size_t)sr * cols + c);
-    if (colscale) v *= colscale[c];
-    dst[(size_t)r * cols + c] = f2bf(v);
-  }
-}
-
-template <typename T>
-__global__ void to_f32_kernel(float* dst, const void* src, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = load_as_f32<T>(src, i);
-}
-
-// ------------------------------------------------------------------------------------------
-// The residual stream x lives in HBM as TWO bf16 planes: hi = bf16(x) and lo = bf16(x - hi), x = hi + lo to 2^-18
-// relative (16 mantissa bits).  hi IS the A operand of the next projection, so a residual update reads 4 B and writes
-// 4 B per element where an fp32 stream with a separate bf16 copy read 4 and wrote 6: the two residual epilogues and the
-// embedding move 20 % fewer bytes, and the chip read-modify-writes the two planes 29 % faster than the fp32 + bf16 form
-// (tools/probes/rmw_probe.hip: 0.168 vs 0.238 ms for [70144, 1472] in 256 x 256 tiles).  The GEMM operands are
-// bf16-rounded either way; the 2^-18 bound per update is far below that rounding (2^-9).
-// ------------------------------------------------------------------------------------------
-// one updated element pair: (hi + lo) + d, re-split; ss accumulates the squares of the values as stored
-__device__ __forceinline__ void hilo_update2(uint32_t h2, uint32_t l2, float d0, float d1, uint32_t& oh, uint32_t& ol,
-                                             float& ss) {
-  const float v0 = (__uint_as_float(h2 << 16) + __uint_as_float(l2 << 16)) + d0;
-  const float v1 = (__uint_as_float(h2 & 0xffff0000u) + __uint_as_float(l2 & 0xffff0000u)) + d1;
-  oh = pack_bf2(v0, v1);
-  const float h0 = __uint_as_float(oh << 16), h1 = __uint_as_float(oh & 0xffff0000u);
-  ol = pack_bf2(v0 - h0, v1 - h1);
-  const float x0 = h0 + __uint_as_float(ol << 16), x1 = h1 + __uint_as_float(ol & 0xffff0000u);
-  // explicit fma chain: the same rounding sequence for every token, wherever it sits in the batch
-  ss = __fmaf_rn(x1, x1, __fmaf_rn(x0, x0, ss));
-}
-
-// ------------------------------------------------------------------------------------------
-// K1: byte-token embedding gather  x[t] = embed[ids[t]]   (HF:678); the table (vocab x D fp32,
-//   2.3 MB for ByT5-small) is L2-resident.  Emits the two planes of x (hi = the A operand of the first
-//   projection) and the row's sum of squares (RMSNorm statistic, applied in that GEMM's epilogue).
-//   rows >= T (tile padding) get token 0 so every workspace row stays finite.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ ids,
-                                                    const float* __restrict__ table,
-                                                    bf16_t* __restrict__ xhi, bf16_t* __restrict__ xlo,
-                                                    float* __restrict__ ssp, int np, int T, int Tp, int D,
-                                                    int vocab, const int32_t* __restrict__ t_dev) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  int rows = Tp;  // Tp stays the leading dimension of the slot-major statistics
-  if (t_dev) {    // token count known on the device only (rp_encode_padded): T / Tp are upper bounds
-    T = *t_dev;
-    rows = min(Tp, (T + 255) & ~255);
-  }
-  if (row >= rows) return;
-  int id = (row < T) ? ids[row] : 0;
-  id = min(max(id, 0), vocab - 1);
-  const float4* src = reinterpret_cast<const float4*>(table + (size_t)id * D);
-  uint4* dh = reinterpret_cast<uint4*>(xhi + (size_t)row * D);
-  uint4* dl = reinterpret_cast<uint4*>(xlo + (size_t)row * D);
-  float ss = 0.f;
-  for (int c = lane; c < (D >> 3); c += 64) {  // 8 features per lane and step
-    const float4 a = src[2 * c], b = src[2 * c + 1];
-    uint4 oh, ol;
-    hilo_update2(0u, 0u, a.x, a.y, oh.x, ol.x, ss);
-    hilo_update2(0u, 0u, a.z, a.w, oh.y, ol.y, ss);
-    hilo_update2(0u, 0u, b.x, b.y, oh.z, ol.z, ss);
-    hilo_update2(0u, 0u, b.z, b.w, oh.w, ol.w, ss);
-    dh[c] = oh;
-    dl[c] = ol;
-  }
-  ss = wave_sum(ss);
-  // sum-of-squares partials of the row (see EpiResid): slot 0 carries the whole row here
-  for (int p = lane; p < np; p += 64) ssp[(size_t)p * Tp + row] = (p == 0) ? ss : 0.f;
-}
-
-constexpr int RMS_MAX_V4 = 8;  // a row is at most 8 float4 per lane of a wave: d_model <= 2048
-
-// ------------------------------------------------------------------------------------------
-// K3/K6/K7/K8: GEMM epilogues
-// ------------------------------------------------------------------------------------------
-// The encoder GEMMs are issued "transposed": the weight matrix is the MFMA row operand (rows of the
-// accumulator tile = output features) and the activations the column operand (cols = tokens).  With
-// the 32x32 C/D layout a lane then owns ONE token (col = lane & 31) and, per 4-register group, FOUR
-// CONSECUTIVE output features (row = 8g + 4hi + 0..3) — so every epilogue moves 8 B (bf16x4) or 16 B
-// (fp32x4) per lane per access instead of 2-4 B, a quarter of the store instructions.
-//   acc[i][j][4g + e]  <->  feature m_base + 32 i + 8 g + 4 hi + e,  token n_base + 32 j + (lane & 31)
-// Each epilogue goes through the wave's private LDS staging area (EPI_STAGE_BYTES, rows of
-// EPI_ROW_BYTES): the accumulators are written token-row-major with ds_write_b128 / b64 (4
-// consecutive features per lane), then read back so that 8 or 16 consecutive lanes cover one token's
-// contiguous 128-B (fp32 x 32) or 64/128-B (bf16) span: global accesses become full cache lines,
-// 16 B per lane, instead of 8-16 B scattered over 32 rows.
-// T5 RMSNorm folded into the GEMMs (HF:59-72).  h = w * x * rsqrt(mean(x^2) + eps) feeds only the QKV
-// and FFN-in projections, so:  (a) w is folded into those weights when they are packed;  (b) the
-// producer of x (embedding kernel / residual-add epilogue) also stores xb = bf16(x), the GEMM A operand,
-// and per-row partial sums of squares ssp[token][p], one slot per 64-feature wave tile (deterministic:
-// no atomics);  (c) the consuming epilogue multiplies each accumulator by rs[token] =
-// rsqrt(sum_p ssp[token][p] / D + eps), reduced once per sub-layer by the tiny rowscale_kernel.  No separate
-// normalisation pass over x remains.
-struct RowScale {
-  const float* rs;  // [tokens] or NULL (no scaling); produced by rowscale_kernel from the ssp partials
-  __device__ __forceinline__ float get(int token) const { return rs ? rs[token] : 1.f; }
-};
-// Passes of at most ~1000 tokens (a single proof state) skip the rowscale launches - there a launch costs more than
-// its work - and the consuming epilogue sums the slots itself, in the same index order (the same bits).  A separate
-// type, instantiated for the small tile configurations only: the big tiles' register allocation stays as it was.
-struct RowScaleFromSlots {
-  const float* ssp;  // [np, ld] slot-major partial sums of squares
-  int np, ld;
-  float inv_d, eps;
-  __device__ __forceinline__ float get(int token) const {
-    float v[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) v[i] = (i < np) ? ssp[(size_t)i * ld + token] : 0.f;
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) s += v[i];
-    return rsqrtf(s * inv_d + eps);
-  }
-};
-
-// rs[token] = rsqrt(sum_p ssp[p][token] / D + eps), slots summed in index order
-__global__ __launch_bounds__(64) void rowscale_kernel(const float* __restrict__ ssp, float* __restrict__ rs, int rows,
-                                                      int np, float inv_d, float eps) {
-  const int t = blockIdx.x * 64 + threadIdx.x;
-  if (t >= rows) return;
-  float v[32];  // np <= 32 (D <= 2048): all slots requested before the first add
-#pragma unroll
-  for (int i = 0; i < 32; ++i) v[i] = (i < np) ? ssp[(size_t)i * rows + t] : 0.f;  // slot-major: coalesced over tokens
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < 32; ++i) s += v[i];  // index order; the zero padding adds exactly nothing
-  rs[t] = rsqrtf(s * inv_d + eps);
-}
-
-template <class RS>
-struct EpiStoreBf16T {  // out[token, feature] = bf16(acc * rs[token])
-  bf16_t* out;
-  int ldo, n_valid;  // n_valid = number of real output features (multiple of 8)
-  RS rs;
-  template <int FM, int FN>
-  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
-    const int hi = lane >> 5, cl = lane & 31;
-    static_assert(FM % 2 == 0, "staging rows hold 64 features (two row fragments)");
-    // 64 token rows x 64 features at a time: staging rows of 128 B
-    constexpr int LPR = 8;              // lanes per token row (16 B each)
-    constexpr int RPI = 64 / LPR;       // token rows per pass
-    const int sub = lane % LPR, rr = lane / LPR;
-    float scv[FN];
-#pragma unroll
-    for (int j = 0; j < FN; ++j) scv[j] = rs.get(n_base + j * 32 + cl);
-#pragma unroll
-    for (int ih = 0; ih < FM; ih += 2) {
-      const int f = m_base + ih * 32 + sub * 8;
-#pragma unroll
-      for (int jb = 0; jb < FN; jb += 2) {
-#pragma unroll
-        for (int jj = 0; jj < 2 && jb + jj < FN; ++jj) {
-          const float sc = scv[jb + jj];
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              uint2 v;
-              v.x = pack_bf2(acc[ih + i][jb + jj][4 * g] * sc, acc[ih + i][jb + jj][4 * g + 1] * sc);
-              v.y = pack_bf2(acc[ih + i][jb + jj][4 * g + 2] * sc, acc[ih + i][jb + jj][4 * g + 3] * sc);
-              *reinterpret_cast<uint2*>(stage + (jj * 32 + cl) * EPI_ROW_BYTES + (i * 32 + 8 * g + 4 * hi) * 2) = v;
-            }
-        }
-        const int nrows = (FN - jb >= 2) ? 64 : 32;
-#pragma unroll
-        for (int t0 = 0; t0 < 64; t0 += RPI) {
-          const int t = t0 + rr;
-          if (t < nrows) {
-            const uint4 v = *reinterpret_cast<const uint4*>(stage + t * EPI_ROW_BYTES + sub * 16);
-            if (f < n_valid) *reinterpret_cast<uint4*>(out + (size_t)(n_base + jb * 32 + t) * ldo + f) = v;
-          }
-        }
-      }
-    }
-  }
-};
-
-struct EpiResid {  // x[token, feature] += acc on the two planes of the residual stream (+ ssp partials)
-  bf16_t* __restrict__ xhi;  // bf16(x): also the next projection's A operand
-  bf16_t* __restrict__ xlo;  // bf16(x - hi)
-  int ldx, n_valid;          // n_valid % 8 == 0
-  float* __restrict__ ssp;   // optional: [np, ssp_ld] partial sums of squares, slot = feature / 64; slot-major so
-                             // that a workgroup's statistics land in whole cache lines (token-major they were
-                             // 16-B fragments of lines shared with workgroups on other XCDs)
-  int np, ssp_ld;
-  template <int FM, int FN>
-  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
-    static_assert(FM % 2 == 0, "one statistic slot per 64 features (two row fragments)");
-    const int hi = lane >> 5, cl = lane & 31;
-    // Blocks of 64 features x 32 tokens.  8 lanes x 16 B cover one token's 64 features = 128 contiguous bytes of
-    // its row on EACH plane (8 tokens per wave-instruction).
-    const int sub = lane & 7, rr = lane >> 3;
-    constexpr int RB = 272;  // staging row: 64 floats + 16 B pad (32 rows = 8704 B <= EPI_STAGE_BYTES)
-    constexpr int NB = (FM / 2) * FN;
-    // The read-modify-write of x is latency-bound unless many loads are in flight: the old values of
-    // the next block(s) are requested before the current one is staged, added and stored.  Loads are
-    // unconditional, from a clamped address: a predicated load would sit in its own basic block and
-    // make hipcc drain vmcnt to 0 around it, which serialises the whole epilogue.
-    // (wave tiles of 128 x 128 keep their accumulators in AGPRs and have the VGPRs for 3 blocks ahead)
-    constexpr int DEPTH = (FM * FN >= 16) ? 4 : 2;
-    uint4 xh[DEPTH][4], xl[DEPTH][4];
-    auto fetch = [&](int b, int p) {
-      const int q = b / FN, j = b % FN;
-      const int f = min(m_base + q * 64 + sub * 8, n_valid - 8);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const size_t off = (size_t)(n_base + j * 32 + c * 8 + rr) * ldx + f;
-        xh[p][c] = *reinterpret_cast<const uint4*>(xhi + off);
-        xl[p][c] = *reinterpret_cast<const uint4*>(xlo + off);
-      }
-    };
-#pragma unroll
-    for (int b = 0; b < DEPTH - 1 && b < NB; ++b) fetch(b, b);
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int q = b / FN, j = b % FN;
-      const int f = m_base + q * 64 + sub * 8;
-      const int slot = (m_base >> 6) + q;
-      if (b + DEPTH - 1 < NB) fetch(b + DEPTH - 1, (b + DEPTH - 1) % DEPTH);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(stage + cl * RB + (i * 32 + 8 * g + 4 * hi) * 4) =
-              make_float4(acc[2 * q + i][j][4 * g], acc[2 * q + i][j][4 * g + 1], acc[2 * q + i][j][4 * g + 2],
-                          acc[2 * q + i][j][4 * g + 3]);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int t = c * 8 + rr;
-        const float4 d0 = *reinterpret_cast<const float4*>(stage + t * RB + sub * 32);
-        const float4 d1 = *reinterpret_cast<const float4*>(stage + t * RB + sub * 32 + 16);
-        float ss = 0.f;
-        if (f < n_valid) {
-          const size_t off = (size_t)(n_base + j * 32 + t) * ldx + f;
-          const uint4 h = xh[b % DEPTH][c], l = xl[b % DEPTH][c];
-          uint4 oh, ol;
-          hilo_update2(h.x, l.x, d0.x, d0.y, oh.x, ol.x, ss);
-          hilo_update2(h.y, l.y, d0.z, d0.w, oh.y, ol.y, ss);
-          hilo_update2(h.z, l.z, d1.x, d1.y, oh.z, ol.z, ss);
-          hilo_update2(h.w, l.w, d1.z, d1.w, oh.w, ol.w, ss);
-          *reinterpret_cast<uint4*>(xhi + off) = oh;
-          *reinterpret_cast<uint4*>(xlo + off) = ol;
-        }
-        if (ssp) {  // fixed shuffle tree over the 8 lanes of the token's 64 features
-          ss += __shfl_xor(ss, 1, 64);
-          ss += __shfl_xor(ss, 2, 64);
-          ss += __shfl_xor(ss, 4, 64);
-          if (sub == 0 && slot < np) ssp[(size_t)slot * ssp_ld + n_base + j * 32 + t] = ss;
-        }
-      }
-    }
-  }
-};
-
-template <class RS>
-struct EpiGegluBf16T {  // W rows interleaved 32 gate / 32 up: even row-fragments gate, odd up
-  bf16_t* out;         // [tokens, n_valid/2]
-  int ldo, n_valid;    // n_valid counts interleaved rows (= 2 * d_ff)
-  RS rs;
-  template <int FM, int FN>
-  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
-    static_assert(FM % 2 == 0, "gate/up fragment pairs");
-    const int hi = lane >> 5, cl = lane & 31;
-    // 64 token rows at a time: staging rows of FM/2*32 outputs bf16 (FM*32 B <= 128 B)
-    constexpr int LPR = FM * 2;         // lanes per token row (16 B each)
-    constexpr int RPI = 64 / LPR;
-    static_assert(FM * 32 <= 128, "staging row");
-    const int sub = lane % LPR, rr = lane / LPR;
-    const int f = (m_base >> 1) + sub * 8;
-    float scv[FN];
-#pragma unroll
-    for (int j = 0; j < FN; ++j) scv[j] = rs.get(n_base + j * 32 + cl);
-#pragma unroll
-    for (int jb = 0; jb < FN; jb += 2) {
-#pragma unroll
-      for (int jj = 0; jj < 2 && jb + jj < FN; ++jj) {
-        const float sc = scv[jb + jj];
-#pragma unroll
-        for (int i = 0; i < FM; i += 2)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            float y[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              y[e] = gelu_new(acc[i][jb + jj][4 * g + e] * sc) * (acc[i + 1][jb + jj][4 * g + e] * sc);
-            uint2 v;
-            v.x = pack_bf2(y[0], y[1]);
-            v.y = pack_bf2(y[2], y[3]);
-            *reinterpret_cast<uint2*>(stage + (jj * 32 + cl) * EPI_ROW_BYTES + ((i >> 1) * 32 + 8 * g + 4 * hi) * 2) = v;
-          }
-      }
-      const int nrows = (FN - jb >= 2) ? 64 : 32;
-#pragma unroll
-      for (int t0 = 0; t0 < 64; t0 += RPI) {
-        const int t = t0 + rr;
-        if (t < nrows) {
-          const uint4 v = *reinterpret_cast<const uint4*>(stage + t * EPI_ROW_BYTES + sub * 16);
-          if (2 * f < n_valid) *reinterpret_cast<uint4*>(out + (size_t)(n_base + jb * 32 + t) * ldo + f) = v;
-        }
-      }
-    }
-  }
-};
-typedef EpiStoreBf16T<RowScale> EpiStoreBf16;
-typedef EpiGegluBf16T<RowScale> EpiGegluBf16;
-typedef EpiStoreBf16T<RowScaleFromSlots> EpiStoreBf16Slots;
-typedef EpiGegluBf16T<RowScaleFromSlots> EpiGegluBf16Slots;
-
-template <class C, class Epi>
-__global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOperand W, int K, int tiles_m,
-                                                          int tiles_n, int group_m, int stagger_ticks,
-                                                          const int32_t* __restrict__ t_dev, Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (stagger_ticks > 0 && blockIdx.x < 256) {
-    // first round only (later workgroups inherit their CU's phase): phase = position among the 256 CUs, uniform
-    // inside every XCD (workgroup b runs on XCD b % 8)
-    const unsigned phase = ((blockIdx.x >> 3) & 31u) * 8u + (blockIdx.x & 7u);
-    const unsigned long long until = wall_clock64() + (unsigned long long)stagger_ticks * phase / 256u;  // 100 MHz
-    while (wall_clock64() < until) __builtin_amdgcn_s_sleep(16);
-  }
-  int nwg = gridDim.x;
-  if (t_dev) {
-    // rp_encode_padded: the grid covers an upper bound of the token count.  The live tiles are re-numbered over
-    // the first nwg workgroups so that they still spread over all 8 XCDs (skipping by tile index left the live
-    // token tiles - the first quarter of the logical range - on two XCDs: 3x slower).
-    tiles_n = (*t_dev + C::BN - 1) / C::BN;
-    nwg = tiles_m * tiles_n;
-    if ((int)blockIdx.x >= nwg) return;
-  }
-  const int logical = xcd_remap(blockIdx.x, nwg);
-  int tm, tn;
-  tile_coords(logical, tiles_n, tiles_m, group_m, tn, tm);  // token tiles grouped, feature tiles inside
-  if constexpr (C::PIPE != 0)
-    gemm_tile_pipe<C>(A, W, K, tm, tn, epi, smem);
-  else
-    gemm_tile<C>(A, W, K, tm, tn, epi, smem);
-}
-
-// `w` = weight matrix [n_rows_w, K] (row operand: tile rows = output features, clamped at the edge),
-// `a` = activations [M, K] (column operand: tile cols = tokens, M a multiple of the token tile).
-template <class C, class Epi>
-static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hipStream_t stream,
-                                int prof_class, int tokens_valid, const int32_t* t_dev) {
-  auto kern = gemm_kernel<C, Epi>;
-  static LdsAttrOnce attr;
-  RP_HIP(attr.ensure((const void*)kern, C::LDS_BYTES));
-  RP_REQUIRE(K % C::BK == 0 && a.rows % C::BN == 0, "gemm: K=%d must be a multiple of %d, M=%d of %d", K, C::BK,
-             a.rows, C::BN);
-  const int rows_needed = (tokens_valid > 0 && tokens_valid < a.rows) ? tokens_valid : a.rows;
-  const int tiles_f = (w.rows + C::BM - 1) / C::BM, tiles_t = (rows_needed + C::BN - 1) / C::BN;
-  // tile order: feature tiles fastest inside groups of `group` token tiles (shared activation panels)
-  const int group = max(1, g_gemm_group_m * 128 / C::BN);
-  ProfScope ps(stream, prof_class);
-  const int stagger_ticks = (C::PIPE != 0 && tiles_f * tiles_t > 512) ? g_gemm_stagger_us[prof_class] * 100 : 0;
-  hipLaunchKernelGGL(kern, dim3(tiles_f * tiles_t), dim3(C::THREADS), C::LDS_BYTES, stream, w, a, K, tiles_f,
-                     tiles_t, group, stagger_ticks, t_dev, epi);
-  RP_CHECK_LAUNCH();
-  return RP_OK;
-}
-
-// rows of the activation workspace are padded to this so every variant tiles the tokens exactly
-constexpr int GEMM_M_ALIGN = 256;
-
-// Which tile configuration a projection runs with.  tokens_valid = real token count of the pass (0: all M rows).
-static int pick_gemm_variant(int prof_class, int M, int n_rows_w, int K, int tokens_valid) {
-  int v = prof_class == RP_K_GEMM_O     ? g_gemm_variant_o
-          : prof_class == RP_K_GEMM_WO  ? g_gemm_variant_wo
-          : prof_class == RP_K_GEMM_QKV ? g_gemm_variant_qkv
-                                        : g_gemm_variant;
-  const bool k64 = (K % 64 == 0), m256 = (M % 256 == 0);
-  // Few tokens (the prover's single-state query): the 256 x 256 tiling would leave
-  // most CUs idle and each workgroup latency-bound on its K loop.  Switch to 64-feature tiles with a
-  // deep LDS ring so every workgroup streams its weight slab with several K-steps of DMA in flight.
-  // Measured per launch (tools/gemm_bench.py, SKINNY=0 FUSED=1; us) at 256 / 512 / 1024 / 2048 tokens:
-  //            64x128x64 (16)    64x128x32 (15)    64x256x32 (12)   128x128x32 (0)    256x256x64 (26)
-  //   FFN-out  27/28/30/ -       29/30/32/60        - / - /47/52    39/41/42/46        - / - /76/78
-  //   QKV      12/13/13/ -       14/14/15/26        - / - /20/21    17/17/18/19        - / - /29/32
-  //   attn-out  8/ 8/ 9/ -        8/ 9/ 9/15        - / - /12/14    11/11/12/13        - / - /18/20
-  //   FFN-in   14/25/47/ -       15/29/53/92        - / - /44/85    19/20/34/64        - / - /35/41
-  // (FFN-out stays ~28 us from 256 to 1024 tokens: 23 feature tiles, each workgroup walking 459 KB of weights.)
-  if (g_gemm_skinny && m256) {
-    const int tv = (tokens_valid > 0 && tokens_valid < M) ? tokens_valid : M;
-    const bool few_tiles = ((n_rows_w + 255) / 256) * (M / 256) < 96;
-    if (few_tiles && g_gemm_skinny_variant != 12) v = g_gemm_skinny_variant;  // forced by a test
-    else if (prof_class == RP_K_GEMM_WI) v = (tv <= 256) ? 16 : (few_tiles || tv <= 1024) ? 0 : v;
-    else if (few_tiles) v = (tv <= 1024) ? 16 : 0;
-  }
-  if ((v == 20 || v == 26) && !k64) v = 9;  // 64-wide K tiles need K % 64 == 0
-  if (v == 16 && !k64) v = 15;
-  if (v >= 5 && !m256) v = 0;
-  return v;
-}
-inline bool small_variant(int v) { return v == 0 || v == 15 || v == 16; }
-
-// GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages[, pipelined]>:
-//   20 / 26  pipelined 256 x 256 x 64, 4 / 8 waves     (the encoder's big GEMMs)
-//   9        plain 256 x 256 x 32, 3 stages             (K % 64 != 0)
-//   0        plain 128 x 128 x 32, 3 stages, 2 blocks/CU (attention-out; token counts not a multiple of 256)
-//   16 / 15  64 x 128 x 64, 4 stages / x 32, 7 stages   (up to ~1024 tokens: single-state queries)
-//   12       64 x 256 x 32, 7 stages                    (on request only)
-// SMALL_ONLY: the epilogue type exists for the small configurations only (pick_gemm_variant said so).
-template <bool SMALL_ONLY = false, class Epi>
-static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, int ldw, int n_rows_w,
-                            int K, Epi epi, hipStream_t stream, int prof_class, int tokens_valid = 0,
-                            const int32_t* t_dev = nullptr, int force_variant = -1) {
-  GemmOperand a{A, lda, M}, w{W, ldw, n_rows_w};
-  const int v = force_variant >= 0 ? force_variant : pick_gemm_variant(prof_class, M, n_rows_w, K, tokens_valid);
-  if constexpr (!SMALL_ONLY) {
-    switch (v) {
-      case 20: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-      case 26: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-      case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-      case 12: return launch_gemm_cfg<GemmCfg<64, 256, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-      default: break;
-    }
-  } else {
-    RP_REQUIRE(small_variant(v), "tile configuration %d has no fused row-scale form", v);
-  }
-  switch (v) {
-    case 15: return launch_gemm_cfg<GemmCfg<64, 128, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-    case 16: return launch_gemm_cfg<GemmCfg<64, 128, 64, 1, 4, 4>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-    default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// K4+K5: T5 self-attention, flash-style, varlen.
-//   scores = q·k (NO 1/sqrt(d) scaling, HF:197) + bias[h, clamp(j-i, -128, 128)]; keys >= len are
-//   excluded (HF uses finfo.min via where(mask, bias, min): identical result whenever a row has
-//   at least one real key, which every real query row does); fp32 online softmax; o = p·v.
-//   The additive bias depends only on j-i and saturates at |j-i| >= max_distance, so it is a
-//   [H, 2*max_distance+1] table (built on the host from relative_attention_bias.weight with HF's
-//   bucket function) instead of HF's dense [1,H,L,L] tensor.
-//
-//   Workgroup = (128 queries of one sequence, one head); wave w owns queries 32w..32w+31.
-//   S^T = K·Q^T is computed so that each lane holds, for ONE query (lane & 31), 16 keys per 32-key
-//   block: the softmax row reductions are in-lane plus one exchange with lane^32.  O^T = V^T·P^T
-//   reuses those registers directly as the MFMA B operand (the k-slot -> key permutation implied
-//   by the accumulator layout is applied to V^T when its A fragment is read from LDS).
-// ------------------------------------------------------------------------------------------
-constexpr int ATT_Q = 128, ATT_KV = 64;
-constexpr int ATT_TAB_MAX = 1024;  // max table entries (2*max_distance+1)
-//   * K and V tiles go HBM -> LDS by LDS-DMA into a 2-stage ring (tile t+1 in flight under the
-//     MFMAs/softmax of tile t, one barrier per tile, no VGPR staging, no ds_write at all);
-//   * V stays row-major in LDS ([d-half][key][32 d], 64-B rows) and its MFMA A fragments
-//     (V^T: 4 consecutive keys for one d per lane) are produced by the gfx950 transpose read
-//     ds_read_b64_tr_b16: within each 16-lane group, lane i supplies the address of
-//     V[k0 + i/4][d0 + 4 (i%4) .. +3] and lane l receives V[k0 .. k0+3][d0 + l]  (mapping measured
-//     with tools/probes/tr_probe.hip); 4 rows x 64 B = one 256-B bank row: conflict-free;
-//   * K is staged with the GEMM's XOR swizzle (slot ^= (row >> 1) & 7 on the DMA source address);
-//   * waves whose 32 queries lie past the sequence end only help with the DMA;
-//   * one workgroup per entry of the pass's work list (worklist_kernel below: 128-query blocks, longest
-//     sequence first; at most T/128 + B entries).  A (max_len/128) x B grid would launch ~6 empty workgroups per
-//     useful one on the benchmark's length mix.
-// ------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(4))) short v4s16;
-constexpr int AT2_K_BYTES = 64 * 128, AT2_V_BYTES = 64 * 128, AT2_STAGE = AT2_K_BYTES + AT2_V_BYTES;
-
-// Work list of one encoder pass, built once and used by all layers: entry = {first token of the sequence, its length,
-// first query of the block, 0}, one per 128-query block, ordered by DESCENDING key count (buckets of 64 keys, longest
-// first; inside a bucket by sequence, then block).  A block's cost grows with its sequence's length (32 key tiles at
-// 2048 tokens against 1-2 for a short state), and the grid is a few rounds deep: dispatched in corpus order, a long
-// sequence met late kept a handful of CUs busy long after everything else had finished; longest-first closes that
-// tail.  It also replaces the two block-wide counting rounds every workgroup of every layer spent finding its sequence.
-// Entries beyond the live count have length 0.  One workgroup; a counting sort over 64 length buckets in LDS.
-constexpr int ATT_BUCKETS = 64;
-constexpr int POOL_CHUNK = 128;  // tokens per workgroup of the pooling pass (pool_partial_kernel)
-// The same launch lays out the pooling pass's list: chunk c of sequence b is entry cu[b] / 128 + b + c = {first token,
-// length, c, b} (strictly increasing in b, at most T/128 + B entries; a gap entry has length 0).
-__global__ __launch_bounds__(1024) void worklist_kernel(const int32_t* __restrict__ cu, int batch,
-                                                        int4* __restrict__ work, int n_slots,
-                                                        int4* __restrict__ pwork, int n_pslots) {
-  __shared__ int s_cnt[ATT_BUCKETS], s_pos[ATT_BUCKETS], s_live;
-  const int tid = threadIdx.x;
-  // bucket k holds sequences of (k, k+1] * 64 keys; the last one everything longer
-  auto bucket_of = [](int len) { return min((len - 1) >> 6, ATT_BUCKETS - 1); };
-  if (tid < ATT_BUCKETS) s_cnt[tid] = 0;
-  __syncthreads();
-  for (int b = tid; b < batch; b += 1024) {
-    const int len = cu[b + 1] - cu[b];
-    if (len > 0) atomicAdd(&s_cnt[bucket_of(len)], (len + ATT_Q - 1) / ATT_Q);
-  }
-  __syncthreads();
-  if (tid < ATT_BUCKETS) {  // blocks of all longer buckets come first
-    int pos = 0;
-    for (int j = ATT_BUCKETS - 1; j > tid; --j) pos += s_cnt[j];
-    s_pos[tid] = pos;
-    if (tid == 0) s_live = pos + s_cnt[0];
-  }
-  __syncthreads();
-  // the order INSIDE a bucket is whatever the atomics give: every block's result is independent of its position
-  for (int b = tid; b < batch; b += 1024) {
-    const int s0 = cu[b], s1 = cu[b + 1], len = s1 - s0;
-    const int pbase = s0 / POOL_CHUNK + b;
-    const int pnext = (b + 1 < batch) ? s1 / POOL_CHUNK + b + 1 : n_pslots;
-    int c = 0;
-    for (; c * POOL_CHUNK < len; ++c) pwork[pbase + c] = make_int4(s0, len, c, b);
-    for (int i = pbase + c; i < pnext; ++i) pwork[i] = make_int4(0, 0, 0, 0);
-    if (b == 0)
-      for (int i = 0; i < pbase; ++i) pwork[i] = make_int4(0, 0, 0, 0);  // cu[0] is 0 in every caller; kept general
-    if (len <= 0) continue;
-    int pos = atomicAdd(&s_pos[bucket_of(len)], (len + ATT_Q - 1) / ATT_Q);
-    for (int q0 = 0; q0 < len; q0 += ATT_Q) work[pos++] = make_int4(s0, len, q0, 0);
-  }
-  for (int i = s_live + tid; i < n_slots; i += 1024) work[i] = make_int4(0, 0, 0, 0);
-  if (batch == 0)
-    for (int i = tid; i < n_pslots; i += 1024) pwork[i] = make_int4(0, 0, 0, 0);
-}
-
-__global__ __launch_bounds__(256, 4) void attention_kernel(const bf16_t* __restrict__ qkv,
-                                                         const int4* __restrict__ work,
-                                                         const float* __restrict__ bias_tab,
-                                                        bf16_t* __restrict__ out, int H, int maxd) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * AT2_STAGE + ATT_TAB_MAX * 4];
-  float* tab = reinterpret_cast<float*>(smem + 2 * AT2_STAGE);
-
-  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, cl = lane & 31;
-  // heads vary fastest in dispatch order: the six workgroups that read the six 128-byte pieces of the same qkv rows
-  // (a 2304-byte row holds every head's q, k and v) run at the same time, so DRAM sees whole rows, not pieces
-  const int h = blockIdx.x;
-  const int4 wk = work[blockIdx.y];
-  const int s0 = wk.x, len = wk.y, q0 = wk.z;
-  if (len == 0) return;
-
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int inner = H * 64, ld = 3 * inner;
-  const int ntab = 2 * maxd + 1;
-  for (int i = tid; i < ntab; i += 256) tab[i] = bias_tab[h * ntab + i];
-
-  const int wq0 = q0 + wave * 32;
-  const bool active = wq0 < len;  // wave-uniform
-  const int qi = wq0 + cl;
-  bf16x8 qf[4];
-  {
-    const bf16_t* qp = qkv + (size_t)(s0 + min(qi, len - 1)) * ld + h * 64 + hi * 8;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const bf16x8*>(qp + c * 16);
-  }
-
-  // DMA pieces of this wave: K pieces {2w, 2w+1} (8 keys x 128 B each), V pieces {2w, 2w+1}
-  // (d-half p >> 2, 16 keys x 64 B each); LDS destinations are lane-linear.
-  const bf16_t* kv_base = qkv + (size_t)s0 * ld + inner + h * 64;
-  auto stage = [&](int kt, int buf) {
-    char* base = smem + buf * AT2_STAGE;
-    const int k0 = kt * ATT_KV;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int p = wave * 2 + e;
-      {
-        const int key = 8 * p + (lane >> 3);
-        const int kc = (lane & 7) ^ ((key >> 1) & 7);
-        const bf16_t* src = kv_base + (size_t)min(k0 + key, len - 1) * ld + kc * 8;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + p * 1024), 16, 0, 0);
-      }
-      {
-        const int key = 16 * (p & 3) + (lane >> 2);
-        const bf16_t* src = kv_base + (size_t)min(k0 + key, len - 1) * ld + inner + (p >> 2) * 32 + (lane & 3) * 8;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + AT2_K_BYTES + p * 1024), 16, 0, 0);
-      }
-    }
-  };
-
-  // fragment offsets
-  int k_off[2][4];
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int key = kb * 32 + cl;
-      k_off[kb][c] = key * 128 + (((c * 2 + hi) ^ ((key >> 1) & 7)) << 4);
-    }
-  // V^T fragment, first transpose-read of slab 0 / d-half 0: row 4 hi + (lane&15)/4, 4 d's at 4 (lane&3) + 16 ((lane>>4)&1)
-  const int v_off0 = AT2_K_BYTES + (4 * hi + ((lane & 15) >> 2)) * 64 + (4 * (lane & 3) + 16 * ((lane >> 4) & 1)) * 2;
-
-  f32x16 o[2];
-#pragma unroll
-  for (int d = 0; d < 2; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  const int n_tiles = (len + ATT_KV - 1) / ATT_KV;
-  stage(0, 0);
-  for (int kt = 0; kt < n_tiles; ++kt) {
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // tile kt complete in LDS; tile kt-1's buffer free (and tab written)
-    if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
-    if (!active) continue;
-    const char* sb = smem + (kt & 1) * AT2_STAGE;
-    const int k0 = kt * ATT_KV;
-    // ---- S^T = K Q^T
-    f32x16 s[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        bf16x8 kf = *reinterpret_cast<const bf16x8*>(sb + k_off[kb][c]);
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], s[kb], 0, 0, 0);
-      }
-    }
-    // ---- relative-position bias + key-padding mask, per 32-key block.  Four cases, wave-uniform:
-    //   saturated right / left (one constant), interior (|j-i| <= maxd everywhere and all keys real:
-    //   the table index is base + compile-time offset, no clamp, no mask), general.
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const int c0 = k0 + kb * 32;
-      const bool all_real = (c0 + 32 <= len);
-      if (c0 - (wq0 + 31) >= maxd && all_real) {
-        const float bb = tab[2 * maxd];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] += bb;
-      } else if (c0 + 31 - wq0 <= -maxd && all_real) {
-        const float bb = tab[0];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] += bb;
-      } else if (c0 + 31 - wq0 <= maxd && c0 - (wq0 + 31) >= -maxd && all_real) {
-        const float* tp = tab + (c0 - qi + maxd + 4 * hi);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] += tp[(r & 3) + 8 * (r >> 2)];
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int j = c0 + mfma32_row(r, hi);
-          const int rel = min(max(j - qi, -maxd), maxd) + maxd;
-          s[kb][r] = (j < len) ? s[kb][r] + tab[rel] : -INFINITY;
-        }
-      }
-    }
-    // ---- online softmax in the exp2 domain: p = 2^((s - m) * log2 e)
-    float mx = s[0][0];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float LOG2E = 1.4426950408889634f;
-    const float mneg = -m_new * LOG2E;
-    float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], LOG2E, mneg));
-        s[kb][r] = p;
-        psum += p;
-      }
-    if (__any(m_new != m_run)) {  // rescale only when some row's running max moved (exact: alpha = 1 otherwise)
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);  // m_run = -inf first -> 0
-      l_run *= alpha;
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-    }
-    l_run += psum;
-    m_run = m_new;
-    // ---- O^T += V^T P^T over four 16-key slabs
-#pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
-      const int kb = sl >> 1, sub = sl & 1;
-      bf16x8 pf;
-      {
-        uint32_t pw[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pw[e] = pack_bf2(s[kb][8 * sub + 2 * e], s[kb][8 * sub + 2 * e + 1]);
-        uint4 t = make_uint4(pw[0], pw[1], pw[2], pw[3]);
-        pf = *reinterpret_cast<bf16x8*>(&t);
-      }
-#pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        const char* vp = sb + v_off0 + d * 4096 + sl * 16 * 64;
-        v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(vp));
-        v4s16 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(vp + 8 * 64));
-        bf16x8 vf;
-        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-        vf[4] = up[0]; vf[5] = up[1]; vf[6] = up[2]; vf[7] = up[3];
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
-      }
-    }
-  }
-
-  if (active && qi < len) {
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.f / l_tot;
-    bf16_t* op = out + (size_t)(s0 + qi) * inner + h * 64;
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 v;
-        v.x = pack_bf2(o[d][4 * g] * inv, o[d][4 * g + 1] * inv);
-        v.y = pack_bf2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
-        *reinterpret_cast<uint2*>(op + d * 32 + 8 * g + 4 * hi) = v;
-      }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// K2(final)+K9+K10: final RMSNorm, masked mean over the sequence's tokens, L2 normalise.
-//   mean_t(w * x_t * rs_t) = w * mean_t(x_t * rs_t); e / max(||e||, 1e-12)  (model.py:108-114)
-//   Two deterministic passes (no atomics, so results are bit-reproducible whatever the batch):
-//   pool_partial_kernel: one workgroup per 128-token chunk of a sequence (the pass's list, worklist_kernel); wave w
-//     takes tokens w, w+4, ...; rs_t from the last residual epilogue's statistics (as for every other RMSNorm);
-//     per-lane partial column sums of x_t * rs_t in registers, combined through LDS, written to
-//     partial[chunk_base(b) + c][D]   (chunk_base(b) = cu[b] / 128 + b);
-//   pool_finish_kernel: one workgroup per sequence sums its chunks in order, applies w / len and the L2
-//     normalisation.
-//   Tried, both without gain: 64-token chunks (twice the workgroups, to balance the unequal chunks of the length mix
-//   over the CUs: 0.129 -> 0.137 ms per pass); the finish done by whichever workgroup arrives last at a per-sequence
-//   counter (one launch instead of two: the device-scope release fence that makes the other chunks' sums visible
-//   across XCDs costs ~2 us per workgroup, serialised per XCD: 0.13 -> 0.45 ms per pass).
-// ------------------------------------------------------------------------------------------
-
-// NV = 16-byte pieces (8 features) per lane and plane covering a row (ceil(D / 512)): 3 for d_model 1472 / 1536,
-// 4 up to 2048.  Four token rows of a wave are in flight before the first is consumed (the rows are independent
-// streams: rs comes from rowscale).
-template <int NV>
-__global__ __launch_bounds__(256) void pool_partial_kernel(const bf16_t* __restrict__ xhi, const bf16_t* __restrict__ xlo,
-                                                           const float* __restrict__ rs,
-                                                           const int4* __restrict__ pwork,
-                                                           float* __restrict__ partial, int D) {
-  __shared__ float red[4][NV * 64 * 8];
-  const int4 wk = pwork[blockIdx.x];
-  const int s0 = wk.x, len = wk.y, c = wk.z, b = wk.w;
-  if (len == 0) return;
-  const int t0 = c * POOL_CHUNK;
-  const int t1 = min(len, t0 + POOL_CHUNK);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nv = D >> 3;
-  float acc[NV][8];
-#pragma unroll
-  for (int i = 0; i < NV; ++i)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
-  // Tokens are accumulated in index order per wave (w, w+4, w+8, ...), whatever the unrolling.
-  constexpr int R = 4;  // rows in flight per wave
-  for (int t = t0 + wave; t < t1; t += 4 * R) {
-    uint4 vh[R][NV], vl[R][NV];
-    float r[R];
-#pragma unroll
-    for (int u = 0; u < R; ++u) {
-      const int tu = t + 4 * u;
-      const bool live = tu < t1;
-      const size_t row = (size_t)(s0 + (live ? tu : t)) * D;
-      const uint4* sh = reinterpret_cast<const uint4*>(xhi + row);
-      const uint4* sl = reinterpret_cast<const uint4*>(xlo + row);
-      r[u] = live ? rs[s0 + tu] : 0.f;
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {  // clamped, unpredicated
-        vh[u][i] = sh[min(lane + 64 * i, nv - 1)];
-        vl[u][i] = sl[min(lane + 64 * i, nv - 1)];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < R; ++u)
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const uint32_t h[4] = {vh[u][i].x, vh[u][i].y, vh[u][i].z, vh[u][i].w};
-        const uint32_t l[4] = {vl[u][i].x, vl[u][i].y, vl[u][i].z, vl[u][i].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float x0 = __uint_as_float(h[e] << 16) + __uint_as_float(l[e] << 16);
-          const float x1 = __uint_as_float(h[e] & 0xffff0000u) + __uint_as_float(l[e] & 0xffff0000u);
-          acc[i][2 * e] = fmaf(x0, r[u], acc[i][2 * e]);
-          acc[i][2 * e + 1] = fmaf(x1, r[u], acc[i][2 * e + 1]);
-        }
-      }
-  }
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int col = lane + 64 * i;
-    if (col < nv) {
-      *reinterpret_cast<float4*>(&red[wave][col * 8]) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
-      *reinterpret_cast<float4*>(&red[wave][col * 8 + 4]) = make_float4(acc[i][4], acc[i][5], acc[i][6], acc[i][7]);
-    }
-  }
-  __syncthreads();
-  float* dst = partial + (size_t)(s0 / POOL_CHUNK + b + c) * D;
-  for (int col = threadIdx.x; col < D; col += 256) dst[col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-}
-
-static void launch_pool_partial(dim3 grid, hipStream_t stream, const bf16_t* xhi, const bf16_t* xlo, const float* rs,
-                                const int4* pwork, float* partial, int D) {
-  if (D <= 3 * 512)
-    hipLaunchKernelGGL(pool_partial_kernel<3>, grid, dim3(256), 0, stream, xhi, xlo, rs, pwork, partial, D);
-  else
-    hipLaunchKernelGGL(pool_partial_kernel<4>, grid, dim3(256), 0, stream, xhi, xlo, rs, pwork, partial, D);
-}
-
-__global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restrict__ partial,
-                                                          const float* __restrict__ w,
-                                                          const int32_t* __restrict__ cu,
-                                                          void* __restrict__ out, int out_bf16, int D) {
-  __shared__ float nrm[4];
-  const int b = blockIdx.x;
-  const int s0 = cu[b], len = cu[b + 1] - s0;
-  const int nchunk = (len + POOL_CHUNK - 1) / POOL_CHUNK;
-  const float* src = partial + (size_t)(s0 / POOL_CHUNK + b) * D;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float inv_len = 1.f / (float)len;
-  float vals[8];
-  float part = 0.f;
-  int cnt = 0;
-  for (int col = threadIdx.x; col < D; col += 256) {
-    float sum = 0.f;
-    for (int c = 0; c < nchunk; ++c) sum += src[(size_t)c * D + col];
-    const float e = sum * inv_len * w[col];
-    vals[cnt++] = e;
-    part += e * e;
-  }
-  part = wave_sum(part);
-  if (lane == 0) nrm[wave] = part;
-  __syncthreads();
-  const float norm = sqrtf((nrm[0] + nrm[1]) + (nrm[2] + nrm[3]));
-  const float sc = 1.f / fmaxf(norm, 1e-12f);
-  cnt = 0;
-  for (int col = threadIdx.x; col < D; col += 256) {
-    const float e = vals[cnt++] * sc;
-    if (out_bf16)
-      reinterpret_cast<bf16_t*>(out)[(size_t)b * D + col] = f2bf(e);
-    else
-      reinterpret_cast<float*>(out)[(size_t)b * D + col] = e;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// host side
-// ------------------------------------------------------------------------------------------
-struct LayerPacked {
-  float* ln_attn;
-  float* ln_ff;
-  bf16_t* wqkv;  // [3*inner, D]
-  bf16_t* wo;    // [D, inner]
-  bf16_t* wi;    // [2F, D] gate/up interleaved by 32
-  bf16_t* wo2;   // [D, F]
-};
-
 }  // namespace rp
 
-struct RpEncoder {
-  RpT5Config cfg;
-  int inner;
-  int maxd;
-  float* embed;        // [V, D] f32
-  float* final_ln;     // [D]
-  float* bias_tab;     // [H, 2*maxd+1]
-  std::vector<rp::LayerPacked> layers;
-  std::vector<void*> allocs;
-};
 
 using namespace rp;
 
