@@ -42,7 +42,7 @@ enum {
 enum { RP_DT_F32 = 0, RP_DT_BF16 = 1 };
 
 /* ABI / build identification; bumps when a signature changes. */
-int32_t rp_abi_version(void);
+int32_t rp_abi_version(void);   /* 2 */
 /* Message of the last error returned on this thread ("" if none). */
 const char* rp_last_error(void);
 
@@ -228,13 +228,60 @@ RpStatus rp_adamw_step(float* param, const float* grad, float* exp_avg, float* e
                        float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Training step: replaces what autograd + Lightning do behind retrieval/model.py:155-181 (`training_step` differentiating
+ * `forward` :116-140 through `_encode` :92-114 and transformers' T5Stack) and common.py:381-405 (`get_optimizers`).
+ * Parameters, gradients and optimizer moments are FLAT fp32 device buffers in one canonical layout:
+ *   embed [V, D] | rel_bias [buckets, H] | final_ln [D] | per layer: ln_attn [D], q, k, v [H*d_kv, D], o [D, H*d_kv],
+ *   ln_ff [D], wi_0, wi_1 [d_ff, D], wo [D, d_ff]      (HF shapes; every tensor starts at a multiple of 64 elements)
+ * rp_train_param_layout writes the rp_train_param_tensors(cfg) + 1 element offsets (last = total length incl. padding).
+ * One step = rp_train_forward (all sequences of the batch - contexts, positives, negatives - packed as ONE varlen pass)
+ *  -> rp_contrastive_mse (+ _backward) on the [batch, D] embeddings -> rp_train_backward -> rp_grad_norm (optional
+ * clipping) -> rp_adamw_step over the flat buffers -> rp_trainer_load_params.  Dropout is not applied (deterministic
+ * step; the reference's T5 dropout 0.1 is stochastic).  d_model and d_ff must be multiples of 64.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct RpTrainer RpTrainer;
+int32_t  rp_train_param_tensors(const RpT5Config* cfg);                 /* 3 + 9 * num_layers */
+RpStatus rp_train_param_layout(const RpT5Config* cfg, int64_t* offsets /* [tensors + 1] */);
+/* `params`: device f32 flat buffer in the layout above.  Allocates the bf16 compute copies (synchronises once). */
+RpStatus rp_trainer_create(const RpT5Config* cfg, const float* params, RpTrainer** out);
+void     rp_trainer_destroy(RpTrainer* tr);
+/* The inference engine on the trainer's current weights (for rp_encode_varlen / rp_encode_padded: validation re-indexes
+ * with the model being trained, retrieval/model.py:212-225); owned by the trainer. */
+RpEncoder* rp_trainer_encoder(RpTrainer* tr);
+/* Refresh every compute copy from the fp32 masters (call after each optimizer step); launch-only. */
+RpStatus rp_trainer_load_params(RpTrainer* tr, const float* params, void* stream);
+size_t   rp_train_workspace_bytes(const RpTrainer* tr, int32_t total_tokens, int32_t batch);
+/* Forward over `batch` packed sequences (ids / cu_seqlens as rp_encode_varlen); out_emb device f32 [batch, d_model] =
+ * _encode's unit-norm rows; the activations the backward needs stay in `workspace`, which must be handed unchanged to
+ * rp_train_backward. */
+RpStatus rp_train_forward(RpTrainer* tr, const int32_t* ids, const int32_t* cu_seqlens, int32_t batch,
+                          int32_t total_tokens, float* out_emb, void* workspace, size_t workspace_bytes, void* stream);
+/* d_emb device f32 [batch, d_model] = d loss / d out_emb;  grads: flat f32 buffer, every element overwritten with
+ * d loss / d parameter (padding gaps untouched: zero them once).  Deterministic: no floating-point atomics on HBM. */
+RpStatus rp_train_backward(RpTrainer* tr, const float* params, const int32_t* ids, const int32_t* cu_seqlens,
+                           int32_t batch, int32_t total_tokens, const float* d_emb, float* grads,
+                           void* workspace, size_t workspace_bytes, void* stream);
+/* out_norm[0] (device) = ||grads||_2 over n floats (Lightning's gradient_clip_val, confs/cli_lean4_random.yaml:19, clips
+ * on it); scratch: 1024 device floats.  Pair with rp_adamw_step_clipped. */
+RpStatus rp_grad_norm(const float* grads, int64_t n, float* out_norm, float* scratch, void* stream);
+/* rp_adamw_step with the gradient scaled by min(1, max_norm / (total_norm[0] + 1e-6)) (torch.nn.utils.clip_grad_norm_);
+ * total_norm: device f32 [1] from rp_grad_norm, or NULL for no clipping. */
+RpStatus rp_adamw_step_clipped(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
+                               float lr, float beta1, float beta2, float eps, float weight_decay,
+                               const float* total_norm, float max_norm, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline
  * object).  While enabled, every kernel launch of the engine is bracketed by an event pair.
  * ------------------------------------------------------------------------------------------- */
 enum {
   RP_K_EMBED = 0, RP_K_RMSNORM = 1, RP_K_GEMM_QKV = 2, RP_K_ATTENTION = 3, RP_K_GEMM_O = 4,
   RP_K_GEMM_WI = 5, RP_K_GEMM_WO = 6, RP_K_POOL = 7, RP_K_SCAN = 8 /* dense / filter pass */, RP_K_SELECT = 9,
-  RP_K_SCAN_SAMPLE = 10 /* sample pass of the two-pass plan */, RP_K_COUNT = 11
+  RP_K_SCAN_SAMPLE = 10 /* sample pass of the two-pass plan */,
+  /* training step (rp_train_*) */
+  RP_K_BWD_DGRAD = 11 /* dY W GEMMs (+ fused GELU / RMSNorm backward) */, RP_K_BWD_WGRAD = 12 /* dY^T X GEMMs */,
+  RP_K_BWD_ATTENTION = 13, RP_K_BWD_OTHER = 14 /* pooling, embedding, row statistics, gradient finishing */,
+  RP_K_OPTIMIZER = 15 /* AdamW, gradient norm, weight re-packing */, RP_K_COUNT = 16
 };
 RpStatus rp_profile_enable(int32_t on);   /* on != 0: start collecting (clears previous records) */
 /* Synchronises the recorded events; total_ms = sum of launch durations, launches = their number. */
@@ -267,6 +314,22 @@ RpStatus rp_dbg_rowscale(const float* ssp /* [np, rows] */, float* rs /* [rows] 
 RpStatus rp_dbg_attention(const void* qkv_bf16, const int32_t* cu_seqlens, const float* bias_tab,
                           void* out_bf16, int32_t batch, int32_t max_len, int32_t num_heads,
                           int32_t rows_total, void* stream);
+/* Training kernels in isolation (tests/test_train_kernels_gpu.py).
+ *   rp_dbg_wgrad: out f32 [splits, ny, nx], partial s = Y[rows of split s]^T X;  Y bf16 [T, ny], X bf16 [T, nx], T % 64 == 0.
+ *   rp_dbg_attention_bwd: runs the forward (att_out, lse_out [H, rows_total]) and both backward kernels on packed qkv;
+ *     att = the O the backward uses for delta (NULL: att_out); dqkv bf16 [rows_total, 3*H*64] (rows of real tokens written);
+ *     dtab f32 [2*128+1, H]: gradient of the [H, 257] bias table, transposed.  Synchronises.
+ *   rp_dbg_dgrad: mode 0 = gated-GELU backward epilogue (A = dx [M, K], W = Wo2^T [N = d_ff, K]; aux0 = gu bf16 [M, 2N],
+ *     aux1 = rs [M]; out0 = dzs bf16 [M, 2N], out1 = row dots f32 [M]); mode 1 = RMSNorm-backward residual epilogue
+ *     (A = dzs [M, K], W [N, K]; aux0 = x bf16 [M, N], aux1 = rcoef [M]; out0 = planes [2, M, N] updated in place).
+ *     variant: tile configuration (0 = 128x128x32, 26 = 256x256x64 pipelined). */
+RpStatus rp_dbg_wgrad(const void* Y, const void* X, float* out, int32_t T, int32_t ny, int32_t nx, int32_t splits,
+                      void* stream);
+RpStatus rp_dbg_attention_bwd(const void* qkv, const void* att, const void* datt, const int32_t* cu_seqlens,
+                              const float* bias_tab, int32_t batch, int32_t num_heads, int32_t rows_total, void* lse_out,
+                              void* att_out, void* dqkv, float* dtab, void* stream);
+RpStatus rp_dbg_dgrad(const void* A, const void* W, int32_t M, int32_t N, int32_t K, int32_t mode, const void* aux0,
+                      const float* aux1, void* out0, float* out1, int32_t variant, void* stream);
 /* Tuning knobs (integers), e.g. "gemm_variant"; returns RP_E_INVALID for unknown names. */
 RpStatus rp_set_option(const char* name, int32_t value);
 

@@ -18,9 +18,9 @@ RP_OK = 0
 RP_DT_F32, RP_DT_BF16 = 0, 1
 RP_TOPK_AUTO, RP_TOPK_DENSE = 0, 1
 RP_EPI_STORE_BF16, RP_EPI_RESID, RP_EPI_GEGLU_BF16 = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 KERNEL_CLASSES = ["embed", "rmsnorm", "gemm_qkv", "attention", "gemm_o", "gemm_wi", "gemm_wo", "pool", "scan",
-                  "select", "scan_sample"]
+                  "select", "scan_sample", "bwd_dgrad", "bwd_wgrad", "bwd_attention", "bwd_other", "optimizer"]
 
 
 class RpT5Config(C.Structure):
@@ -111,6 +111,39 @@ SIGNATURES = {
         C.c_int32,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
          C.c_float, C.c_void_p],
+    ),
+    "rp_adamw_step_clipped": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
+         C.c_float, C.c_void_p, C.c_float, C.c_void_p],
+    ),
+    "rp_train_param_tensors": (C.c_int32, [C.POINTER(RpT5Config)]),
+    "rp_train_param_layout": (C.c_int32, [C.POINTER(RpT5Config), C.POINTER(C.c_int64)]),
+    "rp_trainer_create": (C.c_int32, [C.POINTER(RpT5Config), C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rp_trainer_destroy": (None, [C.c_void_p]),
+    "rp_trainer_encoder": (C.c_void_p, [C.c_void_p]),
+    "rp_trainer_load_params": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rp_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
+    "rp_train_forward": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
+    "rp_train_backward": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+         C.c_size_t, C.c_void_p],
+    ),
+    "rp_grad_norm": (C.c_int32, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rp_dbg_wgrad": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "rp_dbg_attention_bwd": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "rp_dbg_dgrad": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+         C.c_void_p, C.c_int32, C.c_void_p],
     ),
     "rp_dbg_gemm": (
         C.c_int32,

@@ -93,7 +93,7 @@ __device__ __forceinline__ void hilo_update2(uint32_t h2, uint32_t l2, float d0,
 //   projection) and the row's sum of squares (RMSNorm statistic, applied in that GEMM's epilogue).
 //   rows >= T (tile padding) get token 0 so every workspace row stays finite.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ ids,
+static __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ ids,
                                                     const float* __restrict__ table,
                                                     bf16_t* __restrict__ xhi, bf16_t* __restrict__ xlo,
                                                     float* __restrict__ ssp, int np, int T, int Tp, int D,
@@ -173,7 +173,7 @@ struct RowScaleFromSlots {
 };
 
 // rs[token] = rsqrt(sum_p ssp[p][token] / D + eps), slots summed in index order
-__global__ __launch_bounds__(64) void rowscale_kernel(const float* __restrict__ ssp, float* __restrict__ rs, int rows,
+static __global__ __launch_bounds__(64) void rowscale_kernel(const float* __restrict__ ssp, float* __restrict__ rs, int rows,
                                                       int np, float inv_d, float eps) {
   const int t = blockIdx.x * 64 + threadIdx.x;
   if (t >= rows) return;
@@ -234,7 +234,10 @@ struct EpiStoreBf16T {  // out[token, feature] = bf16(acc * rs[token])
   }
 };
 
-struct EpiResid {  // x[token, feature] += acc on the two planes of the residual stream (+ ssp partials)
+// SPLIT_IN (the training forward, rp_train.hip): the old hi plane is read from xhi_in and the new one written to xhi, so
+// the sub-layer's input bf16(x) - an operand of the backward - survives the update at no extra traffic.
+template <bool SPLIT_IN>
+struct EpiResidT {  // x[token, feature] += acc on the two planes of the residual stream (+ ssp partials)
   bf16_t* __restrict__ xhi;  // bf16(x): also the next projection's A operand
   bf16_t* __restrict__ xlo;  // bf16(x - hi)
   int ldx, n_valid;          // n_valid % 8 == 0
@@ -242,6 +245,7 @@ struct EpiResid {  // x[token, feature] += acc on the two planes of the residual
                              // that a workgroup's statistics land in whole cache lines (token-major they were
                              // 16-B fragments of lines shared with workgroups on other XCDs)
   int np, ssp_ld;
+  const bf16_t* __restrict__ xhi_in = nullptr;  // SPLIT_IN only
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
     static_assert(FM % 2 == 0, "one statistic slot per 64 features (two row fragments)");
@@ -264,7 +268,10 @@ struct EpiResid {  // x[token, feature] += acc on the two planes of the residual
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const size_t off = (size_t)(n_base + j * 32 + c * 8 + rr) * ldx + f;
-        xh[p][c] = *reinterpret_cast<const uint4*>(xhi + off);
+        if constexpr (SPLIT_IN)
+          xh[p][c] = *reinterpret_cast<const uint4*>(xhi_in + off);
+        else
+          xh[p][c] = *reinterpret_cast<const uint4*>(xhi + off);
         xl[p][c] = *reinterpret_cast<const uint4*>(xlo + off);
       }
     };
@@ -310,6 +317,8 @@ struct EpiResid {  // x[token, feature] += acc on the two planes of the residual
     }
   }
 };
+
+typedef EpiResidT<false> EpiResid;
 
 template <class RS>
 struct EpiGegluBf16T {  // W rows interleaved 32 gate / 32 up: even row-fragments gate, odd up
@@ -526,7 +535,7 @@ constexpr int ATT_BUCKETS = 64;
 constexpr int POOL_CHUNK = 128;  // tokens per workgroup of the pooling pass (pool_partial_kernel)
 // The same launch lays out the pooling pass's list: chunk c of sequence b is entry cu[b] / 128 + b + c = {first token,
 // length, c, b} (strictly increasing in b, at most T/128 + B entries; a gap entry has length 0).
-__global__ __launch_bounds__(1024) void worklist_kernel(const int32_t* __restrict__ cu, int batch,
+static __global__ __launch_bounds__(1024) void worklist_kernel(const int32_t* __restrict__ cu, int batch,
                                                         int4* __restrict__ work, int n_slots,
                                                         int4* __restrict__ pwork, int n_pslots) {
   __shared__ int s_cnt[ATT_BUCKETS], s_pos[ATT_BUCKETS], s_live;
@@ -566,10 +575,11 @@ __global__ __launch_bounds__(1024) void worklist_kernel(const int32_t* __restric
     for (int i = tid; i < n_pslots; i += 1024) pwork[i] = make_int4(0, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 4) void attention_kernel(const bf16_t* __restrict__ qkv,
+static __global__ __launch_bounds__(256, 4) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                          const int4* __restrict__ work,
                                                          const float* __restrict__ bias_tab,
-                                                        bf16_t* __restrict__ out, int H, int maxd) {
+                                                        bf16_t* __restrict__ out, int H, int maxd,
+                                                         float* __restrict__ lse2, int lse_ld) {
   __shared__ __attribute__((aligned(16))) char smem[2 * AT2_STAGE + ATT_TAB_MAX * 4];
   float* tab = reinterpret_cast<float*>(smem + 2 * AT2_STAGE);
 
@@ -744,6 +754,8 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const bf16_t* __restr
   if (active && qi < len) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
+    // training forward: the row's log-sum-exp in the exp2 domain, p = 2^(s log2 e - lse2) (rp_train.hip recomputes P)
+    if (lse2 && hi == 0) lse2[(size_t)h * lse_ld + s0 + qi] = fmaf(m_run, 1.4426950408889634f, __log2f(l_tot));
     bf16_t* op = out + (size_t)(s0 + qi) * inner + h * 64;
 #pragma unroll
     for (int d = 0; d < 2; ++d)
@@ -849,7 +861,7 @@ static void launch_pool_partial(dim3 grid, hipStream_t stream, const bf16_t* xhi
     hipLaunchKernelGGL(pool_partial_kernel<4>, grid, dim3(256), 0, stream, xhi, xlo, rs, pwork, partial, D);
 }
 
-__global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restrict__ partial,
+static __global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restrict__ partial,
                                                           const float* __restrict__ w,
                                                           const int32_t* __restrict__ cu,
                                                           void* __restrict__ out, int out_bf16, int D) {

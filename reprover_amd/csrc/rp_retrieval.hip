@@ -1219,8 +1219,12 @@ __global__ __launch_bounds__(256) void mse_backward_kernel(const float* __restri
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, size_t n4, size_t n,
                                                     float decay, float beta1, float beta2, float step_size,
-                                                    float inv_sqrt_bc2, float eps) {
+                                                    float inv_sqrt_bc2, float eps, const float* __restrict__ total_norm,
+                                                    float max_norm) {
+  // torch.nn.utils.clip_grad_norm_: grads *= clamp(max_norm / (total_norm + 1e-6), max = 1)
+  const float clip = total_norm ? fminf(max_norm / (total_norm[0] + 1e-6f), 1.f) : 1.f;
   auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+    if (total_norm) gg *= clip;
     pp *= decay;                              // param.mul_(1 - lr * weight_decay)
     mm = fmaf(gg - mm, 1.f - beta1, mm);      // exp_avg.lerp_(grad, 1 - beta1)
     vv = fmaf(gg * gg, 1.f - beta2, vv * beta2);
@@ -1273,7 +1277,15 @@ extern "C" RpStatus rp_contrastive_mse_backward(const float* context_emb, const 
 extern "C" RpStatus rp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                                   int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
                                   void* stream_) {
+  return rp_adamw_step_clipped(param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, weight_decay, nullptr, 0.f,
+                               stream_);
+}
+
+extern "C" RpStatus rp_adamw_step_clipped(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                          int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                          const float* total_norm, float max_norm, void* stream_) {
   RP_REQUIRE(param && grad && exp_avg && exp_avg_sq, "null argument");
+  ProfScope ps((hipStream_t)stream_, RP_K_OPTIMIZER);
   RP_REQUIRE(n > 0 && step >= 1 && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "n=%lld step=%d",
              (long long)n, step);
   RP_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
@@ -1283,7 +1295,7 @@ extern "C" RpStatus rp_adamw_step(float* param, const float* grad, float* exp_av
   const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>((n4 + 511) / 512, 1), 256 * 32);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, param, grad, exp_avg, exp_avg_sq, n4,
                      (size_t)n, 1.f - lr * weight_decay, beta1, beta2, (float)((double)lr / bc1),
-                     (float)(1.0 / std::sqrt(bc2)), eps);
+                     (float)(1.0 / std::sqrt(bc2)), eps, total_norm, max_norm);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

@@ -1,0 +1,639 @@
+// Training step of the retriever on gfx950: encoder forward with saved activations, encoder backward, flat-buffer
+// optimizer support.  Replaces what autograd does behind retrieval/model.py:155-181 (`training_step` differentiating
+// `forward` :116-140 through `_encode` :92-114 and HuggingFace's T5Stack); common.py:381-405 (`get_optimizers`) is
+// rp_adamw_step over the flat parameter buffer.  Device code: rp_train_kernels.h; oracle: oracle/train_ref.py (G11, G12).
+//
+// Parameters, gradients and moments are FLAT fp32 device buffers in one canonical layout (rp_train_param_layout):
+//   embed [V, D] | rel_bias [buckets, H] | final_ln [D] | per layer: ln_attn [D], q, k, v [H*64, D], o [D, H*64],
+//   ln_ff [D], wi_0, wi_1 [F, D], wo [D, F]        (each tensor starts at a multiple of 64 elements)
+// so that the optimizer, the gradient norm and a checkpoint are one launch / one copy each, and the host views any
+// tensor in place.  The engine keeps bf16 compute copies (the forward's packed weights and their transposes for the
+// dgrad GEMMs), refreshed from the fp32 masters by rp_trainer_load_params after every optimizer step.
+//
+// What is saved for the backward (per layer, per token): bf16(x) entering each sub-layer, rs of both RMSNorms, qkv, the
+// attention output and its log-sum-exp, the row-scaled gate/up pre-activations and their gated product: 30.5 KB per token
+// and layer for ByT5-small (366 KB per token at 12 layers; 41 k tokens = 15 GB of the 288 GB).  Nothing is recomputed
+// except the attention probabilities (flash-style, from q, k, the bias table and the log-sum-exp).
+// Dropout: the reference trains with T5's dropout 0.1 (stochastic); this step is the deterministic dropout-free one
+// (the oracle's, fixture G11/G12), bit-reproducible run to run.
+#include "rp_train_kernels.h"
+
+using namespace rp;
+
+namespace {
+
+constexpr int N_GLOBAL = 3;       // embed, rel_bias, final_ln
+constexpr int N_PER_LAYER = 9;    // ln_attn q k v o ln_ff wi_0 wi_1 wo
+enum { P_LN_ATTN = 0, P_Q, P_K, P_V, P_O, P_LN_FF, P_WI0, P_WI1, P_WO };
+
+struct Layout {
+  std::vector<int64_t> off;  // [3 + 9 L + 1], last = total
+  int64_t embed() const { return off[0]; }
+  int64_t rel_bias() const { return off[1]; }
+  int64_t final_ln() const { return off[2]; }
+  int64_t layer(int i, int which) const { return off[N_GLOBAL + i * N_PER_LAYER + which]; }
+  int64_t total() const { return off.back(); }
+};
+
+Layout make_layout(const RpT5Config& c) {
+  const int64_t D = c.d_model, F = c.d_ff, inner = (int64_t)c.num_heads * c.d_kv;
+  Layout l;
+  int64_t o = 0;
+  auto add = [&](int64_t n) {
+    l.off.push_back(o);
+    o += (n + 63) / 64 * 64;
+  };
+  add((int64_t)c.vocab_size * D);
+  add((int64_t)c.rel_num_buckets * c.num_heads);
+  add(D);
+  for (int i = 0; i < c.num_layers; ++i) {
+    add(D);
+    add(inner * D);
+    add(inner * D);
+    add(inner * D);
+    add(D * inner);
+    add(D);
+    add(F * D);
+    add(F * D);
+    add(D * F);
+  }
+  l.off.push_back(o);
+  return l;
+}
+
+struct LayerT {  // transposed bf16 copies for the dgrad GEMMs
+  bf16_t* wqkv_t;  // [D, 3 inner]   (Wqkv')^T
+  bf16_t* wo_t;    // [inner, D]
+  bf16_t* wi_t;    // [D, 2 F]       (Wi')^T, K in packed order
+  bf16_t* wo2_t;   // [F, D]
+};
+
+}  // namespace
+
+struct RpTrainer {
+  RpEncoder* enc = nullptr;  // the forward's packed weights: also usable with rp_encode_varlen / rp_encode_padded
+  Layout lay;
+  std::vector<LayerT> lt;
+  int32_t* bucket_of = nullptr;  // [2 maxd + 1] relative offset -> bucket
+  std::vector<void*> allocs;
+};
+
+namespace {
+
+struct TrainWs {
+  // saved by the forward
+  std::vector<bf16_t*> xa, xf, qkv, att, gu, ff;  // xa has L + 1 entries (xa[L] = the final hi plane)
+  std::vector<float*> lse, rsa, rsf;
+  bf16_t* xlo;
+  float *ssp, *rs_final, *pool;
+  int4 *work, *pwork;
+  // backward scratch
+  bf16_t *dxhi, *dxlo, *dzs, *datt, *dqkv;
+  float *delta, *rdp, *rcoef, *wpart, *dtab_part, *dln_part, *ds_seq, *dwf_seq, *norm_part;
+  size_t wpart_bytes;
+  size_t bytes;
+};
+
+constexpr int WG_SLOTS = 512;  // wgrad launches aim at about this many workgroups (256 CUs, one 128-KiB block each: 2 rounds)
+
+int wgrad_splits(int rows, int cols, int nk) {
+  const int tiles = ((rows + 255) / 256) * ((cols + 255) / 256);
+  int s = (WG_SLOTS + tiles - 1) / tiles;
+  s = std::min(s, std::max(1, nk / 4));
+  return std::max(1, std::min(s, 32));
+}
+
+TrainWs carve_train(const RpTrainer* tr, int T, int batch, char* base) {
+  const RpT5Config& c = tr->enc->cfg;
+  const size_t Tp = align_up((size_t)T, GEMM_M_ALIGN);
+  const size_t D = c.d_model, F = c.d_ff, inner = tr->enc->inner, H = c.num_heads, L = c.num_layers;
+  TrainWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  w.xa.resize(L + 1);
+  w.xf.resize(L); w.qkv.resize(L); w.att.resize(L); w.gu.resize(L); w.ff.resize(L);
+  w.lse.resize(L); w.rsa.resize(L); w.rsf.resize(L);
+  for (size_t i = 0; i <= L; ++i) w.xa[i] = (bf16_t*)take(Tp * D * 2);
+  for (size_t i = 0; i < L; ++i) {
+    w.xf[i] = (bf16_t*)take(Tp * D * 2);
+    w.qkv[i] = (bf16_t*)take(Tp * 3 * inner * 2);
+    w.att[i] = (bf16_t*)take(Tp * inner * 2);
+    w.gu[i] = (bf16_t*)take(Tp * 2 * F * 2);
+    w.ff[i] = (bf16_t*)take(Tp * F * 2);
+    w.lse[i] = (float*)take(H * Tp * 4);
+    w.rsa[i] = (float*)take(Tp * 4);
+    w.rsf[i] = (float*)take(Tp * 4);
+  }
+  w.xlo = (bf16_t*)take(Tp * D * 2);
+  w.ssp = (float*)take(Tp * ((D + 63) / 64) * 4);
+  w.rs_final = (float*)take(Tp * 4);
+  w.pool = (float*)take((Tp / POOL_CHUNK + (size_t)batch + 1) * D * 4);
+  w.work = (int4*)take((Tp / ATT_Q + (size_t)batch + 1) * sizeof(int4));
+  w.pwork = (int4*)take((Tp / POOL_CHUNK + (size_t)batch + 1) * sizeof(int4));
+  w.dxhi = (bf16_t*)take(Tp * D * 2);
+  w.dxlo = (bf16_t*)take(Tp * D * 2);
+  w.dzs = (bf16_t*)take(Tp * 2 * F * 2);
+  w.datt = (bf16_t*)take(Tp * inner * 2);
+  w.dqkv = (bf16_t*)take(Tp * 3 * inner * 2);
+  w.delta = (float*)take(H * Tp * 4);
+  w.rdp = (float*)take(((F + 63) / 64) * Tp * 4);
+  w.rcoef = (float*)take(Tp * 4);
+  const int nk = (int)(Tp / 64);
+  size_t wp = 0;
+  auto need = [&](size_t rows, size_t cols) { wp = std::max(wp, (size_t)wgrad_splits((int)rows, (int)cols, nk) * rows * cols * 4); };
+  need(3 * inner, D);
+  need(D, inner);
+  need(2 * F, D);
+  need(D, F);
+  w.wpart_bytes = wp;
+  w.wpart = (float*)take(wp);
+  w.dtab_part = (float*)take((Tp / ATT_Q + (size_t)batch + 1) * H * (2 * tr->enc->maxd + 1) * 4);
+  w.dln_part = (float*)take(((2 * F + 31) / 32) * D * 4);
+  w.ds_seq = (float*)take((size_t)batch * D * 4);
+  w.dwf_seq = (float*)take((size_t)batch * D * 4);
+  w.norm_part = (float*)take(1024 * 4);
+  w.bytes = off;
+  return w;
+}
+
+// tile configuration of a backward dgrad GEMM: the pipelined 256 x 256 x 64 tile when it fills the chip, else 128 x 128
+int bwd_variant(int n_rows_w, int K, int Tp) {
+  if (K % 64 != 0) return 0;
+  const int tiles = ((n_rows_w + 255) / 256) * (Tp / 256);
+  return tiles >= 192 ? 26 : 0;
+}
+
+template <class C>
+RpStatus launch_wgrad_cfg(const bf16_t* Y, int ldy, int ny, const bf16_t* X, int ldx, int nx, int nk, int splits, float* out,
+                          int ldc, size_t split_stride, hipStream_t stream) {
+  auto kern = wgrad_kernel<C>;
+  static LdsAttrOnce attr;
+  RP_HIP(attr.ensure((const void*)kern, C::LDS_BYTES));
+  const int tiles_m = (ny + C::BM - 1) / C::BM, tiles_n = (nx + C::BN - 1) / C::BN;
+  ProfScope ps(stream, RP_K_BWD_WGRAD);
+  hipLaunchKernelGGL(kern, dim3(splits * tiles_m * tiles_n), dim3(C::THREADS), C::LDS_BYTES, stream, Y, ldy, ny, X, ldx, nx,
+                     nk, splits, tiles_m, tiles_n, out, ldc, split_stride);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+// dW[ny, nx] (fp32, ldc = nx) = Y[:Tp, :ny]^T X[:Tp, :nx]; `splits` partial matrices at out + s * ny * nx
+RpStatus launch_wgrad(const bf16_t* Y, int ldy, int ny, const bf16_t* X, int ldx, int nx, int Tp, int splits, float* out,
+                      hipStream_t stream) {
+  RP_REQUIRE(Tp % 64 == 0 && ny % 8 == 0 && nx % 8 == 0 && ny >= 8 && nx >= 8, "wgrad: Tp=%d ny=%d nx=%d", Tp, ny, nx);
+  return launch_wgrad_cfg<WgradCfg<256, 256, 4, 2, 2>>(Y, ldy, ny, X, ldx, nx, Tp / 64, splits, out, nx, (size_t)ny * nx,
+                                                       stream);
+}
+
+RpStatus run_unfold(const UnfoldArgs& a, hipStream_t stream) {
+  ProfScope ps(stream, RP_K_BWD_OTHER);
+  hipLaunchKernelGGL(unfold_kernel, dim3((a.C + 255) / 256, (a.rows + 31) / 32), dim3(256), 0, stream, a);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+// ---- forward with saved activations -----------------------------------------------------------------------
+RpStatus train_forward(RpTrainer* tr, const int32_t* ids, const int32_t* cu, int batch, int T, float* out_emb,
+                       const TrainWs& w, hipStream_t stream) {
+  RpEncoder* e = tr->enc;
+  const RpT5Config& c = e->cfg;
+  const int D = c.d_model, F = c.d_ff, inner = e->inner, H = c.num_heads, L = c.num_layers;
+  const int Tp = (int)align_up((size_t)T, GEMM_M_ALIGN);
+  const int np = (D + 63) / 64;
+  RpStatus st;
+  auto rowscale = [&](float* rs) {
+    ProfScope ps(stream, RP_K_RMSNORM);
+    hipLaunchKernelGGL(rowscale_kernel, dim3((Tp + 63) / 64), dim3(64), 0, stream, w.ssp, rs, Tp, np, 1.f / (float)D,
+                       c.layer_norm_eps);
+  };
+  {
+    ProfScope ps(stream, RP_K_EMBED);
+    hipLaunchKernelGGL(embed_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.xa[0], w.xlo, w.ssp, np, T, Tp,
+                       D, c.vocab_size, (const int32_t*)nullptr);
+  }
+  const dim3 att_grid(H, T / ATT_Q + batch);
+  hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu, batch, w.work, (int)att_grid.y, w.pwork,
+                     T / POOL_CHUNK + batch);
+  RP_CHECK_LAUNCH();
+  for (int i = 0; i < L; ++i) {
+    const LayerPacked& Lw = e->layers[i];
+    rowscale(w.rsa[i]);
+    if ((st = launch_gemm(w.xa[i], D, Tp, Lw.wqkv, D, 3 * inner, D,
+                          EpiStoreBf16{w.qkv[i], 3 * inner, 3 * inner, RowScale{w.rsa[i]}}, stream, RP_K_GEMM_QKV)))
+      return st;
+    {
+      ProfScope ps(stream, RP_K_ATTENTION);
+      hipLaunchKernelGGL(attention_kernel, att_grid, dim3(256), 0, stream, (const bf16_t*)w.qkv[i], (const int4*)w.work,
+                         (const float*)e->bias_tab, w.att[i], H, e->maxd, w.lse[i], Tp);
+    }
+    // rows T .. Tp of every saved activation must stay finite: they are K rows of the wgrad GEMMs (against zero dY rows)
+    if (Tp > T) RP_HIP(hipMemsetAsync(w.att[i] + (size_t)T * inner, 0, (size_t)(Tp - T) * inner * 2, stream));
+    if ((st = launch_gemm(w.att[i], inner, Tp, Lw.wo, inner, D, inner,
+                          EpiResidT<true>{w.xf[i], w.xlo, D, D, w.ssp, np, Tp, w.xa[i]}, stream, RP_K_GEMM_O)))
+      return st;
+    rowscale(w.rsf[i]);
+    if ((st = launch_gemm(w.xf[i], D, Tp, Lw.wi, D, 2 * F, D,
+                          EpiGegluTrain{EpiStoreBf16{w.gu[i], 2 * F, 2 * F, RowScale{w.rsf[i]}},
+                                        EpiGegluBf16{w.ff[i], F, 2 * F, RowScale{w.rsf[i]}}},
+                          stream, RP_K_GEMM_WI)))
+      return st;
+    if ((st = launch_gemm(w.ff[i], F, Tp, Lw.wo2, F, D, F, EpiResidT<true>{w.xa[i + 1], w.xlo, D, D, w.ssp, np, Tp, w.xf[i]},
+                          stream, RP_K_GEMM_WO)))
+      return st;
+  }
+  rowscale(w.rs_final);
+  {
+    ProfScope ps(stream, RP_K_POOL);
+    launch_pool_partial(dim3(T / POOL_CHUNK + batch), stream, w.xa[L], w.xlo, w.rs_final, (const int4*)w.pwork, w.pool, D);
+    hipLaunchKernelGGL(pool_finish_kernel, dim3(batch), dim3(256), 0, stream, (const float*)w.pool, (const float*)e->final_ln,
+                       cu, (void*)out_emb, 0, D);
+  }
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+// ---- backward ---------------------------------------------------------------------------------------------
+RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, const int32_t* cu, int batch, int T,
+                        const float* d_emb, float* grads, const TrainWs& w, hipStream_t stream) {
+  RpEncoder* e = tr->enc;
+  const RpT5Config& c = e->cfg;
+  const Layout& lay = tr->lay;
+  const int D = c.d_model, F = c.d_ff, inner = e->inner, H = c.num_heads, L = c.num_layers;
+  const int Tp = (int)align_up((size_t)T, GEMM_M_ALIGN);
+  const int nk = Tp / 64, ntab = 2 * e->maxd + 1;
+  const float inv_d = 1.f / (float)D;
+  RpStatus st;
+  const dim3 att_grid(H, T / ATT_Q + batch);
+  RP_HIP(hipMemsetAsync(w.dxhi, 0, (size_t)Tp * D * 2, stream));
+  RP_HIP(hipMemsetAsync(w.dxlo, 0, (size_t)Tp * D * 2, stream));
+  RP_HIP(hipMemsetAsync(w.dtab_part, 0, (size_t)att_grid.y * H * ntab * 4, stream));
+
+  // pooling + final RMSNorm
+  {
+    ProfScope ps(stream, RP_K_BWD_OTHER);
+    hipLaunchKernelGGL(pool_bwd_seq_kernel, dim3(batch), dim3(256), 0, stream, (const float*)w.pool, (const float*)e->final_ln, cu,
+                       d_emb, w.ds_seq, w.dwf_seq, D);
+    hipLaunchKernelGGL(colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, (const float*)w.dwf_seq, batch, D,
+                       grads + lay.final_ln());
+    const dim3 pg(T / POOL_CHUNK + batch);
+    if (D <= 3 * 512)
+      hipLaunchKernelGGL(pool_bwd_tok_kernel<3>, pg, dim3(256), 0, stream, (const bf16_t*)w.xa[L], (const bf16_t*)w.xlo,
+                         (const float*)w.rs_final, (const int4*)w.pwork, (const float*)w.ds_seq, w.dxhi, w.dxlo, D, inv_d);
+    else
+      hipLaunchKernelGGL(pool_bwd_tok_kernel<4>, pg, dim3(256), 0, stream, (const bf16_t*)w.xa[L], (const bf16_t*)w.xlo,
+                         (const float*)w.rs_final, (const int4*)w.pwork, (const float*)w.ds_seq, w.dxhi, w.dxlo, D, inv_d);
+    RP_CHECK_LAUNCH();
+  }
+
+  for (int i = L - 1; i >= 0; --i) {
+    const LayerT& Lt = tr->lt[i];
+    // ---------------- feed-forward sub-layer:  x_out = x + ff Wo2^T,  ff = gelu(g) u,  [g | u] = rs (x Wi'^T)
+    // dWo2 = dx^T ff  (dx: the hi plane of the residual gradient)
+    {
+      const int S = wgrad_splits(D, F, nk);
+      float* dst = grads + lay.layer(i, P_WO);
+      if ((st = launch_wgrad(w.dxhi, D, D, w.ff[i], F, F, Tp, S, S == 1 ? dst : w.wpart, stream))) return st;
+      if (S > 1) {
+        UnfoldArgs a{};
+        a.part = w.wpart; a.split_stride = (size_t)D * F; a.splits = S; a.rows = D; a.C = F; a.mode = UNFOLD_PLAIN; a.g0 = dst;
+        if ((st = run_unfold(a, stream))) return st;
+      }
+    }
+    // dff = dx Wo2 -> gated-GELU backward -> dzs = rs [dg | du] (packed order), row dots
+    if ((st = launch_gemm(w.dxhi, D, Tp, Lt.wo2_t, D, F, D,
+                          EpiGegluBwd{w.gu[i], w.dzs, 2 * F, F, w.rsf[i], w.rdp, (F + 63) / 64, Tp}, stream, RP_K_BWD_DGRAD, 0,
+                          nullptr, bwd_variant(F, D, Tp))))
+      return st;
+    {
+      ProfScope ps(stream, RP_K_BWD_OTHER);
+      hipLaunchKernelGGL(rowdot_finish_kernel, dim3((Tp + 63) / 64), dim3(64), 0, stream, (const float*)w.rdp, (F + 63) / 64, Tp,
+                         (const float*)w.rsf[i], inv_d, w.rcoef, Tp);
+    }
+    // dWi' = dzs^T x  -> unfold (de-interleave gate / up, x ln_ff, d ln_ff)
+    {
+      const int S = wgrad_splits(2 * F, D, nk);
+      if ((st = launch_wgrad(w.dzs, 2 * F, 2 * F, w.xf[i], D, D, Tp, S, w.wpart, stream))) return st;
+      UnfoldArgs a{};
+      a.part = w.wpart; a.split_stride = (size_t)2 * F * D; a.splits = S; a.rows = 2 * F; a.C = D; a.mode = UNFOLD_GEGLU;
+      a.g0 = grads + lay.layer(i, P_WI0); a.g1 = grads + lay.layer(i, P_WI1);
+      a.w0 = params + lay.layer(i, P_WI0); a.w1 = params + lay.layer(i, P_WI1);
+      a.ln = params + lay.layer(i, P_LN_FF); a.dln_part = w.dln_part;
+      if ((st = run_unfold(a, stream))) return st;
+      ProfScope ps(stream, RP_K_BWD_OTHER);
+      hipLaunchKernelGGL(colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, (const float*)w.dln_part, (2 * F + 31) / 32,
+                         D, grads + lay.layer(i, P_LN_FF));
+    }
+    // dx += dzs Wi' - x rcoef   (RMSNorm backward in the epilogue)
+    if ((st = launch_gemm(w.dzs, 2 * F, Tp, Lt.wi_t, 2 * F, D, 2 * F, EpiRmsBwdResid{w.dxhi, w.dxlo, D, D, w.xf[i], w.rcoef},
+                          stream, RP_K_BWD_DGRAD, 0, nullptr, bwd_variant(D, 2 * F, Tp))))
+      return st;
+
+    // ---------------- attention sub-layer:  x_out = x + att Wo^T,  att = Attn(q, k, v),  [q | k | v] = rs (x Wqkv'^T)
+    {
+      const int S = wgrad_splits(D, inner, nk);
+      float* dst = grads + lay.layer(i, P_O);
+      if ((st = launch_wgrad(w.dxhi, D, D, w.att[i], inner, inner, Tp, S, S == 1 ? dst : w.wpart, stream))) return st;
+      if (S > 1) {
+        UnfoldArgs a{};
+        a.part = w.wpart; a.split_stride = (size_t)D * inner; a.splits = S; a.rows = D; a.C = inner; a.mode = UNFOLD_PLAIN;
+        a.g0 = dst;
+        if ((st = run_unfold(a, stream))) return st;
+      }
+    }
+    if ((st = launch_gemm(w.dxhi, D, Tp, Lt.wo_t, D, inner, D, EpiStoreBf16{w.datt, inner, inner, RowScale{nullptr}}, stream,
+                          RP_K_BWD_DGRAD, 0, nullptr, bwd_variant(inner, D, Tp))))
+      return st;
+    {
+      ProfScope ps(stream, RP_K_BWD_ATTENTION);
+      hipLaunchKernelGGL(attn_bwd_kernel<0>, att_grid, dim3(256), 0, stream, (const bf16_t*)w.qkv[i], (const bf16_t*)w.att[i],
+                         (const bf16_t*)w.datt, (const float*)w.lse[i], w.delta, (const int4*)w.work, (const float*)e->bias_tab,
+                         w.dqkv, w.dtab_part, H, e->maxd, Tp);
+      hipLaunchKernelGGL(attn_bwd_kernel<1>, att_grid, dim3(256), 0, stream, (const bf16_t*)w.qkv[i], (const bf16_t*)w.att[i],
+                         (const bf16_t*)w.datt, (const float*)w.lse[i], w.delta, (const int4*)w.work, (const float*)e->bias_tab,
+                         w.dqkv, w.dtab_part, H, e->maxd, Tp);
+      RP_CHECK_LAUNCH();
+    }
+    {
+      ProfScope ps(stream, RP_K_BWD_OTHER);
+      hipLaunchKernelGGL(qkv_scale_dot_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, w.dqkv, (const bf16_t*)w.qkv[i],
+                         (const float*)w.rsa[i], w.rcoef, T, Tp, 3 * inner, inv_d);
+    }
+    {
+      const int S = wgrad_splits(3 * inner, D, nk);
+      if ((st = launch_wgrad(w.dqkv, 3 * inner, 3 * inner, w.xa[i], D, D, Tp, S, w.wpart, stream))) return st;
+      UnfoldArgs a{};
+      a.part = w.wpart; a.split_stride = (size_t)3 * inner * D; a.splits = S; a.rows = 3 * inner; a.C = D; a.mode = UNFOLD_QKV;
+      a.n = inner;
+      a.g0 = grads + lay.layer(i, P_Q); a.g1 = grads + lay.layer(i, P_K); a.g2 = grads + lay.layer(i, P_V);
+      a.w0 = params + lay.layer(i, P_Q); a.w1 = params + lay.layer(i, P_K); a.w2 = params + lay.layer(i, P_V);
+      a.ln = params + lay.layer(i, P_LN_ATTN); a.dln_part = w.dln_part;
+      if ((st = run_unfold(a, stream))) return st;
+      ProfScope ps(stream, RP_K_BWD_OTHER);
+      hipLaunchKernelGGL(colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, (const float*)w.dln_part, (3 * inner + 31) / 32,
+                         D, grads + lay.layer(i, P_LN_ATTN));
+    }
+    if ((st = launch_gemm(w.dqkv, 3 * inner, Tp, Lt.wqkv_t, 3 * inner, D, 3 * inner,
+                          EpiRmsBwdResid{w.dxhi, w.dxlo, D, D, w.xa[i], w.rcoef}, stream, RP_K_BWD_DGRAD, 0, nullptr,
+                          bwd_variant(D, 3 * inner, Tp))))
+      return st;
+  }
+  {
+    ProfScope ps(stream, RP_K_BWD_OTHER);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(c.vocab_size, (D + 255) / 256), dim3(256), 0, stream, ids, T, c.vocab_size,
+                       (const bf16_t*)w.dxhi, (const bf16_t*)w.dxlo, D, grads + lay.embed());
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(H), dim3(256), 0, stream, (const float*)w.dtab_part, (int)att_grid.y, H, ntab,
+                       (const int32_t*)tr->bucket_of, c.rel_num_buckets, grads + lay.rel_bias());
+    RP_CHECK_LAUNCH();
+  }
+  return RP_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int32_t rp_train_param_tensors(const RpT5Config* cfg) {
+  return cfg ? N_GLOBAL + N_PER_LAYER * cfg->num_layers : 0;
+}
+
+extern "C" RpStatus rp_train_param_layout(const RpT5Config* cfg, int64_t* offsets) {
+  RP_REQUIRE(cfg && offsets, "null argument");
+  const Layout l = make_layout(*cfg);
+  for (size_t i = 0; i < l.off.size(); ++i) offsets[i] = l.off[i];
+  return RP_OK;
+}
+
+extern "C" void rp_trainer_destroy(RpTrainer* tr) {
+  if (!tr) return;
+  for (void* p : tr->allocs) (void)hipFree(p);
+  if (tr->enc) rp_encoder_destroy(tr->enc);
+  delete tr;
+}
+
+extern "C" RpStatus rp_trainer_create(const RpT5Config* cfg, const float* params, RpTrainer** out) {
+  RP_REQUIRE(cfg && params && out, "null argument");
+  RP_REQUIRE(cfg->d_model % 64 == 0 && cfg->d_ff % 64 == 0, "training kernels need d_model=%d and d_ff=%d to be multiples of 64",
+             cfg->d_model, cfg->d_ff);
+  RpTrainer* tr = new RpTrainer();
+  tr->lay = make_layout(*cfg);
+  // the inference encoder on the same weights (HF-layout pointers into the flat buffer)
+  std::vector<RpT5LayerWeights> lw(cfg->num_layers);
+  for (int i = 0; i < cfg->num_layers; ++i) {
+    lw[i].ln_attn = params + tr->lay.layer(i, P_LN_ATTN);
+    lw[i].q = params + tr->lay.layer(i, P_Q);
+    lw[i].k = params + tr->lay.layer(i, P_K);
+    lw[i].v = params + tr->lay.layer(i, P_V);
+    lw[i].o = params + tr->lay.layer(i, P_O);
+    lw[i].ln_ff = params + tr->lay.layer(i, P_LN_FF);
+    lw[i].wi_0 = params + tr->lay.layer(i, P_WI0);
+    lw[i].wi_1 = params + tr->lay.layer(i, P_WI1);
+    lw[i].wo = params + tr->lay.layer(i, P_WO);
+  }
+  RpT5Weights wts{params + tr->lay.embed(), params + tr->lay.rel_bias(), params + tr->lay.final_ln(), lw.data()};
+  RpStatus st = rp_encoder_create(cfg, &wts, RP_DT_F32, &tr->enc);
+  if (st != RP_OK) {
+    delete tr;
+    return st;
+  }
+  const int D = cfg->d_model, F = cfg->d_ff, inner = tr->enc->inner;
+  auto alloc = [&](size_t bytes, void** p) -> RpStatus {
+    RP_HIP(hipMalloc(p, bytes));
+    tr->allocs.push_back(*p);
+    return RP_OK;
+  };
+  tr->lt.resize(cfg->num_layers);
+  for (int i = 0; i < cfg->num_layers && st == RP_OK; ++i) {
+    LayerT& t = tr->lt[i];
+    if ((st = alloc((size_t)3 * inner * D * 2, (void**)&t.wqkv_t))) break;
+    if ((st = alloc((size_t)D * inner * 2, (void**)&t.wo_t))) break;
+    if ((st = alloc((size_t)2 * F * D * 2, (void**)&t.wi_t))) break;
+    if ((st = alloc((size_t)D * F * 2, (void**)&t.wo2_t))) break;
+  }
+  const int ntab = 2 * tr->enc->maxd + 1;
+  if (st == RP_OK) st = alloc((size_t)ntab * 4, (void**)&tr->bucket_of);
+  if (st == RP_OK) {
+    std::vector<int32_t> bk(ntab);
+    for (int o = 0; o < ntab; ++o)
+      bk[o] = rp_relative_position_bucket(o - tr->enc->maxd, cfg->rel_num_buckets, cfg->rel_max_distance);
+    if (hipMemcpy(tr->bucket_of, bk.data(), (size_t)ntab * 4, hipMemcpyHostToDevice) != hipSuccess)
+      st = fail(RP_E_HIP, "hipMemcpy of the bucket map failed");
+  }
+  if (st == RP_OK) st = rp_trainer_load_params(tr, params, nullptr);
+  if (st == RP_OK && hipDeviceSynchronize() != hipSuccess) st = fail(RP_E_HIP, "hipDeviceSynchronize failed");
+  if (st != RP_OK) {
+    rp_trainer_destroy(tr);
+    return st;
+  }
+  *out = tr;
+  return RP_OK;
+}
+
+extern "C" RpEncoder* rp_trainer_encoder(RpTrainer* tr) { return tr ? tr->enc : nullptr; }
+
+// Refresh every bf16 compute copy from the fp32 masters (after an optimizer step): the forward's packed weights, the
+// embedding / norm / bias tables, and the transposed copies of the dgrad GEMMs.  Launch-only.
+extern "C" RpStatus rp_trainer_load_params(RpTrainer* tr, const float* params, void* stream_) {
+  RP_REQUIRE(tr && params, "null argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  RpEncoder* e = tr->enc;
+  const RpT5Config& c = e->cfg;
+  const Layout& lay = tr->lay;
+  const int D = c.d_model, F = c.d_ff, inner = e->inner, H = c.num_heads;
+  ProfScope ps(stream, RP_K_OPTIMIZER);
+  RP_HIP(hipMemcpyAsync(e->embed, params + lay.embed(), (size_t)c.vocab_size * D * 4, hipMemcpyDeviceToDevice, stream));
+  RP_HIP(hipMemcpyAsync(e->final_ln, params + lay.final_ln(), (size_t)D * 4, hipMemcpyDeviceToDevice, stream));
+  const int ntab = 2 * e->maxd + 1;
+  hipLaunchKernelGGL(bias_table_kernel, dim3((H * ntab + 255) / 256), dim3(256), 0, stream, params + lay.rel_bias(),
+                     (const int32_t*)tr->bucket_of, H, ntab, e->bias_tab);
+  auto transpose = [&](const bf16_t* in, int R, int C, bf16_t* out) {
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, stream, in, R, C, out);
+  };
+  for (int i = 0; i < c.num_layers; ++i) {
+    LayerPacked& L = e->layers[i];
+    const LayerT& t = tr->lt[i];
+    const float* ln_a = params + lay.layer(i, P_LN_ATTN);
+    const float* ln_f = params + lay.layer(i, P_LN_FF);
+    RP_HIP(hipMemcpyAsync(L.ln_attn, ln_a, (size_t)D * 4, hipMemcpyDeviceToDevice, stream));
+    RP_HIP(hipMemcpyAsync(L.ln_ff, ln_f, (size_t)D * 4, hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL((pack_rows_kernel<float>), dim3(3 * inner), dim3(256), 0, stream, L.wqkv,
+                       (const void*)(params + lay.layer(i, P_Q)), (const void*)(params + lay.layer(i, P_K)),
+                       (const void*)(params + lay.layer(i, P_V)), 3 * inner, D, inner, (int)PACK_CONCAT3, ln_a);
+    hipLaunchKernelGGL((pack_rows_kernel<float>), dim3(D), dim3(256), 0, stream, L.wo, (const void*)(params + lay.layer(i, P_O)),
+                       (const void*)nullptr, (const void*)nullptr, D, inner, 0, (int)PACK_COPY, (const float*)nullptr);
+    hipLaunchKernelGGL((pack_rows_kernel<float>), dim3(2 * F), dim3(256), 0, stream, L.wi,
+                       (const void*)(params + lay.layer(i, P_WI0)), (const void*)(params + lay.layer(i, P_WI1)),
+                       (const void*)nullptr, 2 * F, D, 0, (int)PACK_GEGLU, ln_f);
+    hipLaunchKernelGGL((pack_rows_kernel<float>), dim3(D), dim3(256), 0, stream, L.wo2,
+                       (const void*)(params + lay.layer(i, P_WO)), (const void*)nullptr, (const void*)nullptr, D, F, 0,
+                       (int)PACK_COPY, (const float*)nullptr);
+    transpose(L.wqkv, 3 * inner, D, t.wqkv_t);
+    transpose(L.wo, D, inner, t.wo_t);
+    transpose(L.wi, 2 * F, D, t.wi_t);
+    transpose(L.wo2, D, F, t.wo2_t);
+  }
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" size_t rp_train_workspace_bytes(const RpTrainer* tr, int32_t total_tokens, int32_t batch) {
+  if (!tr || total_tokens <= 0 || batch <= 0) return 0;
+  return carve_train(tr, total_tokens, batch, nullptr).bytes;
+}
+
+extern "C" RpStatus rp_train_forward(RpTrainer* tr, const int32_t* ids, const int32_t* cu_seqlens, int32_t batch, int32_t T,
+                                     float* out_emb, void* workspace, size_t workspace_bytes, void* stream_) {
+  RP_REQUIRE(tr && ids && cu_seqlens && out_emb, "null argument");
+  RP_REQUIRE(batch > 0 && T > 0, "batch=%d total_tokens=%d", batch, T);
+  TrainWs w = carve_train(tr, T, batch, (char*)workspace);
+  if (!workspace || workspace_bytes < w.bytes)
+    return fail(RP_E_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, w.bytes);
+  return train_forward(tr, ids, cu_seqlens, batch, T, out_emb, w, (hipStream_t)stream_);
+}
+
+extern "C" RpStatus rp_train_backward(RpTrainer* tr, const float* params, const int32_t* ids, const int32_t* cu_seqlens,
+                                      int32_t batch, int32_t T, const float* d_emb, float* grads, void* workspace,
+                                      size_t workspace_bytes, void* stream_) {
+  RP_REQUIRE(tr && params && ids && cu_seqlens && d_emb && grads, "null argument");
+  RP_REQUIRE(batch > 0 && T > 0, "batch=%d total_tokens=%d", batch, T);
+  TrainWs w = carve_train(tr, T, batch, (char*)workspace);
+  if (!workspace || workspace_bytes < w.bytes)
+    return fail(RP_E_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, w.bytes);
+  return train_backward(tr, params, ids, cu_seqlens, batch, T, d_emb, grads, w, (hipStream_t)stream_);
+}
+
+// ||g||_2 of n floats -> out_norm[0] (device), deterministic; scratch = 1024 floats
+extern "C" RpStatus rp_grad_norm(const float* grads, int64_t n, float* out_norm, float* scratch, void* stream_) {
+  RP_REQUIRE(grads && out_norm && scratch && n > 0, "null argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  ProfScope ps(stream, RP_K_OPTIMIZER);
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(1024), dim3(256), 0, stream, grads, (size_t)n, scratch);
+  hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)scratch, 1024, out_norm);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+// ---- kernel-level test entry points ------------------------------------------------------------------------
+extern "C" RpStatus rp_dbg_wgrad(const void* Y, const void* X, float* out, int32_t T, int32_t ny, int32_t nx, int32_t splits,
+                                 void* stream_) {
+  RP_REQUIRE(Y && X && out && splits >= 1, "bad argument");
+  return launch_wgrad((const bf16_t*)Y, ny, ny, (const bf16_t*)X, nx, nx, T, splits, out, (hipStream_t)stream_);
+}
+
+extern "C" RpStatus rp_dbg_attention_bwd(const void* qkv, const void* att, const void* datt, const int32_t* cu,
+                                         const float* bias_tab, int32_t batch, int32_t H, int32_t rows_total, void* lse_out,
+                                         void* att_out, void* dqkv, float* dtab /* [H, 257] */, void* stream_) {
+  // forward (writes att_out + lse) then both backward kernels; test entry only: scratch is allocated here
+  const int maxd = 128, ntab = 2 * maxd + 1;
+  hipStream_t stream = (hipStream_t)stream_;
+  const dim3 grid(H, rows_total / ATT_Q + batch);
+  const int n_p = rows_total / POOL_CHUNK + batch;
+  int4* work = nullptr;
+  float *delta = nullptr, *part = nullptr;
+  int32_t* bk = nullptr;
+  RP_HIP(hipMalloc((void**)&work, ((size_t)grid.y + n_p) * sizeof(int4)));
+  RP_HIP(hipMalloc((void**)&delta, (size_t)H * rows_total * 4));
+  RP_HIP(hipMalloc((void**)&part, (size_t)grid.y * H * ntab * 4));
+  RP_HIP(hipMalloc((void**)&bk, (size_t)ntab * 4));
+  RP_HIP(hipMemsetAsync(part, 0, (size_t)grid.y * H * ntab * 4, stream));
+  {
+    std::vector<int32_t> ident(ntab);
+    for (int i = 0; i < ntab; ++i) ident[i] = i;  // identity "buckets": the raw table gradient comes back
+    RP_HIP(hipMemcpy(bk, ident.data(), (size_t)ntab * 4, hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu, batch, work, (int)grid.y, work + grid.y, n_p);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, stream, (const bf16_t*)qkv, (const int4*)work, bias_tab,
+                     (bf16_t*)att_out, H, maxd, (float*)lse_out, rows_total);
+  const bf16_t* o = att ? (const bf16_t*)att : (const bf16_t*)att_out;
+  hipLaunchKernelGGL(attn_bwd_kernel<0>, grid, dim3(256), 0, stream, (const bf16_t*)qkv, o, (const bf16_t*)datt,
+                     (const float*)lse_out, delta, (const int4*)work, bias_tab, (bf16_t*)dqkv, part, H, maxd, rows_total);
+  hipLaunchKernelGGL(attn_bwd_kernel<1>, grid, dim3(256), 0, stream, (const bf16_t*)qkv, o, (const bf16_t*)datt,
+                     (const float*)lse_out, delta, (const int4*)work, bias_tab, (bf16_t*)dqkv, part, H, maxd, rows_total);
+  // [ntab "buckets", H] -> caller's [H, ntab] is the transposed view; the test reads it as [ntab, H]
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(H), dim3(256), 0, stream, (const float*)part, (int)grid.y, H, ntab,
+                     (const int32_t*)bk, ntab, dtab);
+  const hipError_t le = hipGetLastError();
+  (void)hipStreamSynchronize(stream);
+  (void)hipFree(work);
+  (void)hipFree(delta);
+  (void)hipFree(part);
+  (void)hipFree(bk);
+  if (le != hipSuccess) return fail(RP_E_HIP, "attention backward launch failed: %s", hipGetErrorString(le));
+  return RP_OK;
+}
+
+// dgrad epilogues in isolation.  mode 0: EpiGegluBwd (A = dx [M, K], W = Wo2^T [F, K]; aux0 = gu [M, 2F] bf16, aux1 = rs [M];
+// out0 = dzs [M, 2F] bf16, out1 = row dot [M] f32 (slots summed)).  mode 1: EpiRmsBwdResid (A = dzs [M, K], W [N, K];
+// aux0 = x [M, N] bf16, aux1 = rcoef [M]; out0 = the two planes [2, M, N], updated in place).
+extern "C" RpStatus rp_dbg_dgrad(const void* A, const void* W, int32_t M, int32_t N, int32_t K, int32_t mode, const void* aux0,
+                                 const float* aux1, void* out0, float* out1, int32_t variant, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const bf16_t* a = (const bf16_t*)A;
+  const bf16_t* w = (const bf16_t*)W;
+  if (mode == 0) {
+    const int np = (N + 63) / 64;
+    float* rdp = nullptr;
+    float* ones = nullptr;
+    RP_HIP(hipMalloc((void**)&rdp, (size_t)np * M * 4));
+    RP_HIP(hipMalloc((void**)&ones, (size_t)M * 4));
+    std::vector<float> one(M, 1.f);
+    RP_HIP(hipMemcpy(ones, one.data(), (size_t)M * 4, hipMemcpyHostToDevice));
+    RpStatus st = launch_gemm(a, K, M, w, K, N, K, EpiGegluBwd{(const bf16_t*)aux0, (bf16_t*)out0, 2 * N, N, aux1, rdp, np, M},
+                              stream, RP_K_BWD_DGRAD, 0, nullptr, variant);
+    // out1 = sum of the slots (rs = 1, inv_d = 1 turns rowdot_finish into a plain slot sum)
+    if (st == RP_OK)
+      hipLaunchKernelGGL(rowdot_finish_kernel, dim3((M + 63) / 64), dim3(64), 0, stream, (const float*)rdp, np, M,
+                         (const float*)ones, 1.f, out1, M);
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(rdp);
+    (void)hipFree(ones);
+    return st;
+  }
+  return launch_gemm(a, K, M, w, K, N, K,
+                     EpiRmsBwdResid{(bf16_t*)out0, (bf16_t*)out0 + (size_t)M * N, N, N, (const bf16_t*)aux0, aux1}, stream,
+                     RP_K_BWD_DGRAD, 0, nullptr, variant);
+}

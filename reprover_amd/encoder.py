@@ -56,7 +56,6 @@ class HipT5Encoder:
         self.cfg = dict(cfg)
         self.config = SimpleNamespace(hidden_size=cfg["d_model"], **cfg)
         self.max_tokens_per_pass = int(max_tokens_per_pass)
-        self._state_dict_cpu = None
         lib = _lib.load()
         c = _lib.RpT5Config(
             cfg["vocab_size"], cfg["d_model"], cfg["d_kv"], cfg["num_heads"], cfg["d_ff"], cfg["num_layers"],
@@ -89,8 +88,28 @@ class HipT5Encoder:
             del keep
         self._handle = handle
         self._lib = lib
+        self._owner = None
         self._ws: Optional[torch.Tensor] = None
         self._pending_meta: list = []
+        # fp32 host weights, by reference: what a training step starts from (reprover_amd/train.py::HipT5Trainer)
+        self._state_dict_cpu = state_dict
+
+    @classmethod
+    def from_handle(cls, cfg: Dict, handle, device, dtype: torch.dtype, owner) -> "HipT5Encoder":
+        """The inference engine over an RpEncoder owned by someone else (``owner``: a ``HipT5Trainer``, kept alive)."""
+        self = cls.__new__(cls)
+        self.device = _require_gpu(device)
+        self.dtype = dtype
+        self.cfg = dict(cfg)
+        self.config = SimpleNamespace(hidden_size=cfg["d_model"], **cfg)
+        self.max_tokens_per_pass = 1 << 18
+        self._state_dict_cpu = None
+        self._lib = _lib.load()
+        self._handle = handle
+        self._owner = owner
+        self._ws = None
+        self._pending_meta = []
+        return self
 
     # -- construction helpers ---------------------------------------------------------------------
     @classmethod
@@ -124,7 +143,7 @@ class HipT5Encoder:
 
     def __del__(self):
         h = getattr(self, "_handle", None)
-        if h is not None and h.value:
+        if h is not None and h.value and getattr(self, "_owner", None) is None:
             try:
                 self._lib.rp_encoder_destroy(h)
             except Exception:
@@ -188,8 +207,8 @@ class HipT5Encoder:
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
         mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
         assert mask.shape == (B, L)
-        if B * L > self.max_tokens_per_pass:  # rare (huge padded batches): chunk the batch dimension
-            step = max(1, self.max_tokens_per_pass // L)
+        if B * L > self.max_tokens_per_pass and B > 1:  # rare (huge padded batches): chunk the batch dimension;
+            step = max(1, self.max_tokens_per_pass // L)  # a single row always runs as one pass
             return torch.cat([self.encode_padded(ids[i : i + step], mask[i : i + step], defer_check, out_dtype)
                               for i in range(0, B, step)])
         out = torch.empty((B, self.cfg["d_model"]), dtype=out_dtype or self.dtype, device=self.device)
