@@ -167,6 +167,71 @@ def cpu_baseline(cfg, sd_dev, corpus_path, E_dev, state_texts, state_ctx, n_enco
     }
 
 
+def train_step_leg(cfg, sd_dev, dev, batch_size, num_negatives=3, max_seq_len=1024, steps=5):
+    """One training step of the retriever as retrieval/confs/cli_lean4_random.yaml runs it (batch_size 8 per GPU, 3
+    negatives, max_seq_len 1024, AdamW + gradient_clip_val 1.0): forward over the batch's contexts, positives and
+    negatives as ONE packed pass, contrastive MSE and its backward, encoder backward, gradient norm, clipped AdamW over
+    the flat buffers, refresh of the bf16 compute copies.  Contexts draw their lengths from the state mix, premises from
+    the premise mix (both clipped to max_seq_len).  Wall time per step over `steps` steps (synchronised), then the
+    per-class kernel times of an instrumented repeat; GEMM FLOPs: forward linear 2 T P, backward dgrad + wgrad 4 T P
+    (P = the encoder's 217 M linear parameters, T = the pass's padded token count)."""
+    from reprover_amd.train import HipT5Trainer, contrastive_mse, contrastive_mse_backward
+
+    rng = np.random.default_rng(synth.SEED + 900 + batch_size)
+    n_seq = batch_size * (2 + num_negatives)
+    lens = np.concatenate([np.minimum(synth.synth_lengths(rng, batch_size, "mix", lo=16, hi=2048), max_seq_len),
+                           np.minimum(synth.synth_lengths(rng, n_seq - batch_size, "mix", lo=8, hi=2048), max_seq_len)])
+    ids, cu = synth.synth_token_batch(rng, lens)
+    label = torch.zeros(batch_size, batch_size * (1 + num_negatives), device=dev)
+    label[torch.arange(batch_size), torch.arange(batch_size)] = 1.0
+    tr = HipT5Trainer(cfg, {k: v for k, v in sd_dev.items()}, dev, lr=1e-4, warmup_steps=0, gradient_clip_val=1.0)
+
+    def one_step():
+        emb = tr.forward(ids, cu)
+        ctx, prem = emb[:batch_size], emb[batch_size:]
+        loss, sim, lab = contrastive_mse(ctx, prem, label)
+        d_emb = torch.empty_like(emb)
+        contrastive_mse_backward(ctx, prem, sim, lab, d_emb[:batch_size], d_emb[batch_size:])
+        tr.backward(d_emb)
+        tr.optimizer_step()
+        return loss
+
+    l0 = float(one_step())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    _lib.profile_enable(True)
+    for _ in range(steps):
+        one_step()
+    torch.cuda.synchronize()
+    prof = {k: v[0] / steps for k, v in _lib.profile_read().items()}
+    _lib.profile_enable(False)
+    T = int(cu[-1])
+    Tp = (T + 255) // 256 * 256
+    D, F_, inner, L = cfg["d_model"], cfg["d_ff"], cfg["num_heads"] * cfg["d_kv"], cfg["num_layers"]
+    lin = 2.0 * Tp * L * (D * 3 * inner + inner * D + D * 2 * F_ + F_ * D)  # forward linear FLOPs of the pass
+    fwd_gemm_ms = sum(prof[k] for k in ("gemm_qkv", "gemm_o", "gemm_wi", "gemm_wo"))
+    tf = lambda flops, ms_: flops / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
+    out = {
+        "ms_per_step": ms, "sequences": int(n_seq), "tokens": T, "tokens_per_s": T / (ms * 1e-3),
+        "examples_per_s": batch_size / (ms * 1e-3), "loss_first_last": [l0, float(loss)],
+        "kernel_ms_per_step": prof,
+        "forward_gemm_tflops": tf(lin, fwd_gemm_ms), "dgrad_tflops": tf(lin, prof["bwd_dgrad"]),
+        "wgrad_tflops": tf(lin, prof["bwd_wgrad"]),
+        "backward_gemm_tflops": tf(2.0 * lin, prof["bwd_dgrad"] + prof["bwd_wgrad"]),
+        "backward_gemm_mfma_frac": tf(2.0 * lin, prof["bwd_dgrad"] + prof["bwd_wgrad"]) / PEAK_BF16_TFLOPS,
+        "whole_step_mfma_frac": tf(3.0 * lin, ms) / PEAK_BF16_TFLOPS,
+        "config": f"batch_size {batch_size}, {num_negatives} negatives, max_seq_len {max_seq_len}, AdamW lr 1e-4, "
+                  f"gradient_clip_val 1.0, dropout off; one packed pass of {n_seq} sequences",
+    }
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
 def kernel_source_hash() -> str:
     """sha256 (16 hex digits) over the HIP sources: stamps profiles/pmc_traffic.json so that a counter-derived
     traffic figure is only quoted for the kernels it was measured on."""
@@ -198,6 +263,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--premise-sample", type=int, default=4096, help="premises in the encode-throughput leg")
     ap.add_argument("--no-full-reindex", action="store_true", help="skip the 130,000-premise reindex_corpus leg (~20 s)")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the training-step leg")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the premise-encode and scan-only legs (used under rocprofv3 so that every launch of "
                          "the dominant kernel has the step's shape and the stats average is comparable)")
@@ -525,6 +591,13 @@ def main():
                                "host, packed varlen encode on the GPU; BASELINE configs[3] at N = 1"}
             del r2
 
+    # ---- N = 1 only: the training step at the reference's training configuration -------------
+    train = None
+    if world == 1 and not args.headline_only and not args.no_train_step:
+        train = {}
+        for name, bsz in (("reference_conf_batch8", 8), ("batch64", 64)):
+            train[name] = train_step_leg(cfg, sd, dev, bsz)
+
     result = {
         "metric": "retrieve QPS@top-100 (state encode + masked similarity top-k), ByT5-small, 130k-premise corpus",
         "value": qps,
@@ -572,6 +645,7 @@ def main():
             "mfma_frac": (2.0 * BQ * n_loc * D * args.steps / (scan_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if scan_ms > 0 else 0.0,
             "select_ms_per_step": prof["select"][0] / args.steps,
         },
+        "train_step": train,
         "all_encoder_gemms_tflops": all_gemm_tf,
         "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
     }

@@ -315,7 +315,8 @@ RpStatus rp_dbg_attention(const void* qkv_bf16, const int32_t* cu_seqlens, const
                           void* out_bf16, int32_t batch, int32_t max_len, int32_t num_heads,
                           int32_t rows_total, void* stream);
 /* Training kernels in isolation (tests/test_train_kernels_gpu.py).
- *   rp_dbg_wgrad: out f32 [splits, ny, nx], partial s = Y[rows of split s]^T X;  Y bf16 [T, ny], X bf16 [T, nx], T % 64 == 0.
+ *   rp_dbg_wgrad: out f32 [|splits|, ny, nx], partial s = Y[rows of split s]^T X;  Y bf16 [T, ny], X bf16 [T, nx], T % 64 == 0;
+ *     splits > 0: 256 x 256 tiles, splits < 0: 128 x 128 tiles.
  *   rp_dbg_attention_bwd: runs the forward (att_out, lse_out [H, rows_total]) and both backward kernels on packed qkv;
  *     att = the O the backward uses for delta (NULL: att_out); dqkv bf16 [rows_total, 3*H*64] (rows of real tokens written);
  *     dtab f32 [2*128+1, H]: gradient of the [H, 257] bias table, transposed.  Synchronises.

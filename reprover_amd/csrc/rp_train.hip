@@ -94,14 +94,37 @@ struct TrainWs {
   size_t bytes;
 };
 
-constexpr int WG_SLOTS = 512;  // wgrad launches aim at about this many workgroups (256 CUs, one 128-KiB block each: 2 rounds)
-
-int wgrad_splits(int rows, int cols, int nk) {
-  const int tiles = ((rows + 255) / 256) * ((cols + 255) / 256);
-  int s = (WG_SLOTS + tiles - 1) / tiles;
-  s = std::min(s, std::max(1, nk / 4));
-  return std::max(1, std::min(s, 32));
+// How a wgrad GEMM [rows x cols] over nk token tiles is launched: tile configuration (0: 256 x 256, one 128-KiB
+// workgroup per CU; 1: 128 x 128, two per CU) and split-K count, by a small cost model - rounds of workgroups x time of
+// one workgroup's K range, plus the traffic of the fp32 partial matrices (written once, read once by the finishing
+// kernel).  Deterministic in (rows, cols, nk): the same plan sizes the workspace and drives the launch.
+struct WgradPlan {
+  int cfg, splits;
+};
+WgradPlan plan_wgrad(int rows, int cols, int nk) {
+  const double cu_rate = 1.0e15 / 256;       // sustained MFMA rate of one CU on these loops, FLOP/s
+  const double hbm = 4.0e12;                 // partial-matrix traffic, B/s
+  WgradPlan best{0, 1};
+  double best_t = 1e30;
+  for (int cfg = 0; cfg < 2; ++cfg) {
+    const int b = cfg == 0 ? 256 : 128;
+    const int slots = cfg == 0 ? 256 : 512;
+    const double rate = cfg == 0 ? cu_rate : cu_rate * 0.7 / 2;  // per workgroup
+    const int tiles = ((rows + b - 1) / b) * ((cols + b - 1) / b);
+    for (int s = 1; s <= 32 && s * 4 <= std::max(nk, 4); ++s) {
+      const int rounds = (tiles * s + slots - 1) / slots;
+      const double t_wg = 2.0 * b * b * 64.0 * ((nk + s - 1) / s) / rate;
+      const double t_part = s > 1 ? 2.0 * s * (double)rows * cols * 4 / hbm : 0.0;
+      const double tt = rounds * t_wg + t_part + 3e-6;
+      if (tt < best_t) {
+        best_t = tt;
+        best = WgradPlan{cfg, s};
+      }
+    }
+  }
+  return best;
 }
+int wgrad_splits(int rows, int cols, int nk) { return plan_wgrad(rows, cols, nk).splits; }
 
 TrainWs carve_train(const RpTrainer* tr, int T, int batch, char* base) {
   const RpT5Config& c = tr->enc->cfg;
@@ -183,8 +206,12 @@ RpStatus launch_wgrad_cfg(const bf16_t* Y, int ldy, int ny, const bf16_t* X, int
 
 // dW[ny, nx] (fp32, ldc = nx) = Y[:Tp, :ny]^T X[:Tp, :nx]; `splits` partial matrices at out + s * ny * nx
 RpStatus launch_wgrad(const bf16_t* Y, int ldy, int ny, const bf16_t* X, int ldx, int nx, int Tp, int splits, float* out,
-                      hipStream_t stream) {
+                      hipStream_t stream, int force_cfg = -1) {
   RP_REQUIRE(Tp % 64 == 0 && ny % 8 == 0 && nx % 8 == 0 && ny >= 8 && nx >= 8, "wgrad: Tp=%d ny=%d nx=%d", Tp, ny, nx);
+  const int cfg = force_cfg >= 0 ? force_cfg : plan_wgrad(ny, nx, Tp / 64).cfg;
+  if (cfg == 1)
+    return launch_wgrad_cfg<WgradCfg<128, 128, 2, 2, 2>>(Y, ldy, ny, X, ldx, nx, Tp / 64, splits, out, nx, (size_t)ny * nx,
+                                                         stream);
   return launch_wgrad_cfg<WgradCfg<256, 256, 4, 2, 2>>(Y, ldy, ny, X, ldx, nx, Tp / 64, splits, out, nx, (size_t)ny * nx,
                                                        stream);
 }
@@ -277,7 +304,7 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
     ProfScope ps(stream, RP_K_BWD_OTHER);
     hipLaunchKernelGGL(pool_bwd_seq_kernel, dim3(batch), dim3(256), 0, stream, (const float*)w.pool, (const float*)e->final_ln, cu,
                        d_emb, w.ds_seq, w.dwf_seq, D);
-    hipLaunchKernelGGL(colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, (const float*)w.dwf_seq, batch, D,
+    hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(256), 0, stream, (const float*)w.dwf_seq, batch, D,
                        grads + lay.final_ln());
     const dim3 pg(T / POOL_CHUNK + batch);
     if (D <= 3 * 512)
@@ -324,7 +351,7 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
       a.ln = params + lay.layer(i, P_LN_FF); a.dln_part = w.dln_part;
       if ((st = run_unfold(a, stream))) return st;
       ProfScope ps(stream, RP_K_BWD_OTHER);
-      hipLaunchKernelGGL(colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, (const float*)w.dln_part, (2 * F + 31) / 32,
+      hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(256), 0, stream, (const float*)w.dln_part, (2 * F + 31) / 32,
                          D, grads + lay.layer(i, P_LN_FF));
     }
     // dx += dzs Wi' - x rcoef   (RMSNorm backward in the epilogue)
@@ -373,7 +400,7 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
       a.ln = params + lay.layer(i, P_LN_ATTN); a.dln_part = w.dln_part;
       if ((st = run_unfold(a, stream))) return st;
       ProfScope ps(stream, RP_K_BWD_OTHER);
-      hipLaunchKernelGGL(colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, (const float*)w.dln_part, (3 * inner + 31) / 32,
+      hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(256), 0, stream, (const float*)w.dln_part, (3 * inner + 31) / 32,
                          D, grads + lay.layer(i, P_LN_ATTN));
     }
     if ((st = launch_gemm(w.dqkv, 3 * inner, Tp, Lt.wqkv_t, 3 * inner, D, 3 * inner,
@@ -560,8 +587,10 @@ extern "C" RpStatus rp_grad_norm(const float* grads, int64_t n, float* out_norm,
 // ---- kernel-level test entry points ------------------------------------------------------------------------
 extern "C" RpStatus rp_dbg_wgrad(const void* Y, const void* X, float* out, int32_t T, int32_t ny, int32_t nx, int32_t splits,
                                  void* stream_) {
-  RP_REQUIRE(Y && X && out && splits >= 1, "bad argument");
-  return launch_wgrad((const bf16_t*)Y, ny, ny, (const bf16_t*)X, nx, nx, T, splits, out, (hipStream_t)stream_);
+  RP_REQUIRE(Y && X && out && splits != 0, "bad argument");
+  // splits < 0: |splits| partial matrices with the 128 x 128 tile configuration (> 0: the 256 x 256 one)
+  return launch_wgrad((const bf16_t*)Y, ny, ny, (const bf16_t*)X, nx, nx, T, splits < 0 ? -splits : splits, out,
+                      (hipStream_t)stream_, splits < 0 ? 1 : 0);
 }
 
 extern "C" RpStatus rp_dbg_attention_bwd(const void* qkv, const void* att, const void* datt, const int32_t* cu,

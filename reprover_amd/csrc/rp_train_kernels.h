@@ -830,46 +830,75 @@ struct UnfoldArgs {
   const float* ln;       // [C] RMSNorm weight folded into the packed matrix (QKV, GEGLU)
   float* dln_part;       // [rows / 32][C] per-row-block partial column sums of dW' .* W
 };
-// grid = (ceil(C / 256), rows / 32): thread = one column of a 32-row block
+// grid = (ceil(C / 256), ceil(rows / 32)), 256 threads: a 32-row x 256-column tile, wave w takes rows 8 w .. 8 w + 7,
+// a lane 4 consecutive columns (16-byte accesses; every load of a row - the S partials, the master weight - is
+// independent of the others).  The norm-weight gradient's row-block partial is combined over the waves in wave order.
 __global__ __launch_bounds__(256) void unfold_kernel(UnfoldArgs a) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= a.C) return;
-  const int r0 = blockIdx.y * 32;
-  const float lnv = a.mode == UNFOLD_PLAIN ? 1.f : a.ln[c];
-  float dl = 0.f;
-  for (int i = 0; i < 32 && r0 + i < a.rows; ++i) {
-    const int r = r0 + i;
-    float s = 0.f;
-    for (int k = 0; k < a.splits; ++k) s += a.part[(size_t)k * a.split_stride + (size_t)r * a.C + c];
-    if (a.mode == UNFOLD_PLAIN) {
-      a.g0[(size_t)r * a.C + c] = s;
-    } else {
-      int which, sr;
-      if (a.mode == UNFOLD_QKV) {
-        which = r / a.n;
-        sr = r - which * a.n;
-      } else {
-        which = (r >> 5) & 1;
-        sr = (r >> 6) * 32 + (r & 31);
+  __shared__ float4 red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const bool live = c < a.C;  // C % 4 == 0
+  const int r0 = blockIdx.y * 32 + wave * 8;
+  const float4 lnv = (a.mode == UNFOLD_PLAIN || !live) ? make_float4(1.f, 1.f, 1.f, 1.f)
+                                                       : *reinterpret_cast<const float4*>(a.ln + c);
+  float4 dl = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+#pragma unroll 2
+    for (int i = 0; i < 8; ++i) {
+      const int r = r0 + i;
+      if (r >= a.rows) break;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < a.splits; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(a.part + (size_t)k * a.split_stride + (size_t)r * a.C + c);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
-      float* g = which == 0 ? a.g0 : which == 1 ? a.g1 : a.g2;
-      const float* w = which == 0 ? a.w0 : which == 1 ? a.w1 : a.w2;
-      const size_t o = (size_t)sr * a.C + c;
-      g[o] = s * lnv;
-      dl = __builtin_fmaf(s, w[o], dl);
+      if (a.mode == UNFOLD_PLAIN) {
+        *reinterpret_cast<float4*>(a.g0 + (size_t)r * a.C + c) = s;
+      } else {
+        int which, sr;
+        if (a.mode == UNFOLD_QKV) {
+          which = r / a.n;
+          sr = r - which * a.n;
+        } else {
+          which = (r >> 5) & 1;
+          sr = (r >> 6) * 32 + (r & 31);
+        }
+        float* g = which == 0 ? a.g0 : which == 1 ? a.g1 : a.g2;
+        const float* w = which == 0 ? a.w0 : which == 1 ? a.w1 : a.w2;
+        const size_t o = (size_t)sr * a.C + c;
+        const float4 wv = *reinterpret_cast<const float4*>(w + o);
+        *reinterpret_cast<float4*>(g + o) = make_float4(s.x * lnv.x, s.y * lnv.y, s.z * lnv.z, s.w * lnv.w);
+        dl.x = __builtin_fmaf(s.x, wv.x, dl.x);
+        dl.y = __builtin_fmaf(s.y, wv.y, dl.y);
+        dl.z = __builtin_fmaf(s.z, wv.z, dl.z);
+        dl.w = __builtin_fmaf(s.w, wv.w, dl.w);
+      }
     }
   }
-  if (a.mode != UNFOLD_PLAIN) a.dln_part[(size_t)blockIdx.y * a.C + c] = dl;
+  if (a.mode == UNFOLD_PLAIN) return;
+  red[wave][lane] = dl;
+  __syncthreads();
+  if (wave == 0 && live) {
+    const float4 p0 = red[0][lane], p1 = red[1][lane], p2 = red[2][lane], p3 = red[3][lane];
+    *reinterpret_cast<float4*>(a.dln_part + (size_t)blockIdx.y * a.C + c) =
+        make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
+                    (p0.w + p1.w) + (p2.w + p3.w));
+  }
 }
 
-// out[c] = sum_r part[r][c] in row order
+// out[c] = sum_r part[r][c]: 64 columns per workgroup, wave w sums rows w, w + 4, ... in order, then the four wave sums
+// in wave order (fixed association: deterministic)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int rows, int C,
                                                      float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += part[(size_t)r * C + c];
-  out[c] = s;
+  if (c < C)
+    for (int r = wave; r < rows; r += 4) s += part[(size_t)r * C + c];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < C) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // relative_attention_bias.weight's gradient: column sums of the workgroups' table rows, then offsets -> buckets

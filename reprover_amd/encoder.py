@@ -139,7 +139,23 @@ class HipT5Encoder:
         return cls(cfg, sd, device, dtype)
 
     def save_pretrained(self, path: str) -> None:
-        raise NotImplementedError("saving checkpoints is outside the retrieval hot path")
+        """Write an HF-layout checkpoint directory (config.json + model.safetensors) that ``from_pretrained`` - and
+        ``transformers``' T5EncoderModel - read back: the trainer's current fp32 masters when this engine belongs to a
+        ``HipT5Trainer``, else the weights it was built from."""
+        from safetensors.torch import save_file
+
+        sd = self._owner.state_dict() if self._owner is not None else self._state_dict_cpu
+        if sd is None:
+            raise RuntimeError("this encoder holds no fp32 weights to save")
+        os.makedirs(path, exist_ok=True)
+        hf = {k: v for k, v in self.cfg.items()}
+        hf.update(model_type="t5", architectures=["T5EncoderModel"], dropout_rate=0.1, tie_word_embeddings=False,
+                  num_decoder_layers=0, is_encoder_decoder=False)
+        with open(os.path.join(path, "config.json"), "w") as fh:
+            json.dump(hf, fh, indent=1)
+        keep = {k: v.detach().to(torch.float32).cpu().contiguous().clone() for k, v in sd.items()
+                if k != "encoder.embed_tokens.weight"}  # tied to shared.weight: stored once
+        save_file(keep, os.path.join(path, "model.safetensors"))
 
     def __del__(self):
         h = getattr(self, "_handle", None)

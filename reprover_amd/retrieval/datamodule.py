@@ -1,16 +1,16 @@
-"""Evaluation-side data loading of the retriever — the inference half of the reference's
-``retrieval/datamodule.py`` (lean-dojo/ReProver): one example per traced tactic
-(``RetrievalDataset._load_data`` with ``is_train=False``, datamodule.py:44-90), context tokenisation
-in ``collate`` (:130-144), and the val / predict splits (:234-267).  Of the training half only the
-deterministic part is here: ``collate_train`` (the positive / negative tokenisation and the label matrix of
-datamodule.py:146-191), which feeds ``PremiseRetriever.forward``; the random negative sampling of
-``__getitem__`` (:95-128) is not.
+"""Data loading of the retriever - the host side of the reference's ``retrieval/datamodule.py`` (lean-dojo/ReProver):
+one example per traced tactic for evaluation / prediction (``_load_data`` with ``is_train=False``, datamodule.py:44-90),
+one per (tactic, positive premise) for training (:60-75); negative sampling for training examples (``__getitem__``,
+:95-128: in-file negatives first, the rest from the other accessible files); context tokenisation (``collate``,
+:130-144) and the training collate (:146-191: positives, negative lists, label matrix), which feeds
+``PremiseRetriever.forward`` / ``training_step``; the train / val / predict splits (:234-267).
 """
 from __future__ import annotations
 
 import json
 import os
-from typing import Any, Dict, Iterator, List, Optional
+import random
+from typing import Any, Dict, Iterator, List, Optional, Tuple
 
 from ..common import Context, Corpus, Pos, get_all_pos_premises
 
@@ -19,45 +19,75 @@ Batch = Dict[str, Any]
 
 
 class RetrievalDataset:
-    def __init__(self, data_paths: List[str], corpus: Corpus, max_seq_len: int, tokenizer, is_train: bool = False):
-        assert not is_train, "the training branch (negatives, labels) is outside the retrieval hot path"
+    def __init__(self, data_paths: List[str], corpus: Corpus, max_seq_len: int, tokenizer, is_train: bool = False,
+                 num_negatives: int = 0, num_in_file_negatives: int = 0):
+        assert 0 <= num_in_file_negatives <= num_negatives or not is_train
         self.corpus = corpus
         self.max_seq_len = max_seq_len
         self.tokenizer = tokenizer
-        self.is_train = False
+        self.is_train = is_train
+        self.num_negatives = num_negatives
+        self.num_in_file_negatives = num_in_file_negatives
         self.data: List[Example] = []
         for path in data_paths:
             self.data.extend(self._load_data(path))
 
     def _load_data(self, data_path: str) -> List[Example]:
-        data = []
         with open(data_path) as fh:
             theorems = json.load(fh)
+        data = []
         for thm in theorems:
-            file_path = thm["file_path"]
+            head = {k: thm[k] for k in ("url", "commit", "file_path", "full_name", "start")}
             for i, tac in enumerate(thm["traced_tactics"]):
-                context = Context(file_path, thm["full_name"], Pos(*thm["start"]), tac["state_before"])
-                data.append(
-                    {
-                        "url": thm["url"],
-                        "commit": thm["commit"],
-                        "file_path": thm["file_path"],
-                        "full_name": thm["full_name"],
-                        "start": thm["start"],
-                        "tactic_idx": i,
-                        "context": context,
-                        "all_pos_premises": get_all_pos_premises(tac["annotated_tactic"], self.corpus),
-                    }
-                )
+                ex = dict(head, tactic_idx=i,
+                          context=Context(thm["file_path"], thm["full_name"], Pos(*thm["start"]), tac["state_before"]))
+                all_pos = get_all_pos_premises(tac["annotated_tactic"], self.corpus)
+                if not self.is_train:
+                    data.append(dict(ex, all_pos_premises=all_pos))
+                    continue
+                for pos in all_pos:  # training: tactics without premises contribute nothing (datamodule.py:60-75)
+                    data.append(dict(ex, pos_premise=pos, all_pos_premises=all_pos))
         return data
+
+    def negative_pools(self, ex: Example) -> Tuple[List[int], List[int]]:
+        """Premise indexes a training example may draw negatives from (datamodule.py:100-118): ``in_file`` = the other
+        premises of the positive's file - when that is the theorem's own file only those that END BEFORE the theorem
+        (strictly, unlike accessibility's <=); ``outside`` = the premises of every other (transitively) imported
+        file, plus the theorem's own earlier premises when the positive lives elsewhere."""
+        c = self.corpus
+        ctx, pos = ex["context"], ex["pos_premise"]
+        prem = c.all_premises
+        f = c._index[ctx.path]
+        own = [i for i in range(int(c._file_start[f]), int(c._file_start[f + 1]))
+               if prem[i] != pos and prem[i].end < ctx.theorem_pos]
+        same_file = pos.path == ctx.path
+        in_file, outside = (own, []) if same_file else ([], own)
+        for g in c._reach_ids(f):
+            rng = range(int(c._file_start[g]), int(c._file_start[g + 1]))
+            if c._files[g].path == pos.path:
+                in_file += [i for i in rng if prem[i] != pos]
+            else:
+                outside += rng
+        return in_file, outside
+
+    def with_negatives(self, ex: Example) -> Example:
+        """A copy of the example with ``neg_premises`` drawn as the reference draws them: up to
+        ``num_in_file_negatives`` from the in-file pool, the rest from the outside pool (Python's ``random``, so
+        ``random.seed`` governs it; ``ValueError`` from ``random.sample`` when a pool is too small, as upstream)."""
+        in_file, outside = self.negative_pools(ex)
+        k_in = min(len(in_file), self.num_in_file_negatives)
+        picked = random.sample(in_file, k_in) + random.sample(outside, self.num_negatives - k_in)
+        return dict(ex, neg_premises=[self.corpus.all_premises[i] for i in picked])
 
     def __len__(self) -> int:
         return len(self.data)
 
     def __getitem__(self, idx: int) -> Example:
-        return self.data[idx]
+        return self.with_negatives(self.data[idx]) if self.is_train else self.data[idx]
 
     def collate(self, examples: List[Example]) -> Batch:
+        if self.is_train:
+            return collate_train(examples, self.tokenizer, self.max_seq_len, self.num_negatives)
         context = [ex["context"] for ex in examples]
         tok = self.tokenizer(
             [c.serialize() for c in context], padding="longest", max_length=self.max_seq_len, truncation=True,
@@ -73,6 +103,14 @@ class RetrievalDataset:
         """In-order, drop_last=False — what the reference's eval DataLoaders yield."""
         for i in range(0, len(self.data), batch_size):
             yield self.collate(self.data[i : i + batch_size])
+
+    def train_batches(self, batch_size: int) -> Iterator[Batch]:
+        """One epoch as the reference's train DataLoader yields it (datamodule.py:255-264: shuffle=True,
+        drop_last=True), negatives drawn per example as it is fetched."""
+        order = list(range(len(self.data)))
+        random.shuffle(order)
+        for i in range(0, len(order) - batch_size + 1, batch_size):
+            yield self.collate([self[j] for j in order[i : i + batch_size]])
 
 
 def label_matrix(examples: List[Example], num_negatives: int):
@@ -116,16 +154,21 @@ def collate_train(examples: List[Example], tokenizer, max_seq_len: int, num_nega
 
 
 class RetrievalDataModule:
-    """``data_path`` holds ``{train,val,test}.json``; ``corpus_path`` is ``corpus.jsonl``
-    (datamodule.py:201-228).  Only the val and predict splits are built."""
+    """``data_path`` holds ``{train,val,test}.json``; ``corpus_path`` is ``corpus.jsonl`` (datamodule.py:201-267)."""
 
     def __init__(self, data_path: str, corpus_path: str, eval_batch_size: int, max_seq_len: int, tokenizer,
-                 corpus: Optional[Corpus] = None, **_ignored_training_args) -> None:
+                 corpus: Optional[Corpus] = None, num_negatives: int = 0, num_in_file_negatives: int = 0,
+                 batch_size: int = 0, **_ignored) -> None:
+        assert 0 <= num_in_file_negatives <= num_negatives
         self.data_path = data_path
+        self.batch_size = batch_size
         self.eval_batch_size = eval_batch_size
         self.max_seq_len = max_seq_len
+        self.num_negatives = num_negatives
+        self.num_in_file_negatives = num_in_file_negatives
         self.tokenizer = tokenizer
         self.corpus = corpus if corpus is not None else Corpus(corpus_path)
+        self.ds_train: Optional[RetrievalDataset] = None
         self.ds_val: Optional[RetrievalDataset] = None
         self.ds_pred: Optional[RetrievalDataset] = None
 
@@ -133,11 +176,18 @@ class RetrievalDataModule:
         def split(name):
             return os.path.join(self.data_path, f"{name}.json")
 
+        if stage in (None, "fit"):
+            self.ds_train = RetrievalDataset([split("train")], self.corpus, self.max_seq_len, self.tokenizer, is_train=True,
+                                             num_negatives=self.num_negatives,
+                                             num_in_file_negatives=self.num_in_file_negatives)
         if stage in (None, "fit", "validate"):
             self.ds_val = RetrievalDataset([split("val")], self.corpus, self.max_seq_len, self.tokenizer)
         if stage in (None, "fit", "predict"):
             self.ds_pred = RetrievalDataset([split(s) for s in ("train", "val", "test")], self.corpus,
                                             self.max_seq_len, self.tokenizer)
+
+    def train_dataloader(self) -> Iterator[Batch]:
+        return self.ds_train.train_batches(self.batch_size)
 
     def val_dataloader(self) -> Iterator[Batch]:
         return self.ds_val.batches(self.eval_batch_size)

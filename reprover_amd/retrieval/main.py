@@ -1,10 +1,10 @@
-"""``predict`` / ``validate`` driver of the retriever — stands in for the reference's
-``python retrieval/main.py {predict,validate} --config …`` (retrieval/main.py:12-21, a LightningCLI)
-for the inference subcommands.  Reads the same YAML keys the reference's configs use
-(``model.model_name``, ``model.num_retrieved``, ``data.data_path``, ``data.corpus_path``,
-``data.eval_batch_size``, ``data.max_seq_len``; retrieval/confs/*.yaml) and writes
-``<log_dir>/predictions.pickle`` exactly as ``on_predict_epoch_end`` does (model.py:329-336).
-Lightning itself is out of scope; the hooks' bodies live in ``model.py`` here as they do upstream.
+"""``fit`` / ``predict`` / ``validate`` driver of the retriever — stands in for the reference's
+``python retrieval/main.py {fit,predict,validate} --config …`` (retrieval/main.py:12-21, a LightningCLI).
+Reads the same YAML keys the reference's configs use (``model.{model_name,lr,warmup_steps,num_retrieved}``,
+``data.{data_path,corpus_path,num_negatives,num_in_file_negatives,batch_size,eval_batch_size,max_seq_len}``,
+``trainer.{max_steps,gradient_clip_val}``; retrieval/confs/*.yaml) and writes ``<log_dir>/predictions.pickle`` exactly
+as ``on_predict_epoch_end`` does (model.py:329-336).  Lightning itself is out of scope; the hooks' bodies live in
+``model.py`` here as they do upstream, and ``run_fit`` calls them in Lightning's order.
 
 Multi-GPU ``predict``: launch under ``python -m torch.distributed.run --nproc-per-node N -m
 reprover_amd.retrieval.main predict ...``.  Every rank walks the same batches; the index is row-sharded
@@ -40,12 +40,43 @@ def run_predict(model: PremiseRetriever, dm: RetrievalDataModule, log_dir: Optio
     return count
 
 
+def run_fit(model: PremiseRetriever, dm: RetrievalDataModule, max_steps: int, val_every: int = 0, log=print) -> Dict[str, Any]:
+    """The training loop Lightning runs for the reference (model.py:146-181): on_fit_start, then per batch
+    training_step (forward + backward) → optimizer.step (clipping, AdamW) → scheduler.step → on_train_batch_end;
+    epochs until ``max_steps``; validation every ``val_every`` steps (0: never)."""
+    if dm.ds_train is None:
+        dm.setup("fit")
+    model.on_fit_start(dm.corpus)
+    opt = model.configure_optimizers()
+    optimizer, scheduler = opt["optimizer"], opt["lr_scheduler"]["scheduler"]
+    step, losses = 0, []
+    while step < max_steps:
+        n_epoch = 0
+        for batch in dm.train_dataloader():
+            loss = model.training_step(batch, step)
+            optimizer.step()
+            scheduler.step()
+            model.on_train_batch_end(loss, batch, step)
+            losses.append(loss)
+            step += 1
+            n_epoch += 1
+            if val_every and step % val_every == 0:
+                log(f"step {step}: {run_validate(model, dm)}")
+            if step >= max_steps:
+                break
+        if n_epoch == 0:
+            raise ValueError("the training split yields no full batch (drop_last=True)")
+    return {"steps": step, "losses": [float(x) for x in losses]}
+
+
 def run_validate(model: PremiseRetriever, dm: RetrievalDataModule) -> Dict[str, Any]:
     """on_validation_start + validation_step over the val split (model.py:212-268); returns the
     epoch-level Recall@k (k = 1..num_retrieved, in %) and MRR, weighted by examples with premises as
     the reference's ``self.log(..., batch_size=num_with_premises)`` does."""
-    dm.setup("validate")
-    model.load_corpus(dm.corpus)
+    if dm.ds_val is None:
+        dm.setup("validate")
+    if model.corpus is not dm.corpus:
+        model.load_corpus(dm.corpus)
     model.reindex_corpus(dm.eval_batch_size)
     k = model.num_retrieved
     tot_recall = [0.0] * k
@@ -67,8 +98,10 @@ def run_validate(model: PremiseRetriever, dm: RetrievalDataModule) -> Dict[str, 
 
 
 def main(argv=None) -> None:
-    ap = argparse.ArgumentParser(description="Premise retriever: predict / validate on MI355X.")
-    ap.add_argument("subcommand", choices=["predict", "validate"])
+    ap = argparse.ArgumentParser(description="Premise retriever: fit / predict / validate on MI355X.")
+    ap.add_argument("subcommand", choices=["fit", "predict", "validate"])
+    ap.add_argument("--max-steps", type=int, default=None, help="fit: overrides trainer.max_steps")
+    ap.add_argument("--val-every", type=int, default=0, help="fit: validate every N steps (0: never)")
     ap.add_argument("--config", required=True, help="YAML with `model:` and `data:` sections (reference layout)")
     ap.add_argument("--ckpt_path", default=None, help="HF checkpoint dir (overrides model.model_name)")
     ap.add_argument("--log-dir", default=None, help="where predictions.pickle goes (trainer.log_dir upstream)")
@@ -93,8 +126,23 @@ def main(argv=None) -> None:
     model = PremiseRetriever.load_hf(args.ckpt_path or m["model_name"], d["max_seq_len"], device)
     model.num_retrieved = m.get("num_retrieved", 100)
     model.shard_index_over_ranks = world > 1 and args.subcommand == "predict"
-    dm = RetrievalDataModule(d["data_path"], d["corpus_path"], d["eval_batch_size"], d["max_seq_len"], model.tokenizer)
-    if args.subcommand == "predict":
+    dm = RetrievalDataModule(d["data_path"], d["corpus_path"], d["eval_batch_size"], d["max_seq_len"], model.tokenizer,
+                             num_negatives=d.get("num_negatives", 0), num_in_file_negatives=d.get("num_in_file_negatives", 0),
+                             batch_size=d.get("batch_size", 0))
+    if args.subcommand == "fit":
+        assert world == 1, "fit runs one process (data-parallel training is not part of this path)"
+        tcfg = cfg.get("trainer", {})
+        model.lr, model.warmup_steps = float(m.get("lr", 0.0)), int(m.get("warmup_steps", 0))
+        model.gradient_clip_val = tcfg.get("gradient_clip_val")
+        seed = cfg.get("seed_everything")
+        if seed is not None:
+            import random
+
+            random.seed(int(seed))
+            torch.manual_seed(int(seed))
+        out = run_fit(model, dm, args.max_steps or int(tcfg.get("max_steps", 1)), args.val_every)
+        print(f"fit: {out['steps']} steps, loss {out['losses'][0]:.6f} -> {out['losses'][-1]:.6f}")
+    elif args.subcommand == "predict":
         log_dir = args.log_dir or cfg.get("trainer", {}).get("default_root_dir") or os.getcwd()
         os.makedirs(log_dir, exist_ok=True)
         n = run_predict(model, dm, log_dir if rank == 0 else None)

@@ -3,9 +3,11 @@
 
 Same names, argument meaning and error behaviour as the reference for:
 ``load_hf`` (model.py:52-66), ``load_corpus`` (:68-85), ``embedding_size`` (:87-90), ``_encode``
-(:92-114), ``reindex_corpus`` (:183-210), ``retrieve`` (:338-375) and the predict hooks' bodies
-(:274-336), plus the FORWARD of the training loss (``forward``, :116-140).  Backward, ``training_step`` and the
-optimizers are out of scope (last in the ranking, forward first).
+(:92-114), ``reindex_corpus`` (:183-210), ``retrieve`` (:338-375), the predict hooks' bodies
+(:274-336), the training loss ``forward`` (:116-140) and the training hooks ``on_fit_start`` / ``training_step`` /
+``on_train_batch_end`` / ``configure_optimizers`` (:146-181).  There is no autograd graph: ``training_step`` runs the
+forward AND the hand-written backward (reprover_amd/train.py, csrc/rp_train.hip) and leaves every parameter's gradient
+in the trainer's flat buffer; the optimizer object ``configure_optimizers`` returns applies the clipped AdamW update.
 
 What is different underneath: the encoder forward, pooling, similarity, masking and top-k all
 run in hand-written HIP kernels behind the C ABI of libreprover_hip.so; premises are encoded as
@@ -24,6 +26,41 @@ import torch
 from ..common import Context, Corpus, Fp8Index, IndexedCorpus, Pos, Premise, load_index, zip_strict
 from ..encoder import HipT5Encoder
 from ..tokenizer import ByT5Tokenizer
+
+
+class _TrainerOptimizer:
+    """What ``configure_optimizers`` hands out as "optimizer": ``step()`` = gradient clipping + one AdamW update over the
+    trainer's flat buffers + refresh of the bf16 compute copies; ``zero_grad()`` is a no-op (the backward overwrites)."""
+
+    def __init__(self, trainer, model):
+        self.trainer, self.model = trainer, model
+
+    def step(self) -> None:
+        self.trainer.gradient_clip_val = self.model.gradient_clip_val
+        self.trainer.optimizer_step()
+        self.model.embeddings_staled = True
+        self.model._drop_derived()
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        pass
+
+    @property
+    def param_groups(self):
+        return [{"lr": self.trainer.current_lr()}]
+
+
+class _TrainerSchedule:
+    """``get_constant_schedule_with_warmup``: the factor is a function of the optimizer steps taken, which the trainer
+    counts itself, so ``step()`` has nothing to advance."""
+
+    def __init__(self, trainer):
+        self.trainer = trainer
+
+    def step(self) -> None:
+        pass
+
+    def get_last_lr(self):
+        return [self.trainer.current_lr()]
 
 
 class PremiseRetriever:
@@ -70,6 +107,9 @@ class PremiseRetriever:
         # kernels one by one as the batch paths do.
         self.use_graphs = True
         self._single_query = None
+        # training (lazily built by training_step / configure_optimizers: fp32 masters, gradients, AdamW moments)
+        self._trainer = None
+        self.gradient_clip_val: Optional[float] = None  # Lightning's trainer.gradient_clip_val (confs/*.yaml: 1.0)
 
     # -- construction (model.py:52-66) --------------------------------------------------------------
     @classmethod
@@ -231,6 +271,53 @@ class PremiseRetriever:
         return loss
 
     __call__ = forward
+
+    # -- training (model.py:146-181) ------------------------------------------------------------------
+    def train_engine(self):
+        """The ``HipT5Trainer`` behind ``training_step`` (built on first use from the encoder's fp32 weights); from then
+        on ``self.encoder`` is the inference engine over the trainer's CURRENT weights."""
+        if self._trainer is None:
+            from ..train import HipT5Trainer
+
+            sd = getattr(self.encoder, "_state_dict_cpu", None)
+            if sd is None:
+                raise RuntimeError("training needs the encoder's fp32 weights (build the retriever from a checkpoint "
+                                   "or a state dict)")
+            self._trainer = HipT5Trainer(self.encoder.cfg, sd, self.device, lr=self.lr, warmup_steps=self.warmup_steps,
+                                         gradient_clip_val=self.gradient_clip_val, out_dtype=self.encoder.dtype)
+            self.encoder = self._trainer.encoder
+            self._drop_derived()
+        return self._trainer
+
+    def on_fit_start(self, corpus: Optional[Corpus] = None) -> None:
+        """model.py:146-153: take the datamodule's corpus; its embeddings are stale from here on."""
+        if corpus is not None:
+            self.corpus = corpus
+        self._drop_derived()
+        self.corpus_embeddings = None
+        self.embeddings_staled = True
+
+    def training_step(self, batch: Dict[str, Any], _=None) -> torch.Tensor:
+        """model.py:155-167: the contrastive loss of ``forward`` on a training batch (``collate`` with is_train) - and,
+        since nothing records a graph here, its backward: on return every parameter's gradient lies in
+        ``train_engine().grads`` (all five encodes run as ONE packed pass).  Returns the loss (0-dim fp32 device tensor)."""
+        tr = self.train_engine()
+        groups = [(batch["context_ids"], batch["context_mask"]), (batch["pos_premise_ids"], batch["pos_premise_mask"])]
+        groups += list(zip_strict(batch["neg_premises_ids"], batch["neg_premises_mask"]))
+        loss, sim = tr.contrastive_step(groups, batch["label"])
+        self.last_similarity = sim
+        return loss
+
+    def on_train_batch_end(self, outputs=None, batch=None, _=None) -> None:
+        """model.py:169-171."""
+        self.embeddings_staled = True
+
+    def configure_optimizers(self) -> Dict[str, Any]:
+        """common.py:381-405 (``get_optimizers``): AdamW(lr) under the constant schedule with linear warm-up, the
+        scheduler stepping once per optimizer step - in the reference's dictionary shape.  ``optimizer.step()`` applies
+        Lightning's ``gradient_clip_val`` (when set) and the update to the gradients the last ``training_step`` left."""
+        tr = self.train_engine()
+        return {"optimizer": _TrainerOptimizer(tr, self), "lr_scheduler": {"scheduler": _TrainerSchedule(tr), "interval": "step"}}
 
     def encode_texts(self, texts: List[str], out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Tokenise + encode without materialising padding (the packed form the engine consumes)."""

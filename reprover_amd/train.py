@@ -136,14 +136,13 @@ class HipT5Trainer:
         self._lib = _lib.load()
         self.layout = param_layout(cfg)
         total = self.layout[-1][2]
-        flat = torch.zeros(total, dtype=torch.float32)
         emb = "shared.weight" if "shared.weight" in state_dict else "encoder.embed_tokens.weight"
-        for key, shape, off in self.layout[:-1]:
-            src = state_dict[emb if key == "shared.weight" else key].detach().to(torch.float32)
-            assert tuple(src.shape) == tuple(shape), (key, tuple(src.shape), shape)
-            flat[off : off + src.numel()] = src.reshape(-1)
         with torch.cuda.device(self.device):
-            self.params = flat.to(self.device)
+            self.params = torch.zeros(total, dtype=torch.float32, device=self.device)
+            for key, shape, off in self.layout[:-1]:
+                src = state_dict[emb if key == "shared.weight" else key].detach()
+                assert tuple(src.shape) == tuple(shape), (key, tuple(src.shape), shape)
+                self.params[off : off + src.numel()] = src.reshape(-1).to(device=self.device, dtype=torch.float32)
             self.grads = torch.zeros_like(self.params)
             self.exp_avg = torch.zeros_like(self.params)
             self.exp_avg_sq = torch.zeros_like(self.params)

@@ -662,9 +662,163 @@ def g11_train_backward():
     print("g11 ok")
 
 
+def g13_train_examples():
+    """Training-side data loading: the reference's RetrievalDataset with is_train=True - one example per (tactic,
+    positive premise) (datamodule.py:60-75) and the candidate pools of the negative sampling in ``__getitem__``
+    (:95-128).  The pools' ORDER is not reproducible in the reference itself (networkx builds the closure's successor
+    lists from Python sets of path strings), so the fixture pins what is: the pools as sets, and how many negatives
+    come from each (``random.sample`` is intercepted to record its populations)."""
+    import importlib
+    import random as _random
+
+    dmod = importlib.import_module("retrieval.datamodule")
+    files = synth.synth_corpus_records(30, 500, seed=131, max_imports=5)
+    td = tempfile.mkdtemp()
+    cpath = os.path.join(td, "corpus.jsonl")
+    synth.write_corpus_jsonl(cpath, files)
+    split = synth.synth_split(files, 40, seed=132, min_file=8)
+    spath = os.path.join(td, "train.json")
+    json.dump(split, open(spath, "w"))
+    corpus = common.Corpus(cpath)
+    tok = ByT5Tokenizer()
+    num_neg, num_in_file = 3, 1
+    ds = dmod.RetrievalDataset([spath], corpus, num_neg, num_in_file, 256, tok, is_train=True)
+    where = {id(p): i for i, p in enumerate(corpus.all_premises)}
+    calls = []
+    real_sample = _random.sample
+
+    def spy(population, k):
+        calls.append(([where[id(p)] for p in population], k))
+        return real_sample(population, k)
+
+    examples = []
+    dmod.random.sample = spy
+    try:
+        _random.seed(133)
+        for i, ex in enumerate(ds.data):
+            calls.clear()
+            raises = False
+            try:
+                got = ds[i]
+                assert len(got["neg_premises"]) == num_neg
+            except ValueError:  # random.sample: pool smaller than the request (the reference does not guard it)
+                raises = True
+            assert len(calls) == 2
+            (in_file, k_in), (outside, k_out) = calls
+            examples.append({"raises": raises,"file_path": ex["file_path"], "full_name": ex["full_name"], "start": ex["start"],
+                             "tactic_idx": ex["tactic_idx"], "pos_premise": where[id(ex["pos_premise"])],
+                             "all_pos_premises": sorted(where[id(p)] for p in ex["all_pos_premises"]),
+                             "in_file_pool": sorted(in_file), "in_file_multiset": len(in_file) != len(set(in_file)),
+                             "outside_pool": sorted(outside), "k_in": k_in, "k_out": k_out})
+    finally:
+        dmod.random.sample = real_sample
+    json.dump({"corpus_seed": 131, "n_files": 30, "n_premises": 500, "max_imports": 5, "split_seed": 132, "n_theorems": 40,
+               "min_file": 8, "num_negatives": num_neg, "num_in_file_negatives": num_in_file, "examples": examples},
+              open(os.path.join(OUT, "g13_train_examples.json"), "w"))
+    n_in = sum(1 for e in examples if e["k_in"])
+    print(f"g13 ok: {len(examples)} training examples, {n_in} with an in-file negative, "
+          f"{sum(e['raises'] for e in examples)} whose pools are too small (ValueError); "
+          f"pool sizes in-file up to {max(len(e['in_file_pool']) for e in examples)}, outside up to "
+          f"{max(len(e['outside_pool']) for e in examples)}")
+
+
+def g12_train_small_width():
+    """The training step at ByT5-small WIDTH (d_model 1472, 6 heads, d_ff 3584; 2 layers): the reference's
+    ``loss.backward()`` and three AdamW steps as in G11, on a batch whose sequences span several 128-token blocks.  36 M
+    gradients do not fit a fixture: every tensor is pinned by its L2 norm and by its values at 2048 seeded positions
+    (all of them for the small tensors), likewise the parameters after the three steps."""
+    import importlib
+    from types import SimpleNamespace
+
+    from transformers import get_constant_schedule_with_warmup
+
+    from oracle import train_ref
+
+    dmod = importlib.import_module("retrieval.datamodule")
+    cfg = synth.t5_config("byt5-small")
+    cfg["num_layers"] = 2
+    sd = synth.synth_state_dict(cfg, seed=12)
+    model = H.offline_retriever(rm, hf_cfg(cfg), sd, max_seq_len=512)
+    model.eval()
+    files = synth.synth_corpus_records(12, 120, seed=121, code_bytes=(30, 200))
+    td = tempfile.mkdtemp()
+    path = os.path.join(td, "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    corpus = common.Corpus(path)
+    prem = corpus.all_premises
+    where = {id(p): i for i, p in enumerate(prem)}
+    rng = np.random.default_rng(122)
+    n, nneg = 4, 2
+    pick = rng.choice(len(prem), size=n * (2 + nneg), replace=False)
+    examples = []
+    for j in range(n):
+        pos = prem[int(pick[j])]
+        extra = prem[int(pick[n + j])]
+        negs = [prem[int(pick[2 * n + j * nneg + i])] for i in range(nneg)]
+        state = synth.synth_state(rng, int(rng.integers(60, 420)))
+        examples.append({"context": common.Context(pos.path, f"thm{j}", H.Pos(500, 0), state), "pos_premise": pos,
+                         "all_pos_premises": [pos, extra], "neg_premises": negs})
+    examples[1]["neg_premises"][0] = examples[0]["pos_premise"]
+    fake_self = SimpleNamespace(tokenizer=model.tokenizer, max_seq_len=512, num_negatives=nneg, is_train=True)
+    batch = dmod.RetrievalDataset.collate(fake_self, examples)
+    label = batch["label"]
+    lr, warmup = 1e-3, 1
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=lr)
+    sched = get_constant_schedule_with_warmup(opt, warmup)
+    names = {id(p): k for k, p in model.named_parameters()}
+
+    def strip(k):
+        assert k.startswith("encoder."), k
+        return k[len("encoder."):]
+
+    def step(keep):
+        opt.zero_grad()
+        loss = model(batch["context_ids"], batch["context_mask"], batch["pos_premise_ids"], batch["pos_premise_mask"],
+                     batch["neg_premises_ids"], batch["neg_premises_mask"], label)
+        loss.backward()
+        grads = {strip(names[id(p)]): p.grad.detach().clone().numpy() for p in params} if keep else None
+        opt.step()
+        sched.step()
+        return float(loss.detach()), grads
+
+    loss0, grads0 = step(True)
+    loss1, _ = step(False)
+    loss2, _ = step(False)
+    after = {strip(k): p.detach().numpy() for k, p in model.named_parameters()}
+    ctx_texts = [e["context"].serialize() for e in examples]
+    pos_texts = [e["pos_premise"].serialize() for e in examples]
+    neg_texts = [[e["neg_premises"][i].serialize() for e in examples] for i in range(nneg)]
+    o_label = train_ref.label_matrix([where[id(e["pos_premise"])] for e in examples],
+                                     [[where[id(p)] for p in e["neg_premises"]] for e in examples],
+                                     [[where[id(p)] for p in e["all_pos_premises"]] for e in examples])
+    assert np.array_equal(o_label, label.numpy())
+    o_loss, o_grads = train_ref.forward_backward(cfg, sd, ctx_texts, pos_texts, neg_texts, o_label, 512)
+    worst = max(np.abs(o_grads[k] - grads0[k]).max() / (np.abs(grads0[k]).max() + 1e-12) for k in grads0)
+    lens = [int(m.sum()) for m in batch["context_mask"]] + [int(m.sum()) for m in batch["pos_premise_mask"]]
+    print(f"g12: loss {loss0:.6f} (oracle {o_loss:.6f}); worst relative gradient difference oracle vs reference {worst:.2e}; "
+          f"losses {loss0:.6f} {loss1:.6f} {loss2:.6f}; context/positive lengths {lens}")
+    assert abs(o_loss - loss0) < 1e-6 and worst < 5e-4
+    out = {"loss": np.float64(loss0), "losses": np.array([loss0, loss1, loss2]), "label": label.numpy(),
+           "context_texts": np.array(ctx_texts, dtype=object), "pos_texts": np.array(pos_texts, dtype=object),
+           "neg_texts": np.array(neg_texts, dtype=object), "weight_seed": np.int64(12), "max_seq_len": np.int64(512),
+           "lr": np.float64(lr), "warmup_steps": np.int64(warmup), "num_layers": np.int64(2)}
+    srng = np.random.default_rng(123)
+    for k in sorted(grads0):
+        g = grads0[k].reshape(-1)
+        idx = np.sort(srng.choice(g.size, size=min(g.size, 2048), replace=False)).astype(np.int64)
+        out["idx/" + k] = idx
+        out["grad/" + k] = g[idx].astype(np.float32)
+        out["gradnorm/" + k] = np.float64(np.linalg.norm(g.astype(np.float64)))
+        out["after3/" + k] = after[k].reshape(-1)[idx].astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "g12_train_small_width.npz"), **out)
+    print("g12 ok")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     torch.manual_seed(0)
     for name in which:
         {"g1": g1_tokenizer, "g2": g2_serialize, "g3": g3_buckets, "g4": g4_tiny, "g5": g5_small,
-         "g6": g6_nearest, "g7": g7_predict, "g8": g8_eval_data, "g9": g9_base_full_depth, "g10": g10_train_forward, "g11": g11_train_backward}[name]()
+         "g6": g6_nearest, "g7": g7_predict, "g8": g8_eval_data, "g9": g9_base_full_depth, "g10": g10_train_forward, "g11": g11_train_backward,
+         "g12": g12_train_small_width, "g13": g13_train_examples}[name]()

@@ -160,3 +160,23 @@ def test_g11_train_backward_and_adamw(golden_dir):
     assert np.abs(np.array(losses) - g["losses"]).max() < 2e-6 and losses[2] < losses[0]
     for k in P:
         assert np.abs(P[k] - g["after3/" + k]).max() < 5e-6, k
+
+
+def test_g12_train_small_width(golden_dir):
+    """The oracle's backward at ByT5-small width against the reference's sampled gradients (one forward + backward of a
+    2-layer encoder on the CPU: a few seconds)."""
+    from oracle import train_ref
+
+    g = np.load(os.path.join(golden_dir, "g12_train_small_width.npz"), allow_pickle=True)
+    cfg = synth.t5_config("byt5-small")
+    cfg["num_layers"] = int(g["num_layers"])
+    sd = synth.synth_state_dict(cfg, seed=int(g["weight_seed"]))
+    texts = (list(g["context_texts"]), list(g["pos_texts"]), [list(r) for r in g["neg_texts"]])
+    loss, grads = train_ref.forward_backward(cfg, sd, *texts, g["label"], int(g["max_seq_len"]))
+    assert abs(loss - float(g["loss"])) < 1e-6
+    keys = [k[len("grad/"):] for k in g.files if k.startswith("grad/")]
+    assert set(keys) == set(grads)
+    for k in keys:
+        got, want = grads[k].reshape(-1)[g["idx/" + k]], g["grad/" + k]
+        assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max() + 1e-10, k
+        assert abs(np.linalg.norm(grads[k].astype(np.float64)) - float(g["gradnorm/" + k])) <= 1e-5 * float(g["gradnorm/" + k])

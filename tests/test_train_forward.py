@@ -1,4 +1,4 @@
-"""The training forward (forward only): host-side train collate (label matrix) on the CPU, and
+"""The training forward: host-side train collate (label matrix) and negative sampling on the CPU, and
 PremiseRetriever.forward - rp_encode_padded + rp_contrastive_mse - on the GPU, against fixture G10 (the reference's
 own collate + forward, HuggingFace fp32)."""
 import os
@@ -129,3 +129,41 @@ def test_loss_backward_and_adamw_kernels():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
     print(f"rp_adamw_step on {n >> 20} M parameters: {ms:.3f} ms = {28.0 * n / ms / 1e9:.2f} TB/s of 8 (28 B per parameter)")
+
+
+def test_training_examples_and_negative_pools_match_reference(golden_dir):
+    """G13: one training example per (tactic, positive premise) and, for each, the two candidate pools of the negative
+    sampling exactly as the reference's ``__getitem__`` builds them (as sets - their order is not reproducible upstream),
+    the split between in-file and outside negatives, and ``ValueError`` where a pool is too small."""
+    import json
+    import random
+
+    from reprover_amd.retrieval.datamodule import RetrievalDataset
+
+    g = json.load(open(os.path.join(golden_dir, "g13_train_examples.json")))
+    files = synth.synth_corpus_records(g["n_files"], g["n_premises"], seed=g["corpus_seed"], max_imports=g["max_imports"])
+    td = tempfile.mkdtemp()
+    cpath, spath = os.path.join(td, "corpus.jsonl"), os.path.join(td, "train.json")
+    synth.write_corpus_jsonl(cpath, files)
+    json.dump(synth.synth_split(files, g["n_theorems"], seed=g["split_seed"], min_file=g["min_file"]), open(spath, "w"))
+    corpus = Corpus(cpath)
+    ds = RetrievalDataset([spath], corpus, 256, ByT5Tokenizer(), is_train=True, num_negatives=g["num_negatives"],
+                          num_in_file_negatives=g["num_in_file_negatives"])
+    where = {id(p): i for i, p in enumerate(corpus.all_premises)}
+    gold = {(e["full_name"], e["tactic_idx"], e["pos_premise"]): e for e in g["examples"]}
+    assert len(ds) == len(gold) == len(g["examples"])
+    random.seed(1)
+    for i, ex in enumerate(ds.data):
+        e = gold[(ex["full_name"], ex["tactic_idx"], where[id(ex["pos_premise"])])]
+        assert sorted(where[id(p)] for p in ex["all_pos_premises"]) == e["all_pos_premises"]
+        in_file, outside = ds.negative_pools(ex)
+        assert sorted(in_file) == e["in_file_pool"] and sorted(outside) == e["outside_pool"]
+        if e["raises"]:
+            with pytest.raises(ValueError):
+                ds[i]
+            continue
+        negs = [where[id(p)] for p in ds[i]["neg_premises"]]
+        assert len(negs) == g["num_negatives"] and set(negs[: e["k_in"]]) <= set(in_file) and set(negs[e["k_in"]:]) <= set(outside)
+        assert e["k_in"] == min(len(in_file), g["num_in_file_negatives"])
+    batch = next(ds.train_batches(4)) if not any(e["raises"] for e in g["examples"]) else None
+    assert batch is None or batch["label"].shape == (4, 16)

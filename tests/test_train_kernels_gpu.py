@@ -19,7 +19,9 @@ def gen():
 
 
 @pytest.mark.parametrize("T,ny,nx,splits", [(256, 128, 128, 1), (512, 1152, 1472, 3), (1024, 1472, 384, 4),
-                                            (256, 200, 72, 2), (2048, 512, 128, 5)])
+                                            (256, 200, 72, 2), (2048, 512, 128, 5),
+                                            # negative: the 128 x 128 tile configuration
+                                            (256, 128, 128, -1), (512, 1152, 1472, -2), (1024, 1472, 384, -6), (256, 200, 72, -2)])
 def test_wgrad(gen, T, ny, nx, splits):
     r = th.check_wgrad(gen, T, ny, nx, splits)
     print(r)

@@ -18,7 +18,7 @@ def wgrad(Y, X, splits):
     lib = _lib.load()
     T, ny = Y.shape
     nx = X.shape[1]
-    out = torch.full((splits, ny, nx), float("nan"), dtype=torch.float32, device=Y.device)
+    out = torch.full((abs(splits), ny, nx), float("nan"), dtype=torch.float32, device=Y.device)
     _lib.check(lib.rp_dbg_wgrad(_lib.ptr(Y), _lib.ptr(X), _lib.ptr(out), T, ny, nx, splits, _lib.current_stream()),
                "rp_dbg_wgrad")
     torch.cuda.synchronize()
@@ -31,6 +31,7 @@ def check_wgrad(gen, T, ny, nx, splits):
     ref = Y.float().T @ X.float()
     nk = T // 64
     worst_split = 0.0
+    splits = abs(splits)  # (the sign selects the tile configuration)
     for s in range(splits):
         r0, r1 = (s * nk // splits) * 64, ((s + 1) * nk // splits) * 64
         part = Y[r0:r1].float().T @ X[r0:r1].float()
