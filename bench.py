@@ -8,8 +8,9 @@ ids, masks, the index) are resident in HBM when the timed region starts.
 
 N > 1 GPUs (one process per GPU, torch.distributed over RCCL): the index is row-sharded N ways;
 every rank encodes its own 256 states (weak scaling), query embeddings are all-gathered, each
-rank scans its shard for all N*256 queries, the per-shard top-k lists are all-gathered and each
-rank merges the lists of its own queries.  value = (N*256 queries) / max-over-ranks step time.
+rank scans its shard for all N*256 queries, the per-shard top-k lists travel as ONE packed all-gather
+([scores | ids | counts] per rank) and each rank merges the lists of its own queries straight from the receive buffer
+(two collectives per step in all: query embeddings, result block).  value = (N*256 queries) / max-over-ranks step time.
 
 The timed region is un-instrumented; a second pass of the same K steps with an event pair around every launch gives
 the per-kernel split the roofline objects are computed from.  Beside the headline value the line carries, at N = 1
@@ -340,15 +341,19 @@ def main():
 
     q_loc = torch.empty((B_STATES, D), dtype=torch.bfloat16, device=dev)
     q_all = torch.empty((BQ, D), dtype=torch.bfloat16, device=dev) if world > 1 else q_loc
-    out_s = torch.empty((BQ, TOP_K), dtype=torch.float32, device=dev)
-    out_i = torch.empty((BQ, TOP_K), dtype=torch.int32, device=dev)
-    out_c = torch.empty((BQ,), dtype=torch.int32, device=dev)
+    # this rank's lists as views of ONE packed block [scores | ids | counts]: what the all-gather sends (dist.py)
+    from reprover_amd.dist import packed_topk_buffers
+
+    out_i, out_s, out_c = packed_topk_buffers(BQ, TOP_K, dev)
+    send_block = torch.empty(0, dtype=torch.int32, device=dev).set_(out_s.untyped_storage(), 0, (BQ * (2 * TOP_K + 1),))
     ws_bytes = lib.rp_sim_topk_workspace_bytes(BQ, hi - lo, D, TOP_K, 0)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     if world > 1:
-        g_s = torch.empty((world, BQ, TOP_K), dtype=torch.float32, device=dev)
-        g_i = torch.empty((world, BQ, TOP_K), dtype=torch.int32, device=dev)
-        g_c = torch.empty((world, BQ), dtype=torch.int32, device=dev)
+        blk = BQ * (2 * TOP_K + 1)  # 4-byte units per rank
+        g_all = torch.empty((world, blk), dtype=torch.int32, device=dev)  # the receive buffer, read in place by the merge
+        g_s = g_all[:, : BQ * TOP_K].view(torch.float32)
+        g_i = g_all[:, BQ * TOP_K : 2 * BQ * TOP_K]
+        g_c = g_all[:, 2 * BQ * TOP_K :]
         mws_bytes = lib.rp_topk_merge_workspace_bytes(world, B_STATES, TOP_K)
         mws = torch.empty(mws_bytes, dtype=torch.uint8, device=dev)
         f_s = torch.empty((B_STATES, TOP_K), dtype=torch.float32, device=dev)
@@ -373,14 +378,12 @@ def main():
             gather(q_all, q_loc)
         scan()
         if world > 1:
-            gather(g_s, out_s)
-            gather(g_i, out_i)
-            gather(g_c, out_c)
-            sl = slice(rank * B_STATES, (rank + 1) * B_STATES)
-            ms_, mi_, mc_ = g_s[:, sl].contiguous(), g_i[:, sl].contiguous(), g_c[:, sl].contiguous()
-            _lib.check(lib.rp_topk_merge(ms_.data_ptr(), mi_.data_ptr(), mc_.data_ptr(), world, B_STATES, TOP_K,
-                                         f_s.data_ptr(), f_i.data_ptr(), f_c.data_ptr(), mws.data_ptr(), mws_bytes,
-                                         _lib.current_stream()), "rp_topk_merge")
+            gather(g_all, send_block)  # the step's second and last collective: one packed block per rank
+            q0 = rank * B_STATES       # this rank merges its own queries, straight from the receive buffer
+            _lib.check(lib.rp_topk_merge_strided(g_s.data_ptr() + 4 * q0 * TOP_K, g_i.data_ptr() + 4 * q0 * TOP_K,
+                                                 g_c.data_ptr() + 4 * q0, blk, world, B_STATES, TOP_K, f_s.data_ptr(),
+                                                 f_i.data_ptr(), f_c.data_ptr(), mws.data_ptr(), mws_bytes,
+                                                 _lib.current_stream()), "rp_topk_merge_strided")
 
     def barrier():
         if world > 1:

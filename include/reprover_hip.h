@@ -145,6 +145,8 @@ int32_t  rp_relative_position_bucket(int32_t relative_position, int32_t num_buck
  * ------------------------------------------------------------------------------------------- */
 enum { RP_TOPK_AUTO = 0, RP_TOPK_DENSE = 1 /* force the single-pass dense path */ };
 
+/* D = the embedding width for BOTH entry points (the e4m3 one plans with half the 2-byte units per row; its plan can
+ * only differ by taking the first-generation filter kernel, which needs no more workspace than this returns). */
 size_t   rp_sim_topk_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t k, int32_t flags);
 
 /*   Q            device bf16 [B, D]   query embeddings (unit norm)
@@ -158,9 +160,10 @@ size_t   rp_sim_topk_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t k,
  *                entries past out_count[j] are -inf / -1)
  *   out_count    device int32 [B]: min(k, #accessible premises on this rank); the caller maps
  *                a global count < k to the reference's ValueError (common.py:323-324).
- *                -1 is reserved for "internal candidate overflow: call again with RP_TOPK_DENSE"; the
- *                current engine sizes its candidate list (N + k keys per query, part of the
- *                workspace) so that it cannot overflow, callers still honour the contract.
+ *                -1 = "internal candidate overflow: call again with RP_TOPK_DENSE".  The two-pass plan keeps at most
+ *                max(8192, 8 k stride) + k candidate keys per query (about k * stride lie above the sampled bound); a
+ *                query that would need more - adversarial score distributions, or a sample with fewer than k accessible
+ *                rows, which yields no bound - reports -1 and every caller repeats the search with the dense plan.
  *   k <= 1024 (the final selection sorts in LDS); the reference accepts any k.              */
 RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t N, int32_t D,
                      const int32_t* file_of, const int64_t* end_key,
@@ -199,6 +202,24 @@ RpStatus rp_topk_merge(const float* scores, const int32_t* ids, const int32_t* c
                        int32_t R, int32_t B, int32_t k,
                        float* out_scores, int32_t* out_ids, int32_t* out_count,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same merge reading an all-gather's receive buffer as it lies: every rank sent ONE packed block
+ *   [ scores f32 [Bt, k] | ids int32 [Bt, k] | counts int32 [Bt] ]      (Bt = all queries of the step)
+ * so rank r's element [q, i] sits at base + r * rank_stride + q * k + i (4-byte units; rank_stride = Bt * (2 k + 1)) and
+ * a rank merges only its own queries by passing pointers advanced to its first query (scores + q0 * k, ids + q0 * k,
+ * counts + q0) with B = its number of queries.  No copy, no re-layout between the collective and the merge. */
+RpStatus rp_topk_merge_strided(const float* scores, const int32_t* ids, const int32_t* counts, int64_t rank_stride,
+                               int32_t R, int32_t B, int32_t k,
+                               float* out_scores, int32_t* out_ids, int32_t* out_count,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* Per-batch accessibility operand built on the device (replaces the host-side bit transposition of
+ * common.py:280-289's closure for a batch): file_bits_t [F, ceil(B/32)] (as rp_sim_topk takes it) from
+ *   reach     device uint64 [F, ceil(F/64)]   bit g of row f = file f imports file g (transitive closure, resident)
+ *   own_file  device int32 [B]                the file each query's theorem lives in
+ * so a search uploads 12 bytes per query (own_file, q_key). */
+RpStatus rp_build_file_bits(const uint64_t* reach, int32_t F, const int32_t* own_file, int32_t B,
+                            uint32_t* file_bits_t, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training forward, loss part: replaces retrieval/model.py:133-139

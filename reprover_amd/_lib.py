@@ -96,6 +96,12 @@ SIGNATURES = {
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
          C.c_void_p, C.c_size_t, C.c_void_p],
     ),
+    "rp_topk_merge_strided": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+         C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
+    "rp_build_file_bits": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "rp_contrastive_mse_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "rp_contrastive_mse": (
         C.c_int32,

@@ -15,6 +15,7 @@ representation underneath:
 from __future__ import annotations
 
 import json
+import pickle
 import re
 from dataclasses import dataclass, field
 from typing import Any, Dict, Generator, List, Optional, Sequence, Tuple
@@ -177,31 +178,45 @@ class Corpus:
 
     all_premises: List[Premise]
 
-    def __init__(self, jsonl_path: str, _arrays: Optional[Dict[str, np.ndarray]] = None) -> None:
+    def __init__(self, jsonl_path: Optional[str], _arrays: Optional[Dict[str, np.ndarray]] = None,
+                 _files: Optional[Sequence[Tuple["File", Sequence[str]]]] = None) -> None:
         """``_arrays``: the array form persisted in a native index directory (``save_index``); when given,
-        the import closure and the per-premise arrays are taken from it instead of being rebuilt."""
+        the import closure and the per-premise arrays are taken from it instead of being rebuilt.
+        ``_files``: (File, imported paths) pairs in place of a ``corpus.jsonl`` (``from_files``)."""
         self._files: List[File] = []
         self._index: Dict[str, int] = {}
         direct: List[List[int]] = []
         self.all_premises = []
-        with open(jsonl_path) as fh:
-            for line in fh:
-                data = json.loads(line)
-                path = data["path"]
-                assert path not in self._index  # common.py:204
-                f = File.from_data(data)
-                deps = []
-                for imp in data["imports"]:
-                    assert imp in self._index  # imports must precede importers (common.py:211)
-                    deps.append(self._index[imp])
-                self._index[path] = len(self._files)
-                self._files.append(f)
-                direct.append(deps)
-                self.all_premises.extend(f.premises)
+
+        def records():
+            if _files is not None:
+                yield from _files
+                return
+            with open(jsonl_path) as fh:
+                for line in fh:
+                    data = json.loads(line)
+                    yield File.from_data(data), data["imports"]
+
+        for f, imports in records():
+            assert f.path not in self._index  # common.py:204
+            deps = []
+            for imp in imports:
+                assert imp in self._index  # imports must precede importers (common.py:211)
+                deps.append(self._index[imp])
+            self._index[f.path] = len(self._files)
+            self._files.append(f)
+            direct.append(deps)
+            self.all_premises.extend(f.premises)
         if _arrays is not None:
             self._adopt_arrays(_arrays)
         else:
             self._build_arrays(direct)
+
+    @classmethod
+    def from_files(cls, files: Sequence[Tuple["File", Sequence[str]]]) -> "Corpus":
+        """A corpus from (File, paths it imports) pairs in topological order; the imports may be direct or already
+        transitive (the closure is idempotent)."""
+        return cls(None, _files=list(files))
 
     def _adopt_arrays(self, a: Dict[str, np.ndarray]) -> None:
         F, N = len(self._files), len(self.all_premises)
@@ -345,6 +360,36 @@ class Corpus:
         bits_t = np.packbits(padded, axis=1, bitorder="little").view(np.uint32).reshape(F, words)
         return np.ascontiguousarray(bits_t), own, qk
 
+    def query_keys(self, batch_context: Sequence[Context]) -> Tuple[np.ndarray, np.ndarray]:
+        """(own_file int32 [B], q_key int64 [B]): everything a search uploads per query (12 bytes)."""
+        B = len(batch_context)
+        own = np.fromiter((self._index[c.path] for c in batch_context), dtype=np.int32, count=B)  # KeyError
+        qk = np.fromiter((c.theorem_pos.key() for c in batch_context), dtype=np.int64, count=B)
+        return own, qk
+
+    def device_reach(self, device: torch.device) -> torch.Tensor:
+        """The transitive import closure (bit g of row f: f imports g) resident on ``device``: int64 view of
+        uint64 [F, ceil(F / 64)] - 3.1 MB at 5,000 files, uploaded once."""
+        key = "reach:" + str(device)
+        if key not in self._dev:
+            self._dev[key] = torch.from_numpy(np.ascontiguousarray(self._reach).view(np.int64)).to(device)
+        return self._dev[key]
+
+    def device_query_masks(self, batch_context: Sequence[Context], device: torch.device,
+                           out_bits: Optional[torch.Tensor] = None):
+        """The accessibility operands of ``rp_sim_topk`` ON the device: (file_bits_t int32 [F, ceil(B/32)], own_file
+        int32 [B], q_key int64 [B]).  The host sends own_file and q_key (one pinned asynchronous copy of 12 bytes per
+        query); the bit matrix is built there from the resident closure (``rp_build_file_bits``).  Same bits as
+        ``query_masks``."""
+        own, qk = self.query_keys(batch_context)
+        d_own, d_qk = _upload_query_keys(own, qk, device)
+        B, F = len(batch_context), len(self._files)
+        bits = out_bits if out_bits is not None else torch.empty((F, (B + 31) // 32), dtype=torch.int32, device=device)
+        with torch.cuda.device(device):
+            _lib.check(_lib.load().rp_build_file_bits(_lib.ptr(self.device_reach(device)), F, _lib.ptr(d_own), B,
+                                                      _lib.ptr(bits), _lib.current_stream()), "rp_build_file_bits")
+        return bits, d_own, d_qk
+
     def _device_arrays(self, device: torch.device) -> Tuple[torch.Tensor, torch.Tensor]:
         key = str(device)
         if key not in self._dev:
@@ -378,9 +423,8 @@ class Corpus:
         B, D = Q.shape
         N = E.shape[0]
         assert N == len(self.all_premises) and E.shape[1] == D
-        bits_t, own, qk = self.query_masks(batch_context)
         file_of, end_key = self._device_arrays(dev)
-        d_bits, d_own, d_qk = _upload_query_masks(bits_t, own, qk, dev)
+        d_bits, d_own, d_qk = self.device_query_masks(batch_context, dev)
         out_s = torch.empty((B, k), dtype=torch.float32, device=dev)
         out_i = torch.empty((B, k), dtype=torch.int32, device=dev)
         out_c = torch.empty((B,), dtype=torch.int32, device=dev)
@@ -425,7 +469,7 @@ class Corpus:
         host[0].copy_(ids, non_blocking=True)
         host[1].copy_(scores, non_blocking=True)
         host[2].copy_(counts, non_blocking=True)
-        extra = [torch.empty(t.shape, dtype=t.dtype).pin_memory().copy_(t, non_blocking=True) for t in also_copy]
+        extra = [_pinned_small(t).copy_(t, non_blocking=True) for t in also_copy]
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(batch_context_emb.device))
         return PendingSearch(self, premise_embeddings, list(batch_context), batch_context_emb, k, host, done, extra)
@@ -443,44 +487,70 @@ class Corpus:
         return self.launch_nearest_premises(premise_embeddings, batch_context, batch_context_emb, k).finish()
 
 
-_staging: Dict[int, List[list]] = {}  # nbytes -> [[pinned uint8 buffer, event of its last upload], ...], used in turn
+_STAGING_SLOTS = 4  # pinned staging buffers used in turn (a slot is reused four uploads later: long completed)
+_staging: List[list] = []  # [[pinned uint8 buffer, event of its last upload], ...]; buffers grow to the largest batch seen
+_staging_next = 0
 
 
-def _upload_query_masks(bits_t: np.ndarray, own: np.ndarray, qk: np.ndarray, dev: torch.device):
-    """(file_bits_t int32 [F, W], own_file int32 [B], q_key int64 [B]) on the device through ONE asynchronous copy
-    from pinned staging memory.  (Three ``.to(device)`` calls from pageable memory block the host until the stream
-    reaches them - i.e. until the encode launched just before has finished.)"""
+def _upload_query_keys(own: np.ndarray, qk: np.ndarray, dev: torch.device):
+    """(own_file int32 [B], q_key int64 [B]) on the device through ONE asynchronous copy from pinned staging memory
+    (``.to(device)`` from pageable memory would block the host until the stream reaches the copy - i.e. until the
+    encode launched just before has finished).  The staging ring is bounded: ``_STAGING_SLOTS`` buffers in all, each as
+    large as the largest batch seen."""
+    global _staging_next
     B = own.shape[0]
-    n_qk, n_own, n_bits = 8 * B, 4 * B, bits_t.size * 4
-    off_own, off_bits = n_qk, n_qk + ((n_own + 15) // 16) * 16
-    total = off_bits + n_bits
-    ring = _staging.setdefault(total, [])
-    if len(ring) < 3:
-        ring.append([torch.empty(total, dtype=torch.uint8).pin_memory(), None])
-        slot = ring[-1]
+    n_qk, n_own = 8 * B, 4 * B
+    total = n_qk + n_own
+    if len(_staging) < _STAGING_SLOTS:
+        _staging.append([torch.empty(max(total, 4096), dtype=torch.uint8).pin_memory(), None])
+        slot = _staging[-1]
     else:
-        slot = ring.pop(0)
-        ring.append(slot)
-        slot[1].synchronize()  # its previous upload (three searches ago) has long completed
+        slot = _staging[_staging_next]
+        _staging_next = (_staging_next + 1) % _STAGING_SLOTS
+        if slot[1] is not None:
+            slot[1].synchronize()
+        if slot[0].numel() < total:
+            slot[0] = torch.empty(total, dtype=torch.uint8).pin_memory()
     h = slot[0].numpy()
     h[:n_qk].view(np.int64)[:] = qk
-    h[off_own : off_own + n_own].view(np.int32)[:] = own
-    h[off_bits:].view(np.uint32)[:] = bits_t.reshape(-1)
+    h[n_qk:total].view(np.int32)[:] = own
     d = torch.empty(total, dtype=torch.uint8, device=dev)
-    d.copy_(slot[0], non_blocking=True)
+    d.copy_(slot[0][:total], non_blocking=True)
     slot[1] = torch.cuda.Event()
     slot[1].record(torch.cuda.current_stream(dev))
-    return (d[off_bits:].view(torch.int32).view(bits_t.shape), d[off_own : off_own + n_own].view(torch.int32),
-            d[:n_qk].view(torch.int64))
+    return d[n_qk:].view(torch.int32), d[:n_qk].view(torch.int64)
 
 
+_small_ring: List[torch.Tensor] = []
+_small_next = 0
+
+
+def _pinned_small(like: torch.Tensor) -> torch.Tensor:
+    """A pinned host tensor for a few words (the encoder's verdict) from a ring of 16 preallocated 64-byte slots:
+    ``pin_memory()`` is a slow host call and this sits on every predict_step."""
+    global _small_next
+    nbytes = like.numel() * like.element_size()
+    if nbytes > 64:
+        return torch.empty(like.shape, dtype=like.dtype).pin_memory()
+    if not _small_ring:
+        base = torch.empty(16 * 64, dtype=torch.uint8).pin_memory()
+        _small_ring.extend(base[i * 64 : (i + 1) * 64] for i in range(16))
+    slot = _small_ring[_small_next]
+    _small_next = (_small_next + 1) % 16
+    return slot[:nbytes].view(like.dtype).view(like.shape)
+
+
+_PINNED_POOL_SHAPES = 8  # distinct (B, k) result shapes kept (least recently used dropped: pinned memory is bounded)
 _pinned_pool: Dict[Tuple[int, int], List[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]] = {}
 
 
 def _pinned_result_buffers(B: int, k: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """(ids int32 [B,k], scores f32 [B,k], counts int32 [B]) in pinned host memory, from a small pool per shape
     (page-locking costs more than the copy); a set goes back to the pool when its search has been finished."""
-    pool = _pinned_pool.setdefault((B, k), [])
+    pool = _pinned_pool.pop((B, k), [])
+    _pinned_pool[(B, k)] = pool  # most recently used last
+    while len(_pinned_pool) > _PINNED_POOL_SHAPES:
+        _pinned_pool.pop(next(iter(_pinned_pool)))
     if pool:
         return pool.pop()
     return (torch.empty((B, k), dtype=torch.int32).pin_memory(), torch.empty((B, k), dtype=torch.float32).pin_memory(),
@@ -510,7 +580,9 @@ class PendingSearch:
                 raise ValueError
             ids_l, scores_l = ids_h.tolist(), scores_h.tolist()
         finally:
-            _pinned_pool.setdefault((len(self.batch_context), k), []).append(self.host)
+            pool = _pinned_pool.get((len(self.batch_context), k))
+            if pool is not None and len(pool) < 4:
+                pool.append(self.host)
             self.batch_context_emb = None
         prem = self.corpus.all_premises
         return [[prem[i] for i in row] for row in ids_l], scores_l
@@ -683,6 +755,67 @@ def load_index(dir_path: str, with_fp8: bool = False):
         t = load_file(os.path.join(dir_path, "fp8.safetensors"))
         payload = (t["codes"], t["scale"])
     return corpus, emb, payload
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The reference's own index file.  `python retrieval/index.py` (retrieval/index.py:37-40) pickles
+# ``IndexedCorpus(corpus, embeddings)`` with the REFERENCE's classes inside: ``common.Corpus`` (a networkx DiGraph
+# of ``common.File`` nodes), ``common.Premise``, ``lean_dojo.Pos`` - the file a prover user actually has
+# (prover/tactic_generator.py:273-276 loads it).  None of those modules exist here, so the stream is read with a
+# class map: every foreign class becomes a plain attribute bag, and the corpus is rebuilt from what the bags hold -
+# the files in the graph's node order, their premises, and the closure's successor lists as imports.
+# ----------------------------------------------------------------------------------------------------------------
+class _Bag:
+    """Stand-in for a class of the reference stream: keeps whatever state pickle hands it."""
+
+    def __setstate__(self, state):
+        if isinstance(state, tuple) and len(state) == 2 and isinstance(state[1], dict):  # (dict state, slots state)
+            self.__dict__.update(state[0] or {})
+            self.__dict__.update(state[1])
+        elif isinstance(state, dict):
+            self.__dict__.update(state)
+        else:
+            self.__dict__["_state"] = state
+
+
+class _ReferenceUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        root = module.split(".")[0]
+        if root == "reprover_amd" or root in ("torch", "numpy", "collections", "builtins", "copyreg", "_codecs"):
+            return super().find_class(module, name)
+        if root in ("common", "lean_dojo", "networkx", "retrieval"):
+            return type(name, (_Bag,), {"_foreign": f"{module}.{name}"})
+        return super().find_class(module, name)
+
+
+def _is_foreign(obj, name: str) -> bool:
+    return getattr(type(obj), "_foreign", "").endswith("." + name)
+
+
+def _pos_of(bag) -> Pos:
+    return bag if isinstance(bag, Pos) else Pos(int(bag.line_nb), int(bag.column_nb))
+
+
+def load_indexed_corpus_pickle(path: str):
+    """(Corpus, embeddings) from a pickled ``IndexedCorpus`` - this package's own or the reference's
+    (retrieval/index.py:37-40; read without ``lean_dojo`` / ``networkx`` / the reference's ``common`` module)."""
+    with open(path, "rb") as fh:
+        obj = _ReferenceUnpickler(fh).load()
+    if isinstance(obj, IndexedCorpus):
+        return obj.corpus, obj.embeddings
+    if not _is_foreign(obj, "IndexedCorpus"):
+        raise TypeError(f"{path} holds a {type(obj).__name__}, not an IndexedCorpus")
+    graph = obj.corpus.transitive_dep_graph
+    nodes, succ = graph._node, getattr(graph, "_succ", None) or graph._adj
+    files = []
+    for fpath, attrs in nodes.items():  # node order = corpus.jsonl order (common.py:199-213): topological
+        fb = attrs["file"]
+        prem = [Premise(p.path, p.full_name, _pos_of(p.start), _pos_of(p.end), p.code) for p in fb.premises]
+        files.append((File(fb.path, prem), list(succ[fpath])))
+    corpus = Corpus.from_files(files)
+    if len(corpus) != len(obj.corpus.all_premises):
+        raise ValueError("the pickled corpus' premise list does not match its files")
+    return corpus, obj.embeddings
 
 
 def get_all_pos_premises(annot_tac, corpus: Corpus) -> List[Premise]:

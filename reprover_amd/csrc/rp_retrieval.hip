@@ -58,6 +58,7 @@ int g_scan_filter_cfg = 0;   // experiments: 0 = nt premise stream (default), 1 
 int g_scan_sample_cfg = 0;   // experiments: 0 = 128x64x64 3-stage when D % 64 == 0 (default), 1 = 128x64x32 6-stage
                              // (a 6-stage 64-wide ring - five slices in flight - measured the same 23.5 us: not the depth)
 int g_scan_stride = 0;       // experiments: > 0 overrides the sampling stride (power of two)
+int g_scan_cap = 0;          // tests: > 0 overrides the candidate-list capacity (forces the overflow -> dense contract)
 int g_scan_no_epilogue = 0;  // timing only: the filter pass drops every score (main loop in isolation)
 
 __device__ __forceinline__ uint64_t make_key(float score, int32_t id) {
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(SELECT_THREADS) void gather_select_kernel(GatherArg
     return ((word >> (q & 31)) & 1u) || (f == own && a.end_key[p] <= qk);
   };
   auto put_key = [&](uint64_t key, int pos) {
-    out[pos] = key;
+    if (pos < (int)a.cap) out[pos] = key;  // beyond the capacity: counted, not stored (reported as overflow below)
     if (pos < SELECT_LDS_KEYS) sh.staged[pos] = key;
   };
   // ---- phase A: runs -> raw list (one thread per filter block)
@@ -722,8 +723,9 @@ __global__ __launch_bounds__(SELECT_THREADS) void gather_select_kernel(GatherArg
     }
   }
   __syncthreads();
-  const int n = s_out;
-  select_body(sa, q, KeySrc{out, sh.staged, n <= SELECT_LDS_KEYS}, n, false, sh);
+  const bool overflow = s_out > (int)a.cap;  // out_count = -1: the caller repeats the search with the dense plan
+  const int n = min(s_out, (int)a.cap);
+  select_body(sa, q, KeySrc{out, sh.staged, n <= SELECT_LDS_KEYS}, n, overflow, sh);
 }
 
 // (scores, ids, counts)[R, B, k] -> keys[B, R*k]
@@ -736,6 +738,40 @@ __global__ void merge_keys_kernel(const float* scores, const int32_t* ids, const
     const int c = counts[(size_t)r * B + q];
     keys[(size_t)q * R * k + t] = (i < c) ? make_key(scores[src], ids[src]) : 0ull;
   }
+}
+
+// The same from one packed buffer per rank (an all-gather's receive buffer as it lies): element [r, q, i] of scores / ids
+// at base + r * rank_stride + q * k + i, counts at base + r * rank_stride + q (4-byte units).
+__global__ void merge_keys_strided_kernel(const float* scores, const int32_t* ids, const int32_t* counts,
+                                          size_t rank_stride, int R, int k, uint64_t* keys) {
+  const int q = blockIdx.x;
+  for (int t = threadIdx.x; t < R * k; t += blockDim.x) {
+    const int r = t / k, i = t % k;
+    const size_t src = (size_t)r * rank_stride + (size_t)q * k + i;
+    const int c = counts[(size_t)r * rank_stride + q];
+    keys[(size_t)q * R * k + t] = (i < c) ? make_key(scores[src], ids[src]) : 0ull;
+  }
+}
+
+// file_bits_t[f, w] bit j = query 32 w + j may use file f = bit f of row own_file[32 w + j] of the closure matrix
+// `reach` (bit g of row f: f imports g, transitively; F x ceil(F / 64) words, resident on the device): the per-batch
+// accessibility operand of rp_sim_topk built where it is used, from 4 bytes per query.
+__global__ __launch_bounds__(256) void build_file_bits_kernel(const uint64_t* __restrict__ reach, int F, int W64,
+                                                              const int32_t* __restrict__ own_file, int B, int Wq,
+                                                              uint32_t* __restrict__ bits_t) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= F * Wq) return;
+  const int f = i / Wq, w = i - f * Wq;
+  uint32_t word = 0;
+#pragma unroll 8
+  for (int j = 0; j < 32; ++j) {
+    const int q = 32 * w + j;
+    if (q < B) {
+      const int own = own_file[q];
+      word |= (uint32_t)((reach[(size_t)own * W64 + (f >> 6)] >> (f & 63)) & 1ull) << j;
+    }
+  }
+  bits_t[i] = word;
 }
 
 static void launch_select(const SelectArgs& a, int B, hipStream_t stream) {
@@ -780,7 +816,13 @@ static SimPlan plan_sim(int B, int N, int D2, int k, int flags) {
   p.sample_blocks = p.dense_only ? 0 : (p.blocks + stride - 1) / stride;
   p.filter_blocks = p.dense_only ? 0 : p.blocks - p.sample_blocks;
   p.dense_ld = p.dense_only ? (size_t)p.tiles_p * 128 : (size_t)p.sample_blocks * SIM_PB;
-  p.cap = (size_t)N + k;
+  // Candidate-list capacity per query.  About k * stride keys lie above the sampled bound (spread ~ stride * sqrt(k)):
+  // eight times that, never less than 8192 keys, never more than every row.  A query whose list would not fit (adversarial
+  // scores, or a sample that gave no bound because fewer than k sampled rows were accessible) reports out_count = -1 and
+  // the caller re-runs with RP_TOPK_DENSE - the contract of include/reprover_hip.h.  (Sized N + k, the list was
+  // B * N * 8 bytes: 2 GB at 256 x 1M, as large as the dense plan the two-pass one exists to avoid.)
+  p.cap = std::min((size_t)N + k, std::max((size_t)8192, (size_t)8 * k * stride) + k);
+  if (g_scan_cap > 0) p.cap = std::min((size_t)N + k, (size_t)g_scan_cap + k);  // tests: force the overflow path
   size_t off = 0;
   p.off_dense = off;
   off += align_up((size_t)B * p.dense_ld * 8, 256);
@@ -1305,9 +1347,38 @@ extern "C" size_t rp_topk_merge_workspace_bytes(int32_t R, int32_t B, int32_t k)
   return align_up((size_t)R * B * k * 8, 256);
 }
 
+extern "C" RpStatus rp_build_file_bits(const uint64_t* reach, int32_t F, const int32_t* own_file, int32_t B,
+                                       uint32_t* file_bits_t, void* stream_) {
+  RP_REQUIRE(reach && own_file && file_bits_t && F > 0 && B > 0, "bad argument");
+  const int Wq = (B + 31) / 32, W64 = (F + 63) / 64;
+  hipLaunchKernelGGL(build_file_bits_kernel, dim3((F * Wq + 255) / 256), dim3(256), 0, (hipStream_t)stream_, reach, F, W64,
+                     own_file, B, Wq, file_bits_t);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+static RpStatus topk_merge_impl(const float* scores, const int32_t* ids, const int32_t* counts, int64_t rank_stride,
+                                int32_t R, int32_t B, int32_t k, float* out_scores, int32_t* out_ids, int32_t* out_count,
+                                void* workspace, size_t workspace_bytes, void* stream_);
+
 extern "C" RpStatus rp_topk_merge(const float* scores, const int32_t* ids, const int32_t* counts, int32_t R,
                                   int32_t B, int32_t k, float* out_scores, int32_t* out_ids, int32_t* out_count,
                                   void* workspace, size_t workspace_bytes, void* stream_) {
+  return topk_merge_impl(scores, ids, counts, -1, R, B, k, out_scores, out_ids, out_count, workspace, workspace_bytes, stream_);
+}
+
+extern "C" RpStatus rp_topk_merge_strided(const float* scores, const int32_t* ids, const int32_t* counts,
+                                          int64_t rank_stride, int32_t R, int32_t B, int32_t k, float* out_scores,
+                                          int32_t* out_ids, int32_t* out_count, void* workspace, size_t workspace_bytes,
+                                          void* stream_) {
+  RP_REQUIRE(rank_stride > 0, "rank_stride=%lld", (long long)rank_stride);
+  return topk_merge_impl(scores, ids, counts, rank_stride, R, B, k, out_scores, out_ids, out_count, workspace, workspace_bytes,
+                         stream_);
+}
+
+static RpStatus topk_merge_impl(const float* scores, const int32_t* ids, const int32_t* counts, int64_t rank_stride,
+                                int32_t R, int32_t B, int32_t k, float* out_scores, int32_t* out_ids, int32_t* out_count,
+                                void* workspace, size_t workspace_bytes, void* stream_) {
   RP_REQUIRE(scores && ids && counts && out_scores && out_ids && out_count, "null argument");
   RP_REQUIRE(R > 0 && B > 0 && k > 0 && k <= SIM_MAX_K, "R=%d B=%d k=%d", R, B, k);
   const size_t need = rp_topk_merge_workspace_bytes(R, B, k);
@@ -1315,7 +1386,11 @@ extern "C" RpStatus rp_topk_merge(const float* scores, const int32_t* ids, const
     return fail(RP_E_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, need);
   hipStream_t stream = (hipStream_t)stream_;
   uint64_t* keys = (uint64_t*)workspace;
-  hipLaunchKernelGGL(merge_keys_kernel, dim3(B), dim3(256), 0, stream, scores, ids, counts, R, B, k, keys);
+  if (rank_stride < 0)
+    hipLaunchKernelGGL(merge_keys_kernel, dim3(B), dim3(256), 0, stream, scores, ids, counts, R, B, k, keys);
+  else
+    hipLaunchKernelGGL(merge_keys_strided_kernel, dim3(B), dim3(256), 0, stream, scores, ids, counts, (size_t)rank_stride, R,
+                       k, keys);
   RP_CHECK_LAUNCH();
   SelectArgs sa;
   sa.keys = keys;

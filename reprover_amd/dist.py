@@ -9,10 +9,11 @@ process per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI):
     same number of tokens (encode cost ~ tokens), while shards stay contiguous row ranges and global
     premise ids stay ``lo_r + local row``.
   * retrieve: every rank scans its shard for ALL queries of the step with the accessibility mask
-    applied before selection (``rp_sim_topk`` with ``id_offset = lo_r``), then ONE all-gather of the
-    per-rank ``[B, k]`` (score, id) lists + counts (B*k*8 bytes per rank: latency-bound) and a k-way
-    merge (``rp_topk_merge``).  Masked top-k is a decomposable reduction, so the result is exactly
-    the single-GPU result.
+    applied before selection (``rp_sim_topk`` with ``id_offset = lo_r``) and writes its lists straight into ONE
+    packed block ``[scores f32 [B,k] | ids i32 [B,k] | counts i32 [B]]``; ONE all-gather of that block
+    (B*(2k+1)*4 bytes per rank: latency-bound) and a k-way merge that reads the receive buffer as it lies
+    (``rp_topk_merge_strided``: no copies between the collective and the merge).  Masked top-k is a decomposable
+    reduction, so the result is exactly the single-GPU result.
 
 The collective plumbing is backend-agnostic; the two compute steps are injectable so that the
 world_size-2 ``gloo`` tests on CPU can drive the same code with the oracle as the checker.
@@ -86,23 +87,23 @@ def reindex_shard(retriever, shard: IndexShard) -> None:
     shard.embeddings = out
 
 
-def hip_local_topk(shard: IndexShard, batch_context: Sequence[Context], query_emb: torch.Tensor, k: int) -> TopK:
+def hip_local_topk(shard: IndexShard, batch_context: Sequence[Context], query_emb: torch.Tensor, k: int,
+                   flags: Optional[int] = None) -> TopK:
     """Masked top-k of all queries against this rank's rows (global ids), on the GPU.  ``shard.fp8`` (an
-    ``Fp8Index`` of the shard's rows, set by ``IndexShard.quantize``) switches the scan to the e4m3 form."""
+    ``Fp8Index`` of the shard's rows, set by ``IndexShard.quantize``) switches the scan to the e4m3 form.
+    ``flags`` None: the two-pass plan, redone densely if a candidate list overflowed (reads the counts: synchronises);
+    an explicit value: exactly that plan, launch-only (the caller inspects the counts later)."""
     lib = _lib.load()
     dev = query_emb.device
     fp8 = getattr(shard, "fp8", None)
     if fp8 is not None:
-        return _hip_local_topk_fp8(shard, fp8, batch_context, query_emb, k)
+        return _hip_local_topk_fp8(shard, fp8, batch_context, query_emb, k, flags)
     E = as_bf16_matrix(shard.embeddings, dev)
     Q = as_bf16_matrix(query_emb, dev)
     B, D = Q.shape
-    bits_t, own, qk = shard.corpus.query_masks(batch_context)
-    d_bits = torch.from_numpy(bits_t.view(np.int32)).to(dev)
-    d_own, d_qk = torch.from_numpy(own).to(dev), torch.from_numpy(qk).to(dev)
-    out_s = torch.empty((B, k), dtype=torch.float32, device=dev)
-    out_i = torch.empty((B, k), dtype=torch.int32, device=dev)
-    out_c = torch.empty((B,), dtype=torch.int32, device=dev)
+    d_bits, d_own, d_qk = shard.corpus.device_query_masks(batch_context, dev)  # 12 B per query uploaded, pinned + async
+    out_i, out_s, out_c = packed_topk_buffers(B, k, dev)
+
     def scan(flags: int) -> None:
         nbytes = lib.rp_sim_topk_workspace_bytes(B, len(shard), D, k, flags)
         ws = _workspace(dev, nbytes)
@@ -115,6 +116,9 @@ def hip_local_topk(shard: IndexShard, batch_context: Sequence[Context], query_em
             "rp_sim_topk",
         )
 
+    if flags is not None:
+        scan(flags)
+        return out_i, out_s, out_c
     scan(_lib.RP_TOPK_AUTO)
     # The C ABI reserves out_count = -1 for "candidate list overflow: call again with RP_TOPK_DENSE"
     # (include/reprover_hip.h).  The current engine sizes the list so that it cannot overflow, but the contract is
@@ -125,20 +129,17 @@ def hip_local_topk(shard: IndexShard, batch_context: Sequence[Context], query_em
     return out_i, out_s, out_c
 
 
-def _hip_local_topk_fp8(shard: IndexShard, fp8, batch_context: Sequence[Context], query_emb: torch.Tensor, k: int) -> TopK:
+def _hip_local_topk_fp8(shard: IndexShard, fp8, batch_context: Sequence[Context], query_emb: torch.Tensor, k: int,
+                        only_flags: Optional[int] = None) -> TopK:
     from .common import Fp8Index
 
     lib = _lib.load()
     dev = query_emb.device
     Q = Fp8Index.quantize(query_emb)
     B, D = Q.shape
-    bits_t, own, qk = shard.corpus.query_masks(batch_context)
-    d_bits = torch.from_numpy(bits_t.view(np.int32)).to(dev)
-    d_own, d_qk = torch.from_numpy(own).to(dev), torch.from_numpy(qk).to(dev)
-    out_s = torch.empty((B, k), dtype=torch.float32, device=dev)
-    out_i = torch.empty((B, k), dtype=torch.int32, device=dev)
-    out_c = torch.empty((B,), dtype=torch.int32, device=dev)
-    for flags in (_lib.RP_TOPK_AUTO, _lib.RP_TOPK_DENSE):
+    d_bits, d_own, d_qk = shard.corpus.device_query_masks(batch_context, dev)
+    out_i, out_s, out_c = packed_topk_buffers(B, k, dev)
+    for flags in ((_lib.RP_TOPK_AUTO, _lib.RP_TOPK_DENSE) if only_flags is None else (only_flags,)):
         nbytes = lib.rp_sim_topk_workspace_bytes(B, len(shard), D, k, flags)
         ws = _workspace(dev, nbytes)
         _lib.check(
@@ -150,13 +151,35 @@ def _hip_local_topk_fp8(shard: IndexShard, fp8, batch_context: Sequence[Context]
             ),
             "rp_sim_topk_fp8",
         )
-        if not bool((out_c < 0).any()):  # -1 = candidate overflow (reserved by the ABI): redo densely
+        if only_flags is not None or not bool((out_c < 0).any()):  # -1 = candidate overflow (reserved by the ABI): redo densely
             break
     return out_i, out_s, out_c
 
 
+def packed_topk_buffers(B: int, k: int, device) -> TopK:
+    """(ids [B,k], scores [B,k], counts [B]) as views of ONE int32 block laid out [scores | ids | counts]: what a rank
+    contributes to the all-gather, written in place by ``rp_sim_topk``."""
+    block = torch.empty(B * (2 * k + 1), dtype=torch.int32, device=device)
+    return (block[B * k : 2 * B * k].view(B, k), block[: B * k].view(torch.float32).view(B, k), block[2 * B * k :])
+
+
+def _packed_block(ids: torch.Tensor, scores: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
+    """The [scores | ids | counts] block the three tensors are views of (``packed_topk_buffers``); built by one
+    concatenation when they are not (injected compute steps of the CPU tests)."""
+    B, k = ids.shape
+    n = B * (2 * k + 1)
+    st = scores.untyped_storage()
+    if (st.data_ptr() == ids.untyped_storage().data_ptr() == counts.untyped_storage().data_ptr() and st.nbytes() == 4 * n
+            and scores.storage_offset() == 0 and ids.storage_offset() == B * k and counts.storage_offset() == 2 * B * k
+            and scores.is_contiguous() and ids.is_contiguous()):
+        return torch.empty(0, dtype=torch.int32, device=ids.device).set_(st, 0, (n,))
+    return torch.cat([scores.contiguous().view(torch.int32).reshape(-1), ids.to(torch.int32).reshape(-1),
+                      counts.to(torch.int32).reshape(-1)])
+
+
 def hip_merge(ids: torch.Tensor, scores: torch.Tensor, counts: torch.Tensor) -> TopK:
-    """Merge [R, B, k] per-rank lists into the global top-k on the GPU (rp_topk_merge)."""
+    """Merge [R, B, k] per-rank lists into the global top-k on the GPU.  The inputs may be strided views of an
+    all-gather's receive buffer (rank stride > B*k): they are read in place (``rp_topk_merge_strided``)."""
     lib = _lib.load()
     R, B, k = scores.shape
     dev = scores.device
@@ -165,6 +188,15 @@ def hip_merge(ids: torch.Tensor, scores: torch.Tensor, counts: torch.Tensor) -> 
     out_c = torch.empty((B,), dtype=torch.int32, device=dev)
     nbytes = lib.rp_topk_merge_workspace_bytes(R, B, k)
     ws = _workspace(dev, nbytes)
+    rs = scores.stride(0)
+    if (R > 1 and rs != B * k and rs == ids.stride(0) == counts.stride(0) and scores.stride()[1:] == (k, 1)
+            and ids.stride()[1:] == (k, 1) and counts.stride(1) == 1):
+        _lib.check(
+            lib.rp_topk_merge_strided(scores.data_ptr(), ids.data_ptr(), counts.data_ptr(), rs, R, B, k, _lib.ptr(out_s),
+                                      _lib.ptr(out_i), _lib.ptr(out_c), _lib.ptr(ws), nbytes, _lib.current_stream()),
+            "rp_topk_merge_strided",
+        )
+        return out_i, out_s, out_c
     _lib.check(
         lib.rp_topk_merge(_lib.ptr(scores.contiguous()), _lib.ptr(ids.contiguous()), _lib.ptr(counts.contiguous()),
                           R, B, k, _lib.ptr(out_s), _lib.ptr(out_i), _lib.ptr(out_c), _lib.ptr(ws), nbytes,
@@ -212,9 +244,11 @@ def sharded_nearest_premise_ids(
     """Global masked top-k for a batch of queries that every rank holds (e.g. after an all-gather of
     the per-rank query embeddings).  Returns identical tensors on every rank."""
     ids, scores, counts = local_topk(shard, batch_context, query_emb, k)
-    g_ids = all_gather_stack(ids, group)
-    g_scores = all_gather_stack(scores, group)
-    g_counts = all_gather_stack(counts, group)
+    B = ids.shape[0]
+    g = all_gather_stack(_packed_block(ids, scores, counts), group)  # THE collective of the step: [world, B (2k + 1)]
+    g_scores = g[:, : B * k].view(torch.float32).view(-1, B, k)      # views of the receive buffer, rank stride B (2k + 1)
+    g_ids = g[:, B * k : 2 * B * k].view(-1, B, k)
+    g_counts = g[:, 2 * B * k :]
     return merge(g_ids, g_scores, g_counts)
 
 
@@ -227,3 +261,71 @@ def sharded_get_nearest_premises(shard: IndexShard, batch_context: List[Context]
         raise ValueError
     prem = shard.corpus.all_premises
     return [[prem[i] for i in row] for row in ids.cpu().tolist()], scores.cpu().tolist()
+
+
+_rank_count_pool: dict = {}  # (world, B) -> pinned int32 [world, B] buffers (at most 4 each)
+
+
+class PendingShardedSearch:
+    """A sharded search whose merged result is on its way to pinned host memory (``launch_sharded_nearest_premises``):
+    the sharded counterpart of ``common.PendingSearch``, so that ``predict_step`` pipelines both the same way."""
+
+    def __init__(self, shard, batch_context, query_emb, k, group, host, done, extra_host=()):
+        self.shard, self.batch_context, self.query_emb, self.k, self.group = shard, list(batch_context), query_emb, k, group
+        self.host, self.done, self.extra_host = host, done, list(extra_host)
+
+    def finish(self):
+        """Wait for the copy, map ids to ``Premise`` objects; ``ValueError`` as the reference (common.py:323-324)."""
+        self.done.synchronize()
+        ids_h, scores_h, counts_h, rank_counts_h = self.host
+        k = self.k
+        if bool((rank_counts_h < 0).any()):
+            # some rank's candidate list overflowed (out_count = -1, reserved by the ABI).  Every rank holds the same
+            # gathered counts, so every rank takes this branch: redo the step with the dense plan, synchronously.
+            ids, scores, counts = sharded_nearest_premise_ids(
+                self.shard, self.batch_context, self.query_emb, k, self.group,
+                local_topk=lambda s, c, q, kk: hip_local_topk(s, c, q, kk, _lib.RP_TOPK_DENSE))
+            ids_h, scores_h, counts_h = ids.cpu(), scores.cpu(), counts.cpu()
+        self.query_emb = None
+        try:
+            if bool((counts_h < k).any()):
+                raise ValueError
+            ids_l, scores_l = ids_h.tolist(), scores_h.tolist()
+        finally:  # the pinned buffers go back to their pools (bounded: common._PINNED_POOL_SHAPES)
+            from .common import _pinned_pool
+
+            p3 = _pinned_pool.get((len(self.batch_context), k))
+            if p3 is not None and len(p3) < 4:
+                p3.append(self.host[:3])
+            pc = _rank_count_pool.get(tuple(self.host[3].shape))
+            if pc is not None and len(pc) < 4:
+                pc.append(self.host[3])
+        prem = self.shard.corpus.all_premises
+        return [[prem[i] for i in row] for row in ids_l], scores_l
+
+
+def launch_sharded_nearest_premises(shard: IndexShard, batch_context: List[Context], query_emb: torch.Tensor, k: int,
+                                    group=None, also_copy: Sequence[torch.Tensor] = ()) -> PendingShardedSearch:
+    """First half of the sharded ``get_nearest_premises``: local masked top-k (two-pass plan, launch-only), the packed
+    all-gather, the merge and the asynchronous copy of the merged lists (plus every rank's counts, for the overflow
+    contract) to pinned host memory are enqueued; nothing waits.  ``finish()`` is the second half."""
+    ids, scores, counts = hip_local_topk(shard, batch_context, query_emb, k, _lib.RP_TOPK_AUTO)
+    B = ids.shape[0]
+    g = all_gather_stack(_packed_block(ids, scores, counts), group)
+    world = g.shape[0]
+    m_ids, m_scores, m_counts = hip_merge(g[:, B * k : 2 * B * k].view(world, B, k),
+                                          g[:, : B * k].view(torch.float32).view(world, B, k), g[:, 2 * B * k :])
+    from .common import _pinned_result_buffers
+
+    pool = _rank_count_pool.setdefault((world, B), [])
+    host = _pinned_result_buffers(B, k) + ((pool.pop() if pool else torch.empty((world, B), dtype=torch.int32).pin_memory()),)
+    host[0].copy_(m_ids, non_blocking=True)
+    host[1].copy_(m_scores, non_blocking=True)
+    host[2].copy_(m_counts, non_blocking=True)
+    host[3].copy_(g[:, 2 * B * k :], non_blocking=True)
+    from .common import _pinned_small
+
+    extra = [_pinned_small(t).copy_(t, non_blocking=True) for t in also_copy]
+    done = torch.cuda.Event()
+    done.record(torch.cuda.current_stream(query_emb.device))
+    return PendingShardedSearch(shard, batch_context, query_emb, k, group, host, done, extra)

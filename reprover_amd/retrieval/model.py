@@ -116,8 +116,8 @@ class PremiseRetriever:
     def load_hf(cls, ckpt_path: str, max_seq_len: int, device, dtype=None) -> "PremiseRetriever":
         """``dtype`` None → bf16, the reference's own choice on a capable GPU (model.py:59-64).  ``dtype`` selects
         the dtype of the embeddings handed back (``corpus_embeddings``, ``_encode``); the arithmetic is the same for
-        both values - bf16 MFMA operands, fp32 accumulation / residual stream / statistics - where the reference
-        with ``dtype=float32`` would also multiply in fp32.  ``retrieve`` / ``num_retrieved`` accept k <= 1024 (the
+        both values - bf16 MFMA operands, fp32 accumulation and statistics, the residual stream as two bf16 planes
+        (hi + lo: 16 mantissa bits) - where the reference with ``dtype=float32`` would also multiply in fp32.  ``retrieve`` / ``num_retrieved`` accept k <= 1024 (the
         final selection sorts in LDS); the reference accepts any k."""
         return cls(ckpt_path, 0.0, 0, max_seq_len, 100, device=device, dtype=dtype or torch.bfloat16)
 
@@ -141,8 +141,9 @@ class PremiseRetriever:
     # -- corpus (model.py:68-85) --------------------------------------------------------------------
     def load_corpus(self, path_or_corpus: Union[str, Corpus]) -> None:
         """Associate the retriever with a corpus: a ``Corpus``, a ``corpus.jsonl`` (embeddings
-        stale), a pickled ``IndexedCorpus`` with pre-computed embeddings, or a native index
-        directory written by ``common.save_index`` / ``index.py --output-path <dir>/``."""
+        stale), a pickled ``IndexedCorpus`` with pre-computed embeddings - written by this package or by the
+        reference's ``retrieval/index.py`` (its classes are mapped while unpickling: no lean_dojo / networkx
+        needed) -, or a native index directory written by ``common.save_index`` / ``index.py --output-path <dir>/``."""
         self._drop_derived()
         self._attached = False
         if isinstance(path_or_corpus, Corpus):
@@ -162,11 +163,10 @@ class PremiseRetriever:
             self.corpus = Corpus(path)
             self.corpus_embeddings = None
             self.embeddings_staled = True
-        else:
-            with open(path, "rb") as fh:
-                indexed_corpus = pickle.load(fh)
-            self.corpus = indexed_corpus.corpus
-            self.corpus_embeddings = indexed_corpus.embeddings
+        else:  # a pickled IndexedCorpus: this package's, or the REFERENCE's own (retrieval/index.py:37-40)
+            from ..common import load_indexed_corpus_pickle
+
+            self.corpus, self.corpus_embeddings = load_indexed_corpus_pickle(path)
             self.embeddings_staled = False
 
     def _search_operand(self):
@@ -177,9 +177,12 @@ class PremiseRetriever:
         # Keyed on the tensor OBJECT (a strong reference, so its storage cannot be recycled under the tag) and
         # dropped explicitly wherever the matrix is rewritten in place through raw pointers (_drop_derived):
         # data_ptr()/_version would both survive an allocator-recycled block filled by rp_encode_varlen.
-        if self._fp8_index is None or self._fp8_source is not self.corpus_embeddings:
+        ver = getattr(self.corpus_embeddings, "_version", None)
+        if (self._fp8_index is None or self._fp8_source is not self.corpus_embeddings
+                or getattr(self, "_fp8_version", ver) != ver):  # replaced, or written in place through torch
             self._fp8_index = Fp8Index.quantize(self.corpus_embeddings, self.device)
             self._fp8_source = self.corpus_embeddings
+        self._fp8_version = ver
         return self._fp8_index
 
     # ---- one index per GPU, shared by the worker processes on it (reprover_amd/shared_index.py) -------------
@@ -388,15 +391,13 @@ class PremiseRetriever:
         surfaces one call later than in the reference, at the latest when the outputs are read or the epoch ends."""
         # launch-only encode (mask -> lengths -> packed ids on the device)
         context_emb = self.encoder.encode_padded(batch["context_ids"], batch["context_mask"], defer_check=True)
-        if self.index_shard is not None:  # every rank holds the batch; the index is row-sharded (synchronous)
-            from ..dist import sharded_get_nearest_premises
+        if self.index_shard is not None:  # every rank holds the batch; the index is row-sharded: same pipeline
+            from ..dist import launch_sharded_nearest_premises
 
-            self._finish_pending_predict()
-            retrieved_premises, scores = sharded_get_nearest_premises(
-                self.index_shard, batch["context"], context_emb, self.num_retrieved
-            )
-            self.encoder.raise_pending()
-            self._append_predictions(batch, retrieved_premises, scores)
+            launched = launch_sharded_nearest_premises(self.index_shard, batch["context"], context_emb, self.num_retrieved,
+                                                       also_copy=self.encoder.take_pending())
+            previous, self._predict_pending = self._predict_pending, (batch, launched)
+            self._finish_pending_predict(previous)
             return
         assert not self.embeddings_staled
         launched = self.corpus.launch_nearest_premises(
@@ -459,7 +460,9 @@ class PremiseRetriever:
                 from ..single_query import SingleQueryCache
 
                 self._single_query = SingleQueryCache()
-            return self._single_query.retrieve(self, ctx, k)
+            got = self._single_query.retrieve(self, ctx, k)
+            if got is not None:
+                return got  # (None: the captured two-pass search overflowed its candidate list - redo it below)
         context_emb = self.encode_texts([ctx.serialize()])
         if self.corpus_embeddings.device != context_emb.device or self.corpus_embeddings.dtype != torch.bfloat16:
             # a pickled index arrives as fp32 on the CPU (index.py:37-40): move + cast once

@@ -8,8 +8,9 @@ device side - ``rp_encode_padded`` (mask -> lengths -> packed ids -> encoder -> 
 ``rp_sim_topk`` (masked similarity + exact top-k over the resident index) - is captured once per
 (token-length bucket, k) into a hipGraph on static buffers:
 
-    one pinned host buffer   [ids | mask | own_file | q_key | file bits]  --one H2D copy-->  device twin
-    graph replay             (the token count stays on the device: the padded entry point needs no host value)
+    one pinned host buffer   [ids | mask | q_key | own_file]  --one H2D copy-->  device twin
+    graph replay             (the token count stays on the device: the padded entry point needs no host value; the
+                              accessibility bits are built from the resident import closure: rp_build_file_bits)
     one D2H copy             [scores | ids | count | meta]                --one synchronisation
 
 PyTorch supplies the stream-capture plumbing (``torch.cuda.CUDAGraph``) and the memory; every captured node is one
@@ -17,7 +18,7 @@ of the engine's own launches.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -38,8 +39,8 @@ class SingleQueryGraph:
         dev = E.device
         lib = _lib.load()
         F, N, D = corpus.num_files, E.shape[0], E.shape[1]
-        # ---- input block: int64 ids [L], int64 mask [L], int64 q_key, int32 own_file (+ pad), uint32 bits [F]
-        self._n_in = 2 * L * 8 + 16 + 4 * F
+        # ---- input block: int64 ids [L], int64 mask [L], int64 q_key, int32 own_file (+ pad)
+        self._n_in = 2 * L * 8 + 16
         self.h_in = torch.zeros(self._n_in, dtype=torch.uint8).pin_memory()
         self.d_in = torch.zeros(self._n_in, dtype=torch.uint8, device=dev)
         hv, dv = self.h_in.numpy(), self.d_in
@@ -47,12 +48,12 @@ class SingleQueryGraph:
         self.h_mask = hv[L * 8 : 2 * L * 8].view(np.int64)
         self.h_qk = hv[2 * L * 8 : 2 * L * 8 + 8].view(np.int64)
         self.h_own = hv[2 * L * 8 + 8 : 2 * L * 8 + 12].view(np.int32)
-        self.h_bits = hv[2 * L * 8 + 16 :].view(np.uint32)
         self.d_ids = dv[: L * 8].view(torch.int64).view(1, L)
         self.d_mask = dv[L * 8 : 2 * L * 8].view(torch.int64).view(1, L)
         self.d_qk = dv[2 * L * 8 : 2 * L * 8 + 8].view(torch.int64)
         self.d_own = dv[2 * L * 8 + 8 : 2 * L * 8 + 12].view(torch.int32)
-        self.d_bits = dv[2 * L * 8 + 16 :].view(torch.int32).view(F, 1)
+        self.d_bits = torch.zeros((F, 1), dtype=torch.int32, device=dev)  # built by the graph from the resident closure
+        self.reach = corpus.device_reach(dev)
         # ---- output block: int32 meta [4] (16-byte aligned), f32 scores [k], int32 ids [k], int32 count
         self._n_out = 16 + 8 * k + 4
         self.d_out = torch.zeros(self._n_out, dtype=torch.uint8, device=dev)
@@ -86,6 +87,8 @@ class SingleQueryGraph:
         self.encoder.encode_padded_into(self.d_ids, self.d_mask, self.q, self.d_meta, self.ws_enc)
         N, D = self.E.shape
         with torch.cuda.device(self.E.device):
+            _lib.check(lib.rp_build_file_bits(_lib.ptr(self.reach), self.corpus.num_files, _lib.ptr(self.d_own), 1,
+                                              _lib.ptr(self.d_bits), _lib.current_stream()), "rp_build_file_bits")
             _lib.check(
                 lib.rp_sim_topk(_lib.ptr(self.q), _lib.ptr(self.E), 1, N, D, _lib.ptr(self.file_of), _lib.ptr(self.end_key),
                                 _lib.ptr(self.d_bits), self.corpus.num_files, _lib.ptr(self.d_own), _lib.ptr(self.d_qk), 0,
@@ -101,10 +104,8 @@ class SingleQueryGraph:
         self.h_ids[n:] = 0
         self.h_mask[:n] = 1
         self.h_mask[n:] = 0
-        bits_t, own, qk = self.corpus.query_masks([ctx])  # [F, 1] uint32, [1], [1]
-        self.h_bits[:] = bits_t[:, 0]
-        self.h_own[0] = own[0]
-        self.h_qk[0] = qk[0]
+        self.h_own[0] = self.corpus._index[ctx.path]  # KeyError for a file outside the corpus, as query_masks
+        self.h_qk[0] = ctx.theorem_pos.key()
         self.d_in.copy_(self.h_in, non_blocking=True)
         self.graph.replay()
         self.h_out.copy_(self.d_out, non_blocking=True)
@@ -125,7 +126,7 @@ class SingleQueryCache:
         self._graphs.clear()
         self._key = None
 
-    def retrieve(self, retriever, ctx: Context, k: int) -> Tuple[List[Premise], List[float]]:
+    def retrieve(self, retriever, ctx: Context, k: int) -> Optional[Tuple[List[Premise], List[float]]]:
         E, corpus = retriever.corpus_embeddings, retriever.corpus
         key = (id(E), id(corpus))
         if key != self._key:
@@ -139,8 +140,8 @@ class SingleQueryCache:
         if g is None:
             g = self._graphs[(L, k)] = SingleQueryGraph(retriever.encoder, corpus, E, L, k)
         top, scores, count = g.run(ids, ctx)
-        if count < 0:  # reserved by the ABI for candidate overflow (cannot happen with this engine's sizing)
-            raise _lib.HipLibraryError("rp_sim_topk reported a candidate overflow in the captured path")
+        if count < 0:  # candidate-list overflow (out_count = -1): the caller repeats launch by launch, dense plan
+            return None
         if count < k:
             raise ValueError  # fewer than k accessible premises (common.py:323-324)
         prem = corpus.all_premises

@@ -722,6 +722,45 @@ def g13_train_examples():
           f"{max(len(e['outside_pool']) for e in examples)}")
 
 
+def g14_reference_indexed_corpus():
+    """The reference's own index file: ``IndexedCorpus(corpus, embeddings)`` pickled exactly as retrieval/index.py:37-40
+    writes it (the reference's common.Corpus with its networkx graph, common.File / Premise, lean_dojo.Pos inside), for a
+    small corpus and the tiny encoder, plus what the reference's ``retrieve`` returns from it for a few states.  The
+    product reads this file without any of those modules (common.load_indexed_corpus_pickle)."""
+    import pickle
+
+    cfg = synth.t5_config("tiny")
+    sd = synth.synth_state_dict(cfg, seed=14)
+    model = H.offline_retriever(rm, hf_cfg(cfg), sd, max_seq_len=512)
+    files = synth.synth_corpus_records(12, 120, seed=141, max_imports=4, code_bytes=(20, 90))
+    td = tempfile.mkdtemp()
+    path = os.path.join(td, "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    model.load_corpus(path)
+    model.reindex_corpus(batch_size=32)
+    H.Pos.__module__ = "lean_dojo"  # where the stand-in is importable from, as the real class is from its package
+    out_pickle = os.path.join(OUT, "g14_reference_indexed_corpus.pickle")
+    with open(out_pickle, "wb") as fh:  # index.py:37-40
+        pickle.dump(common.IndexedCorpus(model.corpus, model.corpus_embeddings.to(torch.float32).cpu()), fh)
+    where = {id(p): i for i, p in enumerate(model.corpus.all_premises)}
+    rng = np.random.default_rng(142)
+    queries = []
+    for j in range(6):
+        while True:
+            f = int(rng.integers(6, 12))
+            pos = (int(rng.integers(1, 300)), int(rng.integers(0, 40)))
+            if len(model.corpus.get_accessible_premises(files[f]["path"], H.Pos(*pos))) >= 8:
+                break
+        state = synth.synth_state(rng, int(rng.integers(40, 160)))
+        prem, sc = model.retrieve(state, files[f]["path"], f"thm{j}", H.Pos(*pos), 5)
+        queries.append({"path": files[f]["path"], "pos": list(pos), "state": state, "ids": [where[id(p)] for p in prem],
+                        "scores": sc})
+    json.dump({"corpus_seed": 141, "n_files": 12, "n_premises": 120, "max_imports": 4, "code_bytes": [20, 90],
+               "weight_seed": 14, "N": len(model.corpus), "queries": queries, "k": 5},
+              open(os.path.join(OUT, "g14_reference_indexed_corpus.json"), "w"), ensure_ascii=False)
+    print(f"g14 ok: {len(model.corpus)} premises, pickle {os.path.getsize(out_pickle)} bytes")
+
+
 def g12_train_small_width():
     """The training step at ByT5-small WIDTH (d_model 1472, 6 heads, d_ff 3584; 2 layers): the reference's
     ``loss.backward()`` and three AdamW steps as in G11, on a batch whose sequences span several 128-token blocks.  36 M
@@ -816,9 +855,10 @@ def g12_train_small_width():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     torch.manual_seed(0)
     for name in which:
         {"g1": g1_tokenizer, "g2": g2_serialize, "g3": g3_buckets, "g4": g4_tiny, "g5": g5_small,
          "g6": g6_nearest, "g7": g7_predict, "g8": g8_eval_data, "g9": g9_base_full_depth, "g10": g10_train_forward, "g11": g11_train_backward,
-         "g12": g12_train_small_width, "g13": g13_train_examples}[name]()
+         "g12": g12_train_small_width, "g13": g13_train_examples,
+         "g14": g14_reference_indexed_corpus}[name]()

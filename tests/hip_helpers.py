@@ -58,7 +58,7 @@ def attention(qkv, cu, tab, H):
     return out
 
 
-def sim_topk(Q, E, k, masks=None, id_offset=0, flags=0, N=None):
+def sim_topk(Q, E, k, masks=None, id_offset=0, flags=0, N=None, retry_dense=True):
     """masks = (file_of i32 [N], end_key i64 [N], bits_t u32-as-i32 [F, W], own i32 [B], qk i64 [B]) device tensors.
     With flags & RP_TOPK_E_BLOCKED, E is the flat blocked copy and N must be given."""
     lib = _lib.load()
@@ -79,6 +79,8 @@ def sim_topk(Q, E, k, masks=None, id_offset=0, flags=0, N=None):
                                _lib.ptr(own), _lib.ptr(qk), id_offset, k, flags, _lib.ptr(out_s), _lib.ptr(out_i),
                                _lib.ptr(out_c), _lib.ptr(ws), nbytes, _lib.current_stream()), "rp_sim_topk")
     torch.cuda.synchronize()
+    if retry_dense and bool((out_c < 0).any()):  # the ABI's overflow contract, as every product caller honours it
+        return sim_topk(Q, E, k, masks, id_offset, flags | _lib.RP_TOPK_DENSE, N, retry_dense=False)
     return out_i, out_s, out_c
 
 
@@ -96,7 +98,7 @@ def quantize_e4m3(X):
     return codes, scale
 
 
-def sim_topk_fp8(Q8, qs, E8, es, k, masks=None, id_offset=0, flags=0, N=None):
+def sim_topk_fp8(Q8, qs, E8, es, k, masks=None, id_offset=0, flags=0, N=None, retry_dense=True):
     """rp_sim_topk_fp8 on e4m3 codes (uint8) + per-row scales; masks as in sim_topk."""
     lib = _lib.load()
     B, D = Q8.shape
@@ -117,6 +119,8 @@ def sim_topk_fp8(Q8, qs, E8, es, k, masks=None, id_offset=0, flags=0, N=None):
                                    _lib.ptr(out_s), _lib.ptr(out_i), _lib.ptr(out_c), _lib.ptr(ws), nbytes,
                                    _lib.current_stream()), "rp_sim_topk_fp8")
     torch.cuda.synchronize()
+    if retry_dense and bool((out_c < 0).any()):
+        return sim_topk_fp8(Q8, qs, E8, es, k, masks, id_offset, flags | _lib.RP_TOPK_DENSE, N, retry_dense=False)
     return out_i, out_s, out_c
 
 

@@ -80,8 +80,17 @@ def _worker(rank, world, port, corpus_path, out_dir):
         weights = [len(p.code) for p in corpus.all_premises]
         shard = IndexShard(corpus, shard_bounds(weights, world), rank, torch.device("cpu"))
         shard.embeddings = torch.from_numpy(E[shard.lo : shard.hi].copy())
-        ids, scores, counts = sharded_nearest_premise_ids(shard, ctxs, torch.from_numpy(Q), k, None,
-                                                          local_topk=_oracle_local_topk, merge=_oracle_merge)
+        # the step issues ONE collective (the packed [scores | ids | counts] block), whatever the backend entry point
+        calls = []
+        real_ag, real_agt = dist.all_gather, dist.all_gather_into_tensor
+        dist.all_gather = lambda *a, **kw: (calls.append("all_gather"), real_ag(*a, **kw))[1]
+        dist.all_gather_into_tensor = lambda *a, **kw: (calls.append("all_gather_into_tensor"), real_agt(*a, **kw))[1]
+        try:
+            ids, scores, counts = sharded_nearest_premise_ids(shard, ctxs, torch.from_numpy(Q), k, None,
+                                                              local_topk=_oracle_local_topk, merge=_oracle_merge)
+        finally:
+            dist.all_gather, dist.all_gather_into_tensor = real_ag, real_agt
+        assert len(calls) == 1, calls
         # single-process answer
         acc = np.stack([corpus.accessible_mask(c.path, c.theorem_pos) for c in ctxs])
         S = Q @ E.T

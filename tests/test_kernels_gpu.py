@@ -229,10 +229,10 @@ def test_sim_topk_exact_ties_and_order(gen):
 def test_sim_topk_sample_gives_no_bound(gen):
     """The adversarial case for the two-pass plan: every SAMPLED block (rows [256 j stride, +256)) is
     inaccessible, so the sample yields no bound (thr = 0) and every accessible score of the other blocks is a
-    candidate - tens of thousands per query instead of ~k*stride.  The first-generation engine reported this as
-    out_count = -1 (list overflow, capacity 8192 + k); now every lane of the filter kernel owns a run of slots that
-    can hold all of its scores and the candidate list has room for every row, so nothing can overflow and the answer
-    must stay exact."""
+    candidate - tens of thousands per query instead of ~k*stride.  The two-pass plan keeps a BOUNDED candidate list
+    (max(8192, 8 k stride) + k keys per query): such a query is reported as out_count = -1 and the caller repeats the
+    search with RP_TOPK_DENSE (the ABI's contract, honoured by every product caller and by hh.sim_topk) - the answer
+    must stay exact, for both filter generations, and for the sharded form."""
     rng = np.random.default_rng(31)
     B, N, D, k = 9, 70000, 128, 50
     E, Q = _rand_bf16(gen, N, D), _rand_bf16(gen, B, D)
@@ -264,10 +264,12 @@ def test_sim_topk_sample_gives_no_bound(gen):
     for force_new in (1, 0):  # both filter generations (batches <= 128 default to the first)
         _lib.check(lib.rp_set_option(b"scan_force_new", force_new), "opt")
         try:
+            raw = hh.sim_topk(Q, E, k, dm, retry_dense=False)[2].cpu().numpy()
             ids, sc, cnt = hh.sim_topk(Q, E, k, dm)
         finally:
             _lib.check(lib.rp_set_option(b"scan_force_new", 0), "opt")
-        assert (cnt.cpu().numpy() >= 0).all(), "candidate-list overflow must not happen any more"
+        assert raw[0] == -1 and raw[3] == 0 and raw[4] >= 0, "the overflowing query is reported, the small ones are not"
+        assert (cnt.cpu().numpy() >= 0).all()
         hh.check_topk_against_scores(ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy(), S, acc, k, tol=1e-4)
     ids2, sc2, cnt2 = hh.sim_topk(Q, E, k, dm, flags=_lib.RP_TOPK_DENSE)
     assert torch.equal(ids, ids2) and torch.equal(sc, sc2) and torch.equal(cnt, cnt2)
@@ -390,3 +392,70 @@ def test_sim_topk_multi_gpu_shard_shape(gen):
     ids, sc, cnt = hh.sim_topk(Q, E, k, hh.masks_to_device(m, Q.device), id_offset=5 * N)
     S = (Q.float() @ E.float().T).cpu().numpy()
     hh.check_topk_against_scores(ids.cpu().numpy() - 5 * N, sc.cpu().numpy(), cnt.cpu().numpy(), S, acc, k, tol=2e-5)
+
+
+def test_build_file_bits_equals_host_transposition():
+    """rp_build_file_bits (the per-batch accessibility operand built from the device-resident import closure and 4
+    bytes per query) against Corpus.query_masks (the host-side transposition it replaces), incl. B not a multiple of 32."""
+    import tempfile, os
+    from reprover_amd import synth
+    from reprover_amd.common import Context, Corpus, Pos
+
+    files = synth.synth_corpus_records(70, 400, seed=9, max_imports=6)
+    path = os.path.join(tempfile.mkdtemp(), "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    corpus = Corpus(path)
+    rng = np.random.default_rng(4)
+    for B in (1, 31, 32, 77):
+        ctxs = [Context(files[int(f)]["path"], f"t{j}", Pos(int(rng.integers(1, 300)), 0), "a ⊢ b")
+                for j, f in enumerate(rng.integers(0, len(files), size=B))]
+        bits_t, own, qk = corpus.query_masks(ctxs)
+        d_bits, d_own, d_qk = corpus.device_query_masks(ctxs, torch.device("cuda:0"))
+        torch.cuda.synchronize()
+        assert np.array_equal(d_bits.cpu().numpy().view(np.uint32), bits_t)
+        assert np.array_equal(d_own.cpu().numpy(), own) and np.array_equal(d_qk.cpu().numpy(), qk)
+
+
+def test_candidate_overflow_contract_through_the_product(gen):
+    """Force the two-pass plan's candidate list to overflow for every query (option scan_cap = 1: capacity k + 1) and
+    go through the product entry points: Corpus.get_nearest_premises, the hipGraph single-query path and the sharded
+    search must each detect out_count = -1 and deliver, by the dense retry, exactly the answer of an unforced run."""
+    import os, tempfile
+    from reprover_amd import synth
+    from reprover_amd.common import Context, Corpus, Pos
+    from reprover_amd.dist import IndexShard, hip_local_topk
+    from reprover_amd.retrieval.model import PremiseRetriever
+
+    files = synth.synth_corpus_records(60, 40000, seed=77, max_imports=6)
+    path = os.path.join(tempfile.mkdtemp(), "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    corpus = Corpus(path)
+    N, D, B, k = len(corpus), 128, 5, 20
+    E = torch.nn.functional.normalize(torch.randn(N, D, generator=gen, device="cuda"), dim=1).to(torch.bfloat16)
+    Q = torch.nn.functional.normalize(torch.randn(B, D, generator=gen, device="cuda"), dim=1).to(torch.bfloat16)
+    ctxs = [Context(files[50 + j]["path"], f"t{j}", Pos(400, 0), "a ⊢ b") for j in range(B)]
+    lib = _lib.load()
+    want = corpus.nearest_premise_ids(E, ctxs, Q, k)
+    shard = IndexShard(corpus, np.array([0, N]), 0, torch.device("cuda:0"))
+    shard.embeddings = E
+    cfg = synth.t5_config("tiny")
+    model = PremiseRetriever.from_state_dict(cfg, synth.synth_state_dict(cfg), 256, "cuda:0")
+    model.corpus, model.embeddings_staled = corpus, False
+    model.corpus_embeddings = torch.nn.functional.normalize(torch.randn(N, 128, generator=gen, device="cuda"), dim=1).to(torch.bfloat16)
+    ref_single = model.retrieve("a ⊢ b", files[55]["path"], "t", Pos(400, 0), k)
+    _lib.check(lib.rp_set_option(b"scan_cap", 1), "opt")
+    try:
+        raw = corpus.nearest_premise_ids(E, ctxs, Q, k)
+        assert (raw[2] == -1).all(), "every query overflows its k + 1 slots"
+        prem, scores = corpus.get_nearest_premises(E, ctxs, Q, k)  # PendingSearch.finish: dense retry
+        assert [[p.full_name for p in row] for row in prem] == \
+            [[corpus.all_premises[i].full_name for i in row] for row in want[0].cpu().tolist()]
+        assert np.array_equal(np.array(scores, dtype=np.float32), want[1].cpu().numpy())
+        ids, sc, cnt = hip_local_topk(shard, ctxs, Q, k)  # dist: the synchronous form retries densely
+        assert torch.equal(ids, want[0]) and torch.equal(sc, want[1]) and torch.equal(cnt, want[2])
+        model._drop_derived()
+        got_single = model.retrieve("a ⊢ b", files[55]["path"], "t", Pos(400, 0), k)  # graph path -> fallback
+        assert [p.full_name for p in got_single[0]] == [p.full_name for p in ref_single[0]]
+        assert np.allclose(got_single[1], ref_single[1], atol=1e-6)
+    finally:
+        _lib.check(lib.rp_set_option(b"scan_cap", 0), "opt")

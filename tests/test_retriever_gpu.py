@@ -263,3 +263,30 @@ def test_full_size_properties_130k_b256_k100():
     mi, ms, mc = hh.topk_merge(torch.stack([p[1] for p in parts]), torch.stack([p[0] for p in parts]),
                                torch.stack([p[2] for p in parts]))
     assert torch.equal(mi, ids) and torch.equal(ms, sc) and torch.equal(mc, cnt)
+
+
+def test_retrieve_from_the_reference_indexed_corpus_pickle(golden_dir):
+    """G14: load the index file written by the REFERENCE's retrieval/index.py (pickled reference classes inside) and
+    retrieve from it: the premises and scores the reference's own ``retrieve`` returned from that file."""
+    import json
+
+    from reprover_amd import synth
+    from reprover_amd.common import Pos
+    from reprover_amd.retrieval.model import PremiseRetriever
+
+    g = json.load(open(os.path.join(golden_dir, "g14_reference_indexed_corpus.json")))
+    cfg = synth.t5_config("tiny")
+    model = PremiseRetriever.from_state_dict(cfg, synth.synth_state_dict(cfg, seed=g["weight_seed"]), 512, "cuda:0")
+    model.load_corpus(os.path.join(golden_dir, "g14_reference_indexed_corpus.pickle"))
+    assert not model.embeddings_staled and len(model.corpus) == g["N"]
+    where = {id(p): i for i, p in enumerate(model.corpus.all_premises)}
+    for use_graphs in (True, False):
+        model.use_graphs = use_graphs
+        for j, q in enumerate(g["queries"]):
+            prem, scores = model.retrieve(q["state"], q["path"], f"thm{j}", Pos(*q["pos"]), g["k"])
+            want = np.array(q["scores"])
+            assert np.abs(np.array(scores) - want).max() <= 1e-2  # bf16 index + bf16-operand encode of the state
+            got = [where[id(p)] for p in prem]
+            for r, (a, b) in enumerate(zip(got, q["ids"])):  # ids wherever the golden gap to both neighbours exceeds 2 tol
+                gap = min(abs(want[r] - want[r - 1]) if r else 1.0, abs(want[r] - want[r + 1]) if r + 1 < len(want) else 1.0)
+                assert a == b or gap <= 2e-2, (j, r, got, q["ids"])
