@@ -112,12 +112,13 @@ def fast_text_corpus_records(n_files: int, n_premises: int, seed: int):
     return recs
 
 
-def cpu_baseline(cfg, sd_dev, corpus_path, E_dev, state_texts, state_ctx, n_encode=8, b_retrieve=64):
+def cpu_baseline(cfg, sd_dev, corpus_path, E_dev, state_texts, state_ctx, n_encode=16, b_retrieve=256):
     """The reference's CPU path as restated by the oracle (kind "port"), timed on this host: pad-to-longest batch
-    encode in fp32 at BOTH matmul precisions the reference can run at ("medium" = its own setting,
-    retrieval/model.py:26, and "highest"), and `get_nearest_premises` (Q @ E.T, full argsort, per-query Python
-    accessibility walk: common.py:299-326) over the full 130k x 1472 fp32 matrix at B = b_retrieve and B = 1.
-    A bounded sample of the step's workload (~30-40 s of CPU work), medians over the repeats."""
+    encode in fp32 at the reference's own matmul precision ("medium", retrieval/model.py:26; median of 2 passes) and at
+    "highest" (one pass), and `get_nearest_premises` (Q @ E.T, full argsort, per-query Python accessibility walk:
+    common.py:299-326) over the full 130k x 1472 fp32 matrix at the step's B = 256 (median of 3) and at B = 1 (median
+    of 5).  A bounded sample of the step's workload (~60 s of CPU work: the encode runs at about one state per second
+    on 128 threads, so the 256 states of a step would take minutes)."""
     from oracle import common_ref, t5_ref
 
     sd = {k: v.float().cpu() for k, v in sd_dev.items()}
@@ -128,12 +129,16 @@ def cpu_baseline(cfg, sd_dev, corpus_path, E_dev, state_texts, state_ctx, n_enco
             for c in state_ctx[:b_retrieve]]
     enc_s = {}
     q = None
-    for prec in ("medium", "highest"):
+    for prec, reps in (("medium", 2), ("highest", 1)):
         torch.set_float32_matmul_precision(prec)
-        t0 = time.perf_counter()
-        q = t5_ref.encode_texts(cfg, sd, texts, 2048).numpy()
-        enc_s[prec] = time.perf_counter() - t0
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            q = t5_ref.encode_texts(cfg, sd, texts, 2048).numpy()
+            ts.append(time.perf_counter() - t0)
+        enc_s[prec] = float(np.median(ts))
     torch.set_float32_matmul_precision("highest")
+    n_tok_padded = len(texts) * min(2048, max(len(s.encode()) + 1 for s in texts))
     rngq = np.random.default_rng(11)
     Q = rngq.standard_normal((b_retrieve, E.shape[1])).astype(np.float32)
     Q /= np.linalg.norm(Q, axis=1, keepdims=True)
@@ -156,10 +161,11 @@ def cpu_baseline(cfg, sd_dev, corpus_path, E_dev, state_texts, state_ctx, n_enco
         "unit": "queries/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": f"encode: {n_encode} of the step's 256 states, fp32, once per precision ({enc_s['medium']:.1f}s medium, "
-                  f"{enc_s['highest']:.1f}s highest); retrieve: get_nearest_premises on the full 130k x 1472 fp32 index, "
-                  f"B={b_retrieve} median of 3 ({ret_b:.2f}s), B=1 median of 5 ({ret_1 * 1e3:.0f}ms); value = encode(medium) "
-                  f"and retrieve(B={b_retrieve}) rates combined per query",
+        "sample": f"encode: {n_encode} of the step's 256 states as one pad-to-longest batch ({n_tok_padded} padded tokens), "
+                  f"fp32: medium median of 2 ({enc_s['medium']:.1f}s), highest once ({enc_s['highest']:.1f}s); retrieve: "
+                  f"get_nearest_premises on the full 130k x 1472 fp32 index, B={b_retrieve} median of 3 ({ret_b:.2f}s), B=1 "
+                  f"median of 5 ({ret_1 * 1e3:.0f}ms); value = encode(medium) and retrieve(B={b_retrieve}) rates combined "
+                  f"per query",
         "encode_qps_medium": enc_q,
         "encode_qps_highest": n_encode / enc_s["highest"],
         "retrieve_only_qps": ret_q,
@@ -588,7 +594,24 @@ def main():
             torch.cuda.synchronize()
             t_idx = time.perf_counter() - t0
             n_tok = int(sum(min(len(pr.serialize().encode()) + 1, 2048) for pr in r2.corpus.all_premises[:2000]))
+            # the same sweep through the index CLI (retrieval/index.py:13-41): checkpoint load, corpus load, re-index,
+            # D2H and persist, as a user runs it (native index directory; BASELINE configs[3] at N = 1)
+            from reprover_amd.retrieval import index as index_cli
+
+            ckpt = os.path.join(tmp, "ckpt")
+            enc.save_pretrained(ckpt)
+            del r2.corpus_embeddings
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            index_cli.main(["--ckpt_path", ckpt, "--corpus-path", tpath, "--output-path", os.path.join(tmp, "index.rpidx/"),
+                            "--batch-size", "64"])
+            torch.cuda.synchronize()
+            t_cli = time.perf_counter() - t0
             reindex = {"premises": len(r2.corpus), "reindex_corpus_s": t_idx, "premises_per_s": len(r2.corpus) / t_idx,
+                       "index_cli_wall_s": t_cli, "index_cli_premises_per_s": len(r2.corpus) / t_cli,
+                       "index_cli": "python -m reprover_amd.retrieval.index --ckpt_path .. --corpus-path .. --output-path "
+                                    "index.rpidx/ (in process): HF checkpoint load + pack, corpus.jsonl load, re-index, "
+                                    "persist (bf16 safetensors + closure arrays)",
                        "load_corpus_jsonl_s": t_load, "mean_tokens_per_premise_first_2000": n_tok / 2000.0,
                        "path": "PremiseRetriever.reindex_corpus(64) from corpus.jsonl: serialize (regex) + tokenise on the "
                                "host, packed varlen encode on the GPU; BASELINE configs[3] at N = 1"}

@@ -220,9 +220,15 @@ class HipT5Encoder:
         for a mask that is not right-padded or an empty row; with ``defer_check=True`` the call is launch-only and
         the caller runs ``raise_pending()`` at its next synchronisation point (``predict_step`` does)."""
         B, L = input_ids.shape
-        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
-        mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
-        assert mask.shape == (B, L)
+        assert attention_mask.shape == (B, L)
+        if not input_ids.is_cuda and not attention_mask.is_cuda:
+            # host batches (the collate's output): ONE asynchronous copy from pinned staging memory.  A `.to(device)` from
+            # pageable memory blocks the host until the stream reaches the copy, i.e. until the previous batch's encode
+            # and search have finished - which is what kept predict_step's one-batch-deep pipeline from overlapping.
+            ids, mask = self._upload_padded(input_ids, attention_mask)
+        else:
+            ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+            mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
         if B * L > self.max_tokens_per_pass and B > 1:  # rare (huge padded batches): chunk the batch dimension;
             step = max(1, self.max_tokens_per_pass // L)  # a single row always runs as one pass
             return torch.cat([self.encode_padded(ids[i : i + step], mask[i : i + step], defer_check, out_dtype)
@@ -234,6 +240,35 @@ class HipT5Encoder:
         if not defer_check:
             self.raise_pending()
         return out
+
+    _STAGING_SLOTS = 4
+
+    def _upload_padded(self, input_ids: torch.Tensor, attention_mask: torch.Tensor):
+        """(ids, mask) int64 [B, L] on the device from host tensors through a ring of pinned staging buffers (a slot is
+        reused four uploads later, after its copy's event): launch-only for the caller."""
+        B, L = input_ids.shape
+        n = B * L
+        ring = self.__dict__.setdefault("_staging", [])
+        nxt = self.__dict__.get("_staging_next", 0)
+        if len(ring) < self._STAGING_SLOTS:
+            ring.append([torch.empty(max(2 * n, 1 << 16), dtype=torch.int64).pin_memory(), None])
+            slot = ring[-1]
+        else:
+            slot = ring[nxt]
+            self._staging_next = (nxt + 1) % self._STAGING_SLOTS
+            if slot[1] is not None:
+                slot[1].synchronize()
+            if slot[0].numel() < 2 * n:
+                slot[0] = torch.empty(2 * n, dtype=torch.int64).pin_memory()
+        h = slot[0]
+        h[:n].view(B, L).copy_(input_ids)
+        h[n : 2 * n].view(B, L).copy_(attention_mask)
+        with torch.cuda.device(self.device):
+            d = torch.empty(2 * n, dtype=torch.int64, device=self.device)
+            d.copy_(h[: 2 * n], non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record(torch.cuda.current_stream(self.device))
+        return d[:n].view(B, L), d[n:].view(B, L)
 
     def padded_workspace_bytes(self, batch: int, padded_len: int) -> int:
         return int(self._lib.rp_encode_padded_workspace_bytes(self._handle, batch, padded_len))

@@ -30,9 +30,7 @@ def run_predict(model: PremiseRetriever, dm: RetrievalDataModule, log_dir: Optio
     dm.setup("predict")
     model.on_predict_start(dm.corpus, dm.eval_batch_size)
     n = 0
-    for batch in dm.predict_dataloader():
-        batch["context_ids"] = batch["context_ids"].to(model.device)
-        batch["context_mask"] = batch["context_mask"].to(model.device)
+    for batch in dm.predict_dataloader():  # host batches go in as they are: the encoder stages them through pinned memory
         model.predict_step(batch, n)
         n += 1
     count = len(model.predict_step_outputs)
@@ -82,7 +80,7 @@ def run_validate(model: PremiseRetriever, dm: RetrievalDataModule) -> Dict[str, 
     tot_recall = [0.0] * k
     tot_mrr, tot_n = 0.0, 0
     for batch in dm.val_dataloader():
-        emb = model._encode(batch["context_ids"].to(model.device), batch["context_mask"].to(model.device))
+        emb = model._encode(batch["context_ids"], batch["context_mask"])
         retrieved, _ = model.corpus.get_nearest_premises(model.corpus_embeddings, batch["context"], emb, k)
         if not any(len(p) for p in batch["all_pos_premises"]):
             continue
