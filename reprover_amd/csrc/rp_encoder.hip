@@ -24,7 +24,7 @@ thread_local std::string g_last_error;
 // options
 // ------------------------------------------------------------------------------------------
 extern int g_scan_cfg, g_scan_impl, g_scan_filter_cfg, g_scan_sample_cfg, g_scan_stride, g_scan_no_epilogue, g_scan_impl_force_new,
-    g_scan_cap;
+    g_scan_cap, g_train_dbg;
 int g_gemm_group_m = 8;
 // Tile configuration per encoder GEMM (see launch_gemm()), measured at 65536 tokens (tools/gemm_bench.py,
 // profiles/).  20 / 26 = the software-pipelined 256 x 256 x 64 tile with 4 / 8 waves: the same main
@@ -156,6 +156,7 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   if (!strcmp(name, "scan_sample_cfg")) { g_scan_sample_cfg = value; return RP_OK; }
   if (!strcmp(name, "scan_stride")) { g_scan_stride = value; return RP_OK; }
   if (!strcmp(name, "scan_cap")) { g_scan_cap = value; return RP_OK; }
+  if (!strcmp(name, "train_dbg")) { g_train_dbg = value; return RP_OK; }
   if (!strcmp(name, "scan_no_epilogue")) { g_scan_no_epilogue = value; return RP_OK; }
   if (!strcmp(name, "scan_force_new")) { g_scan_impl_force_new = value; return RP_OK; }
   if (!strcmp(name, "scan_impl")) {

@@ -20,6 +20,10 @@
 
 using namespace rp;
 
+namespace rp {
+int g_train_dbg = 0;  // experiments (rp_set_option "train_dbg"): bit 0 = skip the bias-table gradient's LDS atomics
+}
+
 namespace {
 
 constexpr int N_GLOBAL = 3;       // embed, rel_bias, final_ln
@@ -378,10 +382,10 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
       ProfScope ps(stream, RP_K_BWD_ATTENTION);
       hipLaunchKernelGGL(attn_bwd_kernel<0>, att_grid, dim3(256), 0, stream, (const bf16_t*)w.qkv[i], (const bf16_t*)w.att[i],
                          (const bf16_t*)w.datt, (const float*)w.lse[i], w.delta, (const int4*)w.work, (const float*)e->bias_tab,
-                         w.dqkv, w.dtab_part, H, e->maxd, Tp);
+                         w.dqkv, w.dtab_part, H, e->maxd, Tp, g_train_dbg);
       hipLaunchKernelGGL(attn_bwd_kernel<1>, att_grid, dim3(256), 0, stream, (const bf16_t*)w.qkv[i], (const bf16_t*)w.att[i],
                          (const bf16_t*)w.datt, (const float*)w.lse[i], w.delta, (const int4*)w.work, (const float*)e->bias_tab,
-                         w.dqkv, w.dtab_part, H, e->maxd, Tp);
+                         w.dqkv, w.dtab_part, H, e->maxd, Tp, g_train_dbg);
       RP_CHECK_LAUNCH();
     }
     {
@@ -619,9 +623,9 @@ extern "C" RpStatus rp_dbg_attention_bwd(const void* qkv, const void* att, const
                      (bf16_t*)att_out, H, maxd, (float*)lse_out, rows_total);
   const bf16_t* o = att ? (const bf16_t*)att : (const bf16_t*)att_out;
   hipLaunchKernelGGL(attn_bwd_kernel<0>, grid, dim3(256), 0, stream, (const bf16_t*)qkv, o, (const bf16_t*)datt,
-                     (const float*)lse_out, delta, (const int4*)work, bias_tab, (bf16_t*)dqkv, part, H, maxd, rows_total);
+                     (const float*)lse_out, delta, (const int4*)work, bias_tab, (bf16_t*)dqkv, part, H, maxd, rows_total, 0);
   hipLaunchKernelGGL(attn_bwd_kernel<1>, grid, dim3(256), 0, stream, (const bf16_t*)qkv, o, (const bf16_t*)datt,
-                     (const float*)lse_out, delta, (const int4*)work, bias_tab, (bf16_t*)dqkv, part, H, maxd, rows_total);
+                     (const float*)lse_out, delta, (const int4*)work, bias_tab, (bf16_t*)dqkv, part, H, maxd, rows_total, 0);
   // [ntab "buckets", H] -> caller's [H, ntab] is the transposed view; the test reads it as [ntab, H]
   hipLaunchKernelGGL(bias_grad_kernel, dim3(H), dim3(256), 0, stream, (const float*)part, (int)grid.y, H, ntab,
                      (const int32_t*)bk, ntab, dtab);
