@@ -204,31 +204,32 @@ class HipT5Encoder:
             b1 = int(np.searchsorted(cu, cu[b0] + self.max_tokens_per_pass, side="right")) - 1
             b1 = min(max(b1, b0 + 1), B)
             t0, t1 = int(cu[b0]), int(cu[b1])
-            ids_d = torch.from_numpy(np.ascontiguousarray(ids[t0:t1])).pin_memory().to(self.device, non_blocking=True)
-            cu_d = torch.from_numpy((cu[b0 : b1 + 1] - cu[b0]).astype(np.int32)).pin_memory().to(
-                self.device, non_blocking=True)
+            ids_d, cu_d = self._stage(np.asarray(ids[t0:t1], dtype=np.int32), (cu[b0 : b1 + 1] - cu[b0]).astype(np.int32))
             self.encode_packed_device(ids_d, cu_d, b1 - b0, t1 - t0, int(lens[b0:b1].max()), out[b0:b1])
             b0 = b1
         return out
 
     def encode_padded(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, defer_check: bool = False,
                       out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-        """Drop-in for ``_encode(input_ids, attention_mask)`` with right-padded [B, L] inputs: one
+        """Drop-in for ``_encode(input_ids, attention_mask)`` with right-padded [B, L] inputs.  DEVICE tensors: one
         ``rp_encode_padded`` launch sequence — lengths, cu_seqlens, id compaction and the right-padding check all
-        happen on the device; no torch kernels, no host round trip.  The check's verdict arrives asynchronously:
+        happen on the device; no torch kernels, no host round trip.  HOST tensors are packed on the host and take the
+        packed entry point (``_encode_host_batch``: the right-padding check raises at once).  On the device form the
+        check's verdict arrives asynchronously:
         by default it is read back here (one 16-byte copy) and ``ValueError`` is raised, as the packed path does,
         for a mask that is not right-padded or an empty row; with ``defer_check=True`` the call is launch-only and
         the caller runs ``raise_pending()`` at its next synchronisation point (``predict_step`` does)."""
         B, L = input_ids.shape
         assert attention_mask.shape == (B, L)
         if not input_ids.is_cuda and not attention_mask.is_cuda:
-            # host batches (the collate's output): ONE asynchronous copy from pinned staging memory.  A `.to(device)` from
-            # pageable memory blocks the host until the stream reaches the copy, i.e. until the previous batch's encode
-            # and search have finished - which is what kept predict_step's one-batch-deep pipeline from overlapping.
-            ids, mask = self._upload_padded(input_ids, attention_mask)
-        else:
-            ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
-            mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
+            # Host batches (the collate's output) are packed on the host - lengths from the mask, right-padding check,
+            # ids of the real tokens only - and go through the packed entry point: ~4 bytes per REAL token cross PCIe
+            # through pinned staging memory, asynchronously (a `.to(device)` of the padded int64 pair from pageable
+            # memory moved 16 bytes per padded position and blocked the host until the stream reached the copy, i.e.
+            # until the previous batch's encode and search had finished).  Same kernels, same bits as the device form.
+            return self._encode_host_batch(input_ids, attention_mask, out_dtype)
+        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
         if B * L > self.max_tokens_per_pass and B > 1:  # rare (huge padded batches): chunk the batch dimension;
             step = max(1, self.max_tokens_per_pass // L)  # a single row always runs as one pass
             return torch.cat([self.encode_padded(ids[i : i + step], mask[i : i + step], defer_check, out_dtype)
@@ -243,32 +244,63 @@ class HipT5Encoder:
 
     _STAGING_SLOTS = 4
 
-    def _upload_padded(self, input_ids: torch.Tensor, attention_mask: torch.Tensor):
-        """(ids, mask) int64 [B, L] on the device from host tensors through a ring of pinned staging buffers (a slot is
-        reused four uploads later, after its copy's event): launch-only for the caller."""
-        B, L = input_ids.shape
-        n = B * L
+    def _stage(self, *arrays: np.ndarray):
+        """Device views of int32 host arrays uploaded by ONE asynchronous copy from a ring of pinned staging buffers (a
+        slot is reused four uploads later, after its copy's event; page-locking is slow, so slots are sized generously
+        once)."""
+        sizes = [int(a.size) for a in arrays]
+        total = sum(sizes)
         ring = self.__dict__.setdefault("_staging", [])
         nxt = self.__dict__.get("_staging_next", 0)
+        cap = max(1 << 18, 1 << max(total - 1, 1).bit_length())
         if len(ring) < self._STAGING_SLOTS:
-            ring.append([torch.empty(max(2 * n, 1 << 16), dtype=torch.int64).pin_memory(), None])
+            ring.append([torch.empty(cap, dtype=torch.int32).pin_memory(), None])
             slot = ring[-1]
         else:
             slot = ring[nxt]
             self._staging_next = (nxt + 1) % self._STAGING_SLOTS
             if slot[1] is not None:
                 slot[1].synchronize()
-            if slot[0].numel() < 2 * n:
-                slot[0] = torch.empty(2 * n, dtype=torch.int64).pin_memory()
-        h = slot[0]
-        h[:n].view(B, L).copy_(input_ids)
-        h[n : 2 * n].view(B, L).copy_(attention_mask)
+            if slot[0].numel() < total:
+                slot[0] = torch.empty(cap, dtype=torch.int32).pin_memory()
+        h = slot[0].numpy()
+        off = 0
+        for a, n in zip(arrays, sizes):
+            h[off : off + n] = a.reshape(-1)
+            off += n
         with torch.cuda.device(self.device):
-            d = torch.empty(2 * n, dtype=torch.int64, device=self.device)
-            d.copy_(h[: 2 * n], non_blocking=True)
+            d = torch.empty(total, dtype=torch.int32, device=self.device)
+            d.copy_(slot[0][:total], non_blocking=True)
             slot[1] = torch.cuda.Event()
             slot[1].record(torch.cuda.current_stream(self.device))
-        return d[:n].view(B, L), d[n:].view(B, L)
+        out, off = [], 0
+        for n in sizes:
+            out.append(d[off : off + n])
+            off += n
+        return out
+
+    def _encode_host_batch(self, input_ids: torch.Tensor, attention_mask: torch.Tensor,
+                           out_dtype: Optional[torch.dtype]) -> torch.Tensor:
+        ids = input_ids.numpy()
+        mask = attention_mask.numpy() != 0
+        B, L = ids.shape
+        lens = mask.sum(1)
+        if (lens == 0).any() or (mask != (np.arange(L)[None, :] < lens[:, None])).any():
+            raise ValueError("attention_mask must be right-padded (1s then 0s) with at least one token per row, "
+                             "as the tokenizer produces")
+        cu = np.zeros(B + 1, dtype=np.int32)
+        np.cumsum(lens, out=cu[1:])
+        packed = ids[mask].astype(np.int32)  # row-major: sequence after sequence
+        out = torch.empty((B, self.cfg["d_model"]), dtype=out_dtype or self.dtype, device=self.device)
+        b0 = 0
+        while b0 < B:  # passes of at most max_tokens_per_pass tokens (one pass for every realistic batch)
+            b1 = int(np.searchsorted(cu, cu[b0] + self.max_tokens_per_pass, side="right")) - 1
+            b1 = min(max(b1, b0 + 1), B)
+            t0, t1 = int(cu[b0]), int(cu[b1])
+            ids_d, cu_d = self._stage(packed[t0:t1], cu[b0 : b1 + 1] - cu[b0])
+            self.encode_packed_device(ids_d, cu_d, b1 - b0, t1 - t0, int(lens[b0:b1].max()), out[b0:b1])
+            b0 = b1
+        return out
 
     def padded_workspace_bytes(self, batch: int, padded_len: int) -> int:
         return int(self._lib.rp_encode_padded_workspace_bytes(self._handle, batch, padded_len))
