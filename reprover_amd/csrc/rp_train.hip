@@ -521,31 +521,25 @@ extern "C" RpStatus rp_trainer_load_params(RpTrainer* tr, const float* params, v
   const int ntab = 2 * e->maxd + 1;
   hipLaunchKernelGGL(bias_table_kernel, dim3((H * ntab + 255) / 256), dim3(256), 0, stream, params + lay.rel_bias(),
                      (const int32_t*)tr->bucket_of, H, ntab, e->bias_tab);
-  auto transpose = [&](const bf16_t* in, int R, int C, bf16_t* out) {
-    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, stream, in, R, C, out);
-  };
   for (int i = 0; i < c.num_layers; ++i) {
     LayerPacked& L = e->layers[i];
     const LayerT& t = tr->lt[i];
     const float* ln_a = params + lay.layer(i, P_LN_ATTN);
     const float* ln_f = params + lay.layer(i, P_LN_FF);
-    RP_HIP(hipMemcpyAsync(L.ln_attn, ln_a, (size_t)D * 4, hipMemcpyDeviceToDevice, stream));
-    RP_HIP(hipMemcpyAsync(L.ln_ff, ln_f, (size_t)D * 4, hipMemcpyDeviceToDevice, stream));
-    hipLaunchKernelGGL((pack_rows_kernel<float>), dim3(3 * inner), dim3(256), 0, stream, L.wqkv,
-                       (const void*)(params + lay.layer(i, P_Q)), (const void*)(params + lay.layer(i, P_K)),
-                       (const void*)(params + lay.layer(i, P_V)), 3 * inner, D, inner, (int)PACK_CONCAT3, ln_a);
-    hipLaunchKernelGGL((pack_rows_kernel<float>), dim3(D), dim3(256), 0, stream, L.wo, (const void*)(params + lay.layer(i, P_O)),
-                       (const void*)nullptr, (const void*)nullptr, D, inner, 0, (int)PACK_COPY, (const float*)nullptr);
-    hipLaunchKernelGGL((pack_rows_kernel<float>), dim3(2 * F), dim3(256), 0, stream, L.wi,
-                       (const void*)(params + lay.layer(i, P_WI0)), (const void*)(params + lay.layer(i, P_WI1)),
-                       (const void*)nullptr, 2 * F, D, 0, (int)PACK_GEGLU, ln_f);
-    hipLaunchKernelGGL((pack_rows_kernel<float>), dim3(D), dim3(256), 0, stream, L.wo2,
-                       (const void*)(params + lay.layer(i, P_WO)), (const void*)nullptr, (const void*)nullptr, D, F, 0,
-                       (int)PACK_COPY, (const float*)nullptr);
-    transpose(L.wqkv, 3 * inner, D, t.wqkv_t);
-    transpose(L.wo, D, inner, t.wo_t);
-    transpose(L.wi, 2 * F, D, t.wi_t);
-    transpose(L.wo2, D, F, t.wo2_t);
+    RepackArgs a{};
+    int tile0 = 0;
+    auto mat = [&](int k, const float* s0, const float* s1, const float* s2, const float* cs, bf16_t* dst, bf16_t* dst_t,
+                   int rows, int cols, int n, int mode) {
+      a.m[k] = RepackMat{s0, s1, s2, cs, dst, dst_t, rows, cols, n, mode, tile0};
+      tile0 += (rows / 64) * (cols / 64);
+    };
+    mat(0, params + lay.layer(i, P_Q), params + lay.layer(i, P_K), params + lay.layer(i, P_V), ln_a, L.wqkv, t.wqkv_t,
+        3 * inner, D, inner, (int)PACK_CONCAT3);
+    mat(1, params + lay.layer(i, P_O), nullptr, nullptr, nullptr, L.wo, t.wo_t, D, inner, 0, (int)PACK_COPY);
+    mat(2, params + lay.layer(i, P_WI0), params + lay.layer(i, P_WI1), nullptr, ln_f, L.wi, t.wi_t, 2 * F, D, 0,
+        (int)PACK_GEGLU);
+    mat(3, params + lay.layer(i, P_WO), nullptr, nullptr, nullptr, L.wo2, t.wo2_t, D, F, 0, (int)PACK_COPY);
+    hipLaunchKernelGGL(repack_layer_kernel, dim3(tile0), dim3(256), 0, stream, a);
   }
   RP_CHECK_LAUNCH();
   return RP_OK;

@@ -966,11 +966,79 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
   }
 }
 
+// Refresh of one layer's bf16 compute copies from the fp32 masters, ONE launch: for each of the four matrices the packed
+// form the forward reads (fused q|k|v rows / 32-row gate|up interleave / plain; RMSNorm weight folded in column-wise) AND its
+// transpose for the dgrad GEMMs, from a single read of the masters (64 x 64 tiles through LDS).  Every dimension is a
+// multiple of 64 (d_model, d_ff, H * 64).
+struct RepackMat {
+  const float* s0;
+  const float* s1;
+  const float* s2;
+  const float* colscale;  // [cols] or NULL
+  bf16_t* dst;            // [rows, cols]
+  bf16_t* dst_t;          // [cols, rows]
+  int rows, cols, n, mode, tile0;
+};
+struct RepackArgs {
+  RepackMat m[4];
+};
+__global__ __launch_bounds__(256) void repack_layer_kernel(RepackArgs a) {
+  __shared__ bf16_t tile[64][68];
+  int mi = 3;
+  while (mi > 0 && (int)blockIdx.x < a.m[mi].tile0) --mi;
+  const RepackMat& M = a.m[mi];
+  const int t = blockIdx.x - M.tile0;
+  const int tiles_c = M.cols >> 6;
+  const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+  const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;  // 16 threads x float4 = one 64-column row piece
+  float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (M.colscale) cs = *reinterpret_cast<const float4*>(M.colscale + c0 + 4 * q);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + rr + 16 * k;
+    const float* src;
+    int sr;
+    if (M.mode == PACK_CONCAT3) {
+      src = (r < M.n) ? M.s0 : (r < 2 * M.n ? M.s1 : M.s2);
+      sr = r % M.n;
+    } else if (M.mode == PACK_GEGLU) {
+      src = ((r >> 5) & 1) ? M.s1 : M.s0;
+      sr = (r >> 6) * 32 + (r & 31);
+    } else {
+      src = M.s0;
+      sr = r;
+    }
+    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)sr * M.cols + c0 + 4 * q);
+    const uint2 p = make_uint2(pack_bf2(v.x * cs.x, v.y * cs.y), pack_bf2(v.z * cs.z, v.w * cs.w));
+    *reinterpret_cast<uint2*>(M.dst + (size_t)r * M.cols + c0 + 4 * q) = p;
+    *reinterpret_cast<uint2*>(&tile[rr + 16 * k][4 * q]) = p;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = rr + 16 * k;  // a column of the tile = a row of the transpose; this thread's four consecutive rows 4 q ..
+    const uint32_t lo = (uint32_t)tile[4 * q][c] | ((uint32_t)tile[4 * q + 1][c] << 16);
+    const uint32_t hi = (uint32_t)tile[4 * q + 2][c] | ((uint32_t)tile[4 * q + 3][c] << 16);
+    *reinterpret_cast<uint2*>(M.dst_t + (size_t)(c0 + c) * M.rows + r0 + 4 * q) = make_uint2(lo, hi);
+  }
+}
+
 // sum of squares of n floats, deterministic: fixed grid of partials, then one workgroup
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
   __shared__ float red[4];
   float s = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s = __builtin_fmaf(g[i], g[i], s);
+  const size_t n4 = n >> 2;  // 16-byte pieces, four in flight per thread
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += 4 * stride) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const float4*>(g)[min(i + u * stride, n4 - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u * stride < n4)
+        s = __builtin_fmaf(v[u].x, v[u].x, __builtin_fmaf(v[u].y, v[u].y, __builtin_fmaf(v[u].z, v[u].z, __builtin_fmaf(v[u].w, v[u].w, s))));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n4 * 4)) s = __builtin_fmaf(g[n4 * 4 + threadIdx.x], g[n4 * 4 + threadIdx.x], s);
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
