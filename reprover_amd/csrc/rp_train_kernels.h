@@ -59,10 +59,7 @@ typedef __attribute__((ext_vector_type(4))) short tr4_t;
 __device__ __forceinline__ bf16x8 tr_read_pair(const char* lo_p, const char* up_p) {
   const tr4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4_t*)(lo_p));
   const tr4_t up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4_t*)(up_p));
-  bf16x8 f;
-  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-  f[4] = up[0]; f[5] = up[1]; f[6] = up[2]; f[7] = up[3];
-  return f;
+  return __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7);  // the two halves of one 128-bit operand register tuple
 }
 
 // Token tiles [kt0, kt0 + nk) of 64 rows; Y / X rows are always readable (K ranges lie inside the padded token count),
@@ -153,17 +150,41 @@ __device__ __forceinline__ void wgrad_tile(const bf16_t* __restrict__ Y, int ldy
       stage(kt + NSTAGE - 1, nb);
     }
     const char* st = smem + buf * C::STAGE_BYTES;
+    // k-steps software-pipelined by hand (as rp_gemm.h's gemm_tile_pipe): the fragments of k-step s + 1 are read while
+    // the MFMAs of k-step s issue; sched_group_barrier pins ceil(reads / MFMAs) transposing reads behind each MFMA
+    // (left to itself the compiler drained lgkmcnt to 0 four times per tile, the first time behind 20 reads).
+    bf16x8 af[2][FM], bfr[2][FN];
+    auto read_frags = [&](int ks, int pb) {
+#pragma unroll
+      for (int f = 0; f < FM; ++f) af[pb][f] = tr_read_pair(st + a_off[f] + ks * 2048, st + a_off[f] + ks * 2048 + 1024);
+#pragma unroll
+      for (int f = 0; f < FN; ++f) bfr[pb][f] = tr_read_pair(st + b_off[f] + ks * 2048, st + b_off[f] + ks * 2048 + 1024);
+    };
+    read_frags(0, 0);
+    __builtin_amdgcn_sched_barrier(0);  // the first k-step's reads are not part of the interleaving below
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 af[FM], bfr[FN];
-#pragma unroll
-      for (int f = 0; f < FM; ++f) af[f] = tr_read_pair(st + a_off[f] + ks * 2048, st + a_off[f] + ks * 2048 + 1024);
-#pragma unroll
-      for (int f = 0; f < FN; ++f) bfr[f] = tr_read_pair(st + b_off[f] + ks * 2048, st + b_off[f] + ks * 2048 + 1024);
+      if (ks < 3) read_frags(ks + 1, (ks + 1) & 1);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+      if (ks < 3) {
+        constexpr int NREAD = 2 * (FM + FN), NM = FM * FN, PER = (NREAD + NM - 1) / NM;
+        int rd = NREAD;
+#pragma unroll
+        for (int n = 0; n < NM; ++n) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+#pragma unroll
+          for (int qq = 0; qq < PER; ++qq)
+            if (rd > 0) {
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one DS read
+              --rd;
+            }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (++buf == NSTAGE) buf = 0;
   }
