@@ -42,7 +42,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     tmp = f"{LIB_PATH}.{os.getpid()}.tmp"  # per-process: concurrent builders (one per rank) must not share it
     objs = [os.path.join(LIB_DIR, f"{os.path.splitext(s)[0]}.{os.getpid()}.o") for s in SOURCES]
     # one translation unit per process, side by side (a cold build is bound by the slowest unit, not their sum)
-    cmds = [[_hipcc(), *COMPILE_FLAGS, "-c", os.path.join(CSRC, s), "-o", o] for s, o in zip(SOURCES, objs)]
+    # RP_EXPERIMENTS=1: a probe build that also carries the measured-and-rejected tile configurations and timing knobs
+    # (tools/gemm_bench.py, tools/scan_bench.py sweeps); the product build compiles none of them
+    extra = ["-DRP_EXPERIMENTS"] if os.environ.get("RP_EXPERIMENTS") == "1" else []
+    cmds = [[_hipcc(), *COMPILE_FLAGS, *extra, "-c", os.path.join(CSRC, s), "-o", o] for s, o in zip(SOURCES, objs)]
     if verbose:
         for c in cmds:
             print(" ".join(c), flush=True)

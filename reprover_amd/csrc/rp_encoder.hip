@@ -144,6 +144,7 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     g_scan_cfg = value;
     return RP_OK;
   }
+#ifdef RP_EXPERIMENTS  // knobs of measured-and-rejected alternatives and timing probes: probe builds only
   if (!strncmp(name, "gemm_stagger_us_", 16)) {  // gemm_stagger_us_{qkv,o,wi,wo}
     const char* which = name + 16;
     const int cls = !strcmp(which, "qkv") ? RP_K_GEMM_QKV : !strcmp(which, "o") ? RP_K_GEMM_O
@@ -155,9 +156,10 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   if (!strcmp(name, "scan_filter_cfg")) { g_scan_filter_cfg = value; return RP_OK; }
   if (!strcmp(name, "scan_sample_cfg")) { g_scan_sample_cfg = value; return RP_OK; }
   if (!strcmp(name, "scan_stride")) { g_scan_stride = value; return RP_OK; }
-  if (!strcmp(name, "scan_cap")) { g_scan_cap = value; return RP_OK; }
   if (!strcmp(name, "train_dbg")) { g_train_dbg = value; return RP_OK; }
   if (!strcmp(name, "scan_no_epilogue")) { g_scan_no_epilogue = value; return RP_OK; }
+#endif
+  if (!strcmp(name, "scan_cap")) { g_scan_cap = value; return RP_OK; }  // tests: forces the overflow -> dense contract
   if (!strcmp(name, "scan_force_new")) { g_scan_impl_force_new = value; return RP_OK; }
   if (!strcmp(name, "scan_impl")) {
     RP_REQUIRE(value >= 0 && value <= 1, "scan_impl out of range");

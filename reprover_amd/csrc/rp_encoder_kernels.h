@@ -379,6 +379,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOpe
                                                           int tiles_n, int group_m, int stagger_ticks,
                                                           const int32_t* __restrict__ t_dev, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef RP_EXPERIMENTS  // first-round stagger of the big GEMMs (measured neutral): probe builds only
   if (stagger_ticks > 0 && blockIdx.x < 256) {
     // first round only (later workgroups inherit their CU's phase): phase = position among the 256 CUs, uniform
     // inside every XCD (workgroup b runs on XCD b % 8)
@@ -386,6 +387,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOpe
     const unsigned long long until = wall_clock64() + (unsigned long long)stagger_ticks * phase / 256u;  // 100 MHz
     while (wall_clock64() < until) __builtin_amdgcn_s_sleep(16);
   }
+#endif
   int nwg = gridDim.x;
   if (t_dev) {
     // rp_encode_padded: the grid covers an upper bound of the token count.  The live tiles are re-numbered over

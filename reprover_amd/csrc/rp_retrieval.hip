@@ -977,7 +977,7 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   st = fp8 ? launch_scan_cfg<SimCfg8Sample>(qop, eop, D2, n_sub, p.stride, epi, stream)
        : (g_scan_sample_cfg == 0 && D2 % 64 == 0)
            ? launch_scan_cfg<SimCfgSampleK64>(qop, eop, D2, n_sub, p.stride, epi, stream)
-           : launch_scan_cfg<SimCfgSample>(qop, eop, D2, n_sub, p.stride, epi, stream);
+           : launch_scan_cfg<SimCfgSample>(qop, eop, D2, n_sub, p.stride, epi, stream);  // (D % 64 != 0: 32-wide K slices)
   if (st) return st;
   sa.out_keys = cand;
   sa.out_ld = p.cap;
@@ -1012,9 +1012,14 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
     } else {
       EpiSimFilter<0> ef;
       fill(ef);
-      st = g_scan_filter_cfg == 1   ? launch_filter_cfg<SimCfgFilterK32>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
-           : g_scan_filter_cfg == 2 ? launch_filter_cfg<SimCfgFilter>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
-                                    : launch_filter_cfg<SimCfgFilterNt>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+#ifdef RP_EXPERIMENTS  // alternatives measured and rejected: only a probe build (RP_EXPERIMENTS=1) carries them
+      if (g_scan_filter_cfg == 1)
+        st = launch_filter_cfg<SimCfgFilterK32>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+      else if (g_scan_filter_cfg == 2)
+        st = launch_filter_cfg<SimCfgFilter>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+      else
+#endif
+        st = launch_filter_cfg<SimCfgFilterNt>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
     }
   } else {
     epi.filter = 1;
