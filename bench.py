@@ -372,7 +372,10 @@ def main():
                                    qk_d.data_ptr(), lo, TOP_K, 0, out_s.data_ptr(), out_i.data_ptr(),
                                    out_c.data_ptr(), ws.data_ptr(), ws_bytes, _lib.current_stream()), "rp_sim_topk")
 
+    n_collectives = [0]
+
     def gather(dst, src):  # one all-gather: RCCL ncclAllGather on GPUs
+        n_collectives[0] += 1
         if dist.get_backend() == "nccl":
             dist.all_gather_into_tensor(dst, src)
         else:
@@ -398,6 +401,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    barrier()
+    n_collectives[0] = 0
+    step()  # (untimed) count the collectives one step issues: 2 at N > 1 (query embeddings, packed result block), 0 at N = 1
+    collectives_per_step = n_collectives[0]
     barrier()
     t0 = time.perf_counter()  # ---- the timed region: exactly K steps, nothing but the hot path's own launches
     for _ in range(args.steps):
@@ -644,6 +651,7 @@ def main():
             "index": "row-sharded %d-way, bf16 unit-norm random rows" % world,
             "weights": "random-init ByT5-small (d_model 1472, 12 layers, 6 heads, d_ff 3584)",
             "accessible_premises_first_queries": n_acc.tolist(), "all_counts_eq_k": counts_ok, "sharded_merge_equals_single_gpu": merged_ok,
+            "collectives_per_step": collectives_per_step,
         },
         "premises_per_s": prem_per_s,
         "premises_per_s_incl_host_tokenisation": prem_per_s_host,
