@@ -174,11 +174,12 @@ def cpu_baseline(cfg, sd_dev, corpus_path, E_dev, state_texts, state_ctx, n_enco
     }
 
 
-def train_step_leg(cfg, sd_dev, dev, batch_size, num_negatives=3, max_seq_len=1024, steps=5):
+def train_step_leg(cfg, sd_dev, dev, batch_size, num_negatives=3, max_seq_len=1024, steps=5, dropout_rate=0.1):
     """One training step of the retriever as retrieval/confs/cli_lean4_random.yaml runs it (batch_size 8 per GPU, 3
     negatives, max_seq_len 1024, AdamW + gradient_clip_val 1.0): forward over the batch's contexts, positives and
-    negatives as ONE packed pass, contrastive MSE and its backward, encoder backward, gradient norm, clipped AdamW over
-    the flat buffers, refresh of the bf16 compute copies.  Contexts draw their lengths from the state mix, premises from
+    negatives as ONE packed pass (T5's dropout 0.1 at its six sites, as the reference's training mode has it), contrastive
+    MSE and its backward, encoder backward, gradient norm, clipped AdamW over the flat buffers, refresh of the bf16 compute
+    copies.  Contexts draw their lengths from the state mix, premises from
     the premise mix (both clipped to max_seq_len).  Wall time per step over `steps` steps (synchronised), then the
     per-class kernel times of an instrumented repeat; GEMM FLOPs: forward linear 2 T P, backward dgrad + wgrad 4 T P
     (P = the encoder's 217 M linear parameters, T = the pass's padded token count)."""
@@ -191,7 +192,8 @@ def train_step_leg(cfg, sd_dev, dev, batch_size, num_negatives=3, max_seq_len=10
     ids, cu = synth.synth_token_batch(rng, lens)
     label = torch.zeros(batch_size, batch_size * (1 + num_negatives), device=dev)
     label[torch.arange(batch_size), torch.arange(batch_size)] = 1.0
-    tr = HipT5Trainer(cfg, {k: v for k, v in sd_dev.items()}, dev, lr=1e-4, warmup_steps=0, gradient_clip_val=1.0)
+    tr = HipT5Trainer(cfg, {k: v for k, v in sd_dev.items()}, dev, lr=1e-4, warmup_steps=0, gradient_clip_val=1.0,
+                      dropout_rate=dropout_rate)
 
     def one_step():
         emb = tr.forward(ids, cu)
@@ -232,7 +234,8 @@ def train_step_leg(cfg, sd_dev, dev, batch_size, num_negatives=3, max_seq_len=10
         "backward_gemm_mfma_frac": tf(2.0 * lin, prof["bwd_dgrad"] + prof["bwd_wgrad"]) / PEAK_BF16_TFLOPS,
         "whole_step_mfma_frac": tf(3.0 * lin, ms) / PEAK_BF16_TFLOPS,
         "config": f"batch_size {batch_size}, {num_negatives} negatives, max_seq_len {max_seq_len}, AdamW lr 1e-4, "
-                  f"gradient_clip_val 1.0, dropout off; one packed pass of {n_seq} sequences",
+                  f"gradient_clip_val 1.0, dropout {dropout_rate} (T5's dropout_rate: the reference's training mode); one packed "
+                  f"pass of {n_seq} sequences",
     }
     del tr
     torch.cuda.empty_cache()
@@ -630,6 +633,7 @@ def main():
         train = {}
         for name, bsz in (("reference_conf_batch8", 8), ("batch64", 64)):
             train[name] = train_step_leg(cfg, sd, dev, bsz)
+        train["reference_conf_batch8"]["ms_per_step_without_dropout"] = train_step_leg(cfg, sd, dev, 8, dropout_rate=0.0)["ms_per_step"]
 
     result = {
         "metric": "retrieve QPS@top-100 (state encode + masked similarity top-k), ByT5-small, 130k-premise corpus",

@@ -257,8 +257,8 @@ RpStatus rp_adamw_step(float* param, const float* grad, float* exp_avg, float* e
  * rp_train_param_layout writes the rp_train_param_tensors(cfg) + 1 element offsets (last = total length incl. padding).
  * One step = rp_train_forward (all sequences of the batch - contexts, positives, negatives - packed as ONE varlen pass)
  *  -> rp_contrastive_mse (+ _backward) on the [batch, D] embeddings -> rp_train_backward -> rp_grad_norm (optional
- * clipping) -> rp_adamw_step over the flat buffers -> rp_trainer_load_params.  Dropout is not applied (deterministic
- * step; the reference's T5 dropout 0.1 is stochastic).  d_model and d_ff must be multiples of 64.
+ * clipping) -> rp_adamw_step over the flat buffers -> rp_trainer_load_params.  Dropout: rp_trainer_set_dropout (off by
+ * default).  d_model and d_ff must be multiples of 64.
  * ------------------------------------------------------------------------------------------- */
 typedef struct RpTrainer RpTrainer;
 int32_t  rp_train_param_tensors(const RpT5Config* cfg);                 /* 3 + 9 * num_layers */
@@ -269,6 +269,12 @@ void     rp_trainer_destroy(RpTrainer* tr);
 /* The inference engine on the trainer's current weights (for rp_encode_varlen / rp_encode_padded: validation re-indexes
  * with the model being trained, retrieval/model.py:212-225); owned by the trainer. */
 RpEncoder* rp_trainer_encoder(RpTrainer* tr);
+/* Dropout of the following rp_train_forward / rp_train_backward pairs (T5's dropout_rate, 0.1 in the reference's training:
+ * transformers modeling_t5.py :725 embeddings, :168/:360 attention probabilities, :400 / :140 the two residual branches, :110
+ * inside the gated FFN, :745 after the final norm).  Counter-based: element (site, row, column) is kept iff
+ * hash(seed, site, row, column) >= p * 2^32 and scaled by 1 / (1 - p); the backward regenerates the masks of the forward that
+ * ran with the same seed, nothing is stored.  p = 0 (the default) switches it off; pass a fresh seed per step. */
+RpStatus rp_trainer_set_dropout(RpTrainer* tr, float p, uint32_t seed);
 /* Refresh every compute copy from the fp32 masters (call after each optimizer step); launch-only. */
 RpStatus rp_trainer_load_params(RpTrainer* tr, const float* params, void* stream);
 size_t   rp_train_workspace_bytes(const RpTrainer* tr, int32_t total_tokens, int32_t batch);
@@ -350,6 +356,12 @@ RpStatus rp_dbg_wgrad(const void* Y, const void* X, float* out, int32_t T, int32
 RpStatus rp_dbg_attention_bwd(const void* qkv, const void* att, const void* datt, const int32_t* cu_seqlens,
                               const float* bias_tab, int32_t batch, int32_t num_heads, int32_t rows_total, void* lse_out,
                               void* att_out, void* dqkv, float* dtab, void* stream);
+/* out u8 [rows, cols]: 1 where element (site, row0 + r, col0 + c) is kept.  Sites: 0 embeddings, 1 final norm output,
+ * 16 + 8 i + {0 attention probabilities (row = the query's packed token index, col = (head << 12) | key offset in its
+ * sequence), 1 attention residual branch, 2 gated product inside the FFN, 3 FFN residual branch} (row = packed token
+ * index, col = feature). */
+RpStatus rp_dbg_dropout_mask(float p, uint32_t seed, uint32_t site, uint32_t row0, uint32_t col0, int32_t rows,
+                             int32_t cols, uint8_t* out, void* stream);
 RpStatus rp_dbg_dgrad(const void* A, const void* W, int32_t M, int32_t N, int32_t K, int32_t mode, const void* aux0,
                       const float* aux1, void* out0, float* out1, int32_t variant, void* stream);
 /* Tuning knobs (integers), e.g. "gemm_variant"; returns RP_E_INVALID for unknown names. */

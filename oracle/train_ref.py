@@ -52,16 +52,19 @@ TIED = "encoder.embed_tokens.weight"  # HF ties it to shared.weight: one paramet
 
 
 def forward_backward(cfg: Dict, sd: Dict[str, torch.Tensor], context_texts: List[str], pos_texts: List[str],
-                     neg_texts: List[List[str]], label: np.ndarray, max_seq_len: int):
+                     neg_texts: List[List[str]], label: np.ndarray, max_seq_len: int, drop_for_group=None):
     """(loss, {parameter name: d loss / d parameter}) in torch fp32 - autograd over the same restatement the forward
     oracle evaluates (t5_ref._encode_texts).  Dropout is the identity (the reference trains with T5's dropout 0.1,
-    which is stochastic and therefore not something a golden vector can pin)."""
+    which is stochastic and therefore not something a golden vector can pin) unless ``drop_for_group`` is given:
+    ``drop_for_group(g)`` returns the mask object (see t5_ref._encoder_forward) of encode g = 0 contexts, 1 positives,
+    2.. the negative lists - the training step with GIVEN dropout masks, differentiated exactly."""
     W = {k: v.detach().clone().float().requires_grad_(True) for k, v in sd.items() if k != TIED}
     with torch.enable_grad():
-        ctx = t5_ref._encode_texts(cfg, W, context_texts, max_seq_len, len(context_texts))
-        prem = [t5_ref._encode_texts(cfg, W, pos_texts, max_seq_len, len(pos_texts))]
-        for texts in neg_texts:
-            prem.append(t5_ref._encode_texts(cfg, W, texts, max_seq_len, len(texts)))
+        dg = drop_for_group or (lambda g: None)
+        ctx = t5_ref._encode_texts(cfg, W, context_texts, max_seq_len, len(context_texts), dg(0))
+        prem = [t5_ref._encode_texts(cfg, W, pos_texts, max_seq_len, len(pos_texts), dg(1))]
+        for g, texts in enumerate(neg_texts):
+            prem.append(t5_ref._encode_texts(cfg, W, texts, max_seq_len, len(texts), dg(2 + g)))
         sim = ctx @ torch.cat(prem, dim=0).T
         loss = torch.nn.functional.mse_loss(sim, torch.from_numpy(np.asarray(label, dtype=np.float32)))
     loss.backward()

@@ -129,6 +129,11 @@ SIGNATURES = {
     "rp_trainer_destroy": (None, [C.c_void_p]),
     "rp_trainer_encoder": (C.c_void_p, [C.c_void_p]),
     "rp_trainer_load_params": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rp_trainer_set_dropout": (C.c_int32, [C.c_void_p, C.c_float, C.c_uint32]),
+    "rp_dbg_dropout_mask": (
+        C.c_int32,
+        [C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p],
+    ),
     "rp_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
     "rp_train_forward": (
         C.c_int32,

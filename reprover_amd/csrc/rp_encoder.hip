@@ -413,8 +413,8 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
     if (st) return st;
     {
       ProfScope ps(stream, RP_K_ATTENTION);
-      hipLaunchKernelGGL(attention_kernel, att_grid, dim3(256), 0, stream, w.qkv, (const int4*)w.work, e->bias_tab, w.att,
-                         H, e->maxd, (float*)nullptr, 0);
+      hipLaunchKernelGGL(attention_kernel<false>, att_grid, dim3(256), 0, stream, w.qkv, (const int4*)w.work, e->bias_tab, w.att,
+                         H, e->maxd, (float*)nullptr, 0, Drop{0u, 0u, 1.f}, 0u);
     }
     if ((st = launch_gemm(w.att, inner, Tp, L.wo, inner, D, inner, EpiResid{w.xb, w.xlo, D, D, w.ssp, np, Tp}, stream,
                           RP_K_GEMM_O, tv, t_dev)))
@@ -687,8 +687,8 @@ extern "C" RpStatus rp_dbg_attention(const void* qkv, const int32_t* cu, const f
   int4* work = nullptr;
   RP_HIP(hipMallocAsync((void**)&work, ((size_t)grid.y + n_p) * sizeof(int4), stream));
   hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu, batch, work, (int)grid.y, work + grid.y, n_p);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, stream, (const bf16_t*)qkv, (const int4*)work, bias_tab,
-                     (bf16_t*)out, H, maxd, (float*)nullptr, 0);
+  hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, stream, (const bf16_t*)qkv, (const int4*)work, bias_tab,
+                     (bf16_t*)out, H, maxd, (float*)nullptr, 0, Drop{0u, 0u, 1.f}, 0u);
   const hipError_t le = hipGetLastError();
   (void)hipFreeAsync(work, stream);
   if (le != hipSuccess) return rp::fail(RP_E_HIP, "attention launch failed: %s", hipGetErrorString(le));

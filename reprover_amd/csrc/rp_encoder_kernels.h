@@ -66,6 +66,33 @@ __global__ void to_f32_kernel(float* dst, const void* src, int n) {
   if (i < n) dst[i] = load_as_f32<T>(src, i);
 }
 
+// Dropout of the TRAINING step (rp_train.hip; inference never drops): counter-based, so the backward regenerates the mask
+// the forward used from (seed, site, row, column) - nothing is stored.  keep iff hash >= thresh (thresh = p * 2^32; 0 = off),
+// kept values are scaled by 1 / (1 - p)  (torch.nn.Dropout).
+struct Drop {
+  uint32_t seed, thresh;
+  float scale;
+};
+__device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t site, uint32_t row, uint32_t col) {
+  uint32_t h = seed ^ (site * 0x9E3779B1u);
+  h ^= row * 0x85EBCA77u;
+  h = (h << 13) | (h >> 19);
+  h *= 0xC2B2AE3Du;
+  h ^= col * 0x27D4EB2Fu;
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 12;
+  h *= 0x297A2D39u;
+  h ^= h >> 15;
+  return h;
+}
+__device__ __forceinline__ float drop_mul(const Drop& d, uint32_t site, uint32_t row, uint32_t col) {
+  return drop_hash(d.seed, site, row, col) >= d.thresh ? d.scale : 0.f;
+}
+// element ids: (site, row = packed token index, col = feature) - attention probabilities: row = the query's packed token
+// index, col = (head << 12) | key offset inside the sequence
+enum { DROP_SITE_EMBED = 0, DROP_SITE_FINAL = 1, DROP_SITE_LAYER0 = 16 };  // layer i: 16 + 8 i + {0 probs, 1 attn residual, 2 FFN inner, 3 FFN residual}
+
 // ------------------------------------------------------------------------------------------
 // The residual stream x lives in HBM as TWO bf16 planes: hi = bf16(x) and lo = bf16(x - hi), x = hi + lo to 2^-18
 // relative (16 mantissa bits).  hi IS the A operand of the next projection, so a residual update reads 4 B and writes
@@ -246,6 +273,8 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
                              // 16-B fragments of lines shared with workgroups on other XCDs)
   int np, ssp_ld;
   const bf16_t* __restrict__ xhi_in = nullptr;  // SPLIT_IN only
+  Drop drop = {0u, 0u, 1.f};                    // SPLIT_IN only: dropout on the sub-layer's output before the add (HF:140, 400)
+  uint32_t drop_site = 0;
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
     static_assert(FM % 2 == 0, "one statistic slot per 64 features (two row fragments)");
@@ -293,8 +322,21 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int t = c * 8 + rr;
-        const float4 d0 = *reinterpret_cast<const float4*>(stage + t * RB + sub * 32);
-        const float4 d1 = *reinterpret_cast<const float4*>(stage + t * RB + sub * 32 + 16);
+        float4 d0 = *reinterpret_cast<const float4*>(stage + t * RB + sub * 32);
+        float4 d1 = *reinterpret_cast<const float4*>(stage + t * RB + sub * 32 + 16);
+        if constexpr (SPLIT_IN) {
+          if (drop.thresh) {
+            const uint32_t row = (uint32_t)(n_base + j * 32 + t), c0 = (uint32_t)f;
+            d0.x *= drop_mul(drop, drop_site, row, c0);
+            d0.y *= drop_mul(drop, drop_site, row, c0 + 1);
+            d0.z *= drop_mul(drop, drop_site, row, c0 + 2);
+            d0.w *= drop_mul(drop, drop_site, row, c0 + 3);
+            d1.x *= drop_mul(drop, drop_site, row, c0 + 4);
+            d1.y *= drop_mul(drop, drop_site, row, c0 + 5);
+            d1.z *= drop_mul(drop, drop_site, row, c0 + 6);
+            d1.w *= drop_mul(drop, drop_site, row, c0 + 7);
+          }
+        }
         float ss = 0.f;
         if (f < n_valid) {
           const size_t off = (size_t)(n_base + j * 32 + t) * ldx + f;
@@ -577,11 +619,15 @@ static __global__ __launch_bounds__(1024) void worklist_kernel(const int32_t* __
     for (int i = tid; i < n_pslots; i += 1024) pwork[i] = make_int4(0, 0, 0, 0);
 }
 
-static __global__ __launch_bounds__(256, 4) void attention_kernel(const bf16_t* __restrict__ qkv,
+// TRAIN: dropout on the attention probabilities (HF:168, 360: after the softmax; the row sum uses the undropped values)
+// (the dropout instantiation needs more registers than four workgroups per CU leave a wave)
+template <bool TRAIN, bool DROP = false>
+static __global__ __launch_bounds__(256, DROP ? 2 : 4) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                          const int4* __restrict__ work,
                                                          const float* __restrict__ bias_tab,
                                                         bf16_t* __restrict__ out, int H, int maxd,
-                                                         float* __restrict__ lse2, int lse_ld) {
+                                                         float* __restrict__ lse2, int lse_ld, Drop drop,
+                                                         uint32_t drop_site) {
   __shared__ __attribute__((aligned(16))) char smem[2 * AT2_STAGE + ATT_TAB_MAX * 4];
   float* tab = reinterpret_cast<float*>(smem + 2 * AT2_STAGE);
 
@@ -728,6 +774,15 @@ static __global__ __launch_bounds__(256, 4) void attention_kernel(const bf16_t* 
     }
     l_run += psum;
     m_run = m_new;
+    if constexpr (TRAIN && DROP) {
+      {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            s[kb][r] *= drop_mul(drop, drop_site, (uint32_t)(s0 + qi), ((uint32_t)h << 12) | (uint32_t)(k0 + kb * 32 + mfma32_row(r, hi)));
+      }
+    }
     // ---- O^T += V^T P^T over four 16-key slabs
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) {

@@ -14,8 +14,9 @@
 // attention output and its log-sum-exp, the row-scaled gate/up pre-activations and their gated product: 30.5 KB per token
 // and layer for ByT5-small (366 KB per token at 12 layers; 41 k tokens = 15 GB of the 288 GB).  Nothing is recomputed
 // except the attention probabilities (flash-style, from q, k, the bias table and the log-sum-exp).
-// Dropout: the reference trains with T5's dropout 0.1 (stochastic); this step is the deterministic dropout-free one
-// (the oracle's, fixture G11/G12), bit-reproducible run to run.
+// Dropout: T5's dropout (0.1 in the reference's training) at HF's six sites, counter-based (rp_trainer_set_dropout): the
+// backward regenerates the forward's masks.  p = 0 is the deterministic step fixtures G11 / G12 pin; either way the step is
+// bit-reproducible run to run for a given seed.
 #include "rp_train_kernels.h"
 
 using namespace rp;
@@ -79,6 +80,7 @@ struct RpTrainer {
   Layout lay;
   std::vector<LayerT> lt;
   int32_t* bucket_of = nullptr;  // [2 maxd + 1] relative offset -> bucket
+  Drop drop = {0u, 0u, 1.f};     // dropout of the next forward / backward (rp_trainer_set_dropout); thresh 0 = off
   std::vector<void*> allocs;
 };
 
@@ -92,7 +94,7 @@ struct TrainWs {
   float *ssp, *rs_final, *pool;
   int4 *work, *pwork;
   // backward scratch
-  bf16_t *dxhi, *dxlo, *dzs, *datt, *dqkv;
+  bf16_t *dxhi, *dxlo, *dzs, *datt, *dqkv, *dxm;
   float *delta, *rdp, *rcoef, *wpart, *dtab_part, *dln_part, *ds_seq, *dwf_seq, *norm_part;
   size_t wpart_bytes;
   size_t bytes;
@@ -166,6 +168,7 @@ TrainWs carve_train(const RpTrainer* tr, int T, int batch, char* base) {
   w.dzs = (bf16_t*)take(Tp * 2 * F * 2);
   w.datt = (bf16_t*)take(Tp * inner * 2);
   w.dqkv = (bf16_t*)take(Tp * 3 * inner * 2);
+  w.dxm = (bf16_t*)take(Tp * D * 2);  // mask * dx behind a residual-branch dropout (dropout on: else unused)
   w.delta = (float*)take(H * Tp * 4);
   w.rdp = (float*)take(((F + 63) / 64) * Tp * 4);
   w.rcoef = (float*)take(Tp * 4);
@@ -241,10 +244,15 @@ RpStatus train_forward(RpTrainer* tr, const int32_t* ids, const int32_t* cu, int
     hipLaunchKernelGGL(rowscale_kernel, dim3((Tp + 63) / 64), dim3(64), 0, stream, w.ssp, rs, Tp, np, 1.f / (float)D,
                        c.layer_norm_eps);
   };
+  const Drop drop = tr->drop;
   {
     ProfScope ps(stream, RP_K_EMBED);
-    hipLaunchKernelGGL(embed_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.xa[0], w.xlo, w.ssp, np, T, Tp,
-                       D, c.vocab_size, (const int32_t*)nullptr);
+    if (drop.thresh)
+      hipLaunchKernelGGL(embed_train_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, (const float*)e->embed, w.xa[0], w.xlo,
+                         w.ssp, np, T, Tp, D, c.vocab_size, drop);
+    else
+      hipLaunchKernelGGL(embed_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.xa[0], w.xlo, w.ssp, np, T, Tp,
+                         D, c.vocab_size, (const int32_t*)nullptr);
   }
   const dim3 att_grid(H, T / ATT_Q + batch);
   hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu, batch, w.work, (int)att_grid.y, w.pwork,
@@ -252,34 +260,50 @@ RpStatus train_forward(RpTrainer* tr, const int32_t* ids, const int32_t* cu, int
   RP_CHECK_LAUNCH();
   for (int i = 0; i < L; ++i) {
     const LayerPacked& Lw = e->layers[i];
+    const uint32_t site = DROP_SITE_LAYER0 + 8u * (uint32_t)i;  // + {0 probs, 1 attention residual, 2 FFN inner, 3 FFN residual}
     rowscale(w.rsa[i]);
     if ((st = launch_gemm(w.xa[i], D, Tp, Lw.wqkv, D, 3 * inner, D,
                           EpiStoreBf16{w.qkv[i], 3 * inner, 3 * inner, RowScale{w.rsa[i]}}, stream, RP_K_GEMM_QKV)))
       return st;
     {
       ProfScope ps(stream, RP_K_ATTENTION);
-      hipLaunchKernelGGL(attention_kernel, att_grid, dim3(256), 0, stream, (const bf16_t*)w.qkv[i], (const int4*)w.work,
-                         (const float*)e->bias_tab, w.att[i], H, e->maxd, w.lse[i], Tp);
+      if (drop.thresh)
+        hipLaunchKernelGGL((attention_kernel<true, true>), att_grid, dim3(256), 0, stream, (const bf16_t*)w.qkv[i],
+                           (const int4*)w.work, (const float*)e->bias_tab, w.att[i], H, e->maxd, w.lse[i], Tp, drop, site);
+      else
+        hipLaunchKernelGGL((attention_kernel<true, false>), att_grid, dim3(256), 0, stream, (const bf16_t*)w.qkv[i],
+                           (const int4*)w.work, (const float*)e->bias_tab, w.att[i], H, e->maxd, w.lse[i], Tp, drop, site);
     }
     // rows T .. Tp of every saved activation must stay finite: they are K rows of the wgrad GEMMs (against zero dY rows)
     if (Tp > T) RP_HIP(hipMemsetAsync(w.att[i] + (size_t)T * inner, 0, (size_t)(Tp - T) * inner * 2, stream));
     if ((st = launch_gemm(w.att[i], inner, Tp, Lw.wo, inner, D, inner,
-                          EpiResidT<true>{w.xf[i], w.xlo, D, D, w.ssp, np, Tp, w.xa[i]}, stream, RP_K_GEMM_O)))
+                          EpiResidT<true>{w.xf[i], w.xlo, D, D, w.ssp, np, Tp, w.xa[i], drop, site + 1}, stream, RP_K_GEMM_O)))
       return st;
     rowscale(w.rsf[i]);
-    if ((st = launch_gemm(w.xf[i], D, Tp, Lw.wi, D, 2 * F, D,
-                          EpiGegluTrain{EpiStoreBf16{w.gu[i], 2 * F, 2 * F, RowScale{w.rsf[i]}},
-                                        EpiGegluBf16{w.ff[i], F, 2 * F, RowScale{w.rsf[i]}}},
-                          stream, RP_K_GEMM_WI)))
-      return st;
-    if ((st = launch_gemm(w.ff[i], F, Tp, Lw.wo2, F, D, F, EpiResidT<true>{w.xa[i + 1], w.xlo, D, D, w.ssp, np, Tp, w.xf[i]},
-                          stream, RP_K_GEMM_WO)))
+    const EpiStoreBf16 gu_store{w.gu[i], 2 * F, 2 * F, RowScale{w.rsf[i]}};
+    st = drop.thresh ? launch_gemm(w.xf[i], D, Tp, Lw.wi, D, 2 * F, D,
+                                   EpiGegluTrainT<true>{gu_store, w.ff[i], F, 2 * F, RowScale{w.rsf[i]}, drop, site + 2}, stream,
+                                   RP_K_GEMM_WI)
+                     : launch_gemm(w.xf[i], D, Tp, Lw.wi, D, 2 * F, D,
+                                   EpiGegluTrainT<false>{gu_store, w.ff[i], F, 2 * F, RowScale{w.rsf[i]}, drop, site + 2}, stream,
+                                   RP_K_GEMM_WI);
+    if (st) return st;
+    if ((st = launch_gemm(w.ff[i], F, Tp, Lw.wo2, F, D, F,
+                          EpiResidT<true>{w.xa[i + 1], w.xlo, D, D, w.ssp, np, Tp, w.xf[i], drop, site + 3}, stream, RP_K_GEMM_WO)))
       return st;
   }
   rowscale(w.rs_final);
   {
     ProfScope ps(stream, RP_K_POOL);
-    launch_pool_partial(dim3(T / POOL_CHUNK + batch), stream, w.xa[L], w.xlo, w.rs_final, (const int4*)w.pwork, w.pool, D);
+    const dim3 pg(T / POOL_CHUNK + batch);
+    if (!drop.thresh)
+      launch_pool_partial(pg, stream, w.xa[L], w.xlo, w.rs_final, (const int4*)w.pwork, w.pool, D);
+    else if (D <= 3 * 512)
+      hipLaunchKernelGGL(pool_partial_train_kernel<3>, pg, dim3(256), 0, stream, (const bf16_t*)w.xa[L], (const bf16_t*)w.xlo,
+                         (const float*)w.rs_final, (const int4*)w.pwork, w.pool, D, drop);
+    else
+      hipLaunchKernelGGL(pool_partial_train_kernel<4>, pg, dim3(256), 0, stream, (const bf16_t*)w.xa[L], (const bf16_t*)w.xlo,
+                         (const float*)w.rs_final, (const int4*)w.pwork, w.pool, D, drop);
     hipLaunchKernelGGL(pool_finish_kernel, dim3(batch), dim3(256), 0, stream, (const float*)w.pool, (const float*)e->final_ln,
                        cu, (void*)out_emb, 0, D);
   }
@@ -298,7 +322,16 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
   const int nk = Tp / 64, ntab = 2 * e->maxd + 1;
   const float inv_d = 1.f / (float)D;
   RpStatus st;
+  const Drop drop = tr->drop;
   const dim3 att_grid(H, T / ATT_Q + batch);
+  // behind a residual-branch dropout the branch sees mask * dx: one bf16 copy, the operand of its dgrad and wgrad GEMMs
+  auto branch_grad = [&](uint32_t site) -> const bf16_t* {
+    if (!drop.thresh) return w.dxhi;
+    ProfScope ps(stream, RP_K_BWD_OTHER);
+    hipLaunchKernelGGL(mask_dx_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, (const bf16_t*)w.dxhi, (const bf16_t*)w.dxlo,
+                       w.dxm, Tp, D, drop, site);
+    return w.dxm;
+  };
   RP_HIP(hipMemsetAsync(w.dxhi, 0, (size_t)Tp * D * 2, stream));
   RP_HIP(hipMemsetAsync(w.dxlo, 0, (size_t)Tp * D * 2, stream));
   RP_HIP(hipMemsetAsync(w.dtab_part, 0, (size_t)att_grid.y * H * ntab * 4, stream));
@@ -313,21 +346,23 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
     const dim3 pg(T / POOL_CHUNK + batch);
     if (D <= 3 * 512)
       hipLaunchKernelGGL(pool_bwd_tok_kernel<3>, pg, dim3(256), 0, stream, (const bf16_t*)w.xa[L], (const bf16_t*)w.xlo,
-                         (const float*)w.rs_final, (const int4*)w.pwork, (const float*)w.ds_seq, w.dxhi, w.dxlo, D, inv_d);
+                         (const float*)w.rs_final, (const int4*)w.pwork, (const float*)w.ds_seq, w.dxhi, w.dxlo, D, inv_d, drop);
     else
       hipLaunchKernelGGL(pool_bwd_tok_kernel<4>, pg, dim3(256), 0, stream, (const bf16_t*)w.xa[L], (const bf16_t*)w.xlo,
-                         (const float*)w.rs_final, (const int4*)w.pwork, (const float*)w.ds_seq, w.dxhi, w.dxlo, D, inv_d);
+                         (const float*)w.rs_final, (const int4*)w.pwork, (const float*)w.ds_seq, w.dxhi, w.dxlo, D, inv_d, drop);
     RP_CHECK_LAUNCH();
   }
 
   for (int i = L - 1; i >= 0; --i) {
     const LayerT& Lt = tr->lt[i];
+    const uint32_t site = DROP_SITE_LAYER0 + 8u * (uint32_t)i;
     // ---------------- feed-forward sub-layer:  x_out = x + ff Wo2^T,  ff = gelu(g) u,  [g | u] = rs (x Wi'^T)
-    // dWo2 = dx^T ff  (dx: the hi plane of the residual gradient)
+    // dWo2 = dx^T ff  (dx: the hi plane of the residual gradient; mask * dx under dropout)
+    const bf16_t* dxb = branch_grad(site + 3);
     {
       const int S = wgrad_splits(D, F, nk);
       float* dst = grads + lay.layer(i, P_WO);
-      if ((st = launch_wgrad(w.dxhi, D, D, w.ff[i], F, F, Tp, S, S == 1 ? dst : w.wpart, stream))) return st;
+      if ((st = launch_wgrad(dxb, D, D, w.ff[i], F, F, Tp, S, S == 1 ? dst : w.wpart, stream))) return st;
       if (S > 1) {
         UnfoldArgs a{};
         a.part = w.wpart; a.split_stride = (size_t)D * F; a.splits = S; a.rows = D; a.C = F; a.mode = UNFOLD_PLAIN; a.g0 = dst;
@@ -335,8 +370,9 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
       }
     }
     // dff = dx Wo2 -> gated-GELU backward -> dzs = rs [dg | du] (packed order), row dots
-    if ((st = launch_gemm(w.dxhi, D, Tp, Lt.wo2_t, D, F, D,
-                          EpiGegluBwd{w.gu[i], w.dzs, 2 * F, F, w.rsf[i], w.rdp, (F + 63) / 64, Tp}, stream, RP_K_BWD_DGRAD, 0,
+    if ((st = launch_gemm(dxb, D, Tp, Lt.wo2_t, D, F, D,
+                          EpiGegluBwd{w.gu[i], w.dzs, 2 * F, F, w.rsf[i], w.rdp, (F + 63) / 64, Tp, drop, site + 2}, stream,
+                          RP_K_BWD_DGRAD, 0,
                           nullptr, bwd_variant(F, D, Tp))))
       return st;
     {
@@ -364,10 +400,11 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
       return st;
 
     // ---------------- attention sub-layer:  x_out = x + att Wo^T,  att = Attn(q, k, v),  [q | k | v] = rs (x Wqkv'^T)
+    dxb = branch_grad(site + 1);
     {
       const int S = wgrad_splits(D, inner, nk);
       float* dst = grads + lay.layer(i, P_O);
-      if ((st = launch_wgrad(w.dxhi, D, D, w.att[i], inner, inner, Tp, S, S == 1 ? dst : w.wpart, stream))) return st;
+      if ((st = launch_wgrad(dxb, D, D, w.att[i], inner, inner, Tp, S, S == 1 ? dst : w.wpart, stream))) return st;
       if (S > 1) {
         UnfoldArgs a{};
         a.part = w.wpart; a.split_stride = (size_t)D * inner; a.splits = S; a.rows = D; a.C = inner; a.mode = UNFOLD_PLAIN;
@@ -375,17 +412,23 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
         if ((st = run_unfold(a, stream))) return st;
       }
     }
-    if ((st = launch_gemm(w.dxhi, D, Tp, Lt.wo_t, D, inner, D, EpiStoreBf16{w.datt, inner, inner, RowScale{nullptr}}, stream,
+    if ((st = launch_gemm(dxb, D, Tp, Lt.wo_t, D, inner, D, EpiStoreBf16{w.datt, inner, inner, RowScale{nullptr}}, stream,
                           RP_K_BWD_DGRAD, 0, nullptr, bwd_variant(inner, D, Tp))))
       return st;
     {
       ProfScope ps(stream, RP_K_BWD_ATTENTION);
-      hipLaunchKernelGGL(attn_bwd_kernel<0>, att_grid, dim3(256), 0, stream, (const bf16_t*)w.qkv[i], (const bf16_t*)w.att[i],
-                         (const bf16_t*)w.datt, (const float*)w.lse[i], w.delta, (const int4*)w.work, (const float*)e->bias_tab,
-                         w.dqkv, w.dtab_part, H, e->maxd, Tp, g_train_dbg);
-      hipLaunchKernelGGL(attn_bwd_kernel<1>, att_grid, dim3(256), 0, stream, (const bf16_t*)w.qkv[i], (const bf16_t*)w.att[i],
-                         (const bf16_t*)w.datt, (const float*)w.lse[i], w.delta, (const int4*)w.work, (const float*)e->bias_tab,
-                         w.dqkv, w.dtab_part, H, e->maxd, Tp, g_train_dbg);
+      auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, att_grid, dim3(256), 0, stream, (const bf16_t*)w.qkv[i], (const bf16_t*)w.att[i],
+                           (const bf16_t*)w.datt, (const float*)w.lse[i], w.delta, (const int4*)w.work, (const float*)e->bias_tab,
+                           w.dqkv, w.dtab_part, H, e->maxd, Tp, g_train_dbg, drop, site);
+      };
+      if (drop.thresh) {
+        launch(attn_bwd_kernel<0, true>);
+        launch(attn_bwd_kernel<1, true>);
+      } else {
+        launch(attn_bwd_kernel<0, false>);
+        launch(attn_bwd_kernel<1, false>);
+      }
       RP_CHECK_LAUNCH();
     }
     {
@@ -415,7 +458,7 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
   {
     ProfScope ps(stream, RP_K_BWD_OTHER);
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(c.vocab_size, (D + 255) / 256), dim3(256), 0, stream, ids, T, c.vocab_size,
-                       (const bf16_t*)w.dxhi, (const bf16_t*)w.dxlo, D, grads + lay.embed());
+                       (const bf16_t*)w.dxhi, (const bf16_t*)w.dxlo, D, grads + lay.embed(), drop);
     hipLaunchKernelGGL(bias_grad_kernel, dim3(H), dim3(256), 0, stream, (const float*)w.dtab_part, (int)att_grid.y, H, ntab,
                        (const int32_t*)tr->bucket_of, c.rel_num_buckets, grads + lay.rel_bias());
     RP_CHECK_LAUNCH();
@@ -505,6 +548,23 @@ extern "C" RpStatus rp_trainer_create(const RpT5Config* cfg, const float* params
 }
 
 extern "C" RpEncoder* rp_trainer_encoder(RpTrainer* tr) { return tr ? tr->enc : nullptr; }
+
+extern "C" RpStatus rp_trainer_set_dropout(RpTrainer* tr, float p, uint32_t seed) {
+  RP_REQUIRE(tr && p >= 0.f && p < 1.f, "dropout probability %g", (double)p);
+  const double th = (double)p * 4294967296.0;
+  tr->drop = Drop{seed, p > 0.f ? (uint32_t)std::min(th, 4294967295.0) : 0u, p > 0.f ? 1.f / (1.f - p) : 1.f};
+  return RP_OK;
+}
+
+extern "C" RpStatus rp_dbg_dropout_mask(float p, uint32_t seed, uint32_t site, uint32_t row0, uint32_t col0, int32_t rows,
+                                        int32_t cols, uint8_t* out, void* stream_) {
+  RP_REQUIRE(out && rows > 0 && cols > 0 && p > 0.f && p < 1.f, "bad argument");
+  const Drop d{seed, (uint32_t)std::min((double)p * 4294967296.0, 4294967295.0), 1.f / (1.f - p)};
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, (hipStream_t)stream_, d, site, row0, col0,
+                     rows, cols, out);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
 
 // Refresh every bf16 compute copy from the fp32 masters (after an optimizer step): the forward's packed weights, the
 // embedding / norm / bias tables, and the transposed copies of the dgrad GEMMs.  Launch-only.
@@ -613,13 +673,15 @@ extern "C" RpStatus rp_dbg_attention_bwd(const void* qkv, const void* att, const
     RP_HIP(hipMemcpy(bk, ident.data(), (size_t)ntab * 4, hipMemcpyHostToDevice));
   }
   hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu, batch, work, (int)grid.y, work + grid.y, n_p);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, stream, (const bf16_t*)qkv, (const int4*)work, bias_tab,
-                     (bf16_t*)att_out, H, maxd, (float*)lse_out, rows_total);
+  hipLaunchKernelGGL((attention_kernel<true, false>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, (const int4*)work, bias_tab,
+                     (bf16_t*)att_out, H, maxd, (float*)lse_out, rows_total, Drop{0u, 0u, 1.f}, 0u);
   const bf16_t* o = att ? (const bf16_t*)att : (const bf16_t*)att_out;
-  hipLaunchKernelGGL(attn_bwd_kernel<0>, grid, dim3(256), 0, stream, (const bf16_t*)qkv, o, (const bf16_t*)datt,
-                     (const float*)lse_out, delta, (const int4*)work, bias_tab, (bf16_t*)dqkv, part, H, maxd, rows_total, 0);
-  hipLaunchKernelGGL(attn_bwd_kernel<1>, grid, dim3(256), 0, stream, (const bf16_t*)qkv, o, (const bf16_t*)datt,
-                     (const float*)lse_out, delta, (const int4*)work, bias_tab, (bf16_t*)dqkv, part, H, maxd, rows_total, 0);
+  hipLaunchKernelGGL((attn_bwd_kernel<0, false>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, o, (const bf16_t*)datt,
+                     (const float*)lse_out, delta, (const int4*)work, bias_tab, (bf16_t*)dqkv, part, H, maxd, rows_total, 0,
+                     Drop{0u, 0u, 1.f}, 0u);
+  hipLaunchKernelGGL((attn_bwd_kernel<1, false>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, o, (const bf16_t*)datt,
+                     (const float*)lse_out, delta, (const int4*)work, bias_tab, (bf16_t*)dqkv, part, H, maxd, rows_total, 0,
+                     Drop{0u, 0u, 1.f}, 0u);
   // [ntab "buckets", H] -> caller's [H, ntab] is the transposed view; the test reads it as [ntab, H]
   hipLaunchKernelGGL(bias_grad_kernel, dim3(H), dim3(256), 0, stream, (const float*)part, (int)grid.y, H, ntab,
                      (const int32_t*)bk, ntab, dtab);
@@ -649,7 +711,7 @@ extern "C" RpStatus rp_dbg_dgrad(const void* A, const void* W, int32_t M, int32_
     RP_HIP(hipMalloc((void**)&ones, (size_t)M * 4));
     std::vector<float> one(M, 1.f);
     RP_HIP(hipMemcpy(ones, one.data(), (size_t)M * 4, hipMemcpyHostToDevice));
-    RpStatus st = launch_gemm(a, K, M, w, K, N, K, EpiGegluBwd{(const bf16_t*)aux0, (bf16_t*)out0, 2 * N, N, aux1, rdp, np, M},
+    RpStatus st = launch_gemm(a, K, M, w, K, N, K, EpiGegluBwd{(const bf16_t*)aux0, (bf16_t*)out0, 2 * N, N, aux1, rdp, np, M, Drop{0u, 0u, 1.f}, 0u},
                               stream, RP_K_BWD_DGRAD, 0, nullptr, variant);
     // out1 = sum of the slots (rs = 1, inv_d = 1 turns rowdot_finish into a plain slot sum)
     if (st == RP_OK)

@@ -222,6 +222,8 @@ struct EpiGegluBwd {
   const float* __restrict__ rs;   // [tokens]
   float* __restrict__ rdp;        // [np, ld_t]
   int np, ld_t;
+  Drop drop;                      // dropout between the gated product and wo (HF:110): d(product) = mask * dff
+  uint32_t drop_site;
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
     static_assert(FM % 2 == 0, "blocks of 64 features (two row fragments)");
@@ -262,7 +264,11 @@ struct EpiGegluBwd {
         const int token = n_base + j * 32 + t;
         const float4 d0 = *reinterpret_cast<const float4*>(stage + t * RB + sub * 32);
         const float4 d1 = *reinterpret_cast<const float4*>(stage + t * RB + sub * 32 + 16);
-        const float dff[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        float dff[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        if (drop.thresh) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dff[e] *= drop_mul(drop, drop_site, (uint32_t)token, (uint32_t)(f0 + sub * 8 + e));
+        }
         const uint4 gq = gg[b & 1][c], uq = uu[b & 1][c];
         const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w}, uw[4] = {uq.x, uq.y, uq.z, uq.w};
         const float rsv = rs[token];
@@ -367,14 +373,59 @@ struct EpiRmsBwdResid {
   }
 };
 
-// training forward, FFN-in: the gated-GELU output AND the row-scaled pre-activations (packed order) the backward needs
-struct EpiGegluTrain {
+// training forward, FFN-in: the row-scaled pre-activations (packed order) the backward needs AND the gated-GELU output with
+// the dropout that sits between it and wo (HF:110).  The product part is EpiGegluBf16T's, plus the mask.
+template <bool DROP>
+struct EpiGegluTrainT {
   EpiStoreBf16 st;  // gu [tokens, 2 d_ff]
-  EpiGegluBf16 ge;  // ff [tokens, d_ff]
+  bf16_t* out;      // ff [tokens, d_ff] = mask * gelu_new(g) * u
+  int ldo, n_valid;
+  RowScale rs;
+  Drop drop;
+  uint32_t drop_site;
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
-    st.template run<FM, FN>(acc, m_base, n_base, lane, stage);
-    ge.template run<FM, FN>(acc, m_base, n_base, lane, stage);  // same wave-private staging area, LDS ops of a wave are in order
+    st.template run<FM, FN>(acc, m_base, n_base, lane, stage);  // same wave-private staging area, LDS ops of a wave are in order
+    static_assert(FM % 2 == 0 && FM * 32 <= 128, "gate/up fragment pairs; staging row");
+    const int hi = lane >> 5, cl = lane & 31;
+    constexpr int LPR = FM * 2, RPI = 64 / LPR;
+    const int sub = lane % LPR, rr = lane / LPR;
+    const int f = (m_base >> 1) + sub * 8;
+    float scv[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) scv[j] = rs.get(n_base + j * 32 + cl);
+#pragma unroll
+    for (int jb = 0; jb < FN; jb += 2) {
+#pragma unroll
+      for (int jj = 0; jj < 2 && jb + jj < FN; ++jj) {
+        const float sc = scv[jb + jj];
+        const uint32_t row = (uint32_t)(n_base + (jb + jj) * 32 + cl);
+#pragma unroll
+        for (int i = 0; i < FM; i += 2)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              y[e] = gelu_new(acc[i][jb + jj][4 * g + e] * sc) * (acc[i + 1][jb + jj][4 * g + e] * sc);
+              if constexpr (DROP) y[e] *= drop_mul(drop, drop_site, row, (uint32_t)((m_base >> 1) + (i >> 1) * 32 + 8 * g + 4 * hi + e));
+            }
+            uint2 v;
+            v.x = pack_bf2(y[0], y[1]);
+            v.y = pack_bf2(y[2], y[3]);
+            *reinterpret_cast<uint2*>(stage + (jj * 32 + cl) * EPI_ROW_BYTES + ((i >> 1) * 32 + 8 * g + 4 * hi) * 2) = v;
+          }
+      }
+      const int nrows = (FN - jb >= 2) ? 64 : 32;
+#pragma unroll
+      for (int t0 = 0; t0 < 64; t0 += RPI) {
+        const int tt = t0 + rr;
+        if (tt < nrows) {
+          const uint4 v = *reinterpret_cast<const uint4*>(stage + tt * EPI_ROW_BYTES + sub * 16);
+          if (2 * f < n_valid) *reinterpret_cast<uint4*>(out + (size_t)(n_base + jb * 32 + tt) * ldo + f) = v;
+        }
+      }
+    }
   }
 };
 
@@ -394,13 +445,13 @@ struct EpiGegluTrain {
 constexpr int AB_TILE = 64 * 128;                  // 64 rows x 64 d, bf16
 constexpr int AB_STAGE = 2 * AB_TILE + 2 * 256;    // X1, X2, two vectors of 64 floats (MODE 1: lse2, delta)
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ att,
+template <int MODE, bool DROP>
+__global__ __launch_bounds__(256, (DROP && MODE == 1) ? 1 : 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ att,
                                                           const bf16_t* __restrict__ datt, const float* __restrict__ lse2,
                                                           float* __restrict__ delta, const int4* __restrict__ work,
                                                           const float* __restrict__ bias_tab, bf16_t* __restrict__ dqkv,
                                                           float* __restrict__ dtab_part, int H, int maxd, int ld_stat,
-                                                          int dbg_flags) {
+                                                          int dbg_flags, Drop drop, uint32_t drop_site) {
   constexpr int WTAB = (MODE == 0) ? 4 * ATT_TAB_MAX * 4 : 0;
   __shared__ __attribute__((aligned(16))) char smem[2 * AB_STAGE + ATT_TAB_MAX * 4 + WTAB];
   float* tab = reinterpret_cast<float*>(smem + 2 * AB_STAGE);
@@ -561,8 +612,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
           const float del = (MODE == 0) ? delta_n : del_m[e];
           float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[mb][r] + b, LOG2E, -lse));
           if (j >= len || !n_real) p = 0.f;
-          const float ds = p * (dp[mb][r] - del);
-          s[mb][r] = p;
+          // dropout on the probabilities (HF:168): O = (mask P) V, so dV takes mask P, dP = mask (dO V^T), and
+          // delta = dO . O already carries the mask
+          float pm = p, dpv = dp[mb][r];
+          if constexpr (DROP) {
+            const uint32_t qrow = (uint32_t)(s0 + ((MODE == 0) ? ni : j)), kcol = (uint32_t)((MODE == 0) ? j : ni);
+            const float m = drop_mul(drop, drop_site, qrow, ((uint32_t)h << 12) | kcol);
+            pm *= m;
+            dpv *= m;
+          }
+          const float ds = p * (dpv - del);
+          s[mb][r] = pm;
           dp[mb][r] = ds;
           if (MODE == 0) {
             if (sat) {
@@ -653,6 +713,123 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
     for (int i = tid; i < ntab; i += 256)
       dst[i] += (wtab[i] + wtab[ATT_TAB_MAX + i]) + (wtab[2 * ATT_TAB_MAX + i] + wtab[3 * ATT_TAB_MAX + i]);
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// dropout variants of the forward's memory-bound kernels (training only)
+// ------------------------------------------------------------------------------------------
+// embed_kernel + dropout on the embeddings (HF:725)
+__global__ __launch_bounds__(256) void embed_train_kernel(const int32_t* __restrict__ ids, const float* __restrict__ table,
+                                                          bf16_t* __restrict__ xhi, bf16_t* __restrict__ xlo,
+                                                          float* __restrict__ ssp, int np, int T, int Tp, int D, int vocab,
+                                                          Drop drop) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= Tp) return;
+  int id = (row < T) ? ids[row] : 0;
+  id = min(max(id, 0), vocab - 1);
+  const float4* src = reinterpret_cast<const float4*>(table + (size_t)id * D);
+  uint4* dh = reinterpret_cast<uint4*>(xhi + (size_t)row * D);
+  uint4* dl = reinterpret_cast<uint4*>(xlo + (size_t)row * D);
+  float ss = 0.f;
+  for (int c = lane; c < (D >> 3); c += 64) {
+    const float4 a = src[2 * c], b = src[2 * c + 1];
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= drop_mul(drop, DROP_SITE_EMBED, (uint32_t)row, (uint32_t)(c * 8 + e));
+    uint4 oh, ol;
+    hilo_update2(0u, 0u, v[0], v[1], oh.x, ol.x, ss);
+    hilo_update2(0u, 0u, v[2], v[3], oh.y, ol.y, ss);
+    hilo_update2(0u, 0u, v[4], v[5], oh.z, ol.z, ss);
+    hilo_update2(0u, 0u, v[6], v[7], oh.w, ol.w, ss);
+    dh[c] = oh;
+    dl[c] = ol;
+  }
+  ss = wave_sum(ss);
+  for (int p = lane; p < np; p += 64) ssp[(size_t)p * Tp + row] = (p == 0) ? ss : 0.f;
+}
+
+// pool_partial_kernel + dropout on the final RMSNorm's output (HF:745): sum over the chunk's tokens of mask * x * rs
+template <int NV>
+__global__ __launch_bounds__(256) void pool_partial_train_kernel(const bf16_t* __restrict__ xhi, const bf16_t* __restrict__ xlo,
+                                                                 const float* __restrict__ rs,
+                                                                 const int4* __restrict__ pwork, float* __restrict__ partial,
+                                                                 int D, Drop drop) {
+  __shared__ float red[4][NV * 64 * 8];
+  const int4 wk = pwork[blockIdx.x];
+  const int s0 = wk.x, len = wk.y, c = wk.z, b = wk.w;
+  if (len == 0) return;
+  const int t0 = c * POOL_CHUNK, t1 = min(len, t0 + POOL_CHUNK);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = D >> 3;
+  float acc[NV][8];
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+  for (int t = t0 + wave; t < t1; t += 4) {  // tokens in index order per wave, as the inference kernel
+    const size_t row = (size_t)(s0 + t) * D;
+    const float r = rs[s0 + t];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int col = min(lane + 64 * i, nv - 1);
+      const uint4 vh = reinterpret_cast<const uint4*>(xhi + row)[col], vl = reinterpret_cast<const uint4*>(xlo + row)[col];
+      const uint32_t hw[4] = {vh.x, vh.y, vh.z, vh.w}, lw[4] = {vl.x, vl.y, vl.z, vl.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x0 = __uint_as_float(hw[e] << 16) + __uint_as_float(lw[e] << 16);
+        const float x1 = __uint_as_float(hw[e] & 0xffff0000u) + __uint_as_float(lw[e] & 0xffff0000u);
+        const float m0 = drop_mul(drop, DROP_SITE_FINAL, (uint32_t)(s0 + t), (uint32_t)(col * 8 + 2 * e));
+        const float m1 = drop_mul(drop, DROP_SITE_FINAL, (uint32_t)(s0 + t), (uint32_t)(col * 8 + 2 * e + 1));
+        acc[i][2 * e] = fmaf(x0 * m0, r, acc[i][2 * e]);
+        acc[i][2 * e + 1] = fmaf(x1 * m1, r, acc[i][2 * e + 1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int col = lane + 64 * i;
+    if (col < nv) {
+      *reinterpret_cast<float4*>(&red[wave][col * 8]) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+      *reinterpret_cast<float4*>(&red[wave][col * 8 + 4]) = make_float4(acc[i][4], acc[i][5], acc[i][6], acc[i][7]);
+    }
+  }
+  __syncthreads();
+  float* dst = partial + (size_t)(s0 / POOL_CHUNK + b + c) * D;
+  for (int col = threadIdx.x; col < D; col += 256) dst[col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+}
+
+// dxm = bf16(mask * dx): the operand of the dgrad / wgrad GEMMs behind a residual-branch dropout (HF:140, 400) - the branch's
+// output gradient is the residual gradient times the branch's mask
+__global__ __launch_bounds__(256) void mask_dx_kernel(const bf16_t* __restrict__ dxhi, const bf16_t* __restrict__ dxlo,
+                                                      bf16_t* __restrict__ dxm, int rows, int D, Drop drop, uint32_t site) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const uint4* sh = reinterpret_cast<const uint4*>(dxhi + (size_t)row * D);
+  const uint4* sl = reinterpret_cast<const uint4*>(dxlo + (size_t)row * D);
+  uint4* dm = reinterpret_cast<uint4*>(dxm + (size_t)row * D);
+  for (int c = lane; c < (D >> 3); c += 64) {
+    const uint4 vh = sh[c], vl = sl[c];
+    const uint32_t hw[4] = {vh.x, vh.y, vh.z, vh.w}, lw[4] = {vl.x, vl.y, vl.z, vl.w};
+    uint32_t ow[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x0 = __uint_as_float(hw[e] << 16) + __uint_as_float(lw[e] << 16);
+      const float x1 = __uint_as_float(hw[e] & 0xffff0000u) + __uint_as_float(lw[e] & 0xffff0000u);
+      ow[e] = pack_bf2(x0 * drop_mul(drop, site, (uint32_t)row, (uint32_t)(c * 8 + 2 * e)),
+                       x1 * drop_mul(drop, site, (uint32_t)row, (uint32_t)(c * 8 + 2 * e + 1)));
+    }
+    dm[c] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+  }
+}
+
+// test entry: out[r, c] = 1 if element (site, row0 + r, col0 + c) is kept
+__global__ void dropout_mask_kernel(Drop drop, uint32_t site, uint32_t row0, uint32_t col0, int rows, int cols,
+                                    uint8_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  out[i] = drop_mul(drop, site, row0 + (uint32_t)(i / cols), col0 + (uint32_t)(i % cols)) != 0.f;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -762,7 +939,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void pool_bwd_tok_kernel(const bf16_t* __restrict__ xhi, const bf16_t* __restrict__ xlo,
                                                            const float* __restrict__ rs, const int4* __restrict__ pwork,
                                                            const float* __restrict__ ds, bf16_t* __restrict__ dxhi,
-                                                           bf16_t* __restrict__ dxlo, int D, float inv_d) {
+                                                           bf16_t* __restrict__ dxlo, int D, float inv_d, Drop drop) {
   const int4 wk = pwork[blockIdx.x];
   const int s0 = wk.x, len = wk.y, c = wk.z, b = wk.w;
   if (len == 0) return;
@@ -782,8 +959,14 @@ __global__ __launch_bounds__(256) void pool_bwd_tok_kernel(const bf16_t* __restr
     const size_t row = (size_t)(s0 + t) * D;
     const uint4* sh = reinterpret_cast<const uint4*>(xhi + row);
     const uint4* sl = reinterpret_cast<const uint4*>(xlo + row);
-    float xv[NV][8];
+    float xv[NV][8], dsm[NV][8];  // dsm = the sequence's ds with this token's final-dropout mask applied (HF:745)
     float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        dsm[i][e] = drop.thresh ? dsv[i][e] * drop_mul(drop, DROP_SITE_FINAL, (uint32_t)(s0 + t), (uint32_t)(min(lane + 64 * i, nv - 1) * 8 + e))
+                                : dsv[i][e];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const bool live = lane + 64 * i < nv;
@@ -796,7 +979,7 @@ __global__ __launch_bounds__(256) void pool_bwd_tok_kernel(const bf16_t* __restr
       }
       if (live)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dot = __builtin_fmaf(dsv[i][e], xv[i][e], dot);
+        for (int e = 0; e < 8; ++e) dot = __builtin_fmaf(dsm[i][e], xv[i][e], dot);
     }
     dot = wave_sum(dot);
     const float r = rs[s0 + t];
@@ -808,7 +991,7 @@ __global__ __launch_bounds__(256) void pool_bwd_tok_kernel(const bf16_t* __restr
       if (lane + 64 * i >= nv) continue;
       uint4 oh, ol;
       float ss = 0.f;
-      auto v = [&](int e) { return __builtin_fmaf(r, dsv[i][e], -k * xv[i][e]); };
+      auto v = [&](int e) { return __builtin_fmaf(r, dsm[i][e], -k * xv[i][e]); };
       hilo_update2(0u, 0u, v(0), v(1), oh.x, ol.x, ss);
       hilo_update2(0u, 0u, v(2), v(3), oh.y, ol.y, ss);
       hilo_update2(0u, 0u, v(4), v(5), oh.z, ol.z, ss);
@@ -826,7 +1009,7 @@ __global__ __launch_bounds__(256) void pool_bwd_tok_kernel(const bf16_t* __restr
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restrict__ ids, int T, int vocab,
                                                         const bf16_t* __restrict__ dxhi, const bf16_t* __restrict__ dxlo,
-                                                        int D, float* __restrict__ dtable) {
+                                                        int D, float* __restrict__ dtable, Drop drop) {
   __shared__ unsigned long long masks[4];
   const int v = blockIdx.x, col = blockIdx.y * 256 + threadIdx.x;
   const int wave = threadIdx.x >> 6;
@@ -844,8 +1027,12 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restric
       while (mm) {
         const int bit = __builtin_ctzll(mm);
         mm &= mm - 1;
-        const size_t off = (size_t)(base + w * 64 + bit) * D + col;
-        if (col < D) acc += bf2f(dxhi[off]) + bf2f(dxlo[off]);
+        const int tok = base + w * 64 + bit;
+        const size_t off = (size_t)tok * D + col;
+        if (col < D) {
+          const float g = bf2f(dxhi[off]) + bf2f(dxlo[off]);
+          acc += drop.thresh ? g * drop_mul(drop, DROP_SITE_EMBED, (uint32_t)tok, (uint32_t)col) : g;
+        }
       }
     }
     __syncthreads();

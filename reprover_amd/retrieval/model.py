@@ -110,6 +110,9 @@ class PremiseRetriever:
         # training (lazily built by training_step / configure_optimizers: fp32 masters, gradients, AdamW moments)
         self._trainer = None
         self.gradient_clip_val: Optional[float] = None  # Lightning's trainer.gradient_clip_val (confs/*.yaml: 1.0)
+        # T5's dropout in training mode (HF config.dropout_rate, default 0.1 - what the reference trains with); 0 = the
+        # deterministic step.  Read when the training engine is built.
+        self.dropout_rate: float = float(getattr(self.encoder, "cfg", {}).get("dropout_rate", 0.1))
 
     # -- construction (model.py:52-66) --------------------------------------------------------------
     @classmethod
@@ -287,7 +290,8 @@ class PremiseRetriever:
                 raise RuntimeError("training needs the encoder's fp32 weights (build the retriever from a checkpoint "
                                    "or a state dict)")
             self._trainer = HipT5Trainer(self.encoder.cfg, sd, self.device, lr=self.lr, warmup_steps=self.warmup_steps,
-                                         gradient_clip_val=self.gradient_clip_val, out_dtype=self.encoder.dtype)
+                                         gradient_clip_val=self.gradient_clip_val, out_dtype=self.encoder.dtype,
+                                         dropout_rate=self.dropout_rate)
             self.encoder = self._trainer.encoder
             self._drop_derived()
         return self._trainer

@@ -12,8 +12,9 @@ under ``get_constant_schedule_with_warmup``; DeepSpeed's FusedAdam in adam_w_mod
   ``contrastive_mse`` + its backward on the [batch, D] embeddings → ``backward`` (encoder backward: every parameter's
   gradient) → ``optimizer_step`` (gradient norm, clipped AdamW over the flat buffers, bf16 compute copies refreshed).
 
-Dropout is not applied (the reference trains with T5's stochastic dropout 0.1; oracle and fixtures G11 / G12 pin the
-deterministic step).  Oracle: ``oracle/train_ref.py``.
+Dropout (T5's ``dropout_rate``, 0.1 in the reference's training) is supported at HF's six sites with counter-based masks the
+backward regenerates; ``dropout_rate=0`` (this class's default) is the deterministic step fixtures G11 / G12 pin, and the
+dropout step is checked exactly against the oracle differentiated with the SAME masks.  Oracle: ``oracle/train_ref.py``.
 """
 from __future__ import annotations
 
@@ -126,13 +127,20 @@ class HipT5Trainer:
 
     def __init__(self, cfg: Dict, state_dict: Dict[str, torch.Tensor], device, lr: float = 0.0, warmup_steps: int = 0,
                  betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 gradient_clip_val: Optional[float] = None, out_dtype: torch.dtype = torch.bfloat16):
+                 gradient_clip_val: Optional[float] = None, out_dtype: torch.dtype = torch.bfloat16,
+                 dropout_rate: float = 0.0, dropout_seed: int = 3407):
         if cfg.get("feed_forward_proj", "gated-gelu") != "gated-gelu":
             raise _lib.HipLibraryError(f"feed_forward_proj={cfg.get('feed_forward_proj')!r} is not implemented")
         self.device = _require_gpu(device)
         self.cfg = dict(cfg)
         self.lr, self.warmup_steps, self.betas, self.eps, self.weight_decay = lr, warmup_steps, betas, eps, weight_decay
         self.gradient_clip_val = gradient_clip_val
+        # T5's dropout (HF config.dropout_rate; 0.1 in the reference's training): 0 = the deterministic step the fixtures
+        # pin.  Masks are counter-based: forward number n of this trainer draws them from seed (dropout_seed, n), the
+        # backward regenerates them.
+        self.dropout_rate, self.dropout_seed = float(dropout_rate), int(dropout_seed)
+        self._forwards = 0
+        self.last_dropout_seed: Optional[int] = None
         self._lib = _lib.load()
         self.layout = param_layout(cfg)
         total = self.layout[-1][2]
@@ -186,6 +194,25 @@ class HipT5Trainer:
         sd["encoder.embed_tokens.weight"] = sd["shared.weight"]  # tied (HF:1074)
         return sd
 
+    def save_training_state(self, path: str) -> None:
+        """Everything a resumed run needs (what Lightning's ModelCheckpoint keeps for the reference): the fp32 masters,
+        both AdamW moments and the step counter, as one safetensors file in the flat layout."""
+        from safetensors.torch import save_file
+
+        save_file({"params": self.params.cpu(), "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(),
+                   "steps": torch.tensor([self.steps], dtype=torch.int64)}, path)
+
+    def load_training_state(self, path: str) -> None:
+        from safetensors.torch import load_file
+
+        st = load_file(path)
+        assert st["params"].numel() == self.params.numel(), "the state belongs to another geometry"
+        self.params.copy_(st["params"])
+        self.exp_avg.copy_(st["exp_avg"])
+        self.exp_avg_sq.copy_(st["exp_avg_sq"])
+        self.steps = int(st["steps"][0])
+        self.load_params()
+
     def load_params(self) -> None:
         with torch.cuda.device(self.device):
             _lib.check(self._lib.rp_trainer_load_params(self._handle, _lib.ptr(self.params), _lib.current_stream()),
@@ -203,6 +230,10 @@ class HipT5Trainer:
         for ``backward``."""
         batch, T = len(cu) - 1, int(cu[-1])
         assert batch > 0 and T > 0 and len(ids) == T and int(np.diff(cu).min()) > 0
+        seed = (self.dropout_seed * 0x9E3779B1 + self._forwards * 0x85EBCA77 + 1) & 0xFFFFFFFF
+        self._forwards += 1
+        self.last_dropout_seed = seed if self.dropout_rate > 0 else None
+        _lib.check(self._lib.rp_trainer_set_dropout(self._handle, self.dropout_rate, seed), "rp_trainer_set_dropout")
         with torch.cuda.device(self.device):
             ids_d = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int32)).to(self.device)
             cu_d = torch.from_numpy(np.ascontiguousarray(cu, dtype=np.int32)).to(self.device)

@@ -113,6 +113,7 @@ def test_product_training_api_learns_and_reindexes(tmp_path):
     cfg = synth.t5_config("tiny")
     model = PremiseRetriever.from_state_dict(cfg, synth.synth_state_dict(cfg, seed=5), 256, "cuda:0")
     model.lr, model.warmup_steps, model.gradient_clip_val, model.num_retrieved = 2e-3, 2, 1.0, 10
+    assert model.dropout_rate == 0.1  # the reference's training mode (T5 config.dropout_rate); on for this run
     dm = RetrievalDataModule(str(ddir), cpath, 16, 256, model.tokenizer, num_negatives=3, num_in_file_negatives=1, batch_size=8)
     random.seed(3407)
     dm.setup("fit")
@@ -178,3 +179,93 @@ def test_full_depth_gradients_against_the_oracle():
         worst = max(worst, (rel / (rel_env + 1e-30), key))
         assert rel <= 1.2 * rel_env + 1e-2 and cos >= 0.93, (key, rel, rel_env, cos)
     print(f"12 layers: largest engine / envelope error ratio {worst[0]:.3f} ({worst[1]})")
+
+
+class _DeviceMasks:
+    """The dropout multipliers the engine used (rp_dbg_dropout_mask) laid out for the oracle's padded batches."""
+
+    def __init__(self, cfg, p, seed, starts, lens):
+        self.cfg, self.p, self.seed, self.starts, self.lens = cfg, p, seed, starts, lens
+        self.L = int(max(lens))
+
+    def _mask(self, site, row0, col0, rows, cols):
+        from reprover_amd import _lib
+
+        out = torch.empty((rows, cols), dtype=torch.uint8, device="cuda")
+        _lib.check(_lib.load().rp_dbg_dropout_mask(self.p, self.seed, site, row0, col0, rows, cols, _lib.ptr(out),
+                                                   _lib.current_stream()), "rp_dbg_dropout_mask")
+        return out.cpu().float() / (1.0 - self.p)
+
+    def _tokens(self, site, width):
+        m = torch.ones(len(self.lens), self.L, width)
+        for b, (s0, n) in enumerate(zip(self.starts, self.lens)):
+            m[b, :n] = self._mask(site, s0, 0, n, width)
+        return m
+
+    def embed(self):
+        return self._tokens(0, self.cfg["d_model"])
+
+    def final(self):
+        return self._tokens(1, self.cfg["d_model"])
+
+    def attn_resid(self, i):
+        return self._tokens(16 + 8 * i + 1, self.cfg["d_model"])
+
+    def ff_inner(self, i):
+        return self._tokens(16 + 8 * i + 2, self.cfg["d_ff"])
+
+    def ffn_resid(self, i):
+        return self._tokens(16 + 8 * i + 3, self.cfg["d_model"])
+
+    def probs(self, i):
+        H = self.cfg["num_heads"]
+        m = torch.ones(len(self.lens), H, self.L, self.L)
+        for b, (s0, n) in enumerate(zip(self.starts, self.lens)):
+            for h in range(H):
+                m[b, h, :n, :n] = self._mask(16 + 8 * i, s0, h << 12, n, n)
+        return m
+
+
+def test_dropout_step_equals_the_oracle_with_the_same_masks(golden_dir):
+    """T5's dropout (rate 0.1, the reference's training mode) at HF's six sites.  The masks are counter-based, so the test
+    reads back exactly the masks a step used (rp_dbg_dropout_mask), hands them to the oracle (oracle/t5_ref.py applies them
+    where transformers' modeling_t5.py does: :725, :168, :400, :110, :140, :745) and differentiates THAT: loss and every
+    gradient must agree under the same bars as the dropout-free step.  Plus: keep rate, seed handling, reproducibility."""
+    from oracle import train_ref
+    from reprover_amd.train import HipT5Trainer, pack_padded_groups
+
+    cfg, sd, groups, label, g = th.g11_batch(golden_dir)
+    p = 0.1
+    tr = HipT5Trainer(cfg, sd, "cuda:0", lr=1e-3, dropout_rate=p, dropout_seed=7)
+    loss, _ = tr.contrastive_step(groups, label)
+    seed = tr.last_dropout_seed
+    assert seed is not None and abs(float(loss) - float(g["loss"])) > 1e-4, "dropout changes the loss"
+    _, cu = pack_padded_groups(groups)
+    B = groups[0][0].shape[0]
+
+    def drop_for_group(k):
+        seqs = range(k * B, (k + 1) * B)
+        return _DeviceMasks(cfg, p, seed, [int(cu[s]) for s in seqs], [int(cu[s + 1] - cu[s]) for s in seqs])
+
+    texts = (list(g["context_texts"]), list(g["pos_texts"]), [list(r) for r in g["neg_texts"]])
+    loss_ref, grads_ref = train_ref.forward_backward(cfg, sd, *texts, g["label"], int(g["max_seq_len"]), drop_for_group)
+    print(f"dropout step: loss {float(loss):.6f}, oracle with the same masks {loss_ref:.6f} (without dropout {float(g['loss']):.6f})")
+    assert abs(float(loss) - loss_ref) <= 2e-3
+    errs = {}
+    for key, gv in tr.named_gradients():
+        ref = torch.from_numpy(grads_ref[key]).to(gv.device)
+        d = gv - ref
+        errs[key] = (d.abs().max().item(), ref.abs().max().item(), (d.norm() / (ref.norm() + 1e-30)).item())
+    _check_grads(errs)
+    # keep rate of a large mask, and the masks of two sites / two seeds differ
+    big = drop_for_group(0)._mask(16, 0, 0, 512, 512) > 0
+    assert abs(big.float().mean().item() - (1 - p)) < 4e-3
+    other = drop_for_group(0)._mask(17, 0, 0, 512, 512) > 0
+    assert (big != other).float().mean().item() > 0.1
+    # the next forward draws new masks; a trainer with the same dropout_seed reproduces the first step bit for bit
+    first = tr.grads.clone()
+    tr.contrastive_step(groups, label)
+    assert tr.last_dropout_seed != seed and not torch.equal(first, tr.grads)
+    tr2 = HipT5Trainer(cfg, sd, "cuda:0", lr=1e-3, dropout_rate=p, dropout_seed=7)
+    loss2, _ = tr2.contrastive_step(groups, label)
+    assert float(loss2) == float(loss) and torch.equal(tr2.grads, first)

@@ -16,5 +16,6 @@ if __name__ == "__main__":
     dev = torch.device("cuda", 0)
     cfg = synth.t5_config("byt5-small")
     sd = bench.random_init_state_dict(cfg, dev, seed=synth.SEED)
+    p = float(os.environ.get("DROPOUT", "0.1"))
     for bsz in [int(a) for a in sys.argv[1:]] or [8, 64]:
-        print(json.dumps({f"batch{bsz}": bench.train_step_leg(cfg, sd, dev, bsz)}), flush=True)
+        print(json.dumps({f"batch{bsz}": bench.train_step_leg(cfg, sd, dev, bsz, dropout_rate=p)}), flush=True)
