@@ -1,5 +1,5 @@
 """Per-tensor gradient error of the engine against the oracle's fp32 autograd at full depth, layer by layer
-(python tools/grad_depth_diag.py [num_layers]): how does the bf16-operand backward's error grow towards the input?"""
+(python tests/grad_depth_diag.py [num_layers]): how does the bf16-operand backward's error grow towards the input?"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]

@@ -143,7 +143,7 @@ def test_full_depth_gradients_against_the_oracle():
 
     On the sharp synthetic weights (attention logits of std 4) the gradient is ill-conditioned in depth: EXACT fp32
     arithmetic on weights that were merely rounded to bf16 once - the engine's storage format - moves a gradient tensor by
-    2 % (2 layers), 6 % (4 layers), 16 - 35 % (12 layers) in relative L2 (tools/grad_depth_diag.py).  That run is the
+    2 % (2 layers), 6 % (4 layers), 16 - 35 % (12 layers) in relative L2 (tests/grad_depth_diag.py).  That run is the
     envelope, as HuggingFace's bf16 mode is for the forward: per tensor the engine must be no further from the fp32
     gradient than 1.2 x the envelope + 1e-2 (measured: 0.87 - 0.97 x the envelope at 12 layers), with cosine >= 0.93."""
     from oracle import train_ref
