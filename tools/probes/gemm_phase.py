@@ -7,11 +7,14 @@
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-PROBE = os.path.join(ROOT, "reprover_amd", "lib", "libreprover_probe%s.so" % (("_" + os.environ["ABLATE"]) if os.environ.get("ABLATE") else ""))
+# the probe library lives beside this tool, NOT in the product's lib/ (it ships to the GPU box only while it exists here:
+# delete tools/probes/_build/ when done)
+PROBE = os.path.join(ROOT, "tools", "probes", "_build", "libreprover_probe%s.so" % (("_" + os.environ["ABLATE"]) if os.environ.get("ABLATE") else ""))
 if len(sys.argv) > 1 and sys.argv[1] == "build":
-    src = [os.path.join(ROOT, "reprover_amd", "csrc", f) for f in ("rp_encoder.hip", "rp_retrieval.hip")]
+    os.makedirs(os.path.dirname(PROBE), exist_ok=True)
+    src = [os.path.join(ROOT, "reprover_amd", "csrc", f) for f in ("rp_encoder.hip", "rp_retrieval.hip", "rp_train.hip")]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-DRP_PHASE_PROBE", *src, "-o", PROBE])
+                           "-DRP_PHASE_PROBE", "-DRP_EXPERIMENTS", *src, "-o", PROBE])
     print("built", PROBE); sys.exit(0)
 import numpy as np, torch
 from reprover_amd import _lib
