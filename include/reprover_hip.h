@@ -36,13 +36,14 @@ enum {
   RP_E_INVALID = -1,      /* bad argument / unsupported shape                                   */
   RP_E_HIP = -2,          /* a HIP runtime call failed                                          */
   RP_E_WORKSPACE = -3,    /* caller workspace too small                                         */
-  RP_E_UNSUPPORTED = -4   /* model configuration outside what the kernels implement             */
+  RP_E_UNSUPPORTED = -4,  /* model configuration outside what the kernels implement             */
+  RP_E_COMM = -5          /* RCCL could not be bound, or one of its calls failed                */
 };
 
 enum { RP_DT_F32 = 0, RP_DT_BF16 = 1 };
 
 /* ABI / build identification; bumps when a signature changes. */
-int32_t rp_abi_version(void);   /* 2 */
+int32_t rp_abi_version(void);   /* 3 */
 /* Message of the last error returned on this thread ("" if none). */
 const char* rp_last_error(void);
 
@@ -213,6 +214,40 @@ RpStatus rp_topk_merge_strided(const float* scores, const int32_t* ids, const in
                                float* out_scores, int32_t* out_ids, int32_t* out_count,
                                void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The collective of the sharded retrieve step (one all-gather of the per-rank lists, then the
+ * per-query merge).  The reference has no counterpart - it replicates the whole index per process
+ * (retrieval/model.py:274-279, prover/proof_search.py:438-447); this is the exchange its row-sharded replacement needs,
+ * behind the ABI so that a caller without torch.distributed can run it.
+ *
+ * RCCL is bound at run time (dlopen: a copy the process already holds, else librccl.so.1 on the search path, else
+ * /opt/rocm/lib; RP_RCCL_LIB overrides); without it these calls return RP_E_COMM and everything else keeps working.
+ * One communicator per (rank, GPU): rank 0 calls rp_comm_unique_id, the caller carries the 128 bytes to the other ranks
+ * by whatever channel it has (a file, a socket, torch.distributed's store), every rank calls rp_comm_init with its
+ * device current.  Calls are enqueued on `stream`; nothing synchronises; no allocation after rp_comm_init.
+ * ------------------------------------------------------------------------------------------- */
+#define RP_COMM_ID_BYTES 128
+typedef struct RpComm RpComm;
+RpStatus rp_comm_unique_id(void* id_out /* host, RP_COMM_ID_BYTES */);
+RpStatus rp_comm_init(const void* unique_id, int32_t rank, int32_t world, RpComm** out);
+RpStatus rp_comm_destroy(RpComm* comm);
+int32_t  rp_comm_world(const RpComm* comm);
+int32_t  rp_comm_rank(const RpComm* comm);
+/* ncclAllGather of bytes_per_rank bytes (a multiple of 4) from every rank: recv = [world, bytes_per_rank], rank order.
+ * Used as it stands for the query embeddings ([B, D] bf16 per rank) and for persisting a sharded index. */
+RpStatus rp_comm_allgather(RpComm* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+/* The step's exchange in one call: all-gather of this rank's packed block
+ *   send_block  [ scores f32 [Bt, k] | ids int32 [Bt, k] | counts int32 [Bt] ]   (rp_sim_topk wrote into it in place)
+ *   recv_blocks [world, Bt (2 k + 1)] 4-byte units
+ * followed by rp_topk_merge_strided over queries [q0, q0 + B) read from recv_blocks as they lie -> out_* [B, k] / [B].
+ * A rank whose count is -1 (candidate overflow, see rp_sim_topk) contributes nothing to the merge: the caller reads the
+ * gathered counts (recv_blocks[r, 2 Bt k + q], identical on every rank) and, if any is negative, all ranks redo the step
+ * with RP_TOPK_DENSE - what dist.PendingShardedSearch.finish does.
+ * workspace: rp_topk_merge_workspace_bytes(world, B, k). */
+RpStatus rp_allgather_topk(RpComm* comm, const void* send_block, void* recv_blocks, int32_t Bt, int32_t k,
+                           int32_t q0, int32_t B, float* out_scores, int32_t* out_ids, int32_t* out_count,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* Per-batch accessibility operand built on the device (replaces the host-side bit transposition of
  * common.py:280-289's closure for a batch): file_bits_t [F, ceil(B/32)] (as rp_sim_topk takes it) from
  *   reach     device uint64 [F, ceil(F/64)]   bit g of row f = file f imports file g (transitive closure, resident)
@@ -308,7 +343,8 @@ enum {
   /* training step (rp_train_*) */
   RP_K_BWD_DGRAD = 11 /* dY W GEMMs (+ fused GELU / RMSNorm backward) */, RP_K_BWD_WGRAD = 12 /* dY^T X GEMMs */,
   RP_K_BWD_ATTENTION = 13, RP_K_BWD_OTHER = 14 /* pooling, embedding, row statistics, gradient finishing */,
-  RP_K_OPTIMIZER = 15 /* AdamW, gradient norm, weight re-packing */, RP_K_COUNT = 16
+  RP_K_OPTIMIZER = 15 /* AdamW, gradient norm, weight re-packing */,
+  RP_K_COLLECTIVE = 16 /* the all-gather of rp_comm_allgather / rp_allgather_topk */, RP_K_COUNT = 17
 };
 RpStatus rp_profile_enable(int32_t on);   /* on != 0: start collecting (clears previous records) */
 /* Synchronises the recorded events; total_ms = sum of launch durations, launches = their number. */

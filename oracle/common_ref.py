@@ -222,13 +222,17 @@ def masked_topk(sims: np.ndarray, accessible: np.ndarray, k: int) -> Tuple[np.nd
     return ids, sc
 
 
-def format_augmented_state(s: str, premise_texts: Iterable[str], max_len: Optional[int]) -> str:
-    """common.py:357-378 with p_drop = 0: prepend serialized premises (each followed by a blank
-    line) while their total UTF-8 byte length fits in ``max_len - len(bytes(s))``; later
-    premises end up *earlier* in the string."""
+def format_augmented_state(s: str, premise_texts: Iterable[str], max_len: Optional[int], p_drop: float = 0.0) -> str:
+    """common.py:357-378: prepend serialized premises (each followed by a blank line) while their
+    total UTF-8 byte length fits in ``max_len - len(bytes(s))``; later premises end up *earlier* in
+    the string; one ``random.random() < p_drop`` draw per premise, in list order, BEFORE the size test."""
+    import random
+
     budget = (max_len if max_len is not None else 9999999999999999999999) - len(s.encode("utf-8"))
     aug, used = "", 0
     for text in premise_texts:
+        if random.random() < p_drop:
+            continue
         piece = f"{text}\n\n"
         n = len(piece.encode("utf-8"))
         if used + n > budget:

@@ -18,9 +18,9 @@ RP_OK = 0
 RP_DT_F32, RP_DT_BF16 = 0, 1
 RP_TOPK_AUTO, RP_TOPK_DENSE = 0, 1
 RP_EPI_STORE_BF16, RP_EPI_RESID, RP_EPI_GEGLU_BF16 = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 KERNEL_CLASSES = ["embed", "rmsnorm", "gemm_qkv", "attention", "gemm_o", "gemm_wi", "gemm_wo", "pool", "scan",
-                  "select", "scan_sample", "bwd_dgrad", "bwd_wgrad", "bwd_attention", "bwd_other", "optimizer"]
+                  "select", "scan_sample", "bwd_dgrad", "bwd_wgrad", "bwd_attention", "bwd_other", "optimizer", "collective"]
 
 
 class RpT5Config(C.Structure):
@@ -100,6 +100,17 @@ SIGNATURES = {
         C.c_int32,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
          C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
+    "rp_comm_unique_id": (C.c_int32, [C.c_void_p]),
+    "rp_comm_init": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "rp_comm_destroy": (C.c_int32, [C.c_void_p]),
+    "rp_comm_world": (C.c_int32, [C.c_void_p]),
+    "rp_comm_rank": (C.c_int32, [C.c_void_p]),
+    "rp_comm_allgather": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rp_allgather_topk": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
     "rp_build_file_bits": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "rp_contrastive_mse_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libreprover_hip.so")
-SOURCES = ["rp_encoder.hip", "rp_retrieval.hip", "rp_train.hip"]
+SOURCES = ["rp_encoder.hip", "rp_retrieval.hip", "rp_train.hip", "rp_comm.hip"]
 COMPILE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -206,8 +206,85 @@ def hip_merge(ids: torch.Tensor, scores: torch.Tensor, counts: torch.Tensor) -> 
     return out_i, out_s, out_c
 
 
+class HipComm:
+    """An RCCL communicator held by libreprover_hip itself (``rp_comm_*``, include/reprover_hip.h): the step's collective
+    without ``torch.distributed`` in the data path.  Accepted wherever this module takes ``group``.  The 128-byte id made by
+    rank 0 (``HipComm.unique_id()``) reaches the other ranks by any channel the caller has; ``from_torch_group`` uses an
+    existing torch group (gloo is enough) for that one broadcast."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: Optional[torch.device] = None):
+        import ctypes as C
+
+        assert len(unique_id) == 128
+        self.rank, self.world = int(rank), int(world)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().rp_comm_init(C.c_char_p(unique_id), self.rank, self.world, C.byref(handle)), "rp_comm_init")
+        self._handle = handle
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().rp_comm_unique_id(buf), "rp_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_torch_group(cls, group=None, device: Optional[torch.device] = None) -> "HipComm":
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(box[0], rank, world, device)
+
+    def close(self) -> None:
+        if self._handle is not None:
+            handle, self._handle = self._handle, None
+            _lib.check(_lib.load().rp_comm_destroy(handle), "rp_comm_destroy")
+
+    def __del__(self):  # best effort; close() is the explicit form
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def all_gather_stack(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.contiguous()
+        assert t.is_cuda and (t.numel() * t.element_size()) % 4 == 0
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        _lib.check(_lib.load().rp_comm_allgather(self._handle, t.data_ptr(), out.data_ptr(), t.numel() * t.element_size(),
+                                                 _lib.current_stream()), "rp_comm_allgather")
+        return out
+
+    def allgather_topk(self, block: torch.Tensor, Bt: int, k: int, q0: int, B: int):
+        """``rp_allgather_topk``: (ids [B,k], scores [B,k], counts [B]) of queries [q0, q0 + B) merged over the ranks, and
+        the receive buffer [world, Bt (2k + 1)] (its counts section carries every rank's overflow verdict)."""
+        lib = _lib.load()
+        dev = block.device
+        assert block.dtype == torch.int32 and block.is_contiguous() and block.numel() == Bt * (2 * k + 1)
+        recv = torch.empty((self.world, block.numel()), dtype=torch.int32, device=dev)
+        out_s = torch.empty((B, k), dtype=torch.float32, device=dev)
+        out_i = torch.empty((B, k), dtype=torch.int32, device=dev)
+        out_c = torch.empty((B,), dtype=torch.int32, device=dev)
+        nbytes = lib.rp_topk_merge_workspace_bytes(self.world, B, k)
+        ws = _workspace(dev, nbytes)
+        _lib.check(lib.rp_allgather_topk(self._handle, block.data_ptr(), recv.data_ptr(), Bt, k, q0, B, _lib.ptr(out_s),
+                                         _lib.ptr(out_i), _lib.ptr(out_c), _lib.ptr(ws), nbytes, _lib.current_stream()),
+                   "rp_allgather_topk")
+        return out_i, out_s, out_c, recv
+
+
+def _world_rank(group) -> Tuple[int, int]:
+    return (group.world, group.rank) if isinstance(group, HipComm) else (dist.get_world_size(group), dist.get_rank(group))
+
+
 def all_gather_stack(t: torch.Tensor, group=None) -> torch.Tensor:
-    """[world, *t.shape]: one all-gather (RCCL ncclAllGather on GPUs; gloo on CPU)."""
+    """[world, *t.shape]: one all-gather (RCCL ncclAllGather on GPUs - through torch.distributed or, when ``group`` is a
+    ``HipComm``, through the library's own communicator; gloo on CPU)."""
+    if isinstance(group, HipComm):
+        return group.all_gather_stack(t)
     world = dist.get_world_size(group)
     out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
     if dist.get_backend(group) == "nccl":
@@ -222,9 +299,9 @@ def gather_shards(local_rows: torch.Tensor, bounds: np.ndarray, group=None) -> t
     exchange of a multi-GPU re-index that has to persist a single index file (index.py).  Shards
     differ in length (they balance tokens, not rows), so each rank contributes a block padded to the
     longest shard and the padding is dropped after ONE all-gather."""
-    world = dist.get_world_size(group)
+    world, rank = _world_rank(group)
     bounds = np.asarray(bounds, dtype=np.int64)
-    assert len(bounds) == world + 1 and local_rows.shape[0] == bounds[dist.get_rank(group) + 1] - bounds[dist.get_rank(group)]
+    assert len(bounds) == world + 1 and local_rows.shape[0] == bounds[rank + 1] - bounds[rank]
     longest = int(np.diff(bounds).max())
     block = torch.zeros((longest,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype, device=local_rows.device)
     block[: local_rows.shape[0]] = local_rows
@@ -245,6 +322,8 @@ def sharded_nearest_premise_ids(
     the per-rank query embeddings).  Returns identical tensors on every rank."""
     ids, scores, counts = local_topk(shard, batch_context, query_emb, k)
     B = ids.shape[0]
+    if isinstance(group, HipComm) and merge is hip_merge:  # collective + merge as ONE call of the C ABI
+        return group.allgather_topk(_packed_block(ids, scores, counts), B, k, 0, B)[:3]
     g = all_gather_stack(_packed_block(ids, scores, counts), group)  # THE collective of the step: [world, B (2k + 1)]
     g_scores = g[:, : B * k].view(torch.float32).view(-1, B, k)      # views of the receive buffer, rank stride B (2k + 1)
     g_ids = g[:, B * k : 2 * B * k].view(-1, B, k)
@@ -311,10 +390,14 @@ def launch_sharded_nearest_premises(shard: IndexShard, batch_context: List[Conte
     contract) to pinned host memory are enqueued; nothing waits.  ``finish()`` is the second half."""
     ids, scores, counts = hip_local_topk(shard, batch_context, query_emb, k, _lib.RP_TOPK_AUTO)
     B = ids.shape[0]
-    g = all_gather_stack(_packed_block(ids, scores, counts), group)
-    world = g.shape[0]
-    m_ids, m_scores, m_counts = hip_merge(g[:, B * k : 2 * B * k].view(world, B, k),
-                                          g[:, : B * k].view(torch.float32).view(world, B, k), g[:, 2 * B * k :])
+    if isinstance(group, HipComm):  # collective + merge as one call of the C ABI (rp_allgather_topk)
+        m_ids, m_scores, m_counts, g = group.allgather_topk(_packed_block(ids, scores, counts), B, k, 0, B)
+        world = g.shape[0]
+    else:
+        g = all_gather_stack(_packed_block(ids, scores, counts), group)
+        world = g.shape[0]
+        m_ids, m_scores, m_counts = hip_merge(g[:, B * k : 2 * B * k].view(world, B, k),
+                                              g[:, : B * k].view(torch.float32).view(world, B, k), g[:, 2 * B * k :])
     from .common import _pinned_result_buffers
 
     pool = _rank_count_pool.setdefault((world, B), [])

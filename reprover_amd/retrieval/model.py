@@ -103,6 +103,7 @@ class PremiseRetriever:
         # under torch.distributed.run.
         self.shard_index_over_ranks = False
         self.index_shard = None
+        self.shard_group = None  # what the sharded step gathers over: None = torch's default group, or a dist.HipComm
         # Single-state retrieve() as one hipGraph replay (reprover_amd/single_query.py); set False to launch the
         # kernels one by one as the batch paths do.
         self.use_graphs = True
@@ -370,6 +371,9 @@ class PremiseRetriever:
             bounds = rdist.shard_bounds(rdist.premise_token_counts(corpus, self.max_seq_len), dist.get_world_size())
             self.index_shard = rdist.IndexShard(corpus, bounds, dist.get_rank(), self.device)
             rdist.reindex_shard(self, self.index_shard)
+            if os.environ.get("RP_COMM") == "abi" and self.shard_group is None and self.device.type == "cuda":
+                # the step's collective through the library's own RCCL communicator (rp_comm_*) instead of torch's
+                self.shard_group = rdist.HipComm.from_torch_group(device=self.device)
             if self.index_dtype == "fp8":
                 self.index_shard.quantize()  # the sharded search then scans the e4m3 form, like the single-GPU one
             return
@@ -399,7 +403,7 @@ class PremiseRetriever:
             from ..dist import launch_sharded_nearest_premises
 
             launched = launch_sharded_nearest_premises(self.index_shard, batch["context"], context_emb, self.num_retrieved,
-                                                       also_copy=self.encoder.take_pending())
+                                                       group=self.shard_group, also_copy=self.encoder.take_pending())
             previous, self._predict_pending = self._predict_pending, (batch, launched)
             self._finish_pending_predict(previous)
             return

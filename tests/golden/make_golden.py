@@ -853,12 +853,51 @@ def g12_train_small_width():
     np.savez_compressed(os.path.join(OUT, "g12_train_small_width.npz"), **out)
     print("g12 ok")
 
+# ----------------------------------------------------------------------------------------------
+def g15_augmented_state():
+    """The reference's ``format_augmented_state`` (common.py:357-378): the consumer of ``retrieve`` on the prover side.
+    Cases: no budget, budgets that cut the list in the middle (a later, shorter premise still fits: ``continue``, not
+    ``break``), a budget smaller than the state, multi-byte text, and seeded ``p_drop`` (one ``random.random()`` per
+    premise, in list order)."""
+    import random
+
+    P = H.Pos
+    codes = [
+        ("Nat.add_comm", "theorem Nat.add_comm (n m : ℕ) : n + m = m + n := sorry"),
+        ("Foo.bar.baz", "lemma baz : 1 = 1\nlemma bar.baz' : 2 = 2"),
+        ("x", "def x := x + x"),
+        ("List.map", "def map (f : α → β) : List α → List β\n  | [] => []\n  | a::as => f a :: map f as"),
+        ("Set.mem_def", "theorem mem_def {a : α} {s : Set α} : a ∈ s ↔ s a"),
+        ("y", "def y := 0"),
+        ("Real.sqrt", "noncomputable def Real.sqrt (x : ℝ) : ℝ := NNReal.sqrt (Real.toNNReal x)"),
+    ]
+    ref_p = [common.Premise("A.lean", n, P(1, 0), P(2, 0), c) for n, c in codes]
+    states = ["n m : ℕ\n⊢ n + m = m + n", "⊢ True", "α : Type\ns : Set α\na : α\nh : a ∈ s\n⊢ s a"]
+    cases = []
+    for s in states:
+        sb = len(s.encode("utf-8"))
+        sizes = [len((p.serialize() + "\n\n").encode("utf-8")) for p in ref_p]
+        budgets = [None, 0, sb - 1, sb, sb + sizes[0] - 1, sb + sizes[0], sb + sizes[0] + sizes[2],
+                   sb + sum(sizes) - 1, sb + sum(sizes), 2300]
+        for max_len in budgets:
+            for p_drop, seed in ((0.0, 0), (0.5, 3407), (0.9, 11)):
+                random.seed(seed)
+                want = common.format_augmented_state(s, ref_p, max_len, p_drop)
+                random.seed(seed)
+                mine = common_ref.format_augmented_state(s, [p.serialize() for p in ref_p], max_len, p_drop)
+                assert mine == want, (s, max_len, p_drop)
+                cases.append({"state": s, "max_len": max_len, "p_drop": p_drop, "seed": seed, "out": want})
+    json.dump({"premises": [{"path": "A.lean", "full_name": n, "code": c} for n, c in codes], "cases": cases},
+              open(os.path.join(OUT, "g15_augmented_state.json"), "w"), ensure_ascii=False)
+    print("g15 ok:", len(cases), "cases")
+
+
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     torch.manual_seed(0)
     for name in which:
         {"g1": g1_tokenizer, "g2": g2_serialize, "g3": g3_buckets, "g4": g4_tiny, "g5": g5_small,
          "g6": g6_nearest, "g7": g7_predict, "g8": g8_eval_data, "g9": g9_base_full_depth, "g10": g10_train_forward, "g11": g11_train_backward,
          "g12": g12_train_small_width, "g13": g13_train_examples,
-         "g14": g14_reference_indexed_corpus}[name]()
+         "g14": g14_reference_indexed_corpus, "g15": g15_augmented_state}[name]()

@@ -119,6 +119,19 @@ def test_format_augmented_state_matches_oracle():
         assert format_augmented_state(s, prem, budget) == want
 
 
+def test_format_augmented_state_golden_g15(golden_dir):
+    """The product's ``format_augmented_state`` against the REFERENCE's outputs (fixture G15; common.py:357-378):
+    byte budgets that cut the list mid-way, multi-byte states, seeded ``p_drop``."""
+    import json
+    import random
+
+    g = json.load(open(os.path.join(golden_dir, "g15_augmented_state.json")))
+    prem = [Premise(p["path"], p["full_name"], Pos(1, 0), Pos(2, 0), p["code"]) for p in g["premises"]]
+    for c in g["cases"]:
+        random.seed(c["seed"])
+        assert format_augmented_state(c["state"], prem, c["max_len"], c["p_drop"]) == c["out"], c
+
+
 def test_c_abi_loads_and_exports_every_declared_symbol(hip_lib):
     header = open(os.path.join(ROOT, "include", "reprover_hip.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)

@@ -109,6 +109,19 @@ def test_format_augmented_state():
     assert out == "p22\n\np1\n\n" + s
 
 
+def test_g15_augmented_state(golden_dir):
+    """oracle/common_ref.format_augmented_state against the reference's own outputs (G15)."""
+    import json
+    import random
+
+    g = json.load(open(os.path.join(golden_dir, "g15_augmented_state.json")))
+    texts = [common_ref.PremiseRef(p["path"], p["full_name"], common_ref.Pos(1, 0), common_ref.Pos(2, 0), p["code"]).serialize()
+             for p in g["premises"]]
+    for c in g["cases"]:
+        random.seed(c["seed"])
+        assert common_ref.format_augmented_state(c["state"], texts, c["max_len"], c["p_drop"]) == c["out"], c
+
+
 def test_g10_train_forward(golden_dir):
     """oracle/train_ref.py (label matrix + contrastive-MSE forward) against the reference's own collate + forward."""
     from oracle import train_ref
