@@ -331,7 +331,10 @@ def main():
     all_ctx, all_txt = [], []
     for r in range(world):
         rng = np.random.default_rng(synth.SEED + 100 + r)
-        lens = synth.synth_lengths(rng, B_STATES, "mix", lo=16, hi=2048)
+        if r == 0:
+            lens0 = lens = synth.synth_lengths(rng, B_STATES, "mix", lo=16, hi=2048)
+        else:  # weak scaling = the SAME work per GPU: every rank's 256 states carry rank 0's byte lengths (in an order of
+            lens = rng.permutation(lens0)  # their own, other bytes, other files); independent draws differ by +-7 % in tokens
         for j in range(B_STATES):
             f = int(rng.integers(N_FILES // 2, N_FILES))
             txt = synth.synth_state(rng, int(lens[j]) - 1)

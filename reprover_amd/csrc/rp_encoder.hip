@@ -559,6 +559,48 @@ __global__ __launch_bounds__(256) void padded_pack_kernel(const int64_t* __restr
   if (i < len) packed[s0 + i] = (int32_t)ids[(size_t)b * L + i];
 }
 
+// The three kernels above as ONE launch for a single row (the prover's retrieve(): every dependent launch of that path
+// costs 4-5 us as a graph node): the same lens / cu / meta / packed values.
+__global__ __launch_bounds__(1024) void padded_single_kernel(const int64_t* __restrict__ mask, const int64_t* __restrict__ ids,
+                                                             int L, int32_t* __restrict__ lens, int32_t* __restrict__ cu,
+                                                             int32_t* __restrict__ packed, int32_t* __restrict__ meta) {
+  __shared__ int s_cnt[16], s_last[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int cnt = 0, last = 0;
+  for (int i = tid; i < L; i += 1024)
+    if (mask[i] != 0) {
+      ++cnt;
+      last = i + 1;
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    cnt += __shfl_xor(cnt, o, 64);
+    last = max(last, __shfl_xor(last, o, 64));
+  }
+  if (lane == 0) {
+    s_cnt[wave] = cnt;
+    s_last[wave] = last;
+  }
+  __syncthreads();
+  cnt = last = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    cnt += s_cnt[w];
+    last = max(last, s_last[w]);
+  }
+  const bool bad = cnt != last || cnt == 0;
+  if (tid == 0) {
+    lens[0] = bad ? -(cnt + 1) : cnt;
+    cu[0] = 0;
+    cu[1] = cnt;
+    meta[0] = cnt;
+    meta[1] = cnt;
+    meta[2] = bad ? 1 : 0;
+    meta[3] = 0;
+  }
+  for (int i = tid; i < cnt; i += 1024) packed[i] = (int32_t)ids[i];
+}
+
 struct PaddedPrep {
   int32_t *lens, *cu, *packed;
   size_t bytes;
@@ -597,10 +639,15 @@ extern "C" RpStatus rp_encode_padded(RpEncoder* e, const int64_t* input_ids, con
   Workspace w = carve(e, T_max, batch, workspace ? (char*)workspace + pp.bytes : nullptr);
   if (!workspace || workspace_bytes < pp.bytes + w.bytes)
     return fail(RP_E_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, pp.bytes + w.bytes);
-  hipLaunchKernelGGL(padded_lens_kernel, dim3(batch), dim3(256), 0, stream, attention_mask, padded_len, pp.lens);
-  hipLaunchKernelGGL(padded_scan_kernel, dim3(1), dim3(1024), 0, stream, pp.lens, batch, pp.cu, meta);
-  hipLaunchKernelGGL(padded_pack_kernel, dim3((padded_len + 255) / 256, batch), dim3(256), 0, stream, input_ids, pp.cu,
-                     padded_len, pp.packed);
+  if (batch == 1) {
+    hipLaunchKernelGGL(padded_single_kernel, dim3(1), dim3(1024), 0, stream, attention_mask, input_ids, padded_len, pp.lens,
+                       pp.cu, pp.packed, meta);
+  } else {
+    hipLaunchKernelGGL(padded_lens_kernel, dim3(batch), dim3(256), 0, stream, attention_mask, padded_len, pp.lens);
+    hipLaunchKernelGGL(padded_scan_kernel, dim3(1), dim3(1024), 0, stream, pp.lens, batch, pp.cu, meta);
+    hipLaunchKernelGGL(padded_pack_kernel, dim3((padded_len + 255) / 256, batch), dim3(256), 0, stream, input_ids, pp.cu,
+                       padded_len, pp.packed);
+  }
   RP_CHECK_LAUNCH();
   return encode_pass(e, pp.packed, pp.cu, batch, T_max, meta /* meta[0] = token count */, out, out_dtype, w, stream);
 }

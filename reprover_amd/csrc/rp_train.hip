@@ -182,7 +182,7 @@ TrainWs carve_train(const RpTrainer* tr, int T, int batch, char* base) {
   w.wpart_bytes = wp;
   w.wpart = (float*)take(wp);
   w.dtab_part = (float*)take((Tp / ATT_Q + (size_t)batch + 1) * H * (2 * tr->enc->maxd + 1) * 4);
-  w.dln_part = (float*)take(((2 * F + 31) / 32) * D * 4);
+  w.dln_part = (float*)take(((std::max(2 * F, 3 * inner) + 31) / 32) * D * 4);  // row-block partials of d ln: wi (2F rows) / qkv (3 inner)
   w.ds_seq = (float*)take((size_t)batch * D * 4);
   w.dwf_seq = (float*)take((size_t)batch * D * 4);
   w.norm_part = (float*)take(1024 * 4);

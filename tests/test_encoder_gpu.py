@@ -75,6 +75,28 @@ def test_padded_entry_point_equals_packed_and_ignores_padding(tiny, golden_dir):
         tiny._encode(ids.cuda(), bad.cuda())
 
 
+def test_padded_entry_point_single_row(tiny, golden_dir):
+    """B = 1 takes the one-launch preparation (padded_single_kernel: lengths, cu_seqlens, verdict and id compaction of the
+    three-kernel form in one workgroup - the prover's retrieve() path): same embedding as the row inside a batch, for
+    every length incl. 1 token and rows longer than the 1024 threads; same rejections."""
+    g = np.load(os.path.join(golden_dir, "g4_tiny.npz"), allow_pickle=True)
+    ids = torch.from_numpy(g["input_ids"].astype(np.int64)).cuda()
+    mask = torch.from_numpy(g["attention_mask"].astype(np.int64)).cuda()
+    batch = tiny._encode(ids, mask)
+    for b in range(ids.shape[0]):
+        assert torch.equal(tiny._encode(ids[b : b + 1].contiguous(), mask[b : b + 1].contiguous())[0], batch[b]), b
+    rng = np.random.default_rng(5)
+    for n, L in ((1, 1), (1, 40), (1023, 1024), (1025, 1500), (1500, 1500)):
+        row = torch.zeros((1, L), dtype=torch.int64)
+        row[0, :n] = torch.from_numpy(rng.integers(3, 259, n))
+        m = (torch.arange(L)[None, :] < n).to(torch.int64)
+        two = tiny._encode(torch.cat([row, row]).cuda(), torch.cat([m, m]).cuda())  # the three-kernel form
+        assert torch.equal(tiny._encode(row.cuda(), m.cuda())[0], two[0]), (n, L)
+    for bad in ([0, 1, 1, 0], [0, 0, 0, 0], [1, 0, 1, 0]):
+        with pytest.raises(ValueError):
+            tiny._encode(torch.full((1, 4), 70, dtype=torch.int64).cuda(), torch.tensor([bad], dtype=torch.int64).cuda())
+
+
 def test_byt5_small_matches_hf_golden(small, golden_dir):
     g = np.load(os.path.join(golden_dir, "g5_byt5_small.npz"), allow_pickle=True)
     texts = list(g["texts"])
