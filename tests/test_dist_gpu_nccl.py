@@ -50,6 +50,18 @@ def test_sharded_step_over_rccl_world1():
         assert [[p.full_name for p in row] for row in prem] == \
             [[corpus.all_premises[i].full_name for i in row] for row in want[0].cpu().tolist()]
         assert np.array_equal(np.array(sc, dtype=np.float32), want[1].cpu().numpy())
+        # the library's own communicator seeded through this group (what RP_COMM=abi does in on_predict_start): RCCL
+        # carries torch's communicator and the library's side by side
+        from reprover_amd.dist import HipComm
+
+        comm = HipComm.from_torch_group()
+        try:
+            assert (comm.rank, comm.world) == (0, 1)
+            ids2, scores2, counts2 = sharded_nearest_premise_ids(shard, ctxs, Q, k, group=comm)
+            torch.cuda.synchronize()
+            assert torch.equal(ids2, want[0]) and torch.equal(scores2, want[1]) and torch.equal(counts2, want[2])
+        finally:
+            comm.close()
     finally:
         dist.destroy_process_group()
 
