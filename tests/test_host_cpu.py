@@ -265,3 +265,18 @@ def test_reads_the_reference_indexed_corpus_pickle(golden_dir):
         junk = os.path.join(tempfile.mkdtemp(), "junk.pickle")
         pickle.dump({"not": "an index"}, open(junk, "wb"))
         load_indexed_corpus_pickle(junk)
+
+
+def test_comm_entry_points_validate_arguments_without_a_gpu(hip_lib):
+    """rp_comm_* (the sharded step's collective behind the C ABI): argument errors are statuses with a message, a null
+    communicator is harmless - checked here without a GPU and without RCCL being bound."""
+    import ctypes as C
+
+    h = C.c_void_p()
+    assert hip_lib.rp_comm_init(C.c_char_p(b"\0" * 128), 3, 2, C.byref(h)) == -1 and not h.value
+    assert b"rank 3 of 2" in hip_lib.rp_last_error()
+    assert hip_lib.rp_comm_init(None, 0, 1, C.byref(h)) == -1
+    assert hip_lib.rp_comm_world(None) == 0 and hip_lib.rp_comm_rank(None) == -1
+    assert hip_lib.rp_comm_destroy(None) == 0
+    assert hip_lib.rp_comm_allgather(None, None, None, 16, None) == -1
+    assert hip_lib.rp_allgather_topk(None, None, None, 4, 2, 0, 4, None, None, None, None, 0, None) == -1
