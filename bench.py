@@ -265,6 +265,27 @@ def _cpu_model():
     return "unknown"
 
 
+class _Leg:
+    """``with _Leg(name, errors):`` - an auxiliary measurement whose failure must not cost the headline line: the exception
+    is recorded under ``leg_errors[name]`` in the JSON and printed on stderr, and the run goes on."""
+
+    def __init__(self, name, errors):
+        self.name, self.errors = name, errors
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is None or not issubclass(et, Exception):
+            return False
+        import traceback
+
+        self.errors[self.name] = f"{et.__name__}: {ev}"
+        print(f"[bench] leg {self.name} failed:", file=sys.stderr)
+        traceback.print_exception(et, ev, tb, file=sys.stderr)
+        return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -533,126 +554,132 @@ def main():
 
     # ---- N = 1 only: the product API from strings, length tiers, full re-index, single-state latency --------
     product = tiers = reindex = b1 = None
+    leg_errors = {}  # an auxiliary leg that fails is reported here (and on stderr); the headline line is still printed
     if world == 1 and not args.headline_only:
         from reprover_amd.retrieval.model import PremiseRetriever
         from reprover_amd.tokenizer import ByT5Tokenizer
 
-        retr = PremiseRetriever(enc, max_seq_len=1024, num_retrieved=TOP_K)  # predict conf: max_seq_len 1024
-        retr.corpus, retr.corpus_embeddings, retr.embeddings_staled = corpus, E_full, False
-        tok = ByT5Tokenizer()
+        with _Leg("product_api", leg_errors):
+            retr = PremiseRetriever(enc, max_seq_len=1024, num_retrieved=TOP_K)  # predict conf: max_seq_len 1024
+            retr.corpus, retr.corpus_embeddings, retr.embeddings_staled = corpus, E_full, False
+            tok = ByT5Tokenizer()
 
-        def predict_all(rounds=1, bs=64):  # datamodule.py:130-144 collate + model.py:281-327 predict_step, eval batch size 64
-            retr.predict_step_outputs = []
-            for i in [j for _ in range(rounds) for j in range(0, B_STATES, bs)]:
-                ctxs = all_ctx[i : i + bs]
-                t = tok([c.serialize() for c in ctxs], padding="longest", max_length=1024, truncation=True,
-                        return_tensors="pt")
-                b = {"context": ctxs, "context_ids": t.input_ids, "context_mask": t.attention_mask}
-                for key in ("url", "commit", "file_path", "full_name", "start", "tactic_idx", "all_pos_premises"):
-                    b[key] = [None] * len(ctxs)
-                retr.predict_step(b, 0)
-            return retr.predict_step_outputs
+            def predict_all(rounds=1, bs=64):  # datamodule.py:130-144 collate + model.py:281-327 predict_step, eval batch size 64
+                retr.predict_step_outputs = []
+                for i in [j for _ in range(rounds) for j in range(0, B_STATES, bs)]:
+                    ctxs = all_ctx[i : i + bs]
+                    t = tok([c.serialize() for c in ctxs], padding="longest", max_length=1024, truncation=True,
+                            return_tensors="pt")
+                    b = {"context": ctxs, "context_ids": t.input_ids, "context_mask": t.attention_mask}
+                    for key in ("url", "commit", "file_path", "full_name", "start", "tactic_idx", "all_pos_premises"):
+                        b[key] = [None] * len(ctxs)
+                    retr.predict_step(b, 0)
+                return retr.predict_step_outputs
 
-        predict_all()
-        ts = []
-        for _ in range(3):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            outs = predict_all()
-            ts.append(time.perf_counter() - t0)
-        ts4 = []  # the same states four times over = 16 batches: the fill (first collate) and the drain (last batch's
-        for _ in range(3):  # records) of the one-batch-deep pipeline weigh 1/16 instead of 1/4, as in a real predict run
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            outs4 = predict_all(4)
-            ts4.append(time.perf_counter() - t0)
-        assert len(outs4) == 4 * B_STATES
-        predict_all(1, B_STATES)
-        ts256 = []  # eval_batch_size 256 (a data-module setting): the headline step's pass size through the product API - a
-        for _ in range(3):  # 64-state pass costs 7 % more GPU time per token than a 256-state one (tools/padded_vs_packed.py)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            predict_all(4, B_STATES)
-            ts256.append(time.perf_counter() - t0)
-        product = {"qps": B_STATES / float(np.median(ts)), "ms_per_256_states": float(np.median(ts)) * 1e3,
-                   "qps_16_batches": 4 * B_STATES / float(np.median(ts4)),
-                   "qps_eval_batch_256": 4 * B_STATES / float(np.median(ts256)),
-                   "path": "strings -> ByT5 tokenizer (padding=longest, max_length 1024) -> predict_step (rp_encode_padded "
-                           "+ Corpus.get_nearest_premises incl. mask packing, H2D/D2H, Premise mapping), 4 batches of 64",
-                   "n_outputs": len(outs), "premises_per_output": len(outs[0]["retrieved_premises"])}
-
-        tiers = {}
-        for L, n_p in ((128, 2048), (512, 512), (2048, 128)):  # fixed byte-length tiers incl. EOS
-            rngt = np.random.default_rng(synth.SEED + L)
-            tids, tcu = synth.synth_token_batch(rngt, np.full(n_p, L))
-            tout = torch.empty((n_p, D), dtype=torch.bfloat16, device=dev)
-            enc.encode_packed(tids, tcu, tout)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            enc.encode_packed(tids, tcu, tout)
-            torch.cuda.synchronize()
-            tdt = time.perf_counter() - t0
-            tiers[str(L)] = {"premises_per_s": n_p / tdt, "tokens_per_s": n_p * L / tdt, "premises": n_p}
-
-        lat = {}
-        for nbytes in (100, 300, 1000):  # the prover's call: one state per search node (tactic_generator.py:286-292)
-            rngl = np.random.default_rng(synth.SEED + nbytes)
-            st = synth.synth_state(rngl, nbytes)
-            c0 = all_ctx[0]
-            retr.retrieve(st, c0.path, c0.theorem_full_name, c0.theorem_pos, TOP_K)
-            ls = []
-            for _ in range(20):
+            predict_all()
+            ts = []
+            for _ in range(3):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
+                outs = predict_all()
+                ts.append(time.perf_counter() - t0)
+            ts4 = []  # the same states four times over = 16 batches: the fill (first collate) and the drain (last batch's
+            for _ in range(3):  # records) of the one-batch-deep pipeline weigh 1/16 instead of 1/4, as in a real predict run
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                outs4 = predict_all(4)
+                ts4.append(time.perf_counter() - t0)
+            assert len(outs4) == 4 * B_STATES
+            predict_all(1, B_STATES)
+            ts256 = []  # eval_batch_size 256 (a data-module setting): the headline step's pass size through the product API - a
+            for _ in range(3):  # 64-state pass costs 7 % more GPU time per token than a 256-state one (tools/padded_vs_packed.py)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                predict_all(4, B_STATES)
+                ts256.append(time.perf_counter() - t0)
+            product = {"qps": B_STATES / float(np.median(ts)), "ms_per_256_states": float(np.median(ts)) * 1e3,
+                       "qps_16_batches": 4 * B_STATES / float(np.median(ts4)),
+                       "qps_eval_batch_256": 4 * B_STATES / float(np.median(ts256)),
+                       "path": "strings -> ByT5 tokenizer (padding=longest, max_length 1024) -> predict_step (rp_encode_padded "
+                               "+ Corpus.get_nearest_premises incl. mask packing, H2D/D2H, Premise mapping), 4 batches of 64",
+                       "n_outputs": len(outs), "premises_per_output": len(outs[0]["retrieved_premises"])}
+
+        with _Leg("length_tiers", leg_errors):
+            tiers = {}
+            for L, n_p in ((128, 2048), (512, 512), (2048, 128)):  # fixed byte-length tiers incl. EOS
+                rngt = np.random.default_rng(synth.SEED + L)
+                tids, tcu = synth.synth_token_batch(rngt, np.full(n_p, L))
+                tout = torch.empty((n_p, D), dtype=torch.bfloat16, device=dev)
+                enc.encode_packed(tids, tcu, tout)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                enc.encode_packed(tids, tcu, tout)
+                torch.cuda.synchronize()
+                tdt = time.perf_counter() - t0
+                tiers[str(L)] = {"premises_per_s": n_p / tdt, "tokens_per_s": n_p * L / tdt, "premises": n_p}
+
+        with _Leg("b1_latency", leg_errors):
+            lat = {}
+            for nbytes in (100, 300, 1000):  # the prover's call: one state per search node (tactic_generator.py:286-292)
+                rngl = np.random.default_rng(synth.SEED + nbytes)
+                st = synth.synth_state(rngl, nbytes)
+                c0 = all_ctx[0]
                 retr.retrieve(st, c0.path, c0.theorem_full_name, c0.theorem_pos, TOP_K)
-                ls.append(time.perf_counter() - t0)
-            lat[str(nbytes)] = float(np.median(ls)) * 1e3
-        b1 = {"retrieve_wall_ms_by_state_bytes": lat, "k": TOP_K,
-              "path": "PremiseRetriever.retrieve(): tokenise, encode, masked top-100 over the 130k index, D2H, Premise "
-                      "objects; median of 20 calls"}
+                ls = []
+                for _ in range(20):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    retr.retrieve(st, c0.path, c0.theorem_full_name, c0.theorem_pos, TOP_K)
+                    ls.append(time.perf_counter() - t0)
+                lat[str(nbytes)] = float(np.median(ls)) * 1e3
+            b1 = {"retrieve_wall_ms_by_state_bytes": lat, "k": TOP_K,
+                  "path": "PremiseRetriever.retrieve(): tokenise, encode, masked top-100 over the 130k index, D2H, Premise "
+                          "objects; median of 20 calls"}
 
-        if not args.no_full_reindex:
-            tpath = os.path.join(tmp, "corpus_text.jsonl")
-            synth.write_corpus_jsonl(tpath, fast_text_corpus_records(N_FILES, N_PREMISES, synth.SEED))
-            t0 = time.perf_counter()
-            r2 = PremiseRetriever(enc, max_seq_len=2048)
-            r2.load_corpus(tpath)
-            t_load = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            r2.reindex_corpus(batch_size=64)
-            torch.cuda.synchronize()
-            t_idx = time.perf_counter() - t0
-            n_tok = int(sum(min(len(pr.serialize().encode()) + 1, 2048) for pr in r2.corpus.all_premises[:2000]))
-            # the same sweep through the index CLI (retrieval/index.py:13-41): checkpoint load, corpus load, re-index,
-            # D2H and persist, as a user runs it (native index directory; BASELINE configs[3] at N = 1)
-            from reprover_amd.retrieval import index as index_cli
+        with _Leg("reindex_130k", leg_errors):
+            if not args.no_full_reindex:
+                tpath = os.path.join(tmp, "corpus_text.jsonl")
+                synth.write_corpus_jsonl(tpath, fast_text_corpus_records(N_FILES, N_PREMISES, synth.SEED))
+                t0 = time.perf_counter()
+                r2 = PremiseRetriever(enc, max_seq_len=2048)
+                r2.load_corpus(tpath)
+                t_load = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                r2.reindex_corpus(batch_size=64)
+                torch.cuda.synchronize()
+                t_idx = time.perf_counter() - t0
+                n_tok = int(sum(min(len(pr.serialize().encode()) + 1, 2048) for pr in r2.corpus.all_premises[:2000]))
+                # the same sweep through the index CLI (retrieval/index.py:13-41): checkpoint load, corpus load, re-index,
+                # D2H and persist, as a user runs it (native index directory; BASELINE configs[3] at N = 1)
+                from reprover_amd.retrieval import index as index_cli
 
-            ckpt = os.path.join(tmp, "ckpt")
-            enc.save_pretrained(ckpt)
-            del r2.corpus_embeddings
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            index_cli.main(["--ckpt_path", ckpt, "--corpus-path", tpath, "--output-path", os.path.join(tmp, "index.rpidx/"),
-                            "--batch-size", "64"])
-            torch.cuda.synchronize()
-            t_cli = time.perf_counter() - t0
-            reindex = {"premises": len(r2.corpus), "reindex_corpus_s": t_idx, "premises_per_s": len(r2.corpus) / t_idx,
-                       "index_cli_wall_s": t_cli, "index_cli_premises_per_s": len(r2.corpus) / t_cli,
-                       "index_cli": "python -m reprover_amd.retrieval.index --ckpt_path .. --corpus-path .. --output-path "
-                                    "index.rpidx/ (in process): HF checkpoint load + pack, corpus.jsonl load, re-index, "
-                                    "persist (bf16 safetensors + closure arrays)",
-                       "load_corpus_jsonl_s": t_load, "mean_tokens_per_premise_first_2000": n_tok / 2000.0,
-                       "path": "PremiseRetriever.reindex_corpus(64) from corpus.jsonl: serialize (regex) + tokenise on the "
-                               "host, packed varlen encode on the GPU; BASELINE configs[3] at N = 1"}
-            del r2
+                ckpt = os.path.join(tmp, "ckpt")
+                enc.save_pretrained(ckpt)
+                del r2.corpus_embeddings
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                index_cli.main(["--ckpt_path", ckpt, "--corpus-path", tpath, "--output-path", os.path.join(tmp, "index.rpidx/"),
+                                "--batch-size", "64"])
+                torch.cuda.synchronize()
+                t_cli = time.perf_counter() - t0
+                reindex = {"premises": len(r2.corpus), "reindex_corpus_s": t_idx, "premises_per_s": len(r2.corpus) / t_idx,
+                           "index_cli_wall_s": t_cli, "index_cli_premises_per_s": len(r2.corpus) / t_cli,
+                           "index_cli": "python -m reprover_amd.retrieval.index --ckpt_path .. --corpus-path .. --output-path "
+                                        "index.rpidx/ (in process): HF checkpoint load + pack, corpus.jsonl load, re-index, "
+                                        "persist (bf16 safetensors + closure arrays)",
+                           "load_corpus_jsonl_s": t_load, "mean_tokens_per_premise_first_2000": n_tok / 2000.0,
+                           "path": "PremiseRetriever.reindex_corpus(64) from corpus.jsonl: serialize (regex) + tokenise on the "
+                                   "host, packed varlen encode on the GPU; BASELINE configs[3] at N = 1"}
+                del r2
 
     # ---- N = 1 only: the training step at the reference's training configuration -------------
     train = None
     if world == 1 and not args.headline_only and not args.no_train_step:
-        train = {}
-        for name, bsz in (("reference_conf_batch8", 8), ("batch64", 64)):
-            train[name] = train_step_leg(cfg, sd, dev, bsz)
-        train["reference_conf_batch8"]["ms_per_step_without_dropout"] = train_step_leg(cfg, sd, dev, 8, dropout_rate=0.0)["ms_per_step"]
+        with _Leg("train_step", leg_errors):
+            train = {}
+            for name, bsz in (("reference_conf_batch8", 8), ("batch64", 64)):
+                train[name] = train_step_leg(cfg, sd, dev, bsz)
+            train["reference_conf_batch8"]["ms_per_step_without_dropout"] = train_step_leg(cfg, sd, dev, 8, dropout_rate=0.0)["ms_per_step"]
 
     result = {
         "metric": "retrieve QPS@top-100 (state encode + masked similarity top-k), ByT5-small, 130k-premise corpus",
@@ -717,7 +744,10 @@ def main():
             result["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json was measured on other kernel sources "
                                                     "(hash mismatch): traffic withheld; re-run tools/profile_round.sh")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(cfg, sd, corpus_path, E_full, all_txt, all_ctx)
+        with _Leg("cpu_baseline", leg_errors):
+            result["cpu_baseline"] = cpu_baseline(cfg, sd, corpus_path, E_full, all_txt, all_ctx)
+    if leg_errors:
+        result["leg_errors"] = leg_errors
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
