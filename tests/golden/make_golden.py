@@ -15,6 +15,12 @@ import sys
 import tempfile
 import time
 
+if os.environ.get("PYTHONHASHSEED") != "0":
+    # Reproducible bytes: the reference iterates over Python sets of strings (the order of a tactic's positive premises,
+    # networkx's successor lists inside the pickled Corpus of G14), so the interpreter's string-hash seed is pinned.
+    os.environ["PYTHONHASHSEED"] = "0"
+    os.execv(sys.executable, [sys.executable] + sys.argv)
+
 import numpy as np
 import torch
 
@@ -712,6 +718,8 @@ def g13_train_examples():
                              "outside_pool": sorted(outside), "k_in": k_in, "k_out": k_out})
     finally:
         dmod.random.sample = real_sample
+    # the reference lists a tactic's positives in set-iteration order: the fixture is keyed, not ordered
+    examples.sort(key=lambda e: (e["full_name"], e["tactic_idx"], e["pos_premise"]))
     json.dump({"corpus_seed": 131, "n_files": 30, "n_premises": 500, "max_imports": 5, "split_seed": 132, "n_theorems": 40,
                "min_file": 8, "num_negatives": num_neg, "num_in_file_negatives": num_in_file, "examples": examples},
               open(os.path.join(OUT, "g13_train_examples.json"), "w"))
@@ -726,7 +734,9 @@ def g14_reference_indexed_corpus():
     """The reference's own index file: ``IndexedCorpus(corpus, embeddings)`` pickled exactly as retrieval/index.py:37-40
     writes it (the reference's common.Corpus with its networkx graph, common.File / Premise, lean_dojo.Pos inside), for a
     small corpus and the tiny encoder, plus what the reference's ``retrieve`` returns from it for a few states.  The
-    product reads this file without any of those modules (common.load_indexed_corpus_pickle)."""
+    product reads this file without any of those modules (common.load_indexed_corpus_pickle).
+    Regenerating reproduces the file except for 22 bytes: the storage key torch's legacy tensor pickling writes twice
+    is a heap address of the generating process (two 14-digit decimal strings); everything else is byte-identical."""
     import pickle
 
     cfg = synth.t5_config("tiny")
