@@ -121,8 +121,10 @@ class PremiseRetriever:
         """``dtype`` None → bf16, the reference's own choice on a capable GPU (model.py:59-64).  ``dtype`` selects
         the dtype of the embeddings handed back (``corpus_embeddings``, ``_encode``); the arithmetic is the same for
         both values - bf16 MFMA operands, fp32 accumulation and statistics, the residual stream as two bf16 planes
-        (hi + lo: 16 mantissa bits) - where the reference with ``dtype=float32`` would also multiply in fp32.  ``retrieve`` / ``num_retrieved`` accept k <= 1024 (the
-        final selection sorts in LDS); the reference accepts any k."""
+        (hi + lo: 16 mantissa bits) - where the reference with ``dtype=float32`` multiplies fp32 operands under
+        ``torch.set_float32_matmul_precision("medium")`` (model.py:26), a setting that itself licenses bf16-precision
+        products inside fp32 matmuls.  ``retrieve`` / ``num_retrieved`` accept k <= 1024 (the final selection sorts in
+        LDS); the reference accepts any k."""
         return cls(ckpt_path, 0.0, 0, max_seq_len, 100, device=device, dtype=dtype or torch.bfloat16)
 
     @classmethod
