@@ -28,11 +28,12 @@ extern int g_scan_cfg, g_scan_impl, g_scan_filter_cfg, g_scan_sample_cfg, g_scan
 int g_gemm_group_m = 8;
 // Tile configuration per encoder GEMM (see launch_gemm()), measured at 65536 tokens (tools/gemm_bench.py,
 // profiles/).  20 / 26 = the software-pipelined 256 x 256 x 64 tile with 4 / 8 waves: the same main
-// loop; 8 waves finish the heavier epilogues (bf16 store of 1152 features, fp32 residual
-// read-modify-write) sooner, 4 waves win by a hair on the gated-GELU GEMM.  The K = H*64
+// loop; 8 waves finish the epilogues sooner.  The gated-GELU GEMM ran the 4-wave form until round 3 (equal at 65 k tokens
+// in round 2's isolated runs); inside the step the 8-wave form is 1.1 % faster at 70 k tokens (15.15 -> 14.99 ms over the 12
+// launches, three A/B pairs) and 2-5 % at 9-44 k tokens (tools/gemm_bench.py), so every big GEMM uses it now.  The K = H*64
 // attention-output projection is bound by the read-modify-write of x whatever the tiling: two small
 // blocks per CU overlap one block's epilogue with the other's main loop.
-int g_gemm_variant = 20;      // FFN-in (wi_0|wi_1 + gated GELU)
+int g_gemm_variant = 26;      // FFN-in (wi_0|wi_1 + gated GELU)
 int g_gemm_variant_qkv = 26;  // QKV
 int g_gemm_variant_wo = 26;   // FFN-out (+ residual)
 int g_gemm_variant_o = 0;     // attention output (+ residual)
@@ -99,8 +100,7 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   if (!strcmp(name, "gemm_variant_all")) {  // benches/tests: one configuration for every GEMM; -1 = defaults
     RP_REQUIRE(value >= -1 && value <= 30, "gemm_variant_all out of range");
     if (value < 0) {
-      g_gemm_variant = 20;
-      g_gemm_variant_qkv = g_gemm_variant_wo = 26;
+      g_gemm_variant = g_gemm_variant_qkv = g_gemm_variant_wo = 26;
       g_gemm_variant_o = 0;
     } else {
       g_gemm_variant = g_gemm_variant_qkv = g_gemm_variant_wo = g_gemm_variant_o = value;

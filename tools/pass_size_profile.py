@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import importlib.util
 spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
-bench = importlib.util.module_from_spec(spec); sys.argv = ["x"]; spec.loader.exec_module(bench)
+bench = importlib.util.module_from_spec(spec); _argv, sys.argv = sys.argv, ["x"]; spec.loader.exec_module(bench); sys.argv = _argv
 from reprover_amd import _lib, synth
 from reprover_amd.encoder import HipT5Encoder
 from reprover_amd.tokenizer import ByT5Tokenizer
