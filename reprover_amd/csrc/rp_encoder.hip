@@ -36,7 +36,9 @@ int g_gemm_group_m = 8;
 int g_gemm_variant = 26;      // FFN-in (wi_0|wi_1 + gated GELU)
 int g_gemm_variant_qkv = 26;  // QKV
 int g_gemm_variant_wo = 26;   // FFN-out (+ residual)
-int g_gemm_variant_o = 0;     // attention output (+ residual)
+int g_gemm_variant_o = -1;    // attention output (+ residual); -1 = by pass size: two 128 x 128 blocks per CU, or - from 57 k
+                              // tokens - the 8-wave 256 x 256 tile (A/B inside the 70 k-token step: 2.553 -> 2.470 ms per 12
+                              // launches, three pairs; in isolation the two alternate below that size, tools/gemm_bench.py)
 int g_gemm_tail_split = 1;  // big passes: last partial round of 256 x 256 tiles as one round of 128 x 128 tiles
 int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 int g_gemm_skinny = 1;
@@ -101,7 +103,7 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     RP_REQUIRE(value >= -1 && value <= 30, "gemm_variant_all out of range");
     if (value < 0) {
       g_gemm_variant = g_gemm_variant_qkv = g_gemm_variant_wo = 26;
-      g_gemm_variant_o = 0;
+      g_gemm_variant_o = -1;
     } else {
       g_gemm_variant = g_gemm_variant_qkv = g_gemm_variant_wo = g_gemm_variant_o = value;
     }

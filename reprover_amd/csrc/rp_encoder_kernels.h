@@ -475,7 +475,7 @@ constexpr int GEMM_M_ALIGN = 256;
 
 // Which tile configuration a projection runs with.  tokens_valid = real token count of the pass (0: all M rows).
 static int pick_gemm_variant(int prof_class, int M, int n_rows_w, int K, int tokens_valid) {
-  int v = prof_class == RP_K_GEMM_O     ? g_gemm_variant_o
+  int v = prof_class == RP_K_GEMM_O     ? (g_gemm_variant_o >= 0 ? g_gemm_variant_o : (M >= 57344 ? 26 : 0))
           : prof_class == RP_K_GEMM_WO  ? g_gemm_variant_wo
           : prof_class == RP_K_GEMM_QKV ? g_gemm_variant_qkv
                                         : g_gemm_variant;
