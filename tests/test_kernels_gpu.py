@@ -226,6 +226,34 @@ def test_sim_topk_exact_ties_and_order(gen):
         assert (cnt == k).all()
 
 
+def test_sim_topk_random_shapes_exact(gen):
+    """A seeded sweep over shapes nobody picked by hand - B, N, D, k, mask density, id offset - on small-integer embeddings
+    (every product exact, ties everywhere): ids, scores and counts must equal the oracle's masked top-k bit for bit on every
+    plan the library may choose, incl. rows with fewer than k accessible premises."""
+    rng = np.random.default_rng(2027)
+    for case in range(28):
+        B = int(rng.choice([1, 2, 31, 64, 129, 200, 257]))
+        N = int(rng.choice([1, 17, 255, 256, 257, 1000, 4097, 12345, 33000]))
+        D = int(rng.choice([32, 64, 96, 128, 192, 1472]))
+        k = int(rng.choice([1, 2, 10, 100, 333]))
+        density = float(rng.choice([0.02, 0.3, 0.9]))
+        off = int(rng.choice([0, 5000]))
+        E = torch.from_numpy(rng.integers(-2, 3, size=(N, D)).astype(np.float32)).cuda().to(torch.bfloat16)
+        Q = torch.from_numpy(rng.integers(-2, 3, size=(B, D)).astype(np.float32)).cuda().to(torch.bfloat16)
+        m, acc = hh.synth_masks(rng, N, B, F=max(1, min(N, 40)), density=density)
+        S = (Q.float() @ E.float().T).cpu().numpy()
+        n_acc = np.minimum(acc.sum(1), k)
+        want = [common_ref.masked_topk(S[b : b + 1], acc[b : b + 1], int(n_acc[b])) for b in range(B)]
+        for flags in (_lib.RP_TOPK_AUTO, _lib.RP_TOPK_DENSE):
+            ids, sc, cnt = hh.sim_topk(Q, E, k, hh.masks_to_device(m, Q.device), id_offset=off, flags=flags)
+            ids, sc, cnt = ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
+            assert np.array_equal(cnt, n_acc), (case, B, N, D, k)
+            for b in range(B):
+                c = int(n_acc[b])
+                assert np.array_equal(ids[b, :c], want[b][0][0] + off), (case, B, N, D, k, b, flags)
+                assert np.array_equal(sc[b, :c], want[b][1][0]), (case, B, N, D, k, b, flags)
+
+
 def test_sim_topk_sample_gives_no_bound(gen):
     """The adversarial case for the two-pass plan: every SAMPLED block (rows [256 j stride, +256)) is
     inaccessible, so the sample yields no bound (thr = 0) and every accessible score of the other blocks is a
