@@ -42,6 +42,23 @@ def test_ragged_minimal_and_maximal_sequences(tiny):
     assert _cos(got, want).min().item() > 0.9995
 
 
+def test_random_batches_against_the_oracle(tiny):
+    """A seeded sweep of pass shapes (1 .. 80 sequences of 1 .. 900 bytes, multi-byte symbols included): every row against
+    the fp32 oracle, a random member alone against itself in the batch, the padded entry point against the packed one."""
+    cfg, sd, model = tiny
+    rng = np.random.default_rng(77)
+    for case in range(10):
+        n = int(rng.choice([1, 2, 7, 33, 80]))
+        texts = [synth.synth_text(rng, int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 300, 900]))) for _ in range(n)]
+        got = model.encode_texts(texts)
+        want = t5_ref.encode_texts(cfg, sd, texts, 2048, 16)
+        assert _cos(got.cpu(), want).min().item() > 0.9995, case
+        j = int(rng.integers(0, n))
+        assert (model.encode_texts([texts[j]])[0] - got[j]).abs().max().item() < 1e-6, (case, j)
+        t = model.tokenizer(texts, padding="longest", max_length=2048, truncation=True, return_tensors="pt")
+        assert torch.equal(model._encode(t.input_ids.cuda(), t.attention_mask.cuda()), got), case
+
+
 def test_skinny_gemm_configuration_matches_default(tiny):
     cfg, sd, model = tiny
     lib = _lib.load()
