@@ -14,8 +14,9 @@ rank scans its shard for all N*256 queries, the per-shard top-k lists travel as 
 
 The timed region is un-instrumented; a second pass of the same K steps with an event pair around every launch gives
 the per-kernel split the roofline objects are computed from.  Beside the headline value the line carries, at N = 1
-(SURVEY.md §8d): the same 256 queries through the PRODUCT API from strings (`product_api_qps`:
-RetrievalDataset-style collate -> PremiseRetriever.predict_step), premises/s at the fixed length tiers 128 / 512 /
+(SURVEY.md §8d): the same queries through the PRODUCT API from strings (`product_api_qps`: 16 eval batches of 64 states,
+RetrievalDataset-style collate -> PremiseRetriever.predict_step, which gathers host batches into 256-state GPU passes;
+`product_api` also holds the 4-batch figure and the figure with one pass per batch), premises/s at the fixed length tiers 128 / 512 /
 2048 and on the length mix, the wall time of a full 130,000-premise `reindex_corpus`, the wall latency of
 single-state `retrieve()` calls, and the CPU baseline (the oracle on the host cores, bounded sample).
 
@@ -583,13 +584,22 @@ def main():
                 t0 = time.perf_counter()
                 outs = predict_all()
                 ts.append(time.perf_counter() - t0)
-            ts4 = []  # the same states four times over = 16 batches: the fill (first collate) and the drain (last batch's
-            for _ in range(3):  # records) of the one-batch-deep pipeline weigh 1/16 instead of 1/4, as in a real predict run
+            ts4 = []  # the same states four times over = 16 batches: the fill (first collates) and the drain (last pass's
+            for _ in range(3):  # records) of the pipeline weigh 1/4 as much as in the 4-batch figure, as in a real predict run
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 outs4 = predict_all(4)
                 ts4.append(time.perf_counter() - t0)
             assert len(outs4) == 4 * B_STATES
+            default_coalesce, retr.predict_coalesce_states = retr.predict_coalesce_states, 0
+            predict_all()
+            ts_nc = []  # one GPU pass per 64-state batch (predict_coalesce_states = 0): what the pass size costs
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                predict_all(4)
+                ts_nc.append(time.perf_counter() - t0)
+            retr.predict_coalesce_states = default_coalesce
             predict_all(1, B_STATES)
             ts256 = []  # eval_batch_size 256 (a data-module setting): the headline step's pass size through the product API - a
             for _ in range(3):  # 64-state pass costs 7 % more GPU time per token than a 256-state one (tools/padded_vs_packed.py)
@@ -597,11 +607,17 @@ def main():
                 t0 = time.perf_counter()
                 predict_all(4, B_STATES)
                 ts256.append(time.perf_counter() - t0)
-            product = {"qps": B_STATES / float(np.median(ts)), "ms_per_256_states": float(np.median(ts)) * 1e3,
-                       "qps_16_batches": 4 * B_STATES / float(np.median(ts4)),
+            product = {"qps": 4 * B_STATES / float(np.median(ts4)), "ms_per_256_states": float(np.median(ts4)) * 1e3 / 4,
+                       "qps_4_batches": B_STATES / float(np.median(ts)),
+                       "qps_16_batches_one_pass_per_batch": 4 * B_STATES / float(np.median(ts_nc)),
                        "qps_eval_batch_256": 4 * B_STATES / float(np.median(ts256)),
-                       "path": "strings -> ByT5 tokenizer (padding=longest, max_length 1024) -> predict_step (rp_encode_padded "
-                               "+ Corpus.get_nearest_premises incl. mask packing, H2D/D2H, Premise mapping), 4 batches of 64",
+                       "predict_coalesce_states": default_coalesce,
+                       "path": "strings -> ByT5 tokenizer (padding=longest, max_length 1024) -> predict_step at the "
+                               "reference's eval batch of 64 states (host batches gathered into passes of "
+                               "predict_coalesce_states states: packed encode + Corpus.get_nearest_premises incl. masks "
+                               "from the device-resident closure, H2D/D2H, Premise mapping); qps = 16 batches (1024 states) "
+                               "start to finish; qps_4_batches = 256 states, i.e. ONE pass whose collate and record "
+                               "mapping overlap nothing",
                        "n_outputs": len(outs), "premises_per_output": len(outs[0]["retrieved_premises"])}
 
         with _Leg("length_tiers", leg_errors):

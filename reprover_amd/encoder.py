@@ -279,18 +279,35 @@ class HipT5Encoder:
             off += n
         return out
 
-    def _encode_host_batch(self, input_ids: torch.Tensor, attention_mask: torch.Tensor,
-                           out_dtype: Optional[torch.dtype]) -> torch.Tensor:
+    @staticmethod
+    def _pack_host(input_ids: torch.Tensor, attention_mask: torch.Tensor):
+        """(packed int32 ids of the real tokens, per-row lengths) of one right-padded host batch; ``ValueError`` for a mask
+        that is not right-padded or has an empty row (what the device form reports through its verdict word)."""
         ids = input_ids.numpy()
         mask = attention_mask.numpy() != 0
-        B, L = ids.shape
+        L = ids.shape[1]
         lens = mask.sum(1)
         if (lens == 0).any() or (mask != (np.arange(L)[None, :] < lens[:, None])).any():
             raise ValueError("attention_mask must be right-padded (1s then 0s) with at least one token per row, "
                              "as the tokenizer produces")
+        return ids[mask].astype(np.int32), lens  # row-major: sequence after sequence
+
+    def _encode_host_batch(self, input_ids: torch.Tensor, attention_mask: torch.Tensor,
+                           out_dtype: Optional[torch.dtype]) -> torch.Tensor:
+        return self.encode_padded_many([(input_ids, attention_mask)], out_dtype)
+
+    def encode_padded_many(self, batches, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        """Several right-padded HOST batches ``[(input_ids [B_i, L_i], attention_mask [B_i, L_i]), ...]`` as ONE packed
+        pass (rows in order: the embeddings of batch 0, then batch 1, ...).  What ``predict_step`` uses to run the
+        reference's 64-state eval batches at the pass size the GPU is efficient at: four 64-state passes cost 10 % more
+        GPU time than one 256-state pass (tools/pass_size_profile.py), and a row's embedding does not depend on what
+        else is in the pass."""
+        parts = [self._pack_host(i, m) for i, m in batches]
+        packed = np.concatenate([p for p, _ in parts]) if len(parts) > 1 else parts[0][0]
+        lens = np.concatenate([n for _, n in parts]) if len(parts) > 1 else parts[0][1]
+        B = len(lens)
         cu = np.zeros(B + 1, dtype=np.int32)
         np.cumsum(lens, out=cu[1:])
-        packed = ids[mask].astype(np.int32)  # row-major: sequence after sequence
         out = torch.empty((B, self.cfg["d_model"]), dtype=out_dtype or self.dtype, device=self.device)
         b0 = 0
         while b0 < B:  # passes of at most max_tokens_per_pass tokens (one pass for every realistic batch)

@@ -108,6 +108,11 @@ class PremiseRetriever:
         # kernels one by one as the batch paths do.
         self.use_graphs = True
         self._single_query = None
+        # predict_step gathers consecutive HOST batches until this many states are queued and runs them as ONE GPU pass
+        # (the reference's eval batch is 64 states; a 256-state pass costs 10 % less GPU time per state).  0 = every
+        # batch is its own pass.  Records keep their order; they are complete when ``predict_step_outputs`` is read.
+        self.predict_coalesce_states = 256
+        self._predict_stash: List[Dict[str, Any]] = []
         # training (lazily built by training_step / configure_optimizers: fp32 masters, gradients, AdamW moments)
         self._trainer = None
         self.gradient_clip_val: Optional[float] = None  # Lightning's trainer.gradient_clip_val (confs/*.yaml: 1.0)
@@ -381,40 +386,61 @@ class PremiseRetriever:
             return
         self.reindex_corpus(eval_batch_size)
 
-    # ``predict_step_outputs`` (model.py:274, 314-327) - the reference's attribute.  Here the last batch's records
-    # are completed lazily: reading the attribute (or the next predict_step, or on_predict_epoch_end) finishes them.
+    # ``predict_step_outputs`` (model.py:274, 314-327) - the reference's attribute.  Here the records of the batches still
+    # queued or in flight are completed lazily: reading the attribute (or on_predict_epoch_end) launches and finishes them.
     @property
     def predict_step_outputs(self) -> List[Dict[str, Any]]:
+        self._launch_predict(self._take_predict_stash())
         self._finish_pending_predict()
         return self._predict_outputs
 
     @predict_step_outputs.setter
     def predict_step_outputs(self, value: List[Dict[str, Any]]) -> None:
         self._predict_pending = None
+        self._predict_stash = []
         self._predict_outputs = value
 
+    def _take_predict_stash(self) -> List[Dict[str, Any]]:
+        stash, self._predict_stash = self._predict_stash, []
+        return stash
+
     def predict_step(self, batch: Dict[str, Any], _=None) -> None:
-        """model.py:281-327.  One batch deep software pipeline: this call enqueues its own GPU work (encode, masked
-        top-k, copy to pinned memory) and only then completes the PREVIOUS batch's records, so the host-side mapping
-        of batch i - and whatever the caller does between calls: collating batch i+1 - overlaps the GPU work of
-        batch i+1.  Consequence: a ``ValueError`` (fewer than k accessible premises; a mask that is not right-padded)
-        surfaces one call later than in the reference, at the latest when the outputs are read or the epoch ends."""
-        # launch-only encode (mask -> lengths -> packed ids on the device)
-        context_emb = self.encoder.encode_padded(batch["context_ids"], batch["context_mask"], defer_check=True)
+        """model.py:281-327 as a software pipeline.  (1) Consecutive host batches are gathered until
+        ``predict_coalesce_states`` states are queued and then encoded and searched as ONE GPU pass (a row's result does
+        not depend on its pass; the pass size is what the GPU's efficiency depends on).  (2) A pass is only ENQUEUED here
+        (encode, masked top-k, copy to pinned memory); the records of the PREVIOUS pass are completed afterwards, so the
+        host-side mapping - and whatever the caller does between calls: collating the next batch - overlaps GPU work.
+        Consequence: a ``ValueError`` (fewer than k accessible premises; a mask that is not right-padded) surfaces later
+        than in the reference - at the latest when ``predict_step_outputs`` is read or the epoch ends."""
+        host = not batch["context_ids"].is_cuda and not batch["context_mask"].is_cuda
+        if host and self.predict_coalesce_states > len(batch["context"]):
+            self._predict_stash.append(batch)
+            if sum(len(b["context"]) for b in self._predict_stash) >= self.predict_coalesce_states:
+                self._launch_predict(self._take_predict_stash())
+            return
+        self._launch_predict(self._take_predict_stash())  # (keeps the order of the records)
+        self._launch_predict([batch])
+
+    def _launch_predict(self, batches: List[Dict[str, Any]]) -> None:
+        if not batches:
+            return
+        if len(batches) == 1:  # launch-only encode (device form: mask -> lengths -> packed ids on the device)
+            context_emb = self.encoder.encode_padded(batches[0]["context_ids"], batches[0]["context_mask"], defer_check=True)
+        else:
+            context_emb = self.encoder.encode_padded_many([(b["context_ids"], b["context_mask"]) for b in batches])
+        contexts = [c for b in batches for c in b["context"]]
         if self.index_shard is not None:  # every rank holds the batch; the index is row-sharded: same pipeline
             from ..dist import launch_sharded_nearest_premises
 
-            launched = launch_sharded_nearest_premises(self.index_shard, batch["context"], context_emb, self.num_retrieved,
+            launched = launch_sharded_nearest_premises(self.index_shard, contexts, context_emb, self.num_retrieved,
                                                        group=self.shard_group, also_copy=self.encoder.take_pending())
-            previous, self._predict_pending = self._predict_pending, (batch, launched)
-            self._finish_pending_predict(previous)
-            return
-        assert not self.embeddings_staled
-        launched = self.corpus.launch_nearest_premises(
-            self._search_operand(), batch["context"], context_emb, self.num_retrieved,
-            also_copy=self.encoder.take_pending(),  # the encode's right-padding verdict travels with the result
-        )
-        previous, self._predict_pending = self._predict_pending, (batch, launched)
+        else:
+            assert not self.embeddings_staled
+            launched = self.corpus.launch_nearest_premises(
+                self._search_operand(), contexts, context_emb, self.num_retrieved,
+                also_copy=self.encoder.take_pending(),  # the encode's right-padding verdict travels with the result
+            )
+        previous, self._predict_pending = self._predict_pending, (batches, launched)
         self._finish_pending_predict(previous)
 
     def _finish_pending_predict(self, pending="current") -> None:
@@ -422,11 +448,15 @@ class PremiseRetriever:
             pending, self._predict_pending = self._predict_pending, None
         if pending is None:
             return
-        batch, launched = pending
+        batches, launched = pending
         retrieved_premises, scores = launched.finish()
         for verdict in launched.extra_host:
             self.encoder.check_verdict(verdict)
-        self._append_predictions(batch, retrieved_premises, scores)
+        lo = 0
+        for batch in batches:
+            hi = lo + len(batch["context"])
+            self._append_predictions(batch, retrieved_premises[lo:hi], scores[lo:hi])
+            lo = hi
 
     def _append_predictions(self, batch: Dict[str, Any], retrieved_premises, scores) -> None:
         for url, commit, file_path, full_name, start, tactic_idx, ctx, pos_premises, premises, s in zip_strict(

@@ -189,6 +189,50 @@ def test_predict_step_pipeline_order_and_late_errors(g7):
     model.predict_step_outputs = []
 
 
+def test_predict_step_coalesces_host_batches(g7):
+    """Consecutive host batches run as one GPU pass once ``predict_coalesce_states`` states are queued: the same records
+    in the same order as one pass per batch (a row's result does not depend on its pass), a device-tensor batch in
+    between flushes what is queued first, reading the outputs completes everything."""
+    g, z, model, _ = g7
+    k = g["k"]
+    model.num_retrieved = k
+    ctxs = [Context(q["path"], f"thm{j}", Pos(*q["pos"]), q["state"]) for j, q in enumerate(g["queries"][:40])]
+
+    def make_batch(batch, device=None):
+        tok = model.tokenizer([c.serialize() for c in batch], padding="longest", max_length=g["max_seq_len"],
+                              truncation=True, return_tensors="pt")
+        b = {"context": batch, "context_ids": tok.input_ids, "context_mask": tok.attention_mask}
+        if device is not None:
+            b["context_ids"], b["context_mask"] = b["context_ids"].to(device), b["context_mask"].to(device)
+        for key in ("url", "commit", "file_path", "full_name", "start", "tactic_idx", "all_pos_premises"):
+            b[key] = [None] * len(batch)
+        return b
+
+    sizes = [8, 8, 5, 8, 8, 3]  # 40 states in ragged batches
+    cuts = np.cumsum([0] + sizes)
+    old = model.predict_coalesce_states
+    try:
+        runs = {}
+        for coalesce in (0, 16, 256):
+            model.predict_coalesce_states = coalesce
+            model.predict_step_outputs = []
+            for i in range(len(sizes)):
+                model.predict_step(make_batch(ctxs[cuts[i] : cuts[i + 1]], "cuda" if (coalesce == 16 and i == 2) else None), 0)
+                if coalesce == 16 and i == 1:  # 16 states queued: the pass is launched, nothing is complete yet
+                    assert model._predict_stash == [] and model._predict_pending is not None and not model._predict_outputs
+            if coalesce == 256:
+                assert len(model._predict_stash) == len(sizes) and not model._predict_outputs  # all still queued
+            runs[coalesce] = model.predict_step_outputs
+            assert len(runs[coalesce]) == 40 and model._predict_stash == [] and model._predict_pending is None
+        for coalesce in (16, 256):
+            for a, b in zip(runs[0], runs[coalesce]):
+                assert a["context"] is b["context"] and a["scores"] == b["scores"]
+                assert [p.full_name for p in a["retrieved_premises"]] == [p.full_name for p in b["retrieved_premises"]]
+    finally:
+        model.predict_coalesce_states = old
+        model.predict_step_outputs = []
+
+
 def test_retrieve_graph_replay_equals_launch_by_launch(g7):
     """retrieve() as one hipGraph replay (single_query.py: padded encode + masked top-k on static buffers) must
     return exactly what the launch-by-launch path returns - same premises, same scores - for states of every
