@@ -391,13 +391,21 @@ constexpr int SELECT_LDS_KEYS = 8192;  // lists up to this size are staged in LD
 // with 256 threads (one wave per SIMD, nothing to hide the latency behind) a select took ~27 us whatever the batch.
 constexpr int SELECT_THREADS = 1024;
 
-struct SelectShared {
-  uint64_t staged[SELECT_LDS_KEYS];
+// Two shapes of the per-query stages: <1024 threads, 8192 staged keys> (one query list is long: the sample of a 130 k-row
+// index, the candidates behind it) and <512 threads, 4096 / 2048 staged keys> for MANY queries with short lists (the rows of
+// one GPU's shard under all the queries of a multi-GPU step): 40 KB instead of 72 / 136 KB of LDS per workgroup, so four
+// workgroups share a CU instead of two / one.  Same code, same results; lists longer than the staged size are read from
+// global memory in either shape.
+template <int THREADS, int LDS_KEYS>
+struct SelectSharedT {
+  uint64_t staged[LDS_KEYS];
   uint64_t sel[SIM_MAX_K];
-  unsigned long long s_or[SELECT_THREADS / 64], s_and[SELECT_THREADS / 64];
+  unsigned long long s_or[THREADS / 64], s_and[THREADS / 64];
   int hist[256];
   int s_digit, s_need, s_cnt, s_done;
 };
+constexpr int SELECT_THREADS_SMALL = 256, SELECT_LDS_KEYS_SMALL = 4096;
+constexpr int GATHER_LDS_KEYS_SMALL = 2048, GATHER_LDS_ENTRIES_SMALL = 2048;
 
 // the key list of one query: in LDS when it fits, else in global memory
 struct KeySrc {
@@ -408,8 +416,9 @@ struct KeySrc {
 };
 
 // Everything after the list is in place: exact top-k of src[0, n) -> the mode A / mode B outputs of query q.
+template <int THREADS, int LDS_KEYS>
 __device__ __forceinline__ void select_body(const SelectArgs& a, int q, const KeySrc src, int n, bool overflow,
-                                            SelectShared& sh) {
+                                            SelectSharedT<THREADS, LDS_KEYS>& sh) {
   const int tid = threadIdx.x, lane = tid & 63;
   // number of real candidates, and the bits in which they differ at all: the radix passes start at the highest
   // differing bit.  (Scores of one query share sign, exponent and often a few mantissa bits: byte-aligned passes
@@ -420,7 +429,7 @@ __device__ __forceinline__ void select_body(const SelectArgs& a, int q, const Ke
   {
     int c = 0;
     unsigned long long vo = 0ull, va = ~0ull;
-    for (int i = tid; i < n; i += SELECT_THREADS) {
+    for (int i = tid; i < n; i += THREADS) {
       const uint64_t key = src[i];
       if (key != 0ull) {
         ++c;
@@ -445,7 +454,7 @@ __device__ __forceinline__ void select_body(const SelectArgs& a, int q, const Ke
   const int kk = min(a.k, nvalid);
   unsigned long long all_or = 0ull, all_and = ~0ull;
 #pragma unroll
-  for (int w = 0; w < SELECT_THREADS / 64; ++w) {
+  for (int w = 0; w < THREADS / 64; ++w) {
     all_or |= sh.s_or[w];
     all_and &= sh.s_and[w];
   }
@@ -465,7 +474,7 @@ __device__ __forceinline__ void select_body(const SelectArgs& a, int q, const Ke
       const uint32_t dmask = (1u << width) - 1u;
       if (tid < 256) sh.hist[tid] = 0;
       __syncthreads();
-      for (int i = tid; i < n; i += SELECT_THREADS) {
+      for (int i = tid; i < n; i += THREADS) {
         const uint64_t key = src[i];
         const bool in = key != 0ull && (known_shift >= 64 || (key >> known_shift) == known_prefix);
         if (in) atomicAdd(&sh.hist[(int)((uint32_t)(key >> new_shift) & dmask)], 1);
@@ -512,11 +521,11 @@ __device__ __forceinline__ void select_body(const SelectArgs& a, int q, const Ke
   // collect the kk selected keys, pad to a power of two, sort descending
   int P = 1;
   while (P < kk) P <<= 1;
-  for (int i = tid; i < P; i += SELECT_THREADS) sh.sel[i] = 0ull;
+  for (int i = tid; i < P; i += THREADS) sh.sel[i] = 0ull;
   if (tid == 0) sh.s_cnt = 0;
   __syncthreads();
   if (kk > 0) {
-    for (int i = tid; i < n; i += SELECT_THREADS) {
+    for (int i = tid; i < n; i += THREADS) {
       const uint64_t key = src[i];
       if (key >= T && key != 0ull) {
         const int pos = atomicAdd(&sh.s_cnt, 1);
@@ -527,7 +536,7 @@ __device__ __forceinline__ void select_body(const SelectArgs& a, int q, const Ke
   __syncthreads();
   for (int size = 2; size <= P; size <<= 1) {
     for (int strd = size >> 1; strd > 0; strd >>= 1) {
-      for (int i = tid; i < (P >> 1); i += SELECT_THREADS) {
+      for (int i = tid; i < (P >> 1); i += THREADS) {
         const int lo = ((i / strd) * strd * 2) + (i % strd);
         const int hi2 = lo + strd;
         const bool desc = ((lo & size) == 0);
@@ -542,7 +551,7 @@ __device__ __forceinline__ void select_body(const SelectArgs& a, int q, const Ke
   }
 
   if (a.out_keys) {
-    for (int i = tid; i < kk; i += SELECT_THREADS) a.out_keys[(size_t)q * a.out_ld + i] = sh.sel[i];
+    for (int i = tid; i < kk; i += THREADS) a.out_keys[(size_t)q * a.out_ld + i] = sh.sel[i];
     if (tid == 0) {
       a.out_cnt[(size_t)q * SIM_COUNT_STRIDE] = kk;
       const uint64_t th = (kk == a.k) ? sh.sel[kk - 1] : 0ull;
@@ -552,7 +561,7 @@ __device__ __forceinline__ void select_body(const SelectArgs& a, int q, const Ke
     }
   }
   if (a.out_scores) {
-    for (int i = tid; i < a.k; i += SELECT_THREADS) {
+    for (int i = tid; i < a.k; i += THREADS) {
       const bool v = i < kk;
       const uint64_t key = v ? sh.sel[i] : 0ull;
       a.out_scores[(size_t)q * a.k + i] = v ? ord2f((uint32_t)(key >> 32)) : -INFINITY;
@@ -562,8 +571,9 @@ __device__ __forceinline__ void select_body(const SelectArgs& a, int q, const Ke
   }
 }
 
-__global__ __launch_bounds__(SELECT_THREADS) void select_kernel(SelectArgs a) {
-  __shared__ SelectShared sh;
+template <int THREADS, int LDS_KEYS>
+__global__ __launch_bounds__(THREADS) void select_kernel(SelectArgs a) {
+  __shared__ SelectSharedT<THREADS, LDS_KEYS> sh;
   const int q = blockIdx.x, tid = threadIdx.x;
   int n = a.counts ? a.counts[(size_t)q * a.count_stride] : a.n_fixed;
   const bool overflow = a.counts && n > a.cap;
@@ -571,9 +581,9 @@ __global__ __launch_bounds__(SELECT_THREADS) void select_kernel(SelectArgs a) {
   const uint64_t* gsrc = a.keys + (size_t)q * a.ld;
   // The radix passes read the list up to ten times: from LDS when it fits (the sample's 8192 keys, the ~2k
   // candidates of the final stage), from global memory otherwise (dense plans, adversarial candidate counts).
-  const bool in_lds = n <= SELECT_LDS_KEYS;
+  const bool in_lds = n <= LDS_KEYS;
   if (in_lds)
-    for (int i = tid; i < n; i += SELECT_THREADS) sh.staged[i] = gsrc[i];
+    for (int i = tid; i < n; i += THREADS) sh.staged[i] = gsrc[i];
   __syncthreads();
   select_body(a, q, KeySrc{gsrc, sh.staged, in_lds}, n, overflow, sh);
 }
@@ -609,10 +619,11 @@ __device__ __forceinline__ int wave_append_pos(int* counter, bool want) {
   return base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
 }
 
-__global__ __launch_bounds__(SELECT_THREADS) void gather_select_kernel(GatherArgs a, SelectArgs sa) {
-  __shared__ SelectShared sh;
-  __shared__ uint2 raw[GATHER_LDS_ENTRIES];  // {score bits, premise row}
-  __shared__ int s_wave_tot[SELECT_THREADS / 64];
+template <int THREADS, int LDS_KEYS, int RAW_ENTRIES>
+__global__ __launch_bounds__(THREADS) void gather_select_kernel(GatherArgs a, SelectArgs sa) {
+  __shared__ SelectSharedT<THREADS, LDS_KEYS> sh;
+  __shared__ uint2 raw[RAW_ENTRIES];  // {score bits, premise row}
+  __shared__ int s_wave_tot[THREADS / 64];
   __shared__ int s_out;
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qt = q >> 8, qloc = q & 255;
@@ -621,19 +632,19 @@ __global__ __launch_bounds__(SELECT_THREADS) void gather_select_kernel(GatherArg
   const int64_t qk = a.file_of ? a.q_key[q] : 0;
   uint64_t* out = a.cand + (size_t)q * a.cap;  // global copy of the key list (read back only when LDS is too small)
   const int n_sample = a.count[(size_t)q * SIM_COUNT_STRIDE];
-  for (int i = tid; i < n_sample; i += SELECT_THREADS) sh.staged[i] = out[i];  // n_sample <= k <= SIM_MAX_K
+  for (int i = tid; i < n_sample; i += THREADS) sh.staged[i] = out[i];  // n_sample <= k <= SIM_MAX_K
   if (tid == 0) s_out = n_sample;
   auto accessible = [&](int32_t f, uint32_t word, int p) {
     return ((word >> (q & 31)) & 1u) || (f == own && a.end_key[p] <= qk);
   };
   auto put_key = [&](uint64_t key, int pos) {
     if (pos < (int)a.cap) out[pos] = key;  // beyond the capacity: counted, not stored (reported as overflow below)
-    if (pos < SELECT_LDS_KEYS) sh.staged[pos] = key;
+    if (pos < LDS_KEYS) sh.staged[pos] = key;
   };
   // ---- phase A: runs -> raw list (one thread per filter block)
   const i32x4* cnt4 = reinterpret_cast<const i32x4*>(a.scnt + (size_t)q * a.filter_blocks * 4);
   int raw_base = 0;  // raw entries of earlier rounds of this loop (a query has more than 1024 filter blocks at 1M rows)
-  for (int fb0 = 0; fb0 < a.filter_blocks; fb0 += SELECT_THREADS) {
+  for (int fb0 = 0; fb0 < a.filter_blocks; fb0 += THREADS) {
     const int fb = fb0 + tid;
     const int fbc = min(fb, a.filter_blocks - 1);
     const uint2* base = a.slots + ((size_t)(fbc * a.tiles_q + qt) * 256 + qloc) * (4 * SLOT_RUN);
@@ -657,7 +668,7 @@ __global__ __launch_bounds__(SELECT_THREADS) void gather_select_kernel(GatherArg
     int pos = raw_base + incl - mine;
     int round_total = 0;
 #pragma unroll
-    for (int w = 0; w < SELECT_THREADS / 64; ++w) {
+    for (int w = 0; w < THREADS / 64; ++w) {
       const int t = s_wave_tot[w];
       if (w < wave) pos += t;
       round_total += t;
@@ -666,7 +677,7 @@ __global__ __launch_bounds__(SELECT_THREADS) void gather_select_kernel(GatherArg
     auto emit = [&](uint2 en, int part) {
       const int i = (int)(en.y >> 4), r = (int)(en.y & 15u);
       const int p = row_pb + (part >> 1) * 128 + 4 * (part & 1) + i * 32 + (r & 3) + 8 * (r >> 2);
-      if (pos < GATHER_LDS_ENTRIES) {
+      if (pos < RAW_ENTRIES) {
         raw[pos] = make_uint2(en.x, (uint32_t)p);
       } else if (p < a.N) {  // beyond the LDS list (rare): straight through, one entry at a time
         bool ok = true;
@@ -695,16 +706,16 @@ __global__ __launch_bounds__(SELECT_THREADS) void gather_select_kernel(GatherArg
   }
   __syncthreads();
   // ---- phase B: entry-parallel predicate; every gather level of a thread's entries is issued before the next
-  const int nraw = (a.debug & 32) ? 0 : min(raw_base, GATHER_LDS_ENTRIES);
+  const int nraw = (a.debug & 32) ? 0 : min(raw_base, RAW_ENTRIES);
   constexpr int U = 4;
-  for (int e0 = 0; e0 < nraw; e0 += U * SELECT_THREADS) {
+  for (int e0 = 0; e0 < nraw; e0 += U * THREADS) {
     uint2 en[U];
     int32_t f[U];
     uint32_t word[U];
     bool live[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int e = e0 + u * SELECT_THREADS + tid;
+      const int e = e0 + u * THREADS + tid;
       en[u] = raw[min(e, nraw - 1)];
       live[u] = e < nraw && (int)en[u].y < a.N;  // padding rows of the last block never qualify
       if (!live[u]) en[u].y = 0;
@@ -725,7 +736,7 @@ __global__ __launch_bounds__(SELECT_THREADS) void gather_select_kernel(GatherArg
   __syncthreads();
   const bool overflow = s_out > (int)a.cap;  // out_count = -1: the caller repeats the search with the dense plan
   const int n = min(s_out, (int)a.cap);
-  select_body(sa, q, KeySrc{out, sh.staged, n <= SELECT_LDS_KEYS}, n, overflow, sh);
+  select_body(sa, q, KeySrc{out, sh.staged, n <= LDS_KEYS}, n, overflow, sh);
 }
 
 // (scores, ids, counts)[R, B, k] -> keys[B, R*k]
@@ -774,9 +785,16 @@ __global__ __launch_bounds__(256) void build_file_bits_kernel(const uint64_t* __
   bits_t[i] = word;
 }
 
+// many queries with short lists: the small shape (four workgroups per CU)
+static bool select_small(int B, int64_t list_bound) { return B >= 512 && list_bound <= SELECT_LDS_KEYS_SMALL; }
+
 static void launch_select(const SelectArgs& a, int B, hipStream_t stream) {
   ProfScope ps(stream, RP_K_SELECT);
-  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(SELECT_THREADS), 0, stream, a);
+  if (select_small(B, a.counts ? (int64_t)a.cap : (int64_t)a.n_fixed))
+    hipLaunchKernelGGL((select_kernel<SELECT_THREADS_SMALL, SELECT_LDS_KEYS_SMALL>), dim3(B), dim3(SELECT_THREADS_SMALL), 0,
+                       stream, a);
+  else
+    hipLaunchKernelGGL((select_kernel<SELECT_THREADS, SELECT_LDS_KEYS>), dim3(B), dim3(SELECT_THREADS), 0, stream, a);
 }
 
 struct SimPlan {
@@ -1074,7 +1092,14 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   sb.out_count = out_count;
   if (p.new_filter) {  // runs -> predicate -> key list -> select, one kernel
     ProfScope ps(stream, RP_K_SELECT);
-    hipLaunchKernelGGL(gather_select_kernel, dim3(B), dim3(SELECT_THREADS), 0, stream, ga, sb);
+    // ~k * stride keys lie above the sampled bound, ~3 x that before the accessibility predicate: the small shape when
+    // that fits its raw list and many queries share the chip (longer lists stay correct - they spill to the slow path)
+    if (B >= 512 && (int64_t)k * p.stride * 4 <= GATHER_LDS_ENTRIES_SMALL)
+      hipLaunchKernelGGL((gather_select_kernel<SELECT_THREADS_SMALL, GATHER_LDS_KEYS_SMALL, GATHER_LDS_ENTRIES_SMALL>),
+                         dim3(B), dim3(SELECT_THREADS_SMALL), 0, stream, ga, sb);
+    else
+      hipLaunchKernelGGL((gather_select_kernel<SELECT_THREADS, SELECT_LDS_KEYS, GATHER_LDS_ENTRIES>), dim3(B),
+                         dim3(SELECT_THREADS), 0, stream, ga, sb);
   } else {
     launch_select(sb, B, stream);
   }

@@ -231,8 +231,8 @@ def test_sim_topk_random_shapes_exact(gen):
     (every product exact, ties everywhere): ids, scores and counts must equal the oracle's masked top-k bit for bit on every
     plan the library may choose, incl. rows with fewer than k accessible premises."""
     rng = np.random.default_rng(2027)
-    for case in range(28):
-        B = int(rng.choice([1, 2, 31, 64, 129, 200, 257]))
+    for case in range(36):
+        B = int(rng.choice([1, 2, 31, 64, 129, 200, 257, 600, 1024]))  # >= 512 queries: the small-list shape of the per-query stages
         N = int(rng.choice([1, 17, 255, 256, 257, 1000, 4097, 12345, 33000]))
         D = int(rng.choice([32, 64, 96, 128, 192, 1472]))
         k = int(rng.choice([1, 2, 10, 100, 333]))
