@@ -410,16 +410,21 @@ def test_gemm_fused_rmsnorm_pieces_all_variants(gen, variant, M):
         _lib.check(lib.rp_set_option(b"gemm_variant_all", -1), "opt")
 
 
-def test_sim_topk_multi_gpu_shard_shape(gen):
-    """The per-rank call of the 8-GPU bench: all 8 x 256 queries against one 16,250-row shard."""
+@pytest.mark.parametrize("B,N", [(2048, 16250), (1024, 32500), (512, 65000)])
+def test_sim_topk_multi_gpu_shard_shape(gen, B, N):
+    """The per-rank call of the 8- / 4- / 2-GPU bench: all world x 256 queries against one row shard of the 130 k index
+    (>= 512 queries: the per-query stages take their small-list shape where the lists allow it); the dense plan must
+    give the same bits."""
     rng = np.random.default_rng(21)
-    B, N, D, k = 2048, 16250, 1472, 100
+    D, k = 1472, 100
     E = torch.nn.functional.normalize(torch.randn(N, D, generator=gen, device="cuda"), dim=1).to(torch.bfloat16)
     Q = torch.nn.functional.normalize(torch.randn(B, D, generator=gen, device="cuda"), dim=1).to(torch.bfloat16)
     m, acc = hh.synth_masks(rng, N, B, F=600)
     ids, sc, cnt = hh.sim_topk(Q, E, k, hh.masks_to_device(m, Q.device), id_offset=5 * N)
     S = (Q.float() @ E.float().T).cpu().numpy()
     hh.check_topk_against_scores(ids.cpu().numpy() - 5 * N, sc.cpu().numpy(), cnt.cpu().numpy(), S, acc, k, tol=2e-5)
+    ids2, sc2, cnt2 = hh.sim_topk(Q, E, k, hh.masks_to_device(m, Q.device), id_offset=5 * N, flags=_lib.RP_TOPK_DENSE)
+    assert torch.equal(ids, ids2) and torch.equal(sc, sc2) and torch.equal(cnt, cnt2)
 
 
 def test_build_file_bits_equals_host_transposition():
