@@ -23,7 +23,6 @@ thread_local std::string g_last_error;
 // ------------------------------------------------------------------------------------------
 // options
 // ------------------------------------------------------------------------------------------
-extern int g_scan_deep;
 extern int g_scan_cfg, g_scan_impl, g_scan_filter_cfg, g_scan_sample_cfg, g_scan_stride, g_scan_no_epilogue, g_scan_impl_force_new,
     g_scan_cap, g_train_dbg;
 int g_gemm_group_m = 8;
@@ -40,8 +39,6 @@ int g_gemm_variant_wo = 26;   // FFN-out (+ residual)
 int g_gemm_variant_o = -1;    // attention output (+ residual); -1 = by pass size: two 128 x 128 blocks per CU, or - from 57 k
                               // tokens - the 8-wave 256 x 256 tile (A/B inside the 70 k-token step: 2.553 -> 2.470 ms per 12
                               // launches, three pairs; in isolation the two alternate below that size, tools/gemm_bench.py)
-int g_gemm_exact_n = 1;  // feature counts that 256 does not divide: 192-row tiles / a 192-row remainder tile (variants 28 / 29)
-int g_gemm_touch = 1;    // residual epilogues pull their old x lines towards the L2 one k-tile early (EpiResidT::touch)
 int g_gemm_tail_split = 1;  // big passes: last partial round of 256 x 256 tiles as one round of 128 x 128 tiles
 int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 int g_gemm_skinny = 1;
@@ -98,42 +95,32 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     return RP_OK;
   }
   if (!strcmp(name, "gemm_variant")) {
-    RP_REQUIRE(value >= 0 && value <= 40, "gemm_variant out of range");
+    RP_REQUIRE(value >= 0 && value <= 30, "gemm_variant out of range");
     g_gemm_variant = value;
     return RP_OK;
   }
   if (!strcmp(name, "gemm_variant_all")) {  // benches/tests: one configuration for every GEMM; -1 = defaults
-    RP_REQUIRE(value >= -1 && value <= 40, "gemm_variant_all out of range");
+    RP_REQUIRE(value >= -1 && value <= 30, "gemm_variant_all out of range");
     if (value < 0) {
       g_gemm_variant = g_gemm_variant_qkv = g_gemm_variant_wo = 26;
       g_gemm_variant_o = -1;
-      g_gemm_exact_n = 1;
     } else {
       g_gemm_variant = g_gemm_variant_qkv = g_gemm_variant_wo = g_gemm_variant_o = value;
-      g_gemm_exact_n = 0;  // the configuration asked for is the one that runs
     }
     return RP_OK;
   }
-  if (!strcmp(name, "gemm_exact_n")) {
-    g_gemm_exact_n = value != 0;
-    return RP_OK;
-  }
-  if (!strcmp(name, "gemm_touch")) {
-    g_gemm_touch = value != 0;
-    return RP_OK;
-  }
   if (!strcmp(name, "gemm_variant_qkv")) {
-    RP_REQUIRE(value >= 0 && value <= 40, "gemm_variant_qkv out of range");
+    RP_REQUIRE(value >= 0 && value <= 30, "gemm_variant_qkv out of range");
     g_gemm_variant_qkv = value;
     return RP_OK;
   }
   if (!strcmp(name, "gemm_variant_wo")) {
-    RP_REQUIRE(value >= 0 && value <= 40, "gemm_variant_wo out of range");
+    RP_REQUIRE(value >= 0 && value <= 30, "gemm_variant_wo out of range");
     g_gemm_variant_wo = value;
     return RP_OK;
   }
   if (!strcmp(name, "gemm_variant_o")) {
-    RP_REQUIRE(value >= 0 && value <= 40, "gemm_variant_o out of range");
+    RP_REQUIRE(value >= 0 && value <= 30, "gemm_variant_o out of range");
     g_gemm_variant_o = value;
     return RP_OK;
   }
@@ -174,7 +161,6 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   if (!strcmp(name, "train_dbg")) { g_train_dbg = value; return RP_OK; }
   if (!strcmp(name, "scan_no_epilogue")) { g_scan_no_epilogue = value; return RP_OK; }
 #endif
-  if (!strcmp(name, "scan_deep")) { g_scan_deep = value != 0; return RP_OK; }
   if (!strcmp(name, "scan_cap")) { g_scan_cap = value; return RP_OK; }  // tests: forces the overflow -> dense contract
   if (!strcmp(name, "scan_force_new")) { g_scan_impl_force_new = value; return RP_OK; }
   if (!strcmp(name, "scan_impl")) {
@@ -387,8 +373,8 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
   auto main_rows = [&](int prof_class, int n_features, int K) -> int {
     if (!g_gemm_tail_split || t_dev) return Tp;  // (token count known on the device only: one launch)
     const int v = pick_gemm_variant(prof_class, Tp, n_features, K, tv);
-    if (v != 20 && v != 26 && v != 28 && v != 29 && v != 30 && v != 31) return Tp;
-    const int tiles_f = v == 28 ? (n_features + 191) / 192 : (n_features + 255) / 256, tiles_t = Tp / 256;
+    if (v != 20 && v != 26) return Tp;
+    const int tiles_f = (n_features + 255) / 256, tiles_t = Tp / 256;
     int g = tiles_f, b = n_cus;  // gcd
     while (b) {
       const int t = g % b;

@@ -14,7 +14,6 @@ namespace rp {
 extern int g_gemm_group_m, g_gemm_variant, g_gemm_variant_qkv, g_gemm_variant_wo, g_gemm_variant_o, g_gemm_tail_split,
     g_debug_skip_ffn, g_gemm_skinny, g_gemm_skinny_variant;
 extern int g_gemm_stagger_us[RP_K_COUNT];
-extern int g_gemm_touch, g_gemm_exact_n;
 
 // ------------------------------------------------------------------------------------------
 // weight packing (create time only)
@@ -216,7 +215,6 @@ static __global__ __launch_bounds__(64) void rowscale_kernel(const float* __rest
 
 template <class RS>
 struct EpiStoreBf16T {  // out[token, feature] = bf16(acc * rs[token])
-  static constexpr int MAX_FM = 8;  // any even number of 32-feature row fragments per wave
   bf16_t* out;
   int ldo, n_valid;  // n_valid = number of real output features (multiple of 8)
   RS rs;
@@ -277,30 +275,6 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
   const bf16_t* __restrict__ xhi_in = nullptr;  // SPLIT_IN only
   Drop drop = {0u, 0u, 1.f};                    // SPLIT_IN only: dropout on the sub-layer's output before the add (HF:140, 400)
   uint32_t drop_site = 0;
-  int touch_on = 0;       // set by launch_gemm from the gemm_touch option
-  uint32_t touch_tmp = 0;  // destination of the touch loads; kept live until run() has seen its first old value
-  static constexpr int MAX_FM = 8;
-  static constexpr bool HAS_TOUCH = true;
-  // Pull the wave's own piece of the two planes (FM*32 features x FN*32 tokens: FM/2 128-byte lines per token row and
-  // plane) towards the L2 one k-tile before the epilogue reads it: one dword per line and lane, all into ONE
-  // register nobody reads (loads return in order, so later ones simply overwrite it).  The loads are invisible to the
-  // compiler's vmcnt bookkeeping, which only makes its waits conservative (older loads complete first); the register
-  // stays allocated until run() passes it to an empty asm behind the first old value it consumes.
-  template <int FM, int FN>
-  __device__ __forceinline__ void touch(int m_base, int n_base, int lane) {
-    if (!touch_on) return;
-    constexpr int LPR = FM / 2, NI = (FM * FN + 3) / 4;  // lines per row and plane; wave-instructions per plane
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int idx = i * 64 + lane, row = min(idx / LPR, FN * 32 - 1), piece = idx % LPR;
-      const int f = min(m_base + piece * 64, n_valid - 8);
-      const size_t off = (size_t)(n_base + row) * ldx + f;
-      const bf16_t* ph = (SPLIT_IN ? xhi_in : xhi) + off;
-      const bf16_t* pl = xlo + off;
-      asm volatile("global_load_dword %0, %1, off" : "+v"(touch_tmp) : "v"(ph) : "memory");
-      asm volatile("global_load_dword %0, %1, off" : "+v"(touch_tmp) : "v"(pl) : "memory");
-    }
-  }
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
     static_assert(FM % 2 == 0, "one statistic slot per 64 features (two row fragments)");
@@ -315,7 +289,7 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
     // unconditional, from a clamped address: a predicated load would sit in its own basic block and
     // make hipcc drain vmcnt to 0 around it, which serialises the whole epilogue.
     // (wave tiles of 128 x 128 keep their accumulators in AGPRs and have the VGPRs for 3 blocks ahead)
-    constexpr int DEPTH = (FM * FN >= 12) ? 4 : 2;
+    constexpr int DEPTH = (FM * FN >= 16) ? 4 : 2;
     uint4 xh[DEPTH][4], xl[DEPTH][4];
     auto fetch = [&](int b, int p) {
       const int q = b / FN, j = b % FN;
@@ -364,8 +338,6 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
           }
         }
         float ss = 0.f;
-        // end of touch()'s register reservation: the first old value has returned, so every older load has
-        if (b == 0 && c == 0) asm volatile("" ::"v"(touch_tmp), "v"(xh[0][0].x));
         if (f < n_valid) {
           const size_t off = (size_t)(n_base + j * 32 + t) * ldx + f;
           const uint4 h = xh[b % DEPTH][c], l = xl[b % DEPTH][c];
@@ -470,9 +442,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOpe
   const int logical = xcd_remap(blockIdx.x, nwg);
   int tm, tn;
   tile_coords(logical, tiles_n, tiles_m, group_m, tn, tm);  // token tiles grouped, feature tiles inside
-  if constexpr (C::PIPE == 2)
-    gemm_tile_pipe2<C>(A, W, K, tm, tn, epi, smem);
-  else if constexpr (C::PIPE != 0)
+  if constexpr (C::PIPE != 0)
     gemm_tile_pipe<C>(A, W, K, tm, tn, epi, smem);
   else
     gemm_tile<C>(A, W, K, tm, tn, epi, smem);
@@ -488,12 +458,10 @@ static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hi
   RP_HIP(attr.ensure((const void*)kern, C::LDS_BYTES));
   RP_REQUIRE(K % C::BK == 0 && a.rows % C::BN == 0, "gemm: K=%d must be a multiple of %d, M=%d of %d", K, C::BK,
              a.rows, C::BN);
-  RP_REQUIRE(C::PIPE != 2 || K / C::BK >= 3, "gemm: the three-stage ring needs K >= %d", 3 * C::BK);
   const int rows_needed = (tokens_valid > 0 && tokens_valid < a.rows) ? tokens_valid : a.rows;
   const int tiles_f = (w.rows + C::BM - 1) / C::BM, tiles_t = (rows_needed + C::BN - 1) / C::BN;
   // tile order: feature tiles fastest inside groups of `group` token tiles (shared activation panels)
   const int group = max(1, g_gemm_group_m * 128 / C::BN);
-  if constexpr (has_touch<Epi>::value) epi.touch_on = (C::PIPE != 0) ? g_gemm_touch : 0;
   ProfScope ps(stream, prof_class);
   const int stagger_ticks = (C::PIPE != 0 && tiles_f * tiles_t > 512) ? g_gemm_stagger_us[prof_class] * 100 : 0;
   hipLaunchKernelGGL(kern, dim3(tiles_f * tiles_t), dim3(C::THREADS), C::LDS_BYTES, stream, w, a, K, tiles_f,
@@ -501,61 +469,6 @@ static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hi
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
-
-// Feature counts that are not a multiple of the 256-row tile (d_model 1472 = 5 x 256 + 192): CB tiles for the whole
-// multiples and ONE narrower CR tile per token tile for the remainder, in the same launch and the same tile order (the
-// remainder is the last feature tile of its group), so no padded rows are multiplied (4.2 % of the FFN-out MFMAs and
-// of their power).  Both configurations run 256 threads with the token tile in common; every output element is still
-// one K-ascending chain of 32x32x16 steps, so the result does not change by a bit.
-template <class CB, class CR, class Epi>
-__global__ __launch_bounds__(CB::THREADS) void gemm_mixed_kernel(GemmOperand A, GemmOperand W, int K, int tiles_big,
-                                                                 int tiles_n, int group_m,
-                                                                 const int32_t* __restrict__ t_dev, Epi epi) {
-  static_assert(CB::THREADS == CR::THREADS && CB::BN == CR::BN && CB::PIPE != 0 && CR::PIPE != 0, "mixed tile pair");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tiles_m = tiles_big + 1;
-  int nwg = gridDim.x;
-  if (t_dev) {
-    tiles_n = (*t_dev + CB::BN - 1) / CB::BN;
-    nwg = tiles_m * tiles_n;
-    if ((int)blockIdx.x >= nwg) return;
-  }
-  const int logical = xcd_remap(blockIdx.x, nwg);
-  int tm, tn;
-  tile_coords(logical, tiles_n, tiles_m, group_m, tn, tm);
-  if (tm < tiles_big)
-    gemm_tile_pipe<CB>(A, W, K, tm, tn, epi, smem);
-  else
-    gemm_tile_pipe<CR>(A, W, K, tm, tn, epi, smem, tiles_big * CB::BM);
-}
-
-template <class CB, class CR, class Epi>
-static RpStatus launch_gemm_mixed(GemmOperand w, GemmOperand a, int K, Epi epi, hipStream_t stream, int prof_class,
-                                  int tokens_valid, const int32_t* t_dev) {
-  auto kern = gemm_mixed_kernel<CB, CR, Epi>;
-  constexpr int LDS = CB::LDS_BYTES > CR::LDS_BYTES ? CB::LDS_BYTES : CR::LDS_BYTES;
-  static LdsAttrOnce attr;
-  RP_HIP(attr.ensure((const void*)kern, LDS));
-  const int tiles_big = w.rows / CB::BM;
-  RP_REQUIRE(K % CB::BK == 0 && a.rows % CB::BN == 0 && w.rows - tiles_big * CB::BM == CR::BM,
-             "gemm (mixed tiles): K=%d, M=%d, features=%d do not fit %d-row tiles + one of %d", K, a.rows, w.rows, CB::BM,
-             CR::BM);
-  const int rows_needed = (tokens_valid > 0 && tokens_valid < a.rows) ? tokens_valid : a.rows;
-  const int tiles_t = (rows_needed + CB::BN - 1) / CB::BN;
-  const int group = max(1, g_gemm_group_m * 128 / CB::BN);
-  if constexpr (has_touch<Epi>::value) epi.touch_on = g_gemm_touch;
-  ProfScope ps(stream, prof_class);
-  hipLaunchKernelGGL(kern, dim3((tiles_big + 1) * tiles_t), dim3(CB::THREADS), LDS, stream, w, a, K, tiles_big, tiles_t,
-                     group, t_dev, epi);
-  RP_CHECK_LAUNCH();
-  return RP_OK;
-}
-
-// widest per-wave row-fragment count an epilogue's staging scheme accepts (default: 4 = 128 features per wave)
-template <class E, class = void>
-struct epi_max_fm : std::integral_constant<int, 4> {};
-template <class E>
-struct epi_max_fm<E, std::void_t<decltype(E::MAX_FM)>> : std::integral_constant<int, E::MAX_FM> {};
 
 // rows of the activation workspace are padded to this so every variant tiles the tokens exactly
 constexpr int GEMM_M_ALIGN = 256;
@@ -584,18 +497,7 @@ static int pick_gemm_variant(int prof_class, int M, int n_rows_w, int K, int tok
     else if (prof_class == RP_K_GEMM_WI) v = (tv <= 256) ? 16 : (few_tiles || tv <= 1024) ? 0 : v;
     else if (few_tiles) v = (tv <= 1024) ? 16 : 0;
   }
-  // Feature counts the 256-row tile does not divide (3 H d_kv = 1152, d_model = 1472 for ByT5-small):
-  // 192-row tiles when they divide the count exactly (28: QKV, six tiles instead of five with 10 % padding), or the
-  // whole multiples of 256 plus one 192-row remainder tile per token tile (29).  MAX_FM of the epilogue permitting
-  // (launch_gemm falls back to 26 otherwise).
-  if (g_gemm_exact_n && (v == 20 || v == 26) && k64 && m256 && n_rows_w % 256 != 0) {
-    const int padded = (n_rows_w + 255) / 256 * 256 - n_rows_w;
-    if (n_rows_w % 192 == 0 && padded * 20 >= n_rows_w)  // >= 5 % of the rows would be padding
-      v = 28;
-    else if (n_rows_w % 256 == 192)
-      v = 29;
-  }
-  if ((v == 20 || v == 26 || v == 30 || v == 31) && !k64) v = 9;  // 64-wide K tiles need K % 64 == 0
+  if ((v == 20 || v == 26) && !k64) v = 9;  // 64-wide K tiles need K % 64 == 0
   if (v == 16 && !k64) v = 15;
   if (v >= 5 && !m256) v = 0;
   return v;
@@ -604,9 +506,6 @@ inline bool small_variant(int v) { return v == 0 || v == 15 || v == 16; }
 
 // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages[, pipelined]>:
 //   20 / 26  pipelined 256 x 256 x 64, 4 / 8 waves     (the encoder's big GEMMs)
-//   30 / 31  26 / 20 with separate operand rings, weights three stages deep (gemm_tile_pipe2; all 160 KB of LDS)
-//   28       pipelined 192 x 256 x 64, 4 waves         (feature counts 192 divides and 256 does not: QKV of ByT5-small)
-//   29       20's tiles + one 192-row remainder tile   (feature counts = 192 mod 256: d_model 1472)
 //   9        plain 256 x 256 x 32, 3 stages             (K % 64 != 0)
 //   0        plain 128 x 128 x 32, 3 stages, 2 blocks/CU (attention-out; token counts not a multiple of 256)
 //   16 / 15  64 x 128 x 64, 4 stages / x 32, 7 stages   (up to ~1024 tokens: single-state queries)
@@ -617,27 +516,13 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
                             int K, Epi epi, hipStream_t stream, int prof_class, int tokens_valid = 0,
                             const int32_t* t_dev = nullptr, int force_variant = -1) {
   GemmOperand a{A, lda, M}, w{W, ldw, n_rows_w};
-  int v = force_variant >= 0 ? force_variant : pick_gemm_variant(prof_class, M, n_rows_w, K, tokens_valid);
-  if (v == 29 && n_rows_w % 256 != 192) v = 26;  // (forced by a test or a bench on another shape)
+  const int v = force_variant >= 0 ? force_variant : pick_gemm_variant(prof_class, M, n_rows_w, K, tokens_valid);
   if constexpr (!SMALL_ONLY) {
     switch (v) {
       case 20: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
       case 26: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
       case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
       case 12: return launch_gemm_cfg<GemmCfg<64, 256, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-      case 30: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 2>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-      case 31: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 2>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-      case 28:  // 192 x 256 x 64: four waves, each 192 features x 64 tokens (6 x 2 accumulators, 8 fragment reads per 12 MFMAs)
-        if constexpr (epi_max_fm<Epi>::value >= 6)
-          return launch_gemm_cfg<GemmCfg<192, 256, 64, 1, 4, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-        else
-          return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-      case 29:  // 256-row tiles (four waves of 128 x 128) + one 192-row remainder tile per token tile
-        if constexpr (epi_max_fm<Epi>::value >= 6)
-          return launch_gemm_mixed<GemmCfg<256, 256, 64, 2, 2, 2, 1>, GemmCfg<192, 256, 64, 1, 4, 2, 1>>(
-              w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-        else
-          return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
       default: break;
     }
   } else {

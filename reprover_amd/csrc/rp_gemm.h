@@ -70,8 +70,7 @@ struct GemmCfg {
   static constexpr int SLOTS = ROW_BYTES / 16;           // 16-B chunks per row: 4 (BK=32) / 8 (BK=64)
   static constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES;
   static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-  // PIPE = 2 (gemm_tile_pipe2): the A operand has a ring of its own, three stages deep, the W operand two
-  static constexpr int RING_BYTES = PIPE_ == 2 ? 3 * A_BYTES + 2 * W_BYTES : NSTAGE * STAGE_BYTES;
+  static constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;
   static constexpr int LDS_BYTES = RING_BYTES > NWAVES_ * 9216 ? RING_BYTES : NWAVES_ * 9216;
   static constexpr int ROWS_PER_DMA = 1024 / ROW_BYTES;  // rows covered by one wave-instruction
   static constexpr int A_DMA = BM / ROWS_PER_DMA / NWAVES, W_DMA = BN / ROWS_PER_DMA / NWAVES;  // per wave
@@ -108,16 +107,6 @@ template <class E, class = void>
 struct has_prologue : std::false_type {};
 template <class E>
 struct has_prologue<E, std::void_t<decltype(&E::prologue)>> : std::true_type {};
-
-// An epilogue may declare `template <int FM, int FN> void touch(int m_base, int n_base, int lane)`: gemm_tile_pipe
-// calls it once, one k-tile and one k-step before the main loop ends (the slot where a steady-state tile issues its
-// refill is empty there), so a read-modify-write epilogue can pull the lines it is about to update towards the L2
-// while the last MFMAs run.  Epilogue time comes back in full under the chip's power governor (MI355X_MICROARCH.md
-// "DVFS give-back" (3)), main-loop cycles only by half.
-template <class E, class = void>
-struct has_touch : std::false_type {};
-template <class E>
-struct has_touch<E, std::void_t<decltype(E::HAS_TOUCH)>> : std::true_type {};
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -274,9 +263,7 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
 // next tile) sits in front of the last k-step's MFMAs.
 template <class C, class Epilogue>
 __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOperand W, int K, int tile_m,
-                                               int tile_n, Epilogue& epi, char* smem, int m_origin = -1) {
-  // m_origin >= 0: first A row of this tile (a remainder tile of another width behind tile_m full-width ones)
-  const int m0 = m_origin >= 0 ? m_origin : tile_m * C::BM;
+                                               int tile_n, Epilogue& epi, char* smem) {
   // bf16: one MFMA k-step = 16 values = two 16-B slots of a row (one per lane half); e4m3: one k-step =
   // 64 values = four slots (two per lane half), so a 128-B row holds 4 bf16 or 2 e4m3 k-steps.
   constexpr int BK = C::BK, FM = C::FM, FN = C::FN, KS = C::FP8 ? C::ROW_BYTES / 64 : BK / 16;
@@ -304,7 +291,7 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
   for (int d = 0; d < C::A_DMA; ++d) {
     const int row = (wave * C::A_DMA + d) * C::ROWS_PER_DMA + lane / C::SLOTS;
     const int kc = (lane % C::SLOTS) ^ C::swz(row);
-    a_src[d] = A.ptr + A.row_off(m0 + row, kc);
+    a_src[d] = A.ptr + A.row_off(tile_m * C::BM + row, kc);
   }
 #pragma unroll
   for (int d = 0; d < C::W_DMA; ++d) {
@@ -474,10 +461,6 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
       if (++buf == NSTAGE) buf = 0;
       read_frags(smem + buf * C::STAGE_BYTES, 0, 0);
       if (MODE == 2) stage_half(kt + NSTAGE, freed, 0);
-      if constexpr (has_touch<Epilogue>::value) {
-        if (MODE == 1 && kt + 2 == nk)  // the hand-over into the last k-tile
-          epi.template touch<FM, FN>(m0 + wave_row * (FM * 32), tile_n * C::BN + wave_col * (FN * 32), lane);
-      }
     }
     mma((KS - 1) & 1);
     if (MODE == 2)
@@ -500,206 +483,7 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
   __syncthreads();
   RP_TS(2);
 
-  epi.template run<FM, FN>(acc, m0 + wave_row * (FM * 32), tile_n * C::BN + wave_col * (FN * 32), lane,
-                           smem + wave * EPI_STAGE_BYTES);
-  RP_TS(3);
-}
-
-// gemm_tile_pipe with SEPARATE rings for the two operands: A three stages deep, W two (GemmCfg<..., PIPE = 2>;
-// 256 x 256 x 64: 3 x 32 + 2 x 32 KB = all 160 KB of a CU's LDS).  Written for the similarity scan's filter pass,
-// whose A operand (the premise rows) streams from HBM exactly once while its W operand (the query panel) comes from
-// L2: with one ring of two stages the prefetch distance of BOTH is one k-tile, and a k-tile (1.5 - 2 us) is shorter
-// than a loaded HBM round trip.  Here A(kt + 2) is requested while tile kt runs.  vmcnt retires in order, so the
-// issue order decides what a counted wait can leave in flight: tile kt issues, between the MFMAs of its first
-// k-step, W(kt + 1) FIRST (needed at the next hand-over) and A(kt + 2) behind it, and the hand-over into tile kt + 1
-// waits for everything except that youngest A stage:
-//     ... | W(kt+1) A(kt+2) ... wait vmcnt(A_DMA), barrier | W(kt+2) A(kt+3) ... wait vmcnt(A_DMA), barrier | ...
-// ONE loop body serves every tile (the main loop of gemm_tile_pipe is five specialised bodies; with all 256
-// accumulator registers of the 4-wave form live, the register allocator permuted accumulators between such bodies
-// through scratch memory): the refills of the last two tiles are clamped to the last k-tile - duplicates of a slice
-// this CU fetched a tile earlier, landing in ring slots nobody reads any more, drained before the epilogue reuses the
-// LDS - and only the hand-over is skipped, by one scalar branch, in the last tile.
-// Same fragment reads, same MFMA order per output element as gemm_tile_pipe: not a bit of the result changes.
-template <class C, class Epilogue>
-__device__ __forceinline__ void gemm_tile_pipe2(const GemmOperand A, const GemmOperand W, int K, int tile_m,
-                                                int tile_n, Epilogue& epi, char* smem, int m_origin = -1) {
-  constexpr int BK = C::BK, FM = C::FM, FN = C::FN, KS = C::FP8 ? C::ROW_BYTES / 64 : BK / 16;
-  constexpr int RPF = C::FP8 ? 2 : 1;
-  constexpr int NSA = 3;
-  using frag_t = std::conditional_t<C::FP8 != 0, i32x8, bf16x8>;
-  static_assert(KS % 2 == 0 && KS >= 2, "even number of k-steps (fragment double-buffer parity)");
-  RP_TS(0);
-  const int m0 = m_origin >= 0 ? m_origin : tile_m * C::BM;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_row = wave / C::WN, wave_col = wave % C::WN;
-  const int hi = lane >> 5;
-
-  f32x16 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const bf16_t* a_src[C::A_DMA];
-  const bf16_t* w_src[C::W_DMA];
-#pragma unroll
-  for (int d = 0; d < C::A_DMA; ++d) {
-    const int row = (wave * C::A_DMA + d) * C::ROWS_PER_DMA + lane / C::SLOTS;
-    const int kc = (lane % C::SLOTS) ^ C::swz(row);
-    a_src[d] = A.ptr + A.row_off(m0 + row, kc);
-  }
-#pragma unroll
-  for (int d = 0; d < C::W_DMA; ++d) {
-    const int row = (wave * C::W_DMA + d) * C::ROWS_PER_DMA + lane / C::SLOTS;
-    const int kc = (lane % C::SLOTS) ^ C::swz(row);
-    w_src[d] = W.ptr + W.row_off(tile_n * C::BN + row, kc);
-  }
-  const int nk = K / BK;  // >= 2
-  char* const w_ring = smem;                   // 2 x W_BYTES
-  char* const a_ring = smem + 2 * C::W_BYTES;  // 3 x A_BYTES
-  // The K offset of a refill is kept an opaque SCALAR: both operands advance in step here, and left to itself the
-  // loop-strength-reduction pass turns the 16 source pointers into 16 incrementing 64-bit vector induction variables
-  // (32 more live registers and two 64-bit adds per DMA).
-  auto k_elems = [&](int kt) {
-    size_t ko = (size_t)min(kt, nk - 1) * BK;  // past the end: the last k-tile again (see above)
-    asm volatile("" : "+s"(ko));
-    return ko;
-  };
-  auto stage_a = [&](int kt, int slot) {
-    const size_t ko = k_elems(kt);
-#pragma unroll
-    for (int d = 0; d < C::A_DMA; ++d) {
-      if constexpr (C::AAUX == 2)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + ko),
-                                         (lds_ptr_t)(a_ring + slot * C::A_BYTES + (wave * C::A_DMA + d) * 1024), 16, 0, 2);
-      else
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + ko),
-                                         (lds_ptr_t)(a_ring + slot * C::A_BYTES + (wave * C::A_DMA + d) * 1024), 16, 0, 0);
-    }
-  };
-  auto stage_w = [&](int kt, int slot) {
-    const size_t ko = k_elems(kt);
-#pragma unroll
-    for (int d = 0; d < C::W_DMA; ++d)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[d] + ko),
-                                       (lds_ptr_t)(w_ring + slot * C::W_BYTES + (wave * C::W_DMA + d) * 1024), 16, 0, 0);
-  };
-
-  int a_off[FM][KS * RPF], b_off[FN][KS * RPF];
-#pragma unroll
-  for (int ks = 0; ks < KS * RPF; ++ks) {
-    const int slot = C::FP8 ? ((ks >> 1) * 4 + hi * 2 + (ks & 1)) : (ks * 2 + hi);
-#pragma unroll
-    for (int f = 0; f < FM; ++f) a_off[f][ks] = C::off(wave_row * (FM * 32) + f * 32 + (lane & 31), slot);
-#pragma unroll
-    for (int f = 0; f < FN; ++f) b_off[f][ks] = C::off(wave_col * (FN * 32) + f * 32 + (lane & 31), slot);
-  }
-
-  frag_t af[2][FM], bfr[2][FN];
-  auto read_frags = [&](const char* sa, const char* sw, int ks, int p) {
-    if constexpr (C::FP8 != 0) {
-#pragma unroll
-      for (int f = 0; f < FM; ++f) {
-        const i32x4 lo = *reinterpret_cast<const i32x4*>(sa + a_off[f][2 * ks]);
-        const i32x4 up = *reinterpret_cast<const i32x4*>(sa + a_off[f][2 * ks + 1]);
-        af[p][f] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
-      }
-#pragma unroll
-      for (int f = 0; f < FN; ++f) {
-        const i32x4 lo = *reinterpret_cast<const i32x4*>(sw + b_off[f][2 * ks]);
-        const i32x4 up = *reinterpret_cast<const i32x4*>(sw + b_off[f][2 * ks + 1]);
-        bfr[p][f] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
-      }
-    } else {
-#pragma unroll
-      for (int f = 0; f < FM; ++f) af[p][f] = *reinterpret_cast<const bf16x8*>(sa + a_off[f][ks]);
-#pragma unroll
-      for (int f = 0; f < FN; ++f) bfr[p][f] = *reinterpret_cast<const bf16x8*>(sw + b_off[f][ks]);
-    }
-  };
-  auto mma = [&](int p) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        if constexpr (C::FP8 != 0)
-          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[p][i], bfr[p][j], acc[i][j], 0, 0, 0, 0x7f7f7f7f,
-                                                                      0, 0x7f7f7f7f);
-        else
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[p][i], bfr[p][j], acc[i][j], 0, 0, 0);
-      }
-  };
-  auto hint_order = [](auto nread_tag, auto ndma_tag) {
-    constexpr int NREAD = decltype(nread_tag)::value, NDMA = decltype(ndma_tag)::value, NM = FM * FN;
-    constexpr int PER = (NREAD + NDMA + NM - 1) / NM;
-    int rd = NREAD, dm = NDMA;
-#pragma unroll
-    for (int n = 0; n < NM; ++n) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#pragma unroll
-      for (int q = 0; q < PER; ++q) {
-        if (rd > 0) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          --rd;
-        } else if (dm > 0) {
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          --dm;
-        }
-      }
-    }
-  };
-
-  // prologue: W(0) A(0) A(1); tile 0 (which issues W(1), A(2) itself) may start once W(0) and A(0) have landed
-  stage_w(0, 0);
-  stage_a(0, 0);
-  stage_a(1, 1);
-  wait_vmcnt<C::A_DMA>();
-  __builtin_amdgcn_s_barrier();
-  RP_TS(1);
-  read_frags(a_ring, w_ring, 0, 0);
-
-  using NoDma = std::integral_constant<int, 0>;
-  using Reads = std::integral_constant<int, (FM + FN) * RPF>;
-  int wb = 0, ab = 0;  // ring slots of the current tile
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* sa = a_ring + ab * C::A_BYTES;
-    const char* sw = w_ring + wb * C::W_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < KS - 1; ++ks) {
-      read_frags(sa, sw, ks + 1, (ks + 1) & 1);
-      if (ks == 0) {
-        stage_w(kt + 1, wb ^ 1);                      // the slot tile kt - 1 left
-        stage_a(kt + 2, ab == 0 ? NSA - 1 : ab - 1);  // likewise
-      }
-      mma(ks & 1);
-      if (ks == 0)
-        hint_order(Reads(), std::integral_constant<int, C::A_DMA + C::W_DMA>());
-      else
-        hint_order(Reads(), NoDma());
-    }
-    if (kt + 1 < nk) {
-      // every fragment of tile kt is in registers once this wave's LDS reads have returned
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      wait_vmcnt<C::A_DMA>();        // this wave's share of W(kt + 1), A(kt + 1) has landed; A(kt + 2) may be in flight
-      __builtin_amdgcn_s_barrier();  // ... and everyone's; the slots of tile kt are free
-      wb ^= 1;
-      if (++ab == NSA) ab = 0;
-      read_frags(a_ring + ab * C::A_BYTES, w_ring + wb * C::W_BYTES, 0, 0);
-      if constexpr (has_touch<Epilogue>::value) {
-        if (kt + 2 == nk) epi.template touch<FM, FN>(m0 + wave_row * (FM * 32), tile_n * C::BN + wave_col * (FN * 32), lane);
-      }
-    }
-    mma((KS - 1) & 1);
-  }
-  wait_vmcnt<0>();  // the clamped refills of the last tiles
-  __syncthreads();
-  RP_TS(2);
-
-  epi.template run<FM, FN>(acc, m0 + wave_row * (FM * 32), tile_n * C::BN + wave_col * (FN * 32), lane,
+  epi.template run<FM, FN>(acc, tile_m * C::BM + wave_row * (FM * 32), tile_n * C::BN + wave_col * (FN * 32), lane,
                            smem + wave * EPI_STAGE_BYTES);
   RP_TS(3);
 }

@@ -50,12 +50,6 @@ typedef GemmCfg<256, 256, 32, 2, 2, 4, 1> SimCfgFilterK32;
 typedef GemmCfg<128, 64, 64, 2, 2, 3> SimCfgSampleK64;
 // default: the premise stream (read once, by one CU) carries the nt cache policy: -7 % filter time
 typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 0, 2> SimCfgFilterNt;
-// the filter tile with separate operand rings (gemm_tile_pipe2): premises three stages deep - A(kt + 2) is requested while
-// tile kt runs - queries two; the rings fill the CU's 160 KB, so the per-tile bounds / scales are read from global
-// memory in the epilogue instead of riding into LDS behind the ring
-typedef GemmCfg<256, 256, 64, 2, 2, 2, 2, 0, 2> SimCfgFilterDeep;
-typedef GemmCfg<256, 256, 64, 2, 2, 2, 2, 1, 2> SimCfg8FilterDeep;
-int g_scan_deep = 1;  // 1: the filter pass runs the three-stage premise ring (option scan_deep)
 constexpr int SIM_FILTER_META_BYTES = 3072;  // per-tile metadata behind the ring (EpiSimFilter::prologue)
 int g_scan_cfg = 0;   // 0: auto; 1: force 128-query tiles in the dense path
 int g_scan_impl = 0;  // 0: auto (pipelined filter kernel when the shape allows); 1: first-generation filter kernel
@@ -277,8 +271,7 @@ struct EpiSimFilter {
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* /*stage*/) {
     static_assert(FM * 16 == SLOT_RUN, "a lane's scores for one query fill exactly one run");
     const int hi = lane >> 5, cl = lane & 31;
-    const bool gmeta = meta_off < 0;  // no metadata in LDS (the rings fill it): bounds / scales straight from global memory
-    const char* meta = smem + (gmeta ? 0 : meta_off);
+    const char* meta = smem + meta_off;
     const float* s_tau = reinterpret_cast<const float*>(meta + M_TAU);
     const float* s_qs = reinterpret_cast<const float*>(meta + M_QS);
     const float* s_es = reinterpret_cast<const float*>(meta + M_ES);
@@ -291,9 +284,8 @@ struct EpiSimFilter {
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int ql = ql0 + j * 32 + cl;
-      const int qg = min(q0 + ql, B - 1);
-      tauv[j] = (debug_drop_all & 1) ? INFINITY : (gmeta ? tau[qg] : s_tau[ql]);
-      qsv[j] = FP8 ? (gmeta ? q_scale[qg] : s_qs[ql]) : 1.f;
+      tauv[j] = (debug_drop_all & 1) ? INFINITY : s_tau[ql];
+      qsv[j] = FP8 ? s_qs[ql] : 1.f;
       run_ptr[j] = slots + ((size_t)wg_tile * 256 + ql) * (4 * SLOT_RUN) + part;
       n[j] = 0;
     }
@@ -303,14 +295,9 @@ struct EpiSimFilter {
       if constexpr (FP8 != 0) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          if (gmeta) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(s_es + pl0 + i * 32 + 8 * g + 4 * hi);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) esv[4 * g + e] = e_scale[min(m_base + i * 32 + 8 * g + 4 * hi + e, N - 1)];
-          } else {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(s_es + pl0 + i * 32 + 8 * g + 4 * hi);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) esv[4 * g + e] = v[e];
-          }
+          for (int e = 0; e < 4; ++e) esv[4 * g + e] = v[e];
         }
       }
 #pragma unroll
@@ -341,15 +328,12 @@ __global__ __launch_bounds__(C::THREADS) void sim_filter_kernel(GemmOperand Eop,
   const int fb = logical / tiles_q;
   const int pb = fb + fb / (stride - 1) + 1;  // the fb-th block that is not a multiple of stride
   epi.smem = smem;
-  epi.meta_off = C::PIPE == 2 ? -1 : C::RING_BYTES;
+  epi.meta_off = C::RING_BYTES;
   epi.p0 = pb * C::BM;
   epi.q0 = qt * C::BN;
   epi.wg_tile = logical;
   epi.fb = fb;
-  if constexpr (C::PIPE == 2)
-    gemm_tile_pipe2<C>(Eop, Qop, K, pb, qt, epi, smem);
-  else
-    gemm_tile_pipe<C>(Eop, Qop, K, pb, qt, epi, smem);
+  gemm_tile_pipe<C>(Eop, Qop, K, pb, qt, epi, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -900,7 +884,7 @@ template <class C>
 static RpStatus launch_filter_cfg(GemmOperand e, GemmOperand q, int D2, int n_blocks, int stride,
                                   const EpiSimFilter<C::FP8>& epi, hipStream_t stream) {
   if (n_blocks <= 0) return RP_OK;
-  constexpr int LDS = C::PIPE == 2 ? C::RING_BYTES : C::RING_BYTES + SIM_FILTER_META_BYTES;
+  constexpr int LDS = C::RING_BYTES + SIM_FILTER_META_BYTES;
   static LdsAttrOnce attr;
   RP_HIP(attr.ensure((const void*)sim_filter_kernel<C>, LDS));
   const int tiles_q = (epi.B + C::BN - 1) / C::BN;
@@ -1042,9 +1026,7 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
     if (fp8) {
       EpiSimFilter<1> ef;
       fill(ef);
-      st = g_scan_deep
-               ? launch_filter_cfg<SimCfg8FilterDeep>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
-               : launch_filter_cfg<SimCfg8Filter>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+      st = launch_filter_cfg<SimCfg8Filter>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
     } else {
       EpiSimFilter<0> ef;
       fill(ef);
@@ -1055,9 +1037,7 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
         st = launch_filter_cfg<SimCfgFilter>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
       else
 #endif
-        st = g_scan_deep
-                 ? launch_filter_cfg<SimCfgFilterDeep>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
-                 : launch_filter_cfg<SimCfgFilterNt>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+        st = launch_filter_cfg<SimCfgFilterNt>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
     }
   } else {
     epi.filter = 1;

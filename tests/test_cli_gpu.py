@@ -195,3 +195,26 @@ def test_predict_two_ranks_sharded_index_equals_one(workdir):
         assert [(p.path, p.full_name, tuple(p.start)) for p in x["retrieved_premises"]] == \
                [(p.path, p.full_name, tuple(p.start)) for p in y["retrieved_premises"]]
         assert x["scores"] == y["scores"]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's scaling command when it does not
+    wrap the script in torch.distributed.run) starts its two ranks itself.  Here both ranks share this box's one GPU and
+    gather over gloo (a functional run of the N > 1 step, not a measurement): ONE JSON line, two collectives per step,
+    and the sharded search + merge equals the single-GPU answer."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RP_BENCH_SHARE_GPU="1", RP_BENCH_BACKEND="gloo")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--headline-only"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["sharded_merge_equals_single_gpu"] is True
+    assert d["config"]["collectives_per_step"] == 2
+    assert d["config"]["all_counts_eq_k"] is True

@@ -280,3 +280,34 @@ def test_comm_entry_points_validate_arguments_without_a_gpu(hip_lib):
     assert hip_lib.rp_comm_destroy(None) == 0
     assert hip_lib.rp_comm_allgather(None, None, None, 16, None) == -1
     assert hip_lib.rp_allgather_topk(None, None, None, 4, 2, 0, 4, None, None, None, None, 0, None) == -1
+
+
+def test_bench_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):
+    """bench.py --gpus 4 with no WORLD_SIZE in the environment re-runs itself under torch.distributed.run, one rank
+    per GPU, rendezvous on 127.0.0.1 (the driver contract's command line); under a launcher it does not."""
+    import subprocess
+    import sys
+
+    import bench
+
+    seen = {}
+
+    def fake_call(cmd, *a, **k):
+        seen["cmd"] = cmd
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    # a mismatch between the launcher's world size and --gpus is an error message, not an assertion
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=2" in str(e.value.code)

@@ -326,16 +326,13 @@ def test_sim_topk_filter_generations_agree(gen, B, N, D, k):
     _lib.check(lib.rp_set_option(b"scan_force_new", 1), "opt")  # batches <= 128 default to the first generation
     try:
         a = hh.sim_topk(Q, E, k, dm, id_offset=1000)
-        _lib.check(lib.rp_set_option(b"scan_deep", 0), "opt")  # the two-stage single ring instead of the 3 + 2 rings
-        c = hh.sim_topk(Q, E, k, dm, id_offset=1000)
         _lib.check(lib.rp_set_option(b"scan_impl", 1), "opt")
         b = hh.sim_topk(Q, E, k, dm, id_offset=1000)
     finally:
         _lib.check(lib.rp_set_option(b"scan_impl", 0), "opt")
-        _lib.check(lib.rp_set_option(b"scan_deep", 1), "opt")
         _lib.check(lib.rp_set_option(b"scan_force_new", 0), "opt")
-    for x, y, z in zip(a, b, c):
-        assert torch.equal(x, y) and torch.equal(x, z)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
     hh.check_topk_against_scores(a[0].cpu().numpy() - 1000, a[1].cpu().numpy(), a[2].cpu().numpy(), _scores(Q, E), acc, k,
                                  tol=1e-4)
 
@@ -371,7 +368,7 @@ def test_shard_merge_equals_single_shot(gen):
     assert torch.equal(mi, ids) and torch.equal(ms, sc) and torch.equal(mc, cnt)
 
 
-@pytest.mark.parametrize("variant", [20, 26, 28, 29, 30, 31, 16, 15, 12, 0, 9])
+@pytest.mark.parametrize("variant", [20, 26, 16, 15, 12, 0, 9])
 @pytest.mark.parametrize("M", [256, 768])
 def test_gemm_fused_rmsnorm_pieces_all_variants(gen, variant, M):
     """Residual epilogue on the two planes + per-64-feature sums of squares, and the row-scaled
@@ -411,46 +408,6 @@ def test_gemm_fused_rmsnorm_pieces_all_variants(gen, variant, M):
     finally:
         _lib.check(lib.rp_set_option(b"gemm_skinny", 1), "opt")
         _lib.check(lib.rp_set_option(b"gemm_variant_all", -1), "opt")
-
-
-@pytest.mark.parametrize("touch", [0, 1])
-def test_gemm_exact_n_tiles_do_not_change_a_bit(gen, touch):
-    """Feature counts 256 does not divide run on 192-row tiles (QKV: 1152 = 6 x 192) or on 256-row tiles + one 192-row
-    remainder tile (d_model 1472 = 5 x 256 + 192) instead of padded 256-row tiles.  Every output element stays one
-    K-ascending chain of 32x32x16 steps, so the planes, the statistic slots and the stored projection are the same BITS;
-    so are they with and without the epilogue's early touch of the old x lines (which only moves cache lines)."""
-    lib = _lib.load()
-    M, N, K = 1280, 1472, 448
-    np_ = (N + 63) // 64
-    A, W = _rand_bf16(gen, M, K), _rand_bf16(gen, N, K, scale=K ** -0.5)
-    x0 = hh.split_planes(torch.randn(M, N, generator=gen, device="cuda"))
-    W2 = _rand_bf16(gen, 1152, N, scale=N ** -0.5)
-    A2 = _rand_bf16(gen, M, N)
-    res = {}
-    _lib.check(lib.rp_set_option(b"gemm_skinny", 0), "opt")
-    try:
-        for v in (26, 20, 29, 28, 30, 31):
-            _lib.check(lib.rp_set_option(b"gemm_variant_all", v), "opt")
-            _lib.check(lib.rp_set_option(b"gemm_touch", touch if v != 26 else 0), "opt")
-            planes = x0.clone()
-            ssp = torch.full((np_, M), float("nan"), device="cuda")
-            _lib.check(lib.rp_dbg_gemm_fused(A.data_ptr(), W.data_ptr(), planes.data_ptr(), M, N, K, N, _lib.RP_EPI_RESID, None,
-                                             0, 0.0, 0.0, None, ssp.data_ptr(), np_, _lib.current_stream()), "fused")
-            out = torch.empty(M, 1152, dtype=torch.bfloat16, device="cuda")
-            _lib.check(lib.rp_dbg_gemm(A2.data_ptr(), W2.data_ptr(), out.data_ptr(), M, 1152, N, 1152, _lib.RP_EPI_STORE_BF16,
-                                       _lib.current_stream()), "gemm")
-            torch.cuda.synchronize()
-            res[v] = (planes, ssp, out)
-        ref = A2.float() @ W2.float().T
-        assert (res[26][2].float() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-3
-        for v in (20, 29, 28, 30, 31):
-            for a, b, what in zip(res[26], res[v], ("planes", "statistic slots", "stored projection")):
-                assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a.view(torch.int32),
-                                   b.view(torch.int16) if b.dtype == torch.bfloat16 else b.view(torch.int32)), (v, what)
-    finally:
-        _lib.check(lib.rp_set_option(b"gemm_skinny", 1), "opt")
-        _lib.check(lib.rp_set_option(b"gemm_variant_all", -1), "opt")
-        _lib.check(lib.rp_set_option(b"gemm_touch", 1), "opt")
 
 
 @pytest.mark.parametrize("B,N", [(2048, 16250), (1024, 32500), (512, 65000)])

@@ -8,7 +8,6 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 variants = [int(v) for v in os.environ.get("VARIANTS", "26,20,9,0").split(",")]
 groups = [int(v) for v in os.environ.get("GROUP_M", "8").split(",")]
 staggers = [int(v) for v in os.environ.get("STAGGER", "0").split(",")]  # gemm_stagger_us_* values (first-round spread)
-touches = [int(v) for v in os.environ.get("TOUCH", "1").split(",")]  # gemm_touch: residual epilogues prefetch their x lines
 OPT = {"wi": b"gemm_stagger_us_wi", "wo": b"gemm_stagger_us_wo", "qk": b"gemm_stagger_us_qkv", "o ": b"gemm_stagger_us_o"}
 if os.environ.get("SKINNY") is not None:  # 0: the variant asked for is the variant run, whatever the token count
     _lib.check(lib.rp_set_option(b"gemm_skinny", int(os.environ["SKINNY"])), "opt")
@@ -54,14 +53,10 @@ for name, N, K, epi in shapes:
     errs = {}
     for rnd in range(ROUNDS + 1):  # round 0 = correctness + warm-up; then interleaved timing rounds
         for v in variants:
-            for gm in [(g_, s_, t_) for g_ in groups for s_ in staggers for t_ in touches]:
-                if gm[2] and epi != _lib.RP_EPI_RESID and len(touches) > 1:
-                    continue  # only the residual epilogues have a touch stage
+            for gm in [(g_, s_) for g_ in groups for s_ in staggers]:
                 _lib.check(lib.rp_set_option(b"gemm_variant_all", v), "opt")
                 _lib.check(lib.rp_set_option(b"gemm_group_m", gm[0]), "opt")
-                _lib.check(lib.rp_set_option(b"gemm_touch", gm[2]), "opt")
-                if gm[1]:
-                    _lib.check(lib.rp_set_option(OPT[name[:2]], gm[1]), "opt")
+                _lib.check(lib.rp_set_option(OPT[name[:2]], gm[1]), "opt")
                 if rnd == 0:
                     if epi == _lib.RP_EPI_RESID:
                         out.zero_()
@@ -86,5 +81,5 @@ for name, N, K, epi in shapes:
                 times.setdefault((v, gm), []).append(e0.elapsed_time(e1) / iters)
     for (v, gm), ts in times.items():
         best, med = min(ts), sorted(ts)[len(ts) // 2]
-        print(f"{name} M={M} N={N} K={K} variant={v:2d} group_m,stagger_us,touch={gm}: best {best:7.3f} ms {2.0*M*N*K/best/1e9:7.1f} TF | "
+        print(f"{name} M={M} N={N} K={K} variant={v:2d} group_m,stagger_us={gm}: best {best:7.3f} ms {2.0*M*N*K/best/1e9:7.1f} TF | "
               f"median {med:7.3f} ms {2.0*M*N*K/med/1e9:7.1f} TF  maxerr {errs[(v, gm)]:.3e}", flush=True)
