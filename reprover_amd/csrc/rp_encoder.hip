@@ -39,6 +39,7 @@ int g_gemm_variant_wo = 26;   // FFN-out (+ residual)
 int g_gemm_variant_o = -1;    // attention output (+ residual); -1 = by pass size: two 128 x 128 blocks per CU, or - from 57 k
                               // tokens - the 8-wave 256 x 256 tile (A/B inside the 70 k-token step: 2.553 -> 2.470 ms per 12
                               // launches, three pairs; in isolation the two alternate below that size, tools/gemm_bench.py)
+int g_gemm_rs_lds = 1;      // big tiles: the RMSNorm statistic is reduced in the consuming GEMM from slot rows DMA'd into LDS (RowScaleLds)
 int g_gemm_tail_split = 1;  // big passes: last partial round of 256 x 256 tiles as one round of 128 x 128 tiles
 int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 int g_gemm_skinny = 1;
@@ -131,6 +132,10 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   if (!strcmp(name, "gemm_skinny_variant")) {
     RP_REQUIRE(value == 12 || value == 15, "gemm_skinny_variant must be 12 or 15");
     g_gemm_skinny_variant = value;
+    return RP_OK;
+  }
+  if (!strcmp(name, "gemm_rs_lds")) {
+    g_gemm_rs_lds = value != 0;
     return RP_OK;
   }
   if (!strcmp(name, "gemm_tail_split")) {
@@ -358,6 +363,10 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
                         small_variant(pick_gemm_variant(RP_K_GEMM_WI, Tp, 2 * F, D, tv));
   const RowScale rs{w.rs};
   const RowScaleFromSlots rs_slots{w.ssp, np, Tp, 1.f / (float)D, c.layer_norm_eps};
+  const RowScaleLds rs_lds{w.ssp, np, Tp, 1.f / (float)D, c.layer_norm_eps};
+  // big tiles: each of the two row-scaled projections reduces the statistic itself from LDS (no rowscale launch)
+  const bool lds_qkv = !fused_rs && g_gemm_rs_lds && np <= 32 && big_variant(pick_gemm_variant(RP_K_GEMM_QKV, Tp, 3 * inner, D, tv));
+  const bool lds_wi = !fused_rs && g_gemm_rs_lds && np <= 32 && big_variant(pick_gemm_variant(RP_K_GEMM_WI, Tp, 2 * F, D, tv));
   // Tail of the FFN-out launch.  1644 tiles of 256 x 256 on 256 CUs are 6.42 rounds: the seventh runs 108 tiles
   // while 148 CUs idle (70 k tokens).  The token rows that make whole rounds go to the big tiles; the rest (18 token
   // tiles here) runs as ONE round of 128 x 128 tiles, two workgroups per CU.  Same K-ascending chains per output
@@ -407,11 +416,13 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerPacked& L = e->layers[i];
     // attention sub-layer: qkv = rs * (xb Wqkv'^T)  ->  attention  ->  x += att Wo^T  (+ xb, ssp refreshed)
-    launch_rowscale();
+    if (!lds_qkv) launch_rowscale();
     st = fused_rs ? launch_gemm<true>(w.xb, D, Tp, L.wqkv, D, 3 * inner, D,
                                       EpiStoreBf16Slots{w.qkv, 3 * inner, 3 * inner, rs_slots}, stream, RP_K_GEMM_QKV, tv, t_dev)
-                  : launch_gemm(w.xb, D, Tp, L.wqkv, D, 3 * inner, D, EpiStoreBf16{w.qkv, 3 * inner, 3 * inner, rs}, stream,
-                                RP_K_GEMM_QKV, tv, t_dev);
+         : lds_qkv ? launch_gemm_big(w.xb, D, Tp, L.wqkv, D, 3 * inner, D,
+                                     EpiStoreBf16Lds{{w.qkv, 3 * inner, 3 * inner, rs_lds}}, stream, RP_K_GEMM_QKV, tv, t_dev)
+                   : launch_gemm(w.xb, D, Tp, L.wqkv, D, 3 * inner, D, EpiStoreBf16{w.qkv, 3 * inner, 3 * inner, rs}, stream,
+                                 RP_K_GEMM_QKV, tv, t_dev);
     if (st) return st;
     {
       ProfScope ps(stream, RP_K_ATTENTION);
@@ -422,10 +433,12 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
                           RP_K_GEMM_O, tv, t_dev)))
       return st;
     if (g_debug_skip_ffn) continue;
-    launch_rowscale();
+    if (!lds_wi) launch_rowscale();
     // feed-forward sub-layer: ff = gelu(rs * g) * (rs * u)  ->  x += ff Wo2^T  (+ xb, ssp refreshed)
     st = fused_rs ? launch_gemm<true>(w.xb, D, Tp, L.wi, D, 2 * F, D, EpiGegluBf16Slots{w.ff, F, 2 * F, rs_slots}, stream,
                                       RP_K_GEMM_WI, tv, t_dev)
+         : lds_wi ? launch_gemm_big(w.xb, D, Tp, L.wi, D, 2 * F, D, EpiGegluBf16Lds{{w.ff, F, 2 * F, rs_lds}}, stream,
+                                    RP_K_GEMM_WI, tv, t_dev)
                   : launch_gemm(w.xb, D, Tp, L.wi, D, 2 * F, D, EpiGegluBf16{w.ff, F, 2 * F, rs}, stream, RP_K_GEMM_WI, tv,
                                 t_dev);
     if (st) return st;

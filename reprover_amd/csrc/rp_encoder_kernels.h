@@ -12,7 +12,7 @@ namespace rp {
 
 // tuning knobs (defined in rp_encoder.hip, set through rp_set_option)
 extern int g_gemm_group_m, g_gemm_variant, g_gemm_variant_qkv, g_gemm_variant_wo, g_gemm_variant_o, g_gemm_tail_split,
-    g_debug_skip_ffn, g_gemm_skinny, g_gemm_skinny_variant;
+    g_debug_skip_ffn, g_gemm_skinny, g_gemm_skinny_variant, g_gemm_rs_lds;
 extern int g_gemm_stagger_us[RP_K_COUNT];
 
 // ------------------------------------------------------------------------------------------
@@ -198,6 +198,45 @@ struct RowScaleFromSlots {
     return rsqrtf(s * inv_d + eps);
   }
 };
+
+// The big tiles (256 tokens per workgroup, gemm_tile_pipe) reduce the statistic in the consuming GEMM as well, without a
+// register cost in the main loop: the tile's slot rows - np x 256 floats, one 1-KiB LDS-DMA piece per slot - ride into
+// LDS behind the operand ring before the first operand DMA (the epilogue's prologue hook: in-order vmcnt has them
+// landed long before the epilogue), and the epilogue sums a token's np slots from LDS in index order: the bits
+// rowscale_kernel produces, 24 launches per pass fewer (6.7 us each + their boundaries at 70 k tokens).
+struct RowScaleLds {
+  static constexpr int EXTRA_LDS = 32 * 1024;  // np <= 32 slot rows of 256 floats
+  const float* ssp;  // [np, ld] slot-major partial sums of squares
+  int np, ld;
+  float inv_d, eps;
+  const float* lds = nullptr;  // set by prologue()
+  int n0 = 0;
+  __device__ __forceinline__ void prologue(char* extra, int wave, int lane, int tok0) {
+    lds = reinterpret_cast<const float*>(extra);
+    n0 = tok0;
+    const int nw = (int)blockDim.x >> 6;
+    for (int p = wave; p < np; p += nw)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ssp + (size_t)p * ld + tok0 + lane * 4), (lds_ptr_t)(extra + p * 1024), 16,
+                                       0, 0);
+  }
+  __device__ __forceinline__ float get(int token) const {
+    const float* p = lds + (token - n0);
+    float s = 0.f;  // slots in index order, as rowscale_kernel (whose zero padding beyond np adds exactly nothing)
+#pragma unroll 4
+    for (int i = 0; i < np; ++i) s += p[i * 256];
+    return rsqrtf(s * inv_d + eps);
+  }
+};
+// an epilogue whose row scale has a prologue of its own exposes it to gemm_tile_pipe
+template <class Base>
+struct WithRsPrologue : Base {
+  static constexpr int EXTRA_LDS = decltype(Base::rs)::EXTRA_LDS;
+  __device__ __forceinline__ void prologue(char* extra, int wave, int lane, int n0) { this->rs.prologue(extra, wave, lane, n0); }
+};
+template <class E, class = void>
+struct epi_extra_lds : std::integral_constant<int, 0> {};
+template <class E>
+struct epi_extra_lds<E, std::void_t<decltype(E::EXTRA_LDS)>> : std::integral_constant<int, E::EXTRA_LDS> {};
 
 // rs[token] = rsqrt(sum_p ssp[p][token] / D + eps), slots summed in index order
 static __global__ __launch_bounds__(64) void rowscale_kernel(const float* __restrict__ ssp, float* __restrict__ rs, int rows,
@@ -415,6 +454,8 @@ typedef EpiStoreBf16T<RowScale> EpiStoreBf16;
 typedef EpiGegluBf16T<RowScale> EpiGegluBf16;
 typedef EpiStoreBf16T<RowScaleFromSlots> EpiStoreBf16Slots;
 typedef EpiGegluBf16T<RowScaleFromSlots> EpiGegluBf16Slots;
+typedef WithRsPrologue<EpiStoreBf16T<RowScaleLds>> EpiStoreBf16Lds;
+typedef WithRsPrologue<EpiGegluBf16T<RowScaleLds>> EpiGegluBf16Lds;
 
 template <class C, class Epi>
 __global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOperand W, int K, int tiles_m,
@@ -454,8 +495,11 @@ template <class C, class Epi>
 static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hipStream_t stream,
                                 int prof_class, int tokens_valid, const int32_t* t_dev) {
   auto kern = gemm_kernel<C, Epi>;
+  constexpr int LDS = (epi_extra_lds<Epi>::value ? C::RING_BYTES : C::LDS_BYTES) + epi_extra_lds<Epi>::value;
+  static_assert(epi_extra_lds<Epi>::value == 0 || (C::PIPE != 0 && C::RING_BYTES >= C::NWAVES * EPI_STAGE_BYTES),
+                "metadata behind the ring: pipelined tiles only");
   static LdsAttrOnce attr;
-  RP_HIP(attr.ensure((const void*)kern, C::LDS_BYTES));
+  RP_HIP(attr.ensure((const void*)kern, LDS));
   RP_REQUIRE(K % C::BK == 0 && a.rows % C::BN == 0, "gemm: K=%d must be a multiple of %d, M=%d of %d", K, C::BK,
              a.rows, C::BN);
   const int rows_needed = (tokens_valid > 0 && tokens_valid < a.rows) ? tokens_valid : a.rows;
@@ -464,8 +508,8 @@ static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hi
   const int group = max(1, g_gemm_group_m * 128 / C::BN);
   ProfScope ps(stream, prof_class);
   const int stagger_ticks = (C::PIPE != 0 && tiles_f * tiles_t > 512) ? g_gemm_stagger_us[prof_class] * 100 : 0;
-  hipLaunchKernelGGL(kern, dim3(tiles_f * tiles_t), dim3(C::THREADS), C::LDS_BYTES, stream, w, a, K, tiles_f,
-                     tiles_t, group, stagger_ticks, t_dev, epi);
+  hipLaunchKernelGGL(kern, dim3(tiles_f * tiles_t), dim3(C::THREADS), LDS, stream, w, a, K, tiles_f, tiles_t, group,
+                     stagger_ticks, t_dev, epi);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
@@ -533,6 +577,18 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
     case 16: return launch_gemm_cfg<GemmCfg<64, 128, 64, 1, 4, 4>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
     default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
   }
+}
+
+inline bool big_variant(int v) { return v == 20 || v == 26; }
+// epilogues that exist for the pipelined 256 x 256 tiles only (metadata behind the ring)
+template <class Epi>
+static RpStatus launch_gemm_big(const bf16_t* A, int lda, int M, const bf16_t* W, int ldw, int n_rows_w, int K, Epi epi,
+                                hipStream_t stream, int prof_class, int tokens_valid, const int32_t* t_dev) {
+  GemmOperand a{A, lda, M}, w{W, ldw, n_rows_w};
+  const int v = pick_gemm_variant(prof_class, M, n_rows_w, K, tokens_valid);
+  RP_REQUIRE(big_variant(v), "tile configuration %d has no LDS row-scale form", v);
+  if (v == 20) return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
+  return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
 }
 
 // ------------------------------------------------------------------------------------------

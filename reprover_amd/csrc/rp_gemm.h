@@ -100,9 +100,9 @@ struct GemmOperand {
   __device__ __forceinline__ size_t k_off(int kt, int BK) const { return (size_t)kt * BK; }
 };
 
-// An epilogue may declare `void prologue(char* extra_lds, int wave, int lane)`: gemm_tile_pipe calls it
-// before the first operand DMA so that per-tile metadata can ride into LDS (beyond the ring) by LDS-DMA
-// and be complete, by the in-order vmcnt accounting, long before the epilogue reads it.
+// An epilogue may declare `void prologue(char* extra_lds, int wave, int lane, int n0)` (n0 = first W row of the
+// tile): gemm_tile_pipe calls it before the first operand DMA so that per-tile metadata can ride into LDS (beyond
+// the ring) by LDS-DMA and be complete, by the in-order vmcnt accounting, long before the epilogue reads it.
 template <class E, class = void>
 struct has_prologue : std::false_type {};
 template <class E>
@@ -300,7 +300,7 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
     w_src[d] = W.ptr + W.row_off(tile_n * C::BN + row, kc);
   }
   const int nk = K / BK;
-  if constexpr (has_prologue<Epilogue>::value) epi.prologue(smem + C::RING_BYTES, wave, lane);
+  if constexpr (has_prologue<Epilogue>::value) epi.prologue(smem + C::RING_BYTES, wave, lane, tile_n * C::BN);
   // half 0: the A image of a stage, half 1: the W image (issued one k-step apart, see tile_body)
   auto stage_half = [&](int kt, int buf, int half) {
     char* base = smem + buf * C::STAGE_BYTES;

@@ -254,7 +254,7 @@ struct EpiSimFilter {
 
   static constexpr int M_TAU = 0, M_QS = 1024, M_ES = 2048;  // metadata layout (bytes from meta_off)
 
-  __device__ __forceinline__ void prologue(char* meta, int wave, int lane) {
+  __device__ __forceinline__ void prologue(char* meta, int wave, int lane, int /*n0*/) {
     auto dma4 = [&](const void* g, char* dst) {
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)dst, 4, 0, 0);
     };
