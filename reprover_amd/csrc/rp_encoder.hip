@@ -40,6 +40,8 @@ int g_gemm_variant_o = -1;    // attention output (+ residual); -1 = by pass siz
                               // tokens - the 8-wave 256 x 256 tile (A/B inside the 70 k-token step: 2.553 -> 2.470 ms per 12
                               // launches, three pairs; in isolation the two alternate below that size, tools/gemm_bench.py)
 int g_gemm_rs_lds = 1;      // big tiles: the RMSNorm statistic is reduced in the consuming GEMM from slot rows DMA'd into LDS (RowScaleLds)
+int g_gemm_small_pipe = 1;  // few-token passes: the 64 x 128 x 64 tile on the software-pipelined loop (variant 17) instead of the plain one (16)
+int g_gemm_helpers = 64;      // few-token launches: up to this many surplus workgroups prefetch the weight rows (0 = off)
 int g_gemm_tail_split = 1;  // big passes: last partial round of 256 x 256 tiles as one round of 128 x 128 tiles
 int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 int g_gemm_skinny = 1;
@@ -132,6 +134,15 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   if (!strcmp(name, "gemm_skinny_variant")) {
     RP_REQUIRE(value == 12 || value == 15, "gemm_skinny_variant must be 12 or 15");
     g_gemm_skinny_variant = value;
+    return RP_OK;
+  }
+  if (!strcmp(name, "gemm_helpers")) {
+    RP_REQUIRE(value >= 0 && value <= 248, "gemm_helpers out of range");
+    g_gemm_helpers = value & ~7;
+    return RP_OK;
+  }
+  if (!strcmp(name, "gemm_small_pipe")) {
+    g_gemm_small_pipe = value != 0;
     return RP_OK;
   }
   if (!strcmp(name, "gemm_rs_lds")) {

@@ -12,7 +12,7 @@ namespace rp {
 
 // tuning knobs (defined in rp_encoder.hip, set through rp_set_option)
 extern int g_gemm_group_m, g_gemm_variant, g_gemm_variant_qkv, g_gemm_variant_wo, g_gemm_variant_o, g_gemm_tail_split,
-    g_debug_skip_ffn, g_gemm_skinny, g_gemm_skinny_variant, g_gemm_rs_lds;
+    g_debug_skip_ffn, g_gemm_skinny, g_gemm_skinny_variant, g_gemm_rs_lds, g_gemm_small_pipe, g_gemm_helpers;
 extern int g_gemm_stagger_us[RP_K_COUNT];
 
 // ------------------------------------------------------------------------------------------
@@ -457,10 +457,36 @@ typedef EpiGegluBf16T<RowScaleFromSlots> EpiGegluBf16Slots;
 typedef WithRsPrologue<EpiStoreBf16T<RowScaleLds>> EpiStoreBf16Lds;
 typedef WithRsPrologue<EpiGegluBf16T<RowScaleLds>> EpiGegluBf16Lds;
 
+// Weight prefetch by the CUs a few-token launch leaves idle.  A pass of one proof state runs 18 - 112 workgroups, each
+// streaming its 64 weight rows from HBM (a single-state retrieve() walks all 434 MB of weights: nothing is cached from
+// call to call), and ONE CU pulls about 17 GB/s out of HBM however deep its ring is (measured: the FFN-out projection,
+// 23 workgroups x 459 KB, takes 27 us on weights from HBM and 20 us on L2-resident ones, tools/gemm_bench.py COLD=48).
+// The surplus workgroups of the launch touch those rows ahead of the compute workgroups - one dword per 128-byte
+// line, K-major so that the first k-tiles arrive first - each on the XCD whose L2 its rows' consumer reads from
+// (workgroup b runs on XCD b % 8 - observed, speed only - and xcd_remap gives every XCD a contiguous range of tiles).
+// Helpers change no result: they only move cache lines.
+__device__ __forceinline__ void gemm_prefetch_helper(const GemmOperand& A, int K, int BM, int nwg, int tiles_n, int hb,
+                                                     int n_helpers) {
+  const int x = hb & 7, j = hb >> 3, H = n_helpers >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q, cnt = q + (x < r ? 1 : 0);
+  if (cnt <= 0 || j >= H) return;
+  const int f0 = base / tiles_n, f1 = (base + cnt - 1) / tiles_n;  // feature tiles this XCD's workgroups read
+  const int r0 = f0 * BM, nrows = min((f1 + 1) * BM, A.rows) - r0;
+  if (nrows <= 0) return;
+  const int total = nrows * (K >> 6);  // 128-byte lines
+  uint32_t tmp = 0;
+  for (int l = j * (int)blockDim.x + (int)threadIdx.x; l < total; l += H * (int)blockDim.x) {
+    const bf16_t* p = A.ptr + (size_t)(r0 + l % nrows) * A.ld + (size_t)(l / nrows) * 64;
+    asm volatile("global_load_dword %0, %1, off" : "+v"(tmp) : "v"(p) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(tmp)::"memory");
+}
+
 template <class C, class Epi>
 __global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOperand W, int K, int tiles_m,
                                                           int tiles_n, int group_m, int stagger_ticks,
-                                                          const int32_t* __restrict__ t_dev, Epi epi) {
+                                                          const int32_t* __restrict__ t_dev, Epi epi, int n_helpers) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef RP_EXPERIMENTS  // first-round stagger of the big GEMMs (measured neutral): probe builds only
   if (stagger_ticks > 0 && blockIdx.x < 256) {
@@ -471,15 +497,22 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOpe
     while (wall_clock64() < until) __builtin_amdgcn_s_sleep(16);
   }
 #endif
-  int nwg = gridDim.x;
+  const int n_grid = (int)gridDim.x - n_helpers;  // compute workgroups (an upper bound with t_dev), padded to a multiple of 8
+  int nwg = n_helpers ? tiles_m * tiles_n : n_grid;
   if (t_dev) {
     // rp_encode_padded: the grid covers an upper bound of the token count.  The live tiles are re-numbered over
     // the first nwg workgroups so that they still spread over all 8 XCDs (skipping by tile index left the live
     // token tiles - the first quarter of the logical range - on two XCDs: 3x slower).
-    tiles_n = (*t_dev + C::BN - 1) / C::BN;
+    const int t_live = *t_dev;
+    tiles_n = (t_live + C::BN - 1) / C::BN;
     nwg = tiles_m * tiles_n;
-    if ((int)blockIdx.x >= nwg) return;
+    W.rows = max(1, min(W.rows, t_live));  // (the token operand: rows beyond the live count read the last live row)
   }
+  if ((int)blockIdx.x >= n_grid) {
+    gemm_prefetch_helper(A, K, C::BM, nwg, tiles_n, (int)blockIdx.x - n_grid, n_helpers);
+    return;
+  }
+  if ((int)blockIdx.x >= nwg) return;
   const int logical = xcd_remap(blockIdx.x, nwg);
   int tm, tn;
   tile_coords(logical, tiles_n, tiles_m, group_m, tn, tm);  // token tiles grouped, feature tiles inside
@@ -508,8 +541,19 @@ static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hi
   const int group = max(1, g_gemm_group_m * 128 / C::BN);
   ProfScope ps(stream, prof_class);
   const int stagger_ticks = (C::PIPE != 0 && tiles_f * tiles_t > 512) ? g_gemm_stagger_us[prof_class] * 100 : 0;
-  hipLaunchKernelGGL(kern, dim3(tiles_f * tiles_t), dim3(C::THREADS), LDS, stream, w, a, K, tiles_f, tiles_t, group,
-                     stagger_ticks, t_dev, epi);
+  // few-token launches (one group of token tiles, well under one round of the chip) on weights worth prefetching: the idle
+  // CUs become prefetch helpers (above)
+  int n_grid = tiles_f * tiles_t, n_helpers = 0;
+  const int n_cus = 256;
+  if (g_gemm_helpers && n_grid <= n_cus / 2 && tiles_t <= group && (size_t)w.rows * K * 2 >= ((size_t)2 << 20)) {
+    n_grid = (n_grid + 7) & ~7;
+    n_helpers = std::min(g_gemm_helpers, (n_cus - n_grid) & ~7);
+  }
+  // token rows beyond the valid count are read as copies of the last valid row (the operand clamps at `rows`): the 27
+  // padding rows of a 101-token state cost one cache line per DMA piece instead of eight
+  a.rows = rows_needed;
+  hipLaunchKernelGGL(kern, dim3(n_grid + n_helpers), dim3(C::THREADS), LDS, stream, w, a, K, tiles_f, tiles_t, group,
+                     stagger_ticks, t_dev, epi, n_helpers);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
@@ -543,16 +587,18 @@ static int pick_gemm_variant(int prof_class, int M, int n_rows_w, int K, int tok
   }
   if ((v == 20 || v == 26) && !k64) v = 9;  // 64-wide K tiles need K % 64 == 0
   if (v == 16 && !k64) v = 15;
+  if (v == 16 && g_gemm_small_pipe) v = 17;  // the same tile on the software-pipelined loop
   if (v >= 5 && !m256) v = 0;
   return v;
 }
-inline bool small_variant(int v) { return v == 0 || v == 15 || v == 16; }
+inline bool small_variant(int v) { return v == 0 || (v >= 15 && v <= 17); }
 
 // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages[, pipelined]>:
 //   20 / 26  pipelined 256 x 256 x 64, 4 / 8 waves     (the encoder's big GEMMs)
 //   9        plain 256 x 256 x 32, 3 stages             (K % 64 != 0)
 //   0        plain 128 x 128 x 32, 3 stages, 2 blocks/CU (attention-out; token counts not a multiple of 256)
-//   16 / 15  64 x 128 x 64, 4 stages / x 32, 7 stages   (up to ~1024 tokens: single-state queries)
+//   17       64 x 128 x 64, 4 stages, pipelined loop    (up to ~1024 tokens: single-state queries)
+//   16 / 15  the same on the plain loop / x 32, 7 stages (16: kept selectable; 15: K % 64 != 0)
 //   12       64 x 256 x 32, 7 stages                    (on request only)
 // SMALL_ONLY: the epilogue type exists for the small configurations only (pick_gemm_variant said so).
 template <bool SMALL_ONLY = false, class Epi>
@@ -575,6 +621,7 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
   switch (v) {
     case 15: return launch_gemm_cfg<GemmCfg<64, 128, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
     case 16: return launch_gemm_cfg<GemmCfg<64, 128, 64, 1, 4, 4>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
+    case 17: return launch_gemm_cfg<GemmCfg<64, 128, 64, 1, 4, 4, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
     default: return launch_gemm_cfg<GemmCfg<128, 128, 32, 2, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
   }
 }

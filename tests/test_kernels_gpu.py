@@ -368,7 +368,7 @@ def test_shard_merge_equals_single_shot(gen):
     assert torch.equal(mi, ids) and torch.equal(ms, sc) and torch.equal(mc, cnt)
 
 
-@pytest.mark.parametrize("variant", [20, 26, 16, 15, 12, 0, 9])
+@pytest.mark.parametrize("variant", [20, 26, 17, 16, 15, 12, 0, 9])
 @pytest.mark.parametrize("M", [256, 768])
 def test_gemm_fused_rmsnorm_pieces_all_variants(gen, variant, M):
     """Residual epilogue on the two planes + per-64-feature sums of squares, and the row-scaled
@@ -408,6 +408,34 @@ def test_gemm_fused_rmsnorm_pieces_all_variants(gen, variant, M):
     finally:
         _lib.check(lib.rp_set_option(b"gemm_skinny", 1), "opt")
         _lib.check(lib.rp_set_option(b"gemm_variant_all", -1), "opt")
+
+
+def test_few_token_gemm_pipelined_loop_and_prefetch_helpers_change_no_bit(gen):
+    """Passes of one proof state run the 64 x 128 x 64 tile on the software-pipelined loop (variant 17), and the launch's
+    surplus workgroups prefetch the weight rows into the consumers' L2 (gemm_helpers).  Neither may change a bit of the
+    result: same MFMA chain per element as the plain loop (variant 16), and helpers only move cache lines.  Token rows
+    beyond the valid count are read as copies of the last valid row: the valid rows cannot notice."""
+    lib = _lib.load()
+    M, N, K = 256, 1152, 1472  # a QKV projection: 3.4 MB of weights, 36 workgroups -> helpers apply
+    A, W = _rand_bf16(gen, M, K), _rand_bf16(gen, N, K, scale=K ** -0.5)
+    ref = A.float() @ W.float().T
+    res = []
+    try:
+        for opts in ({"gemm_small_pipe": 1, "gemm_helpers": 64}, {"gemm_small_pipe": 1, "gemm_helpers": 0},
+                     {"gemm_small_pipe": 0, "gemm_helpers": 0}, {"gemm_small_pipe": 0, "gemm_helpers": 248}):
+            for k_, v_ in opts.items():
+                _lib.check(lib.rp_set_option(k_.encode(), v_), "opt")
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+            _lib.check(lib.rp_dbg_gemm(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, N, _lib.RP_EPI_STORE_BF16,
+                                       _lib.current_stream()), "gemm")
+            torch.cuda.synchronize()
+            res.append(out)
+    finally:
+        _lib.check(lib.rp_set_option(b"gemm_small_pipe", 1), "opt")
+        _lib.check(lib.rp_set_option(b"gemm_helpers", 64), "opt")
+    assert (res[0].float() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-3
+    for other in res[1:]:
+        assert torch.equal(res[0].view(torch.int16), other.view(torch.int16))
 
 
 @pytest.mark.parametrize("B,N", [(2048, 16250), (1024, 32500), (512, 65000)])

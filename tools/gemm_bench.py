@@ -42,12 +42,20 @@ for name, N, K, epi in shapes:
     np_ = (N + 63) // 64
     ssp = torch.empty(np_, M, device=dev) if fused else None
 
+    # COLD=n: n copies of the weight matrix, used in rotation (n x N x K x 2 bytes past the 256 MB Infinity Cache: every launch
+    # streams its weights from HBM, as a single-state retrieve() does - 434 MB of weights per pass)
+    ncold = int(os.environ.get("COLD", "0"))
+    Ws = [W] + [W.clone() for _ in range(max(0, ncold - 1))]
+    turn = [0]
+
     def run():
+        Wc = Ws[turn[0] % len(Ws)]
+        turn[0] += 1
         if fused:
-            _lib.check(lib.rp_dbg_gemm_fused(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, N, epi, None, 0, 0.0,
+            _lib.check(lib.rp_dbg_gemm_fused(A.data_ptr(), Wc.data_ptr(), out.data_ptr(), M, N, K, N, epi, None, 0, 0.0,
                                              0.0, None, ssp.data_ptr(), np_, _lib.current_stream()), "gemm")
         else:
-            _lib.check(lib.rp_dbg_gemm(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, N, epi,
+            _lib.check(lib.rp_dbg_gemm(A.data_ptr(), Wc.data_ptr(), out.data_ptr(), M, N, K, N, epi,
                                        _lib.current_stream()), "gemm")
     times = {}
     errs = {}
@@ -56,7 +64,8 @@ for name, N, K, epi in shapes:
             for gm in [(g_, s_) for g_ in groups for s_ in staggers]:
                 _lib.check(lib.rp_set_option(b"gemm_variant_all", v), "opt")
                 _lib.check(lib.rp_set_option(b"gemm_group_m", gm[0]), "opt")
-                _lib.check(lib.rp_set_option(OPT[name[:2]], gm[1]), "opt")
+                if gm[1]:  # (the stagger knob exists in RP_EXPERIMENTS builds only)
+                    _lib.check(lib.rp_set_option(OPT[name[:2]], gm[1]), "opt")
                 if rnd == 0:
                     if epi == _lib.RP_EPI_RESID:
                         out.zero_()
