@@ -33,7 +33,8 @@ Rccl* rccl() {
       for (const char* n : names)
         if (n && !x.handle) x.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
     if (!x.handle) {
-      x.error = std::string("librccl.so not found (set RP_RCCL_LIB): ") + (dlerror() ? dlerror() : "");
+      const char* why = dlerror();  // (one call: dlerror() clears the message it returns)
+      x.error = std::string("librccl.so not found (set RP_RCCL_LIB): ") + (why ? why : "");
       return x;
     }
     auto sym = [&](const char* name) {

@@ -90,7 +90,7 @@ __device__ __forceinline__ float drop_mul(const Drop& d, uint32_t site, uint32_t
   return drop_hash(d.seed, site, row, col) >= d.thresh ? d.scale : 0.f;
 }
 // element ids: (site, row = packed token index, col = feature) - attention probabilities: row = the query's packed token
-// index, col = (head << 12) | key offset inside the sequence
+// index, col = (head << 20) | key offset inside the sequence (sequences of up to 2^20 tokens: far beyond any max_seq_len)
 enum { DROP_SITE_EMBED = 0, DROP_SITE_FINAL = 1, DROP_SITE_LAYER0 = 16 };  // layer i: 16 + 8 i + {0 probs, 1 attn residual, 2 FFN inner, 3 FFN residual}
 
 // ------------------------------------------------------------------------------------------
@@ -883,7 +883,7 @@ static __global__ __launch_bounds__(256, DROP ? 2 : 4) void attention_kernel(con
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            s[kb][r] *= drop_mul(drop, drop_site, (uint32_t)(s0 + qi), ((uint32_t)h << 12) | (uint32_t)(k0 + kb * 32 + mfma32_row(r, hi)));
+            s[kb][r] *= drop_mul(drop, drop_site, (uint32_t)(s0 + qi), ((uint32_t)h << 20) | (uint32_t)(k0 + kb * 32 + mfma32_row(r, hi)));
       }
     }
     // ---- O^T += V^T P^T over four 16-key slabs

@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256, (DROP && MODE == 1) ? 1 : 2) void attn_bwd_ker
           float pm = p, dpv = dp[mb][r];
           if constexpr (DROP) {
             const uint32_t qrow = (uint32_t)(s0 + ((MODE == 0) ? ni : j)), kcol = (uint32_t)((MODE == 0) ? j : ni);
-            const float m = drop_mul(drop, drop_site, qrow, ((uint32_t)h << 12) | kcol);
+            const float m = drop_mul(drop, drop_site, qrow, ((uint32_t)h << 20) | kcol);
             pm *= m;
             dpv *= m;
           }

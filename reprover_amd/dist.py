@@ -121,9 +121,9 @@ def hip_local_topk(shard: IndexShard, batch_context: Sequence[Context], query_em
         return out_i, out_s, out_c
     scan(_lib.RP_TOPK_AUTO)
     # The C ABI reserves out_count = -1 for "candidate list overflow: call again with RP_TOPK_DENSE"
-    # (include/reprover_hip.h).  The current engine sizes the list so that it cannot overflow, but the contract is
-    # honoured here as in Corpus.get_nearest_premises: a rank whose list overflowed must not drop out of the
-    # merge (merge_keys treats a negative count as "no candidates").
+    # (include/reprover_hip.h).  The list is bounded (plan_sim: 8 k stride keys, at least 8192), so adversarial scores or a
+    # sample without a bound CAN overflow it; the contract is honoured here as in Corpus.get_nearest_premises: a rank whose
+    # list overflowed must not drop out of the merge (merge_keys treats a negative count as "no candidates").
     if bool((out_c < 0).any()):
         scan(_lib.RP_TOPK_DENSE)
     return out_i, out_s, out_c
@@ -253,9 +253,11 @@ class HipComm:
     def all_gather_stack(self, t: torch.Tensor) -> torch.Tensor:
         t = t.contiguous()
         assert t.is_cuda and (t.numel() * t.element_size()) % 4 == 0
+        assert t.device == self.device, f"tensor on {t.device}, communicator on {self.device}"
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        _lib.check(_lib.load().rp_comm_allgather(self._handle, t.data_ptr(), out.data_ptr(), t.numel() * t.element_size(),
-                                                 _lib.current_stream()), "rp_comm_allgather")
+        with torch.cuda.device(self.device):  # the stream handed over must be the communicator device's current stream
+            _lib.check(_lib.load().rp_comm_allgather(self._handle, t.data_ptr(), out.data_ptr(), t.numel() * t.element_size(),
+                                                     _lib.current_stream()), "rp_comm_allgather")
         return out
 
     def allgather_topk(self, block: torch.Tensor, Bt: int, k: int, q0: int, B: int):
@@ -270,9 +272,11 @@ class HipComm:
         out_c = torch.empty((B,), dtype=torch.int32, device=dev)
         nbytes = lib.rp_topk_merge_workspace_bytes(self.world, B, k)
         ws = _workspace(dev, nbytes)
-        _lib.check(lib.rp_allgather_topk(self._handle, block.data_ptr(), recv.data_ptr(), Bt, k, q0, B, _lib.ptr(out_s),
-                                         _lib.ptr(out_i), _lib.ptr(out_c), _lib.ptr(ws), nbytes, _lib.current_stream()),
-                   "rp_allgather_topk")
+        assert dev == self.device, f"block on {dev}, communicator on {self.device}"
+        with torch.cuda.device(self.device):
+            _lib.check(lib.rp_allgather_topk(self._handle, block.data_ptr(), recv.data_ptr(), Bt, k, q0, B, _lib.ptr(out_s),
+                                             _lib.ptr(out_i), _lib.ptr(out_c), _lib.ptr(ws), nbytes, _lib.current_stream()),
+                       "rp_allgather_topk")
         return out_i, out_s, out_c, recv
 
 

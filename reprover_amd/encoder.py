@@ -47,7 +47,7 @@ class HipT5Encoder:
     """T5 encoder weights resident on one GPU + the packed varlen forward."""
 
     def __init__(self, cfg: Dict, state_dict: Dict[str, torch.Tensor], device, dtype: torch.dtype = torch.bfloat16,
-                 max_tokens_per_pass: int = 1 << 18):
+                 max_tokens_per_pass: int = 1 << 18, keep_master_weights: bool = True):
         if cfg.get("feed_forward_proj", "gated-gelu") != "gated-gelu":
             raise _lib.HipLibraryError(f"feed_forward_proj={cfg.get('feed_forward_proj')!r} is not implemented")
         self.device = _require_gpu(device)
@@ -91,8 +91,16 @@ class HipT5Encoder:
         self._owner = None
         self._ws: Optional[torch.Tensor] = None
         self._pending_meta: list = []
-        # fp32 host weights, by reference: what a training step starts from (reprover_amd/train.py::HipT5Trainer)
-        self._state_dict_cpu = state_dict
+        # The fp32 weights a training step (reprover_amd/train.py::HipT5Trainer) or ``save_pretrained`` starts from.  Kept on
+        # the HOST (a dict of device tensors would pin a second, fp32 copy of the weights in HBM beside the packed bf16
+        # one for the encoder's lifetime); ``keep_master_weights=False`` keeps nothing - what a process that only
+        # retrieves wants (the reference runs many retriever actors per node), and ``train_engine`` then reloads from
+        # ``self.source_path`` when the encoder came from a checkpoint directory.
+        self.source_path: Optional[str] = None
+        if keep_master_weights:
+            self._state_dict_cpu = {k: (v.detach().to("cpu") if v.is_cuda else v) for k, v in state_dict.items()}
+        else:
+            self._state_dict_cpu = None
 
     @classmethod
     def from_handle(cls, cfg: Dict, handle, device, dtype: torch.dtype, owner) -> "HipT5Encoder":
@@ -104,6 +112,7 @@ class HipT5Encoder:
         self.config = SimpleNamespace(hidden_size=cfg["d_model"], **cfg)
         self.max_tokens_per_pass = 1 << 18
         self._state_dict_cpu = None
+        self.source_path = None
         self._lib = _lib.load()
         self._handle = handle
         self._owner = owner
@@ -113,7 +122,8 @@ class HipT5Encoder:
 
     # -- construction helpers ---------------------------------------------------------------------
     @classmethod
-    def from_pretrained(cls, path: str, device, dtype: torch.dtype = torch.bfloat16) -> "HipT5Encoder":
+    def from_pretrained(cls, path: str, device, dtype: torch.dtype = torch.bfloat16,
+                        keep_master_weights: bool = True) -> "HipT5Encoder":
         """Load a HuggingFace T5/ByT5 checkpoint directory (config.json + model.safetensors or
         pytorch_model.bin; key names SURVEY.md App. B.5; decoder.* keys are ignored)."""
         if not os.path.isdir(path):
@@ -127,6 +137,7 @@ class HipT5Encoder:
             relative_attention_max_distance=hf.get("relative_attention_max_distance", 128),
             layer_norm_epsilon=hf.get("layer_norm_epsilon", 1e-6),
             feed_forward_proj=hf.get("feed_forward_proj", "relu"),
+            dropout_rate=hf.get("dropout_rate", 0.1),
         )
         st = os.path.join(path, "model.safetensors")
         if os.path.exists(st):
@@ -136,7 +147,22 @@ class HipT5Encoder:
         else:
             sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
         sd = {k: v for k, v in sd.items() if not k.startswith("decoder.") and not k.startswith("lm_head")}
-        return cls(cfg, sd, device, dtype)
+        enc = cls(cfg, sd, device, dtype, keep_master_weights=keep_master_weights)
+        enc.source_path = path
+        return enc
+
+    def master_weights(self) -> Optional[Dict[str, torch.Tensor]]:
+        """The fp32 weights this engine was built from: the kept host dict, or re-read from ``source_path``."""
+        if self._state_dict_cpu is None and self.source_path is not None:
+            st = os.path.join(self.source_path, "model.safetensors")
+            if os.path.exists(st):
+                from safetensors.torch import load_file
+
+                sd = load_file(st)
+            else:
+                sd = torch.load(os.path.join(self.source_path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+            self._state_dict_cpu = {k: v for k, v in sd.items() if not k.startswith("decoder.") and not k.startswith("lm_head")}
+        return self._state_dict_cpu
 
     def save_pretrained(self, path: str) -> None:
         """Write an HF-layout checkpoint directory (config.json + model.safetensors) that ``from_pretrained`` - and
@@ -144,13 +170,13 @@ class HipT5Encoder:
         ``HipT5Trainer``, else the weights it was built from."""
         from safetensors.torch import save_file
 
-        sd = self._owner.state_dict() if self._owner is not None else self._state_dict_cpu
+        sd = self._owner.state_dict() if self._owner is not None else self.master_weights()
         if sd is None:
             raise RuntimeError("this encoder holds no fp32 weights to save")
         os.makedirs(path, exist_ok=True)
         hf = {k: v for k, v in self.cfg.items()}
-        hf.update(model_type="t5", architectures=["T5EncoderModel"], dropout_rate=0.1, tie_word_embeddings=False,
-                  num_decoder_layers=0, is_encoder_decoder=False)
+        hf.update(model_type="t5", architectures=["T5EncoderModel"], dropout_rate=self.cfg.get("dropout_rate", 0.1),
+                  tie_word_embeddings=False, num_decoder_layers=0, is_encoder_decoder=False)
         with open(os.path.join(path, "config.json"), "w") as fh:
             json.dump(hf, fh, indent=1)
         keep = {k: v.detach().to(torch.float32).cpu().contiguous().clone() for k, v in sd.items()

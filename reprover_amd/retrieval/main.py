@@ -38,16 +38,34 @@ def run_predict(model: PremiseRetriever, dm: RetrievalDataModule, log_dir: Optio
     return count
 
 
-def run_fit(model: PremiseRetriever, dm: RetrievalDataModule, max_steps: int, val_every: int = 0, log=print) -> Dict[str, Any]:
+def save_fit_checkpoint(model: PremiseRetriever, ckpt_dir: str) -> str:
+    """What Lightning's ModelCheckpoint keeps for the reference, in this engine's forms: ``<ckpt_dir>/`` is a HuggingFace
+    checkpoint directory of the CURRENT weights (``load_hf`` / ``transformers`` read it back) and
+    ``<ckpt_dir>/training_state.safetensors`` the flat fp32 masters, both AdamW moments, the step counter and the dropout
+    stream (``HipT5Trainer.load_training_state`` resumes from it)."""
+    os.makedirs(ckpt_dir, exist_ok=True)
+    model.encoder.save_pretrained(ckpt_dir)
+    model.train_engine().save_training_state(os.path.join(ckpt_dir, "training_state.safetensors"))
+    return ckpt_dir
+
+
+def run_fit(model: PremiseRetriever, dm: RetrievalDataModule, max_steps: int, val_every: int = 0, log=print,
+            ckpt_dir: Optional[str] = None, ckpt_every: int = 0, resume_from: Optional[str] = None) -> Dict[str, Any]:
     """The training loop Lightning runs for the reference (model.py:146-181): on_fit_start, then per batch
     training_step (forward + backward) → optimizer.step (clipping, AdamW) → scheduler.step → on_train_batch_end;
-    epochs until ``max_steps``; validation every ``val_every`` steps (0: never)."""
+    epochs until ``max_steps``; validation every ``val_every`` steps (0: never).  With ``ckpt_dir`` the weights and the
+    optimizer state are written there at the end (and every ``ckpt_every`` steps); ``resume_from`` = such a directory."""
+    if getattr(dm, "batch_size", 1) <= 0:
+        raise ValueError(f"fit needs data.batch_size > 0 (got {dm.batch_size})")
     if dm.ds_train is None:
         dm.setup("fit")
     model.on_fit_start(dm.corpus)
     opt = model.configure_optimizers()
     optimizer, scheduler = opt["optimizer"], opt["lr_scheduler"]["scheduler"]
     step, losses = 0, []
+    if resume_from:
+        model.train_engine().load_training_state(os.path.join(resume_from, "training_state.safetensors"))
+        step = model.train_engine().steps
     while step < max_steps:
         n_epoch = 0
         for batch in dm.train_dataloader():
@@ -60,11 +78,15 @@ def run_fit(model: PremiseRetriever, dm: RetrievalDataModule, max_steps: int, va
             n_epoch += 1
             if val_every and step % val_every == 0:
                 log(f"step {step}: {run_validate(model, dm)}")
+            if ckpt_dir and ckpt_every and step % ckpt_every == 0 and step < max_steps:
+                save_fit_checkpoint(model, ckpt_dir)
             if step >= max_steps:
                 break
         if n_epoch == 0:
             raise ValueError("the training split yields no full batch (drop_last=True)")
-    return {"steps": step, "losses": [float(x) for x in losses]}
+    if ckpt_dir:
+        save_fit_checkpoint(model, ckpt_dir)
+    return {"steps": step, "losses": [float(x) for x in losses], "checkpoint": ckpt_dir}
 
 
 def run_validate(model: PremiseRetriever, dm: RetrievalDataModule) -> Dict[str, Any]:
@@ -75,23 +97,15 @@ def run_validate(model: PremiseRetriever, dm: RetrievalDataModule) -> Dict[str, 
         dm.setup("validate")
     if model.corpus is not dm.corpus:
         model.load_corpus(dm.corpus)
-    model.reindex_corpus(dm.eval_batch_size)
+    model.on_validation_start(dm.eval_batch_size)
+    for i, batch in enumerate(dm.val_dataloader()):
+        model.validation_step(batch, i)
+    out = model.epoch_metrics()
     k = model.num_retrieved
-    tot_recall = [0.0] * k
-    tot_mrr, tot_n = 0.0, 0
-    for batch in dm.val_dataloader():
-        emb = model._encode(batch["context_ids"], batch["context_mask"])
-        retrieved, _ = model.corpus.get_nearest_premises(model.corpus_embeddings, batch["context"], emb, k)
-        if not any(len(p) for p in batch["all_pos_premises"]):
-            continue
-        recall, mrr, n = recall_and_mrr(batch["all_pos_premises"], retrieved, k)
-        for j in range(k):
-            tot_recall[j] += recall[j] * n
-        tot_mrr += mrr * n
-        tot_n += n
-    out = {f"Recall@{j + 1}_val": tot_recall[j] / max(tot_n, 1) for j in range(k)}
-    out["MRR"] = tot_mrr / max(tot_n, 1)
-    out["num_with_premises"] = tot_n
+    for j in range(k):
+        out.setdefault(f"Recall@{j + 1}_val", 0.0)
+    out.setdefault("MRR", 0.0)
+    out["num_with_premises"] = int(model.logged_metrics.get("MRR", [0.0, 0.0])[1])
     return out
 
 
@@ -102,7 +116,10 @@ def main(argv=None) -> None:
     ap.add_argument("--val-every", type=int, default=0, help="fit: validate every N steps (0: never)")
     ap.add_argument("--config", required=True, help="YAML with `model:` and `data:` sections (reference layout)")
     ap.add_argument("--ckpt_path", default=None, help="HF checkpoint dir (overrides model.model_name)")
-    ap.add_argument("--log-dir", default=None, help="where predictions.pickle goes (trainer.log_dir upstream)")
+    ap.add_argument("--log-dir", default=None, help="where predictions.pickle goes (trainer.log_dir upstream); fit: the "
+                                                    "checkpoint is written to <log-dir>/checkpoint")
+    ap.add_argument("--ckpt-every", type=int, default=0, help="fit: also checkpoint every N steps (0: only at the end)")
+    ap.add_argument("--resume-from", default=None, help="fit: a checkpoint directory written by an earlier fit")
     args = ap.parse_args(argv)
     with open(args.config) as fh:
         cfg = yaml.safe_load(fh)
@@ -138,8 +155,14 @@ def main(argv=None) -> None:
 
             random.seed(int(seed))
             torch.manual_seed(int(seed))
-        out = run_fit(model, dm, args.max_steps or int(tcfg.get("max_steps", 1)), args.val_every)
-        print(f"fit: {out['steps']} steps, loss {out['losses'][0]:.6f} -> {out['losses'][-1]:.6f}")
+            model.dropout_seed = int(seed)  # different seeds, different dropout masks
+        if int(d.get("batch_size", 0)) <= 0:
+            raise SystemExit("fit: the config's data.batch_size must be a positive integer")
+        log_dir = args.log_dir or tcfg.get("default_root_dir") or os.getcwd()
+        out = run_fit(model, dm, args.max_steps or int(tcfg.get("max_steps", 1)), args.val_every,
+                      ckpt_dir=os.path.join(log_dir, "checkpoint"), ckpt_every=args.ckpt_every, resume_from=args.resume_from)
+        first = f"{out['losses'][0]:.6f} -> {out['losses'][-1]:.6f}" if out["losses"] else "(no step taken)"
+        print(f"fit: {out['steps']} steps, loss {first}; checkpoint {out['checkpoint']}")
     elif args.subcommand == "predict":
         log_dir = args.log_dir or cfg.get("trainer", {}).get("default_root_dir") or os.getcwd()
         os.makedirs(log_dir, exist_ok=True)

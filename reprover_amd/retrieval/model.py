@@ -88,6 +88,8 @@ class PremiseRetriever:
         self.corpus_embeddings: Optional[torch.Tensor] = None
         self.embeddings_staled = True
         self._predict_outputs: List[Dict[str, Any]] = []
+        self.logged_metrics: Dict[str, List[float]] = {}  # what validation_step logs (name -> [weighted sum, weight])
+        self.frozen = False
         self._predict_pending = None  # (batch, PendingSearch) of the last predict_step, finished lazily
         # "bf16": search the embedding matrix as it is (the reference's behaviour).  "fp8": search an
         # e4m3 copy with per-row scales (BASELINE.json configs[4]); ``corpus_embeddings`` stays what the
@@ -119,6 +121,7 @@ class PremiseRetriever:
         # T5's dropout in training mode (HF config.dropout_rate, default 0.1 - what the reference trains with); 0 = the
         # deterministic step.  Read when the training engine is built.
         self.dropout_rate: float = float(getattr(self.encoder, "cfg", {}).get("dropout_rate", 0.1))
+        self.dropout_seed: int = 3407  # the dropout masks' stream; retrieval/main.py derives it from `seed_everything`
 
     # -- construction (model.py:52-66) --------------------------------------------------------------
     @classmethod
@@ -131,6 +134,68 @@ class PremiseRetriever:
         products inside fp32 matmuls.  ``retrieve`` / ``num_retrieved`` accept k <= 1024 (the final selection sorts in
         LDS); the reference accepts any k."""
         return cls(ckpt_path, 0.0, 0, max_seq_len, 100, device=device, dtype=dtype or torch.bfloat16)
+
+    @classmethod
+    def load(cls, ckpt_path: str, device, freeze: bool = False) -> "PremiseRetriever":
+        """model.py:48-50 -> common.py:414-425 ``load_checkpoint``: build the retriever from a PyTorch-Lightning checkpoint
+        FILE of the reference's ``PremiseRetriever`` (what ``generation/model.py:82-84`` and the prover load).  Such a file
+        is a ``torch.save``d dict: ``hyper_parameters`` (``save_hyperparameters()``: model_name, lr, warmup_steps,
+        max_seq_len, num_retrieved) and ``state_dict`` whose keys carry the attribute prefix ``encoder.`` in front of the
+        HuggingFace ``T5EncoderModel`` names.  The T5 geometry comes from ``<model_name>/config.json`` when
+        ``model_name`` is a local directory, else from the tensor shapes (d_kv = 64; T5's default bucket / distance /
+        epsilon values).  A checkpoint DIRECTORY is a DeepSpeed ZeRO checkpoint (common.py:408-411): its conversion
+        script is DeepSpeed's own and out of scope here.  ``freeze`` (``model.freeze()``
+        upstream: no gradients) has nothing to switch off here - there is no autograd graph - but a frozen retriever
+        refuses ``training_step``."""
+        if not os.path.exists(ckpt_path):
+            raise FileExistsError(f"Checkpoint {ckpt_path} does not exist.")  # common.py:409-410
+        if os.path.isdir(ckpt_path):
+            if os.path.exists(os.path.join(ckpt_path, "zero_to_fp32.py")):
+                raise NotImplementedError(
+                    f"{ckpt_path} is a DeepSpeed ZeRO checkpoint: convert it with its own zero_to_fp32.py to a Lightning "
+                    "checkpoint file first (the conversion is DeepSpeed code, not part of this engine)")
+            return cls.load_hf(ckpt_path, 2048, device)  # a HuggingFace directory: the load_hf path
+        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+        if not isinstance(ckpt, dict) or "state_dict" not in ckpt:
+            raise ValueError(f"{ckpt_path} is not a PyTorch-Lightning checkpoint (no 'state_dict')")
+        hp = dict(ckpt.get("hyper_parameters") or {})
+        sd = {}
+        for k, v in ckpt["state_dict"].items():
+            if k.startswith("encoder.") and torch.is_tensor(v):
+                sd[k[len("encoder."):]] = v.detach().to(torch.float32)
+        if "shared.weight" not in sd and "encoder.embed_tokens.weight" in sd:
+            sd["shared.weight"] = sd["encoder.embed_tokens.weight"]
+        if "shared.weight" not in sd:
+            raise ValueError(f"{ckpt_path}: no T5 encoder weights under the 'encoder.' prefix")
+        cfg = cls._t5_config_from(hp.get("model_name"), sd)
+        enc = HipT5Encoder(cfg, sd, device, torch.bfloat16)
+        model = cls(enc, lr=float(hp.get("lr", 0.0)), warmup_steps=int(hp.get("warmup_steps", 0)),
+                    max_seq_len=int(hp.get("max_seq_len", 2048)), num_retrieved=int(hp.get("num_retrieved", 100)))
+        model.frozen = bool(freeze)
+        return model
+
+    @staticmethod
+    def _t5_config_from(model_name, sd: Dict[str, torch.Tensor]) -> Dict[str, Any]:
+        import json
+
+        n_layers = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.block."))
+        q = sd["encoder.block.0.layer.0.SelfAttention.q.weight"]
+        cfg = dict(vocab_size=sd["shared.weight"].shape[0], d_model=sd["shared.weight"].shape[1], d_kv=64,
+                   num_heads=q.shape[0] // 64, num_layers=n_layers,
+                   relative_attention_num_buckets=sd["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"].shape[0],
+                   relative_attention_max_distance=128, layer_norm_epsilon=1e-6, dropout_rate=0.1)
+        if "encoder.block.0.layer.1.DenseReluDense.wi_0.weight" in sd:
+            cfg.update(d_ff=sd["encoder.block.0.layer.1.DenseReluDense.wi_0.weight"].shape[0], feed_forward_proj="gated-gelu")
+        else:
+            cfg.update(d_ff=sd["encoder.block.0.layer.1.DenseReluDense.wi.weight"].shape[0], feed_forward_proj="relu")
+        if isinstance(model_name, str) and os.path.isfile(os.path.join(model_name, "config.json")):
+            with open(os.path.join(model_name, "config.json")) as fh:
+                hf = json.load(fh)
+            for k in ("d_kv", "num_heads", "relative_attention_num_buckets", "relative_attention_max_distance",
+                      "layer_norm_epsilon", "feed_forward_proj", "dropout_rate"):
+                if k in hf:
+                    cfg[k] = hf[k]
+        return cfg
 
     @classmethod
     def from_state_dict(cls, cfg: Dict, state_dict: Dict[str, torch.Tensor], max_seq_len: int, device,
@@ -293,13 +358,13 @@ class PremiseRetriever:
         if self._trainer is None:
             from ..train import HipT5Trainer
 
-            sd = getattr(self.encoder, "_state_dict_cpu", None)
+            sd = self.encoder.master_weights() if hasattr(self.encoder, "master_weights") else None
             if sd is None:
                 raise RuntimeError("training needs the encoder's fp32 weights (build the retriever from a checkpoint "
                                    "or a state dict)")
             self._trainer = HipT5Trainer(self.encoder.cfg, sd, self.device, lr=self.lr, warmup_steps=self.warmup_steps,
                                          gradient_clip_val=self.gradient_clip_val, out_dtype=self.encoder.dtype,
-                                         dropout_rate=self.dropout_rate)
+                                         dropout_rate=self.dropout_rate, dropout_seed=self.dropout_seed)
             self.encoder = self._trainer.encoder
             self._drop_derived()
         return self._trainer
@@ -312,10 +377,48 @@ class PremiseRetriever:
         self.corpus_embeddings = None
         self.embeddings_staled = True
 
+    # -- validation (model.py:212-268) ----------------------------------------------------------------
+    def log(self, name: str, value, on_epoch: bool = True, sync_dist: bool = True, batch_size: int = 1, **_) -> None:
+        """Lightning's ``self.log(..., on_epoch=True, batch_size=n)``: the epoch value is the mean over the steps weighted
+        by ``batch_size``.  Kept in ``logged_metrics`` (name -> [weighted sum, weight]); read with ``epoch_metrics()``."""
+        acc = self.logged_metrics.setdefault(name, [0.0, 0.0])
+        acc[0] += float(value) * batch_size
+        acc[1] += batch_size
+
+    def epoch_metrics(self) -> Dict[str, float]:
+        return {k: (v[0] / v[1] if v[1] else 0.0) for k, v in self.logged_metrics.items()}
+
+    def on_validation_start(self, eval_batch_size: Optional[int] = None) -> None:
+        """model.py:212-213: re-index the corpus with the datamodule's eval batch size (argument, or
+        ``self.trainer.datamodule.eval_batch_size`` when a Lightning-style trainer object is attached)."""
+        if eval_batch_size is None:
+            tr = getattr(self, "trainer", None)
+            eval_batch_size = tr.datamodule.eval_batch_size if tr is not None else 64
+        self.logged_metrics = {}
+        self.reindex_corpus(eval_batch_size)
+
+    def validation_step(self, batch: Dict[str, Any], batch_idx: int = 0) -> None:
+        """model.py:215-268: retrieve for the batch, then Recall@1..k (in %) and MRR over the examples that have positive
+        premises, logged with ``batch_size = num_with_premises`` as upstream."""
+        from .evaluate import recall_and_mrr
+
+        context_emb = self._encode(batch["context_ids"], batch["context_mask"])
+        assert not self.embeddings_staled
+        retrieved, _ = self.corpus.get_nearest_premises(self.corpus_embeddings, batch["context"], context_emb,
+                                                        self.num_retrieved)
+        if not any(len(p) for p in batch["all_pos_premises"]):
+            return  # (upstream logs the mean of an empty list - NaN with batch_size 0 - here: nothing)
+        recall, mrr, n = recall_and_mrr(batch["all_pos_premises"], retrieved, self.num_retrieved)
+        for j in range(self.num_retrieved):
+            self.log(f"Recall@{j + 1}_val", recall[j], on_epoch=True, sync_dist=True, batch_size=n)
+        self.log("MRR", mrr, on_epoch=True, sync_dist=True, batch_size=n)
+
     def training_step(self, batch: Dict[str, Any], _=None) -> torch.Tensor:
         """model.py:155-167: the contrastive loss of ``forward`` on a training batch (``collate`` with is_train) - and,
         since nothing records a graph here, its backward: on return every parameter's gradient lies in
         ``train_engine().grads`` (all five encodes run as ONE packed pass).  Returns the loss (0-dim fp32 device tensor)."""
+        if getattr(self, "frozen", False):
+            raise RuntimeError("this retriever was loaded with freeze=True")
         tr = self.train_engine()
         groups = [(batch["context_ids"], batch["context_mask"]), (batch["pos_premise_ids"], batch["pos_premise_mask"])]
         groups += list(zip_strict(batch["neg_premises_ids"], batch["neg_premises_mask"]))

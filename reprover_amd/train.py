@@ -200,13 +200,20 @@ class HipT5Trainer:
         from safetensors.torch import save_file
 
         save_file({"params": self.params.cpu(), "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(),
-                   "steps": torch.tensor([self.steps], dtype=torch.int64)}, path)
+                   "steps": torch.tensor([self.steps], dtype=torch.int64),
+                   # the dropout stream: a resumed run continues the mask sequence instead of replaying it from forward 0
+                   "dropout": torch.tensor([self.dropout_seed, self._forwards], dtype=torch.int64)}, path)
 
     def load_training_state(self, path: str) -> None:
         from safetensors.torch import load_file
 
         st = load_file(path)
-        assert st["params"].numel() == self.params.numel(), "the state belongs to another geometry"
+        for key, mine in (("params", self.params), ("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+            if key not in st or st[key].numel() != mine.numel():
+                raise ValueError(f"{path}: '{key}' has {st[key].numel() if key in st else 'no'} elements, this encoder's flat "
+                                 f"layout has {mine.numel()} (the state belongs to another geometry)")
+        if "dropout" in st:
+            self.dropout_seed, self._forwards = int(st["dropout"][0]), int(st["dropout"][1])
         self.params.copy_(st["params"])
         self.exp_avg.copy_(st["exp_avg"])
         self.exp_avg_sq.copy_(st["exp_avg_sq"])

@@ -218,3 +218,64 @@ def test_bench_launches_its_own_ranks():
     assert d["config"]["sharded_merge_equals_single_gpu"] is True
     assert d["config"]["collectives_per_step"] == 2
     assert d["config"]["all_counts_eq_k"] is True
+
+
+def test_load_lightning_checkpoint_file(workdir, tmp_path):
+    """PremiseRetriever.load(ckpt_path, device, freeze) (reference retrieval/model.py:48-50 -> common.py:414-425): a
+    PyTorch-Lightning checkpoint FILE - ``state_dict`` under the ``encoder.`` attribute prefix + ``hyper_parameters`` as
+    ``save_hyperparameters()`` records them - gives the retriever the HF directory of the same weights gives, bit for bit;
+    the geometry comes from the tensor shapes when ``model_name`` is not a local directory.  (Written here in Lightning's
+    layout: pytorch_lightning itself is not in this image, so the file cannot come from the reference's own trainer.)"""
+    d, ckpt, cpath, sdir, splits, cfg, sd = workdir
+    state = {"encoder." + k: v.clone() for k, v in sd.items()}
+    state["some_metric.total"] = torch.zeros(())  # non-encoder entries are ignored (strict=False upstream)
+    path = str(tmp_path / "last.ckpt")
+    torch.save({"epoch": 3, "global_step": 1000, "pytorch-lightning_version": "2.0.0", "state_dict": state,
+                "hyper_parameters": {"model_name": "google/byt5-small", "lr": 1e-4, "warmup_steps": 2000,
+                                     "max_seq_len": 256, "num_retrieved": 10}}, path)
+    a = PremiseRetriever.load(path, "cuda:0", freeze=True)
+    b = PremiseRetriever.load_hf(ckpt, 256, "cuda:0")
+    assert (a.max_seq_len, a.num_retrieved, a.lr, a.warmup_steps) == (256, 10, 1e-4, 2000)
+    for key in ("d_model", "num_heads", "num_layers", "d_ff", "vocab_size"):
+        assert a.encoder.cfg[key] == cfg[key], key
+    texts = ["theorem foo (a b : Nat) : a + b = b + a", "x"]
+    assert torch.equal(a.encode_texts(texts), b.encode_texts(texts))
+    with pytest.raises(RuntimeError, match="freeze"):
+        a.training_step({})
+    with pytest.raises(FileExistsError):
+        PremiseRetriever.load(str(tmp_path / "missing.ckpt"), "cuda:0", freeze=False)
+    ds = tmp_path / "zero_ckpt"
+    ds.mkdir()
+    (ds / "zero_to_fp32.py").write_text("# DeepSpeed's conversion script lives here")
+    with pytest.raises(NotImplementedError, match="DeepSpeed"):
+        PremiseRetriever.load(str(ds), "cuda:0", freeze=False)
+    # a HuggingFace directory goes the load_hf way
+    c = PremiseRetriever.load(ckpt, "cuda:0", freeze=False)
+    assert torch.equal(c.encode_texts(texts), b.encode_texts(texts))
+
+
+def test_validation_hooks_on_the_class(workdir):
+    """on_validation_start / validation_step as methods of PremiseRetriever (reference retrieval/model.py:212-268), called
+    the way Lightning calls them, give the epoch metrics run_validate reports (the oracle's Recall@k / MRR)."""
+    from reprover_amd.retrieval.datamodule import RetrievalDataModule
+
+    d, ckpt, cpath, sdir, splits, cfg, sd = workdir
+    model = PremiseRetriever.load_hf(ckpt, 256, "cuda:0")
+    model.num_retrieved = 10
+    dm = RetrievalDataModule(sdir, cpath, 16, 256, model.tokenizer)
+    dm.setup("validate")
+    model.load_corpus(dm.corpus)
+
+    class _Trainer:  # the attribute Lightning sets; only datamodule.eval_batch_size is read
+        datamodule = dm
+
+    model.trainer = _Trainer()
+    model.on_validation_start()
+    assert not model.embeddings_staled
+    for i, batch in enumerate(dm.val_dataloader()):
+        assert model.validation_step(batch, i) is None
+    got = model.epoch_metrics()
+    want = main_cli.run_validate(model, dm)
+    assert set(f"Recall@{j + 1}_val" for j in range(10)) <= set(got) and "MRR" in got
+    for k_, v_ in got.items():
+        assert abs(v_ - want[k_]) < 1e-12, k_

@@ -139,6 +139,22 @@ def test_product_training_api_learns_and_reindexes(tmp_path):
     model.encoder.save_pretrained(str(tmp_path / "ckpt"))
     again = PremiseRetriever.load_hf(str(tmp_path / "ckpt"), 256, "cuda:0")
     assert torch.equal(again.encode_texts(["theorem foo : a = b"]).float().cpu(), after)
+    # the checkpoint a `fit` run leaves behind (what Lightning's ModelCheckpoint is to the reference): an HF directory of the
+    # current weights + the optimizer state; a second run resumes from it at the step it stopped
+    fresh = PremiseRetriever.from_state_dict(cfg, synth.synth_state_dict(cfg, seed=5), 256, "cuda:0")
+    fresh.lr, fresh.warmup_steps, fresh.gradient_clip_val, fresh.num_retrieved = 2e-3, 2, 1.0, 10
+    out2 = run_fit(fresh, dm, max_steps=5, ckpt_dir=str(tmp_path / "fit" / "checkpoint"))
+    assert out2["steps"] == 5 and os.path.exists(tmp_path / "fit" / "checkpoint" / "training_state.safetensors")
+    trained = fresh.encode_texts(["theorem foo : a = b"]).float().cpu()
+    from_ckpt = PremiseRetriever.load_hf(str(tmp_path / "fit" / "checkpoint"), 256, "cuda:0")
+    assert torch.equal(from_ckpt.encode_texts(["theorem foo : a = b"]).float().cpu(), trained)
+    from_ckpt.lr, from_ckpt.warmup_steps, from_ckpt.gradient_clip_val, from_ckpt.num_retrieved = 2e-3, 2, 1.0, 10
+    out3 = run_fit(from_ckpt, dm, max_steps=7, resume_from=str(tmp_path / "fit" / "checkpoint"))
+    assert out3["steps"] == 7 and len(out3["losses"]) == 2  # 5 steps were already taken
+    assert from_ckpt.train_engine()._forwards == fresh.train_engine()._forwards + 2  # the dropout stream continued
+    dm.batch_size = 0
+    with pytest.raises(ValueError, match="batch_size"):
+        run_fit(model, dm, max_steps=1)
 
 
 def test_full_depth_gradients_against_the_oracle():
@@ -226,7 +242,7 @@ class _DeviceMasks:
         m = torch.ones(len(self.lens), H, self.L, self.L)
         for b, (s0, n) in enumerate(zip(self.starts, self.lens)):
             for h in range(H):
-                m[b, h, :n, :n] = self._mask(16 + 8 * i, s0, h << 12, n, n)
+                m[b, h, :n, :n] = self._mask(16 + 8 * i, s0, h << 20, n, n)
         return m
 
 
