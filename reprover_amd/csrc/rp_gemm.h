@@ -55,8 +55,12 @@ __device__ unsigned long long g_handover_ts[8 * 64 * 3];
 __device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 // Tile configuration: block tile BM x BN x BK, WM x WN waves, NSTAGE-deep LDS ring.
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSTAGE_, int PIPE_ = 0, int FP8_ = 0, int AAUX_ = 0>
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSTAGE_, int PIPE_ = 0, int FP8_ = 0, int AAUX_ = 0, int KTAIL_ = 0>
 struct GemmCfg {
+  // KTAIL = 1 (gemm_tile_pipe): K may end half a k-tile early (K % BK == BK / 2).  The last tile then carries only its
+  // first half: the lanes whose 16-byte chunk lies in the missing half fetch the chunk BK/2 earlier instead (a duplicate,
+  // never multiplied, never out of bounds) and the tile runs half its k-steps.
+  static constexpr int KTAIL = KTAIL_;
   static constexpr int AAUX = AAUX_;  // cache-policy bits of the A operand's LDS-DMA (2 = nt: streamed once)
   // FP8 = 1: the operands are e4m3 bytes, addressed as if they were bf16 rows of half the length (BK,
   // K and the operands' ld all count 2-byte units); only the fragment reads and the MFMA differ.
@@ -299,7 +303,13 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
     const int kc = (lane % C::SLOTS) ^ C::swz(row);
     w_src[d] = W.ptr + W.row_off(tile_n * C::BN + row, kc);
   }
-  const int nk = K / BK;
+  const int nk = C::KTAIL != 0 ? (K + BK / 2) / BK : K / BK;  // (KTAIL: K % BK is 0 or BK / 2)
+  const bool has_tail = C::KTAIL != 0 && nk * BK != K;
+  // tail tile: element offset added to the DMA source of lanes whose chunk lies beyond K (0 for the others).  With 128-byte
+  // rows (8 rows, 8 chunks per DMA piece) the swizzle's top bit is the parity of the piece index, so the chunk lies in the
+  // upper half iff ((lane >> 2) ^ piece) & 1: two values per lane, one for even and one for odd pieces.
+  static_assert(C::KTAIL == 0 || (BK == 64 && C::SLOTS == 8 && C::ROWS_PER_DMA == 8), "KTAIL: 128-byte rows");
+  const int fix_lane = (lane >> 2) & 1;
   if constexpr (has_prologue<Epilogue>::value) epi.prologue(smem + C::RING_BYTES, wave, lane, tile_n * C::BN);
   // half 0: the A image of a stage, half 1: the W image (issued one k-step apart, see tile_body)
   auto stage_half = [&](int kt, int buf, int half) {
@@ -313,21 +323,24 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
 #if defined(RP_PHASE_PROBE) && defined(RP_PROBE_SAME_TILE)
     kt = kt & 1;  // timing only: every refill re-reads the first two K-tiles (L2 hits)
 #endif
+    const int fix_mask = (C::KTAIL != 0 && has_tail && kt == nk - 1) ? -1 : 0;  // (scalar)
     if (half == 0) {
 #pragma unroll
       for (int d = 0; d < C::A_DMA; ++d) {
+        const bf16_t* src = a_src[d] + A.k_off(kt, BK);
+        if constexpr (C::KTAIL != 0) src += ((((fix_lane ^ (wave * C::A_DMA + d)) & 1) ? -(BK / 2) : 0) & fix_mask);
         if constexpr (C::AAUX == 2)
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + A.k_off(kt, BK)),
-                                           (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024), 16, 0, 2);
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024), 16, 0, 2);
         else
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + A.k_off(kt, BK)),
-                                           (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024), 16, 0, 0);
       }
     } else {
 #pragma unroll
-      for (int d = 0; d < C::W_DMA; ++d)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[d] + W.k_off(kt, BK)),
-                                         (lds_ptr_t)(base + C::A_BYTES + (wave * C::W_DMA + d) * 1024), 16, 0, 0);
+      for (int d = 0; d < C::W_DMA; ++d) {
+        const bf16_t* src = w_src[d] + W.k_off(kt, BK);
+        if constexpr (C::KTAIL != 0) src += ((((fix_lane ^ (wave * C::W_DMA + d)) & 1) ? -(BK / 2) : 0) & fix_mask);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + C::A_BYTES + (wave * C::W_DMA + d) * 1024), 16, 0, 0);
+      }
     }
   };
   auto stage = [&](int kt, int buf) {
@@ -373,6 +386,15 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
 #pragma unroll
       for (int f = 0; f < FN; ++f) bfr[p][f] = *reinterpret_cast<const bf16x8*>(st + b_off[f][ks]);
     }
+  };
+  auto zero_a_if = [&](int p, bool z) {
+#pragma unroll
+    for (int f = 0; f < FM; ++f)
+#pragma unroll
+      for (int e = 0; e < (int)(sizeof(frag_t) / 4); ++e) {
+        int v = reinterpret_cast<int*>(&af[p][f])[e];
+        reinterpret_cast<int*>(&af[p][f])[e] = z ? 0 : v;
+      }
   };
   auto mma = [&](int p) {
 #pragma unroll
@@ -436,10 +458,16 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
     constexpr int MODE = decltype(mode_tag)::value;
     constexpr bool PEND = decltype(pend_tag)::value != 0;
     const char* st = smem + buf * C::STAGE_BYTES;
+    // KTAIL: the last tile of a K that ends half a tile early multiplies its lower k-steps only: the A fragments of the
+    // upper ones are replaced by zeros (selects, no branch: a branch around MFMAs made the register allocator copy
+    // accumulators), and acc + (+0 x b) is acc bit for bit - an accumulator that starts at +0 never holds -0, and the
+    // duplicate chunks the B side reads are finite values of the operand itself
+    const bool half_tile = C::KTAIL != 0 && MODE == 0 && has_tail;
 #pragma unroll
     for (int ks = 0; ks < KS - 1; ++ks) {
       read_frags(st, ks + 1, (ks + 1) & 1);
       if (PEND && ks == 0) stage_half(kt - 1 + NSTAGE, buf == 0 ? NSTAGE - 1 : buf - 1, 1);
+      if (C::KTAIL != 0 && MODE == 0 && ks >= KS / 2) zero_a_if(ks & 1, half_tile);
       mma(ks & 1);
       if (PEND && ks == 0)
         hint_order(Reads(), std::integral_constant<int, C::W_DMA>());
@@ -462,6 +490,7 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
       read_frags(smem + buf * C::STAGE_BYTES, 0, 0);
       if (MODE == 2) stage_half(kt + NSTAGE, freed, 0);
     }
+    if (C::KTAIL != 0 && MODE == 0) zero_a_if((KS - 1) & 1, half_tile);
     mma((KS - 1) & 1);
     if (MODE == 2)
       hint_order(Reads(), std::integral_constant<int, C::A_DMA>());
@@ -479,7 +508,7 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
     ++kt;
   }
   for (; kt + 1 < nk; ++kt) tile_body(kt, I1(), I0());
-  tile_body(kt, I0(), I0());
+  tile_body(kt, I0(), I0());  // (a half tile skips its upper k-steps inside the body: no second set of MFMA code)
   __syncthreads();
   RP_TS(2);
 

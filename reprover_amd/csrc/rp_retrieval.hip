@@ -44,6 +44,8 @@ typedef GemmCfg<128, 64, 32, 2, 2, 6, 0, 1> SimCfg8Sample;
 // fragment, so the per-query bound sits in 4 registers and the pre-test is one v_cmp per score (EpiSimFilter).
 typedef GemmCfg<256, 256, 64, 2, 2, 2, 1> SimCfgFilter;
 typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 1> SimCfg8Filter;
+// the same for rows that end half a k-tile early (D = 1472 e4m3 bytes = 11.5 tiles of 128): GemmCfg::KTAIL
+typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 1, 0, 1> SimCfg8FilterTail;
 // the same tile with 32-wide K slices in a 4-deep ring: three slices (48 KB of premises) in flight per CU instead of
 // one (32 KB) - the premise operand streams from HBM, not from L2 like an encoder GEMM's weights
 typedef GemmCfg<256, 256, 32, 2, 2, 4, 1> SimCfgFilterK32;
@@ -809,7 +811,7 @@ struct SimPlan {
 };
 
 // D2 = operand row length in 2-byte units
-static SimPlan plan_sim(int B, int N, int D2, int k, int flags) {
+static SimPlan plan_sim(int B, int N, int D2, int k, int flags, bool fp8 = false) {
   SimPlan p;
   p.bm = (B > 128 && g_scan_cfg != 1) ? 256 : 128;
   p.tiles_q = (B + p.bm - 1) / p.bm;
@@ -830,7 +832,9 @@ static SimPlan plan_sim(int B, int N, int D2, int k, int flags) {
   // second-generation filter: needs whole 128-B operand rows per K-tile; its 256-query tile does the MFMA work of
   // 256 queries whatever B is, so small batches (single-state queries) stay on the first-generation kernel, whose
   // 128-query tiles are HBM-bound there (measured at B = 1: 142 vs 171 us per call)
-  p.new_filter = !p.dense_only && g_scan_impl == 0 && (D2 % 64 == 0) && (B > 128 || g_scan_impl_force_new);
+  // (e4m3 rows may end half a k-tile early - 1472 bytes = 11.5 x 128: SimCfg8FilterTail)
+  p.new_filter = !p.dense_only && g_scan_impl == 0 && (D2 % 64 == 0 || (fp8 && D2 % 64 == 32 && D2 > 64)) &&
+                 (B > 128 || g_scan_impl_force_new);
   p.sample_blocks = p.dense_only ? 0 : (p.blocks + stride - 1) / stride;
   p.filter_blocks = p.dense_only ? 0 : p.blocks - p.sample_blocks;
   p.dense_ld = p.dense_only ? (size_t)p.tiles_p * 128 : (size_t)p.sample_blocks * SIM_PB;
@@ -922,7 +926,7 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   if (file_of) RP_REQUIRE(end_key && file_bits_t && own_file && q_key && F > 0, "mask arrays incomplete");
   hipStream_t stream = (hipStream_t)stream_;
   const int D2 = fp8 ? D / 2 : D;  // row length in 2-byte units
-  const SimPlan p = plan_sim(B, N, D2, k, flags);
+  const SimPlan p = plan_sim(B, N, D2, k, flags, fp8);
   if (!workspace || workspace_bytes < p.bytes)
     return fail(RP_E_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, p.bytes);
   char* ws = (char*)workspace;
@@ -1026,7 +1030,8 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
     if (fp8) {
       EpiSimFilter<1> ef;
       fill(ef);
-      st = launch_filter_cfg<SimCfg8Filter>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+      st = (D2 % 64 == 0) ? launch_filter_cfg<SimCfg8Filter>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
+                          : launch_filter_cfg<SimCfg8FilterTail>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
     } else {
       EpiSimFilter<0> ef;
       fill(ef);
