@@ -43,7 +43,7 @@ enum {
 enum { RP_DT_F32 = 0, RP_DT_BF16 = 1 };
 
 /* ABI / build identification; bumps when a signature changes. */
-int32_t rp_abi_version(void);   /* 3 */
+int32_t rp_abi_version(void);   /* 4 */
 /* Message of the last error returned on this thread ("" if none). */
 const char* rp_last_error(void);
 
@@ -165,7 +165,8 @@ size_t   rp_sim_topk_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t k,
  *                max(8192, 8 k stride) + k candidate keys per query (about k * stride lie above the sampled bound); a
  *                query that would need more - adversarial score distributions, or a sample with fewer than k accessible
  *                rows, which yields no bound - reports -1 and every caller repeats the search with the dense plan.
- *   k <= 1024 (the final selection sorts in LDS); the reference accepts any k.              */
+ *   k <= 1024 per call (the final selection sorts in LDS).  The reference accepts any k (common.py:299-326):
+ *   rp_sim_topk_after continues the same ranking page by page, which is how the host shim serves k > 1024.    */
 RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t N, int32_t D,
                      const int32_t* file_of, const int64_t* end_key,
                      const uint32_t* file_bits_t, int32_t F,
@@ -173,6 +174,20 @@ RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t N, int32_t
                      int32_t id_offset, int32_t k, int32_t flags,
                      float* out_scores, int32_t* out_ids, int32_t* out_count,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* The next page of rp_sim_topk's ranking: identical arguments plus, per query, the LAST entry of what the caller already
+ * holds - after_score device f32 [B], after_id device int32 [B] (the id as written by the previous call, id_offset
+ * included; after_id[j] < 0: no bound for query j).  Only premises that come strictly after (after_score[j], after_id[j])
+ * in the (score descending, id ascending) order qualify; out_count counts those (min(k, remaining accessible)).  Pages
+ * concatenate to exactly what one call with a larger k would return: the order is total (ids break ties).          */
+RpStatus rp_sim_topk_after(const void* Q, const void* E, int32_t B, int32_t N, int32_t D,
+                           const int32_t* file_of, const int64_t* end_key,
+                           const uint32_t* file_bits_t, int32_t F,
+                           const int32_t* own_file, const int64_t* q_key,
+                           int32_t id_offset, const float* after_score, const int32_t* after_id,
+                           int32_t k, int32_t flags,
+                           float* out_scores, int32_t* out_ids, int32_t* out_count,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * e4m3 index (BASELINE.json configs[4]: fp8 similarity).  No reference counterpart: the reference
@@ -194,6 +209,16 @@ RpStatus rp_sim_topk_fp8(const void* Q8, const float* q_scale, const void* E8, c
                          int32_t id_offset, int32_t k, int32_t flags,
                          float* out_scores, int32_t* out_ids, int32_t* out_count,
                          void* workspace, size_t workspace_bytes, void* stream);
+
+RpStatus rp_sim_topk_fp8_after(const void* Q8, const float* q_scale, const void* E8, const float* e_scale,
+                               int32_t B, int32_t N, int32_t D,
+                               const int32_t* file_of, const int64_t* end_key,
+                               const uint32_t* file_bits_t, int32_t F,
+                               const int32_t* own_file, const int64_t* q_key,
+                               int32_t id_offset, const float* after_score, const int32_t* after_id,
+                               int32_t k, int32_t flags,
+                               float* out_scores, int32_t* out_ids, int32_t* out_count,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* Merge R per-rank results (as gathered by an RCCL all-gather) into the global top-k.
  *   scores device f32 [R, B, k], ids device int32 [R, B, k], counts device int32 [R, B]

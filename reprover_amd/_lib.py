@@ -18,7 +18,7 @@ RP_OK = 0
 RP_DT_F32, RP_DT_BF16 = 0, 1
 RP_TOPK_AUTO, RP_TOPK_DENSE = 0, 1
 RP_EPI_STORE_BF16, RP_EPI_RESID, RP_EPI_GEGLU_BF16 = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 KERNEL_CLASSES = ["embed", "rmsnorm", "gemm_qkv", "attention", "gemm_o", "gemm_wi", "gemm_wo", "pool", "scan",
                   "select", "scan_sample", "bwd_dgrad", "bwd_wgrad", "bwd_attention", "bwd_other", "optimizer", "collective"]
 
@@ -80,6 +80,12 @@ SIGNATURES = {
          C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
          C.c_size_t, C.c_void_p],
     ),
+    "rp_sim_topk_after": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+         C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
     "rp_quantize_rows_e4m3": (
         C.c_int32,
         [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
@@ -89,6 +95,12 @@ SIGNATURES = {
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
          C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
          C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
+    "rp_sim_topk_fp8_after": (
+        C.c_int32,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+         C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
     "rp_topk_merge_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "rp_topk_merge": (

@@ -173,6 +173,9 @@ class File:
         return self.premises == []
 
 
+MAX_K_PER_CALL = 1024  # keys one rp_sim_topk call selects and sorts per query (include/reprover_hip.h)
+
+
 class Corpus:
     """The retrieval corpus: a DAG of files whose premises can be retrieved (common.py:181-326)."""
 
@@ -407,7 +410,12 @@ class Corpus:
         k: int,
         dense: bool = False,
     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        """Device-side search: (ids int32 [B,k], scores f32 [B,k], counts int32 [B]) on the GPU."""
+        """Device-side search: (ids int32 [B,k], scores f32 [B,k], counts int32 [B]) on the GPU.  One library call sorts
+        at most ``MAX_K_PER_CALL`` = 1024 keys per query; a larger k (the reference accepts any, common.py:299-326) is
+        served page by page - ``rp_sim_topk_after`` continues the ranking behind the last entry of the page before -
+        and the pages concatenate to exactly the single-call answer (the order is total: ids break ties)."""
+        if k > MAX_K_PER_CALL:
+            return self._nearest_premise_ids_paged(premise_embeddings, batch_context, batch_context_emb, k, dense)
         lib = _lib.load()
         dev = batch_context_emb.device
         if dev.type != "cuda":
@@ -450,6 +458,60 @@ class Corpus:
             ),
             "rp_sim_topk",
         )
+        return out_i, out_s, out_c
+
+    def _nearest_premise_ids_paged(self, premise_embeddings, batch_context, batch_context_emb, k: int, dense: bool):
+        lib = _lib.load()
+        dev = batch_context_emb.device
+        if dev.type != "cuda":
+            raise _lib.HipLibraryError("nearest-premise search runs on the GPU only (no CPU fallback)")
+        fp8 = isinstance(premise_embeddings, Fp8Index)
+        E = premise_embeddings if fp8 else as_bf16_matrix(premise_embeddings, dev)
+        Q = Fp8Index.quantize(batch_context_emb) if fp8 else as_bf16_matrix(batch_context_emb, dev)
+        B, D = Q.shape
+        N = E.shape[0]
+        file_of, end_key = self._device_arrays(dev)
+        d_bits, d_own, d_qk = self.device_query_masks(batch_context, dev)
+        out_s = torch.full((B, k), float("-inf"), dtype=torch.float32, device=dev)
+        out_i = torch.full((B, k), -1, dtype=torch.int32, device=dev)
+        out_c = torch.zeros((B,), dtype=torch.int32, device=dev)
+        flags = _lib.RP_TOPK_DENSE if dense else _lib.RP_TOPK_AUTO
+        P = MAX_K_PER_CALL
+        ws_bytes = lib.rp_sim_topk_workspace_bytes(B, N, D, P, flags)
+        ws = _workspace(dev, ws_bytes)
+        pg_s = torch.empty((B, P), dtype=torch.float32, device=dev)
+        pg_i = torch.empty((B, P), dtype=torch.int32, device=dev)
+        pg_c = torch.empty((B,), dtype=torch.int32, device=dev)
+        after_s = torch.zeros((B,), dtype=torch.float32, device=dev)
+        after_i = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        masks = (_lib.ptr(file_of), _lib.ptr(end_key), _lib.ptr(d_bits), len(self._files), _lib.ptr(d_own), _lib.ptr(d_qk), 0)
+        for lo in range(0, k, P):
+            kk = min(P, k - lo)
+            ps, pi = pg_s.view(-1)[: B * kk].view(B, kk), pg_i.view(-1)[: B * kk].view(B, kk)  # the call writes [B, kk] rows
+            outs = (kk, flags, _lib.ptr(ps), _lib.ptr(pi), _lib.ptr(pg_c), _lib.ptr(ws), ws_bytes, _lib.current_stream())
+            if fp8:
+                head = (_lib.ptr(Q.codes), _lib.ptr(Q.scale), _lib.ptr(E.codes), _lib.ptr(E.scale), B, N, D)
+                st = (lib.rp_sim_topk_fp8(*head, *masks, *outs) if lo == 0 else
+                      lib.rp_sim_topk_fp8_after(*head, *masks, _lib.ptr(after_s), _lib.ptr(after_i), *outs))
+            else:
+                head = (_lib.ptr(Q), _lib.ptr(E), B, N, D)
+                st = (lib.rp_sim_topk(*head, *masks, *outs) if lo == 0 else
+                      lib.rp_sim_topk_after(*head, *masks, _lib.ptr(after_s), _lib.ptr(after_i), *outs))
+            _lib.check(st, "rp_sim_topk (page)")
+            if bool((pg_c < 0).any()):  # candidate overflow on this page: the whole search again, dense plan
+                if dense:
+                    raise _lib.HipLibraryError("rp_sim_topk reported an overflow under RP_TOPK_DENSE")
+                return self._nearest_premise_ids_paged(premise_embeddings, batch_context, batch_context_emb, k, True)
+            out_s[:, lo : lo + kk] = ps
+            out_i[:, lo : lo + kk] = pi
+            out_c += pg_c
+            # the next page starts behind this page's last entry; a query whose page came back short has nothing left
+            full = pg_c == kk
+            last = (pg_c.clamp(min=1) - 1).long().unsqueeze(1)
+            after_s = torch.where(full, ps.gather(1, last).squeeze(1), torch.full_like(after_s, float("-inf"))).contiguous()
+            after_i = torch.where(full, pi.gather(1, last).squeeze(1), torch.full_like(after_i, 2 ** 31 - 1)).contiguous()
+            if not bool(full.any()):
+                break
         return out_i, out_s, out_c
 
     def launch_nearest_premises(

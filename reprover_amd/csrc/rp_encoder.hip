@@ -88,7 +88,7 @@ void prof_end(hipStream_t stream) {
 
 using namespace rp;
 
-extern "C" int32_t rp_abi_version(void) { return 3; }
+extern "C" int32_t rp_abi_version(void) { return 4; }
 extern "C" const char* rp_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" RpStatus rp_set_option(const char* name, int32_t value) {

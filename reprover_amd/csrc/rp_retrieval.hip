@@ -82,6 +82,9 @@ struct EpiSim {
   // e4m3 operands: score = acc * q_scale[query] * e_scale[premise] (NULL: bf16 operands, score = acc)
   const float* q_scale;
   const float* e_scale;
+  // paging (rp_sim_topk_after): only keys strictly BELOW key(after_score[q], after_id[q]) qualify (NULL: no bound)
+  const float* after_score;
+  const int32_t* after_id;
   // output
   int filter;          // 0: dense write, 1: append keys > thr
   uint64_t* dense;     // [B, dense_ld]
@@ -112,9 +115,11 @@ struct EpiSim {
     int64_t* s_qk = reinterpret_cast<int64_t*>(smem + 2048);            // [bm]
     uint64_t* s_thr = reinterpret_cast<uint64_t*>(smem + 2048 + 2048);  // [bm]
     float* s_qs = reinterpret_cast<float*>(smem + 6144);                // [bm]
+    uint64_t* s_upper = reinterpret_cast<uint64_t*>(smem + 7168);       // [bm] keys >= this are not candidates
     for (int t = threadIdx.x; t < bm; t += blockDim.x) {
       const int q = tile_q0 + t;
       const bool ok = q < B;
+      s_upper[t] = (ok && after_id && after_id[q] >= 0) ? make_key(after_score[q], after_id[q]) : ~0ull;
       s_qs[t] = (ok && q_scale) ? q_scale[q] : 1.f;
       s_own[t] = (ok && file_of) ? own_file[q] : -1;
       s_qk[t] = (ok && file_of) ? q_key[q] : 0;
@@ -159,7 +164,8 @@ struct EpiSim {
             bool ok = pvalid && (q < B);
             if (file_of) ok = ok && accessible(w[i], rr, f, ek, s_own[ql], s_qk[ql]);
             const float sc = q_scale ? (acc[i][j][r] * s_qs[ql]) * es : acc[i][j][r];
-            const uint64_t key = ok ? make_key(sc, id) : 0ull;
+            uint64_t key = ok ? make_key(sc, id) : 0ull;
+            if (key >= s_upper[ql]) key = 0ull;
             if (q < B && (p + slot_shift) < (int)dense_ld) dense[(size_t)q * dense_ld + p + slot_shift] = key;
           }
       } else {
@@ -177,7 +183,7 @@ struct EpiSim {
               bool ok = pvalid && (q < B);
               if (file_of) ok = ok && accessible(w[i], rr, f, ek, s_own[ql], s_qk[ql]);
               const uint64_t key = ok ? make_key(sc, id) : 0ull;
-              if (key > s_thr[ql]) {
+              if (key > s_thr[ql] && key < s_upper[ql]) {
                 const int pos = atomicAdd(&count[(size_t)q * SIM_COUNT_STRIDE], 1);
                 if (pos < cap) cand[(size_t)q * cap + pos] = key;
               }
@@ -357,6 +363,8 @@ struct GatherArgs {
   const int32_t* own_file;
   const int64_t* q_key;
   const uint64_t* thr;
+  const float* after_score;  // paging bound (NULL: none), as EpiSim
+  const int32_t* after_id;
   uint64_t* cand;  // [B, cap]: entries [0, count) hold the sample's top keys on entry
   size_t cap;
   int32_t* count;  // [B * SIM_COUNT_STRIDE]
@@ -630,6 +638,7 @@ __global__ __launch_bounds__(THREADS) void gather_select_kernel(GatherArgs a, Se
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qt = q >> 8, qloc = q & 255;
   const uint64_t thr = a.thr[q];
+  const uint64_t upper = (a.after_id && a.after_id[q] >= 0) ? make_key(a.after_score[q], a.after_id[q]) : ~0ull;
   const int32_t own = a.file_of ? a.own_file[q] : -1;
   const int64_t qk = a.file_of ? a.q_key[q] : 0;
   uint64_t* out = a.cand + (size_t)q * a.cap;  // global copy of the key list (read back only when LDS is too small)
@@ -688,7 +697,7 @@ __global__ __launch_bounds__(THREADS) void gather_select_kernel(GatherArgs a, Se
           ok = accessible(f, a.bits_t[(size_t)f * a.bits_words + (q >> 5)], p);
         }
         const uint64_t key = make_key(__uint_as_float(en.x), p + a.id_offset);
-        if (ok && key > thr) put_key(key, atomicAdd(&s_out, 1));
+        if (ok && key > thr && key < upper) put_key(key, atomicAdd(&s_out, 1));
       }
       ++pos;
     };
@@ -730,7 +739,7 @@ __global__ __launch_bounds__(THREADS) void gather_select_kernel(GatherArgs a, Se
       bool ok = live[u];
       if (a.file_of && ok) ok = accessible(f[u], word[u], (int)en[u].y);
       const uint64_t key = make_key(__uint_as_float(en[u].x), (int32_t)en[u].y + a.id_offset);
-      ok = ok && key > thr;
+      ok = ok && key > thr && key < upper;
       const int pos = wave_append_pos(&s_out, ok);
       if (ok) put_key(key, pos);
     }
@@ -911,7 +920,8 @@ extern "C" size_t rp_sim_topk_workspace_bytes(int32_t B, int32_t N, int32_t D, i
 }
 
 // shared by the bf16 and the e4m3 entry points (q_scale/e_scale NULL = bf16 operands)
-static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale, const float* e_scale, int32_t B,
+static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale, const float* e_scale,
+                              const float* after_score, const int32_t* after_id, int32_t B,
                               int32_t N, int32_t D, const int32_t* file_of, const int64_t* end_key,
                               const uint32_t* file_bits_t, int32_t F, const int32_t* own_file, const int64_t* q_key,
                               int32_t id_offset, int32_t k, int32_t flags, float* out_scores, int32_t* out_ids,
@@ -938,8 +948,11 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
 
   GemmOperand qop{(const bf16_t*)Q, D2, B}, eop{(const bf16_t*)E, D2, N};
   EpiSim epi;
+  RP_REQUIRE((after_score == nullptr) == (after_id == nullptr), "after_score and after_id go together");
   epi.q_scale = q_scale;
   epi.e_scale = e_scale;
+  epi.after_score = after_score;
+  epi.after_id = after_id;
   epi.file_of = file_of;
   epi.end_key = end_key;
   epi.N = N;
@@ -1074,6 +1087,8 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
     ga.own_file = own_file;
     ga.q_key = q_key;
     ga.thr = thr;
+    ga.after_score = after_score;
+    ga.after_id = after_id;
     ga.cand = cand;
     ga.cap = p.cap;
     ga.count = count;
@@ -1117,8 +1132,21 @@ extern "C" RpStatus rp_sim_topk(const void* Q, const void* E, int32_t B, int32_t
                                 int32_t F, const int32_t* own_file, const int64_t* q_key, int32_t id_offset,
                                 int32_t k, int32_t flags, float* out_scores, int32_t* out_ids, int32_t* out_count,
                                 void* workspace, size_t workspace_bytes, void* stream_) {
-  return sim_topk_impl(Q, E, nullptr, nullptr, B, N, D, file_of, end_key, file_bits_t, F, own_file, q_key, id_offset, k,
-                       flags, out_scores, out_ids, out_count, workspace, workspace_bytes, stream_);
+  return sim_topk_impl(Q, E, nullptr, nullptr, nullptr, nullptr, B, N, D, file_of, end_key, file_bits_t, F, own_file, q_key,
+                       id_offset, k, flags, out_scores, out_ids, out_count, workspace, workspace_bytes, stream_);
+}
+
+// The next page of the same ranking: only premises that come strictly AFTER (after_score[q], after_id[q]) in the (score
+// descending, id ascending) order qualify - what a caller asks for when k exceeds the 1024 keys one call can sort.
+extern "C" RpStatus rp_sim_topk_after(const void* Q, const void* E, int32_t B, int32_t N, int32_t D,
+                                      const int32_t* file_of, const int64_t* end_key, const uint32_t* file_bits_t,
+                                      int32_t F, const int32_t* own_file, const int64_t* q_key, int32_t id_offset,
+                                      const float* after_score, const int32_t* after_id, int32_t k, int32_t flags,
+                                      float* out_scores, int32_t* out_ids, int32_t* out_count, void* workspace,
+                                      size_t workspace_bytes, void* stream_) {
+  RP_REQUIRE(after_score && after_id, "null paging arrays (use rp_sim_topk for the first page)");
+  return sim_topk_impl(Q, E, nullptr, nullptr, after_score, after_id, B, N, D, file_of, end_key, file_bits_t, F, own_file,
+                       q_key, id_offset, k, flags, out_scores, out_ids, out_count, workspace, workspace_bytes, stream_);
 }
 
 extern "C" RpStatus rp_sim_topk_fp8(const void* Q8, const float* q_scale, const void* E8, const float* e_scale,
@@ -1128,8 +1156,21 @@ extern "C" RpStatus rp_sim_topk_fp8(const void* Q8, const float* q_scale, const 
                                     float* out_scores, int32_t* out_ids, int32_t* out_count, void* workspace,
                                     size_t workspace_bytes, void* stream_) {
   RP_REQUIRE(q_scale && e_scale, "null scale array");
-  return sim_topk_impl(Q8, E8, q_scale, e_scale, B, N, D, file_of, end_key, file_bits_t, F, own_file, q_key, id_offset,
-                       k, flags, out_scores, out_ids, out_count, workspace, workspace_bytes, stream_);
+  return sim_topk_impl(Q8, E8, q_scale, e_scale, nullptr, nullptr, B, N, D, file_of, end_key, file_bits_t, F, own_file,
+                       q_key, id_offset, k, flags, out_scores, out_ids, out_count, workspace, workspace_bytes, stream_);
+}
+
+extern "C" RpStatus rp_sim_topk_fp8_after(const void* Q8, const float* q_scale, const void* E8, const float* e_scale,
+                                          int32_t B, int32_t N, int32_t D, const int32_t* file_of,
+                                          const int64_t* end_key, const uint32_t* file_bits_t, int32_t F,
+                                          const int32_t* own_file, const int64_t* q_key, int32_t id_offset,
+                                          const float* after_score, const int32_t* after_id, int32_t k, int32_t flags,
+                                          float* out_scores, int32_t* out_ids, int32_t* out_count, void* workspace,
+                                          size_t workspace_bytes, void* stream_) {
+  RP_REQUIRE(q_scale && e_scale, "null scale array");
+  RP_REQUIRE(after_score && after_id, "null paging arrays (use rp_sim_topk_fp8 for the first page)");
+  return sim_topk_impl(Q8, E8, q_scale, e_scale, after_score, after_id, B, N, D, file_of, end_key, file_bits_t, F, own_file,
+                       q_key, id_offset, k, flags, out_scores, out_ids, out_count, workspace, workspace_bytes, stream_);
 }
 
 // ------------------------------------------------------------------------------------------

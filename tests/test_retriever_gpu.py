@@ -334,3 +334,56 @@ def test_retrieve_from_the_reference_indexed_corpus_pickle(golden_dir):
             for r, (a, b) in enumerate(zip(got, q["ids"])):  # ids wherever the golden gap to both neighbours exceeds 2 tol
                 gap = min(abs(want[r] - want[r - 1]) if r else 1.0, abs(want[r] - want[r + 1]) if r + 1 < len(want) else 1.0)
                 assert a == b or gap <= 2e-2, (j, r, got, q["ids"])
+
+
+@pytest.mark.parametrize("index_dtype", ["bf16", "fp8"])
+def test_k_beyond_1024_is_served_in_pages(index_dtype):
+    """The reference's get_nearest_premises accepts any k (common.py:299-326); one rp_sim_topk call sorts at most 1024
+    keys per query.  Larger k goes page by page (rp_sim_topk_after continues the ranking behind the previous page's last
+    entry): the concatenation must be exactly the oracle's masked ranking on the same operands - ties included (a dozen
+    duplicated rows straddle the page boundaries) - and a query with fewer than k accessible premises raises ValueError."""
+    from reprover_amd.common import Fp8Index
+    from oracle import fp8_ref
+
+    files = synth.synth_corpus_records(40, 6000, seed=77, max_imports=8)
+    path = os.path.join(tempfile.mkdtemp(), "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    corpus, ref = Corpus(path), common_ref.CorpusRef(path)
+    N, D, B, k = len(corpus), 128, 6, 2500
+    rng = np.random.default_rng(78)
+    E = rng.standard_normal((N, D)).astype(np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    E[1000:1012] = E[999]  # exact ties: the id order decides, also across a page boundary
+    Qm = rng.standard_normal((B, D)).astype(np.float32)
+    Qm /= np.linalg.norm(Qm, axis=1, keepdims=True)
+    late = [f for f in files[-6:]]  # late files import (transitively) most of the corpus
+    ctxs = [Context(f["path"], f"t{j}", Pos(10_000, 0), f"h{j} ⊢ g") for j, f in enumerate(late)]
+    rctx = [common_ref.ContextRef(c.path, c.theorem_full_name, common_ref.Pos(*c.theorem_pos), c.state) for c in ctxs]
+    n_acc = [int(corpus.accessible_mask(c.path, c.theorem_pos).sum()) for c in ctxs]
+    keep = [j for j in range(B) if n_acc[j] >= k]
+    assert len(keep) >= 3, n_acc
+    Ed, Qd = torch.from_numpy(E).cuda(), torch.from_numpy(Qm).cuda()
+    where = {id(p): i for i, p in enumerate(corpus.all_premises)}
+    if index_dtype == "bf16":
+        Eb, Qb = _bf16_round(E), _bf16_round(Qm)
+        operand, tol = Ed, 1e-5
+        want_i, want_s = ref.get_nearest_premises(Eb, [rctx[j] for j in keep], Qb[keep], k)
+    else:
+        operand, tol = Fp8Index.quantize(Ed), 1e-5
+        q8 = Fp8Index.quantize(Qd)
+        S = fp8_ref.scores_fp8(q8.codes.cpu().numpy(), q8.scale.cpu().numpy(), operand.codes.cpu().numpy(),
+                               operand.scale.cpu().numpy())
+        acc = np.stack([corpus.accessible_mask(ctxs[j].path, ctxs[j].theorem_pos) for j in keep])
+        want_i, want_s = common_ref.masked_topk(S[keep], acc, k)
+        want_i, want_s = want_i.tolist(), want_s.tolist()
+    prem, scores = corpus.get_nearest_premises(operand, [ctxs[j] for j in keep], Qd[keep], k)
+    got = [[where[id(p)] for p in row] for row in prem]
+    assert all(len(r) == k and len(set(r)) == k for r in got)
+    checked, bad = hh.gap_rule_ids(got, want_i, want_s, tol=2e-6)
+    assert bad == 0 and checked > k
+    assert np.abs(np.array(scores) - np.array(want_s)).max() < tol
+    for row, sc in zip(got, scores):  # one total order across the pages: score descending, id ascending among equals
+        assert all(sc[i] > sc[i + 1] or (sc[i] == sc[i + 1] and row[i] < row[i + 1]) for i in range(k - 1))
+    assert n_acc[0] < N  # (a theorem never sees the premises behind it in its own file)
+    with pytest.raises(ValueError):
+        corpus.get_nearest_premises(operand, [ctxs[0]], Qd[[0]], N)
