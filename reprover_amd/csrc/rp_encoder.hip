@@ -293,7 +293,7 @@ extern "C" RpStatus rp_encoder_create(const RpT5Config* cfg, const RpT5Weights* 
   if (cfg->d_model % 32 || cfg->d_model > RMS_MAX_V4 * 256 || cfg->d_ff % 32)
     return fail(RP_E_UNSUPPORTED, "d_model=%d (multiple of 32, <= %d) / d_ff=%d (multiple of 32) unsupported",
                 cfg->d_model, RMS_MAX_V4 * 256, cfg->d_ff);
-  if (2 * cfg->rel_max_distance + 1 > ATT_TAB_MAX)
+  if (2 * cfg->rel_max_distance + 1 + 128 > ATT_TAB_MAX)  // (+ the attention kernel's 2 x 64 padding entries)
     return fail(RP_E_UNSUPPORTED, "relative_attention_max_distance=%d too large", cfg->rel_max_distance);
   RP_REQUIRE(weight_dtype == RP_DT_F32 || weight_dtype == RP_DT_BF16, "weight_dtype");
   RpEncoder* e = new RpEncoder();

@@ -654,7 +654,7 @@ static RpStatus launch_gemm_big(const bf16_t* A, int lda, int M, const bf16_t* W
 //   by the accumulator layout is applied to V^T when its A fragment is read from LDS).
 // ------------------------------------------------------------------------------------------
 constexpr int ATT_Q = 128, ATT_KV = 64;
-constexpr int ATT_TAB_MAX = 1024;  // max table entries (2*max_distance+1)
+constexpr int ATT_TAB_MAX = 1024;  // max table entries (2*max_distance+1) + the kernel's 2 x 64 entries of padding
 //   * K and V tiles go HBM -> LDS by LDS-DMA into a 2-stage ring (tile t+1 in flight under the
 //     MFMAs/softmax of tile t, one barrier per tile, no VGPR staging, no ds_write at all);
 //   * V stays row-major in LDS ([d-half][key][32 d], 64-B rows) and its MFMA A fragments
@@ -745,7 +745,12 @@ static __global__ __launch_bounds__(256, DROP ? 2 : 4) void attention_kernel(con
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int inner = H * 64, ld = 3 * inner;
   const int ntab = 2 * maxd + 1;
-  for (int i = tid; i < ntab; i += 256) tab[i] = bias_tab[h * ntab + i];
+  // The LDS copy of the head's table carries TAB_PAD saturated entries on either side: a 32-key x 32-query block whose
+  // offsets straddle +-maxd (they span 63 values) then indexes it without clamping, like an interior block.  Without the
+  // padding those blocks took the per-score path below (clamp, compare, select: ~3 x the instructions), and the kernel is
+  // bound by VALU issue (profiles/r04_attention_ablation.md).
+  constexpr int TAB_PAD = 64;
+  for (int i = tid; i < ntab + 2 * TAB_PAD; i += 256) tab[i] = bias_tab[h * ntab + min(max(i - TAB_PAD, 0), ntab - 1)];
 
   const int wq0 = q0 + wave * 32;
   const bool active = wq0 < len;  // wave-uniform
@@ -828,22 +833,22 @@ static __global__ __launch_bounds__(256, DROP ? 2 : 4) void attention_kernel(con
       const int c0 = k0 + kb * 32;
       const bool all_real = (c0 + 32 <= len);
       if (c0 - (wq0 + 31) >= maxd && all_real) {
-        const float bb = tab[2 * maxd];
+        const float bb = tab[2 * maxd + TAB_PAD];
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kb][r] += bb;
       } else if (c0 + 31 - wq0 <= -maxd && all_real) {
-        const float bb = tab[0];
+        const float bb = tab[TAB_PAD];
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kb][r] += bb;
-      } else if (c0 + 31 - wq0 <= maxd && c0 - (wq0 + 31) >= -maxd && all_real) {
-        const float* tp = tab + (c0 - qi + maxd + 4 * hi);
+      } else if (all_real) {  // every offset of the block lies within maxd + 62 of zero: inside the padded table
+        const float* tp = tab + (c0 - qi + maxd + TAB_PAD + 4 * hi);
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kb][r] += tp[(r & 3) + 8 * (r >> 2)];
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = c0 + mfma32_row(r, hi);
-          const int rel = min(max(j - qi, -maxd), maxd) + maxd;
+          const int rel = min(max(j - qi, -maxd), maxd) + maxd + TAB_PAD;
           s[kb][r] = (j < len) ? s[kb][r] + tab[rel] : -INFINITY;
         }
       }
