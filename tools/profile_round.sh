@@ -2,7 +2,7 @@
 # rocprofv3 evidence for the bench command: kernel-trace + stats (one run), then PMC passes
 # (separate runs, --kernel-trace only, as the guide prescribes).  Summaries -> gpurun_out/prof_*/
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
-R=${ROUND:-r02}
+R=${ROUND:-r04}
 timeout -k 5 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$R -o bench --output-format csv -- \
   python bench.py --steps 5 --warmup 2 --no-cpu-baseline --headline-only > gpurun_out/prof_$R.log 2>&1
 tail -1 gpurun_out/prof_$R.log | cut -c1-400
@@ -18,7 +18,8 @@ for r in rows[:25]:
 open("gpurun_out/prof_${R}_kernel_stats_top.csv","w").write("\n".join(out)+"\n")
 print("\n".join(out[:16]))
 PY
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+           "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum"; do
   tag=$(echo $grp | cut -d' ' -f1)
   timeout -k 5 180 rocprofv3 --kernel-trace --pmc $grp -d gpurun_out/pmc_${R}_$tag -o bench --output-format csv -- \
     python bench.py --steps 2 --warmup 1 --no-cpu-baseline --headline-only > gpurun_out/pmc_${R}_$tag.log 2>&1
