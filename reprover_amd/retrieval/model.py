@@ -131,8 +131,8 @@ class PremiseRetriever:
         both values - bf16 MFMA operands, fp32 accumulation and statistics, the residual stream as two bf16 planes
         (hi + lo: 16 mantissa bits) - where the reference with ``dtype=float32`` multiplies fp32 operands under
         ``torch.set_float32_matmul_precision("medium")`` (model.py:26), a setting that itself licenses bf16-precision
-        products inside fp32 matmuls.  ``retrieve`` / ``num_retrieved`` accept k <= 1024 (the final selection sorts in
-        LDS); the reference accepts any k."""
+        products inside fp32 matmuls.  ``retrieve`` / ``num_retrieved`` accept any k, as the reference does (one library call
+        sorts at most 1024 keys per query; beyond that ``Corpus.get_nearest_premises`` pages through ``rp_sim_topk_after``)."""
         return cls(ckpt_path, 0.0, 0, max_seq_len, 100, device=device, dtype=dtype or torch.bfloat16)
 
     @classmethod
