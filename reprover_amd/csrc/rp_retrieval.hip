@@ -395,27 +395,28 @@ struct SelectArgs {
   int32_t* out_count;  // [B]
 };
 
-constexpr int SELECT_LDS_KEYS = 8192;  // lists up to this size are staged in LDS once (64 KB) and every pass reads LDS
+// Per-query stages: what bounds them is LATENCY (a chain of ~10 dependent global / LDS round trips per query), so what they
+// need is workgroups per CU, i.e. little LDS and few registers each:
+//  * select_kernel keeps the list in REGISTERS (KPT keys per thread, every pass walks them with static indices); LDS holds
+//    only the histograms and the output list;
+//  * gather_select_kernel's raw-entry list and key list share one LDS buffer (the key list grows from the front into what
+//    the raw list has already given up);
+//  * two shapes each: <1024 threads> for a few queries with long lists (one per CU is all there is), <256 threads, k <= 128>
+//    for MANY queries with short lists (the rows of one GPU's shard under all the queries of a multi-GPU step): 8 workgroups
+//    per CU - 2048 queries are one round of the chip.  Same code, same results; lists that do not fit are read from global
+//    memory in either shape.
+constexpr int SELECT_THREADS = 1024, SELECT_KPT = 8;          // 8192 keys in registers
+constexpr int SELECT_THREADS_SMALL = 256, SELECT_KPT_SMALL = 16;  // 4096
+constexpr int SELECT_SMALL_MAX_K = 128;
 
-// 1024 threads: every phase is a short latency-bound loop over the list (LDS read -> compare -> LDS atomic), and
-// with 256 threads (one wave per SIMD, nothing to hide the latency behind) a select took ~27 us whatever the batch.
-constexpr int SELECT_THREADS = 1024;
-
-// Two shapes of the per-query stages: <1024 threads, 8192 staged keys> (one query list is long: the sample of a 130 k-row
-// index, the candidates behind it) and <512 threads, 4096 / 2048 staged keys> for MANY queries with short lists (the rows of
-// one GPU's shard under all the queries of a multi-GPU step): 40 KB instead of 72 / 136 KB of LDS per workgroup, so four
-// workgroups share a CU instead of two / one.  Same code, same results; lists longer than the staged size are read from
-// global memory in either shape.
-template <int THREADS, int LDS_KEYS>
+template <int THREADS, int SEL_CAP>
 struct SelectSharedT {
-  uint64_t staged[LDS_KEYS];
-  uint64_t sel[SIM_MAX_K];
+  uint64_t sel[SEL_CAP];
   unsigned long long s_or[THREADS / 64], s_and[THREADS / 64];
-  int hist[256];
-  int s_digit, s_need, s_cnt, s_done;
+  int s_cntw[THREADS / 64];
+  int hist[3][256];  // radix pass p counts into hist[p % 3] (see select_body)
+  int s_cnt;
 };
-constexpr int SELECT_THREADS_SMALL = 256, SELECT_LDS_KEYS_SMALL = 4096;
-constexpr int GATHER_LDS_KEYS_SMALL = 2048, GATHER_LDS_ENTRIES_SMALL = 2048;
 
 // the key list of one query: in LDS when it fits, else in global memory
 struct KeySrc {
@@ -426,27 +427,31 @@ struct KeySrc {
 };
 
 // Everything after the list is in place: exact top-k of src[0, n) -> the mode A / mode B outputs of query q.
-template <int THREADS, int LDS_KEYS>
-__device__ __forceinline__ void select_body(const SelectArgs& a, int q, const KeySrc src, int n, bool overflow,
-                                            SelectSharedT<THREADS, LDS_KEYS>& sh) {
+// `each(f)` calls f(key) for every key of the list this thread is responsible for (0 = "not a candidate" may be among them).
+template <int THREADS, int SEL_CAP, class Each>
+__device__ __forceinline__ void select_body(const SelectArgs& a, int q, Each each, bool overflow,
+                                            SelectSharedT<THREADS, SEL_CAP>& sh) {
   const int tid = threadIdx.x, lane = tid & 63;
   // number of real candidates, and the bits in which they differ at all: the radix passes start at the highest
   // differing bit.  (Scores of one query share sign, exponent and often a few mantissa bits: byte-aligned passes
   // from bit 63 spent their first rounds sending every key - and every 0 = "not a candidate" - to ONE histogram
   // bin, thousands of LDS atomics on one address.)
+  // One workgroup barrier per phase: what a later phase needs cleared (the first histogram, the output list, the append
+  // counter) is cleared here, before the first barrier; every wave then derives the same decisions from the same LDS
+  // words by itself (no "wave 0 decides, barrier, everyone reads").
+  for (int i = tid; i < SEL_CAP; i += THREADS) sh.sel[i] = 0ull;
+  if (tid < 256) sh.hist[0][tid] = 0;
   if (tid == 0) sh.s_cnt = 0;
-  __syncthreads();
   {
     int c = 0;
     unsigned long long vo = 0ull, va = ~0ull;
-    for (int i = tid; i < n; i += THREADS) {
-      const uint64_t key = src[i];
+    each([&](uint64_t key) {
       if (key != 0ull) {
         ++c;
         vo |= key;
         va &= key;
       }
-    }
+    });
     c = (int)wave_sum((float)c);  // exact: c <= 2^24 per wave
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -454,21 +459,21 @@ __device__ __forceinline__ void select_body(const SelectArgs& a, int q, const Ke
       va &= __shfl_xor(va, o, 64);
     }
     if (lane == 0) {
-      atomicAdd(&sh.s_cnt, c);
+      sh.s_cntw[tid >> 6] = c;
       sh.s_or[tid >> 6] = vo;
       sh.s_and[tid >> 6] = va;
     }
   }
   __syncthreads();
-  const int nvalid = sh.s_cnt;
-  const int kk = min(a.k, nvalid);
+  int nvalid = 0;
   unsigned long long all_or = 0ull, all_and = ~0ull;
 #pragma unroll
   for (int w = 0; w < THREADS / 64; ++w) {
+    nvalid += sh.s_cntw[w];
     all_or |= sh.s_or[w];
     all_and &= sh.s_and[w];
   }
-  __syncthreads();
+  const int kk = min(a.k, nvalid);
 
   uint64_t T = ~0ull;  // keys >= T are selected
   if (kk > 0) {
@@ -478,72 +483,100 @@ __device__ __forceinline__ void select_body(const SelectArgs& a, int q, const Ke
     uint64_t known_prefix = known_shift >= 64 ? 0ull : (all_and >> known_shift);
     int need = kk;
     bool done = known_shift == 0;  // a single distinct key
-    while (!done) {
+    // Pass p counts into hist[p % 3] and clears hist[(p + 1) % 3] for the next pass while it counts: that buffer's last
+    // readers were the scans of pass p - 2, which every wave finished before it arrived at the barrier of pass p - 1.
+    for (int p = 0; !done; ++p) {
       const int new_shift = max(known_shift - 8, 0);
       const int width = known_shift - new_shift;
       const uint32_t dmask = (1u << width) - 1u;
-      if (tid < 256) sh.hist[tid] = 0;
-      __syncthreads();
-      for (int i = tid; i < n; i += THREADS) {
-        const uint64_t key = src[i];
+      int* const h = sh.hist[p % 3];
+      if (tid < 256) sh.hist[(p + 1) % 3][tid] = 0;
+      each([&](uint64_t key) {
         const bool in = key != 0ull && (known_shift >= 64 || (key >> known_shift) == known_prefix);
-        if (in) atomicAdd(&sh.hist[(int)((uint32_t)(key >> new_shift) & dmask)], 1);
-      }
+        if (in) atomicAdd(&h[(int)((uint32_t)(key >> new_shift) & dmask)], 1);
+      });
       __syncthreads();
-      if (tid < 64) {  // wave 0: lane l owns digits 255-4l .. 252-4l (descending)
-        const int d0 = 255 - 4 * lane;
-        const int h0 = sh.hist[d0], h1 = sh.hist[d0 - 1], h2 = sh.hist[d0 - 2], h3 = sh.hist[d0 - 3];
-        const int mine = h0 + h1 + h2 + h3;
-        int incl = mine;
+      // every wave: lane l owns digits 255-4l .. 252-4l (descending)
+      const int d0 = 255 - 4 * lane;
+      const int h0 = h[d0], h1 = h[d0 - 1], h2 = h[d0 - 2], h3 = h[d0 - 3];
+      const int mine = h0 + h1 + h2 + h3;
+      int incl = mine;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          int t = __shfl_up(incl, o, 64);
-          if (lane >= o) incl += t;
-        }
-        const int excl = incl - mine;
-        if (excl < need && incl >= need) {  // the crossing happens in this lane's 4 digits
-          int cum = excl, d = d0, hsel = h0;
-          const int hs[4] = {h0, h1, h2, h3};
+      for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      const int excl = incl - mine;
+      const bool crossing = excl < need && incl >= need;  // the need-th key from the top lies in this lane's 4 digits
+      int d = d0, take = need - excl, hsel = h0;
+      {
+        const int hs[4] = {h0, h1, h2, h3};
+        int before = excl;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            if (cum + hs[t] >= need) {
-              d = d0 - t;
-              hsel = hs[t];
-              break;
-            }
-            cum += hs[t];
+        for (int t = 0; t < 4; ++t) {  // the first digit whose cumulative count reaches `need`
+          if (before < need && before + hs[t] >= need) {
+            d = d0 - t;
+            hsel = hs[t];
+            take = need - before;
           }
-          sh.s_digit = d;
-          sh.s_need = need - cum;          // how many to take inside the chosen bucket
-          sh.s_done = (hsel == need - cum);  // whole bucket taken: no need to refine further
+          before += hs[t];
         }
       }
-      __syncthreads();
-      known_prefix = (known_prefix << width) | (uint64_t)sh.s_digit;
+      const unsigned long long cm = __ballot(crossing);  // exactly one lane: the bucket holds at least `need` keys
+      const int src_lane = (int)__builtin_ctzll(cm);
+      const int digit = __shfl(d, src_lane, 64);
+      const int need_in = __shfl(take, src_lane, 64);      // how many to take inside the chosen bucket
+      const int bucket = __shfl(hsel, src_lane, 64);
+      known_prefix = (known_prefix << width) | (uint64_t)digit;
       known_shift = new_shift;
-      need = sh.s_need;
-      done = sh.s_done || new_shift == 0;
-      __syncthreads();
+      need = need_in;
+      done = bucket == need_in || new_shift == 0;  // whole bucket taken: no need to refine further
     }
     T = known_shift >= 64 ? 0ull : (known_prefix << known_shift);
   }
 
-  // collect the kk selected keys, pad to a power of two, sort descending
+  // collect the kk selected keys (the list was zeroed above: padded to a power of two for the sort), sort descending
   int P = 1;
   while (P < kk) P <<= 1;
-  for (int i = tid; i < P; i += THREADS) sh.sel[i] = 0ull;
-  if (tid == 0) sh.s_cnt = 0;
-  __syncthreads();
   if (kk > 0) {
-    for (int i = tid; i < n; i += THREADS) {
-      const uint64_t key = src[i];
+    each([&](uint64_t key) {
       if (key >= T && key != 0ull) {
         const int pos = atomicAdd(&sh.s_cnt, 1);
-        if (pos < SIM_MAX_K) sh.sel[pos] = key;
+        if (pos < SEL_CAP) sh.sel[pos] = key;
       }
-    }
+    });
   }
   __syncthreads();
+  if (P <= 128) {
+    // the common case (k <= 128): ONE wave sorts the list in registers, two keys per lane (element e = lane + 64 r), the
+    // same bitonic network through lane exchanges - 28 stages without a workgroup barrier each (with 1024 threads a
+    // barrier stage cost more than the compare it guarded)
+    if (tid < 64) {
+      uint64_t v0 = lane < P ? sh.sel[lane] : 0ull, v1 = lane + 64 < P ? sh.sel[lane + 64] : 0ull;
+      auto xchg = [&](uint64_t& v, int e, int size, int strd) {
+        const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)v, strd, 64);
+        const uint32_t ohi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), strd, 64);
+        const uint64_t o = ((uint64_t)ohi << 32) | olo;
+        const bool lower = (e & strd) == 0, desc = (e & size) == 0;
+        v = (lower == desc) ? (v > o ? v : o) : (v < o ? v : o);
+      };
+      for (int size = 2; size <= 128; size <<= 1)
+        for (int strd = size >> 1; strd > 0; strd >>= 1) {
+          if (strd == 64) {  // partner = the lane's other register (only in the last merge: descending)
+            const uint64_t hi_ = v0 > v1 ? v0 : v1, lo_ = v0 > v1 ? v1 : v0;
+            v0 = hi_;
+            v1 = lo_;
+          } else {
+            xchg(v0, lane, size, strd);
+            xchg(v1, lane + 64, size, strd);
+          }
+        }
+      // (a list padded to P < 128 sorts as one of 128: the zero padding ends up behind every key)
+      if (lane < P) sh.sel[lane] = v0;
+      if (lane + 64 < P) sh.sel[lane + 64] = v1;
+    }
+    __syncthreads();
+  } else
   for (int size = 2; size <= P; size <<= 1) {
     for (int strd = size >> 1; strd > 0; strd >>= 1) {
       for (int i = tid; i < (P >> 1); i += THREADS) {
@@ -581,21 +614,32 @@ __device__ __forceinline__ void select_body(const SelectArgs& a, int q, const Ke
   }
 }
 
-template <int THREADS, int LDS_KEYS>
-__global__ __launch_bounds__(THREADS) void select_kernel(SelectArgs a) {
-  __shared__ SelectSharedT<THREADS, LDS_KEYS> sh;
+template <int THREADS, int KPT>
+__global__ __launch_bounds__(THREADS, THREADS <= 512 ? 8 : 4) void select_kernel(SelectArgs a) {
+  __shared__ SelectSharedT<THREADS, SIM_MAX_K> sh;
   const int q = blockIdx.x, tid = threadIdx.x;
   int n = a.counts ? a.counts[(size_t)q * a.count_stride] : a.n_fixed;
   const bool overflow = a.counts && n > a.cap;
   if (n > a.cap && a.counts) n = a.cap;
   const uint64_t* gsrc = a.keys + (size_t)q * a.ld;
-  // The radix passes read the list up to ten times: from LDS when it fits (the sample's 8192 keys, the ~2k
-  // candidates of the final stage), from global memory otherwise (dense plans, adversarial candidate counts).
-  const bool in_lds = n <= LDS_KEYS;
-  if (in_lds)
-    for (int i = tid; i < n; i += THREADS) sh.staged[i] = gsrc[i];
-  __syncthreads();
-  select_body(a, q, KeySrc{gsrc, sh.staged, in_lds}, n, overflow, sh);
+  // The passes read the list about six times: from registers when it fits (the sample's keys), from global memory
+  // otherwise (dense plans, adversarial candidate counts).
+  if (n <= KPT * THREADS) {
+    uint64_t keys[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int i = j * THREADS + tid;
+      keys[j] = i < n ? gsrc[i] : 0ull;
+    }
+    select_body(a, q, [&](auto&& f) {
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) f(keys[j]);
+    }, overflow, sh);
+  } else {
+    select_body(a, q, [&](auto&& f) {
+      for (int i = tid; i < n; i += THREADS) f(gsrc[i]);
+    }, overflow, sh);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -609,7 +653,12 @@ __global__ __launch_bounds__(THREADS) void select_kernel(SelectArgs a) {
 // version took a wave-aggregated LDS atomic per entry round: 20 of its 37 us); the predicate's dependent gathers
 // run for all raw survivors of a thread level by level.
 // ------------------------------------------------------------------------------------------
-constexpr int GATHER_LDS_ENTRIES = 8192;
+// raw-entry capacity of the LDS list (+ SEL_CAP keys of the sample in front of it, see the kernel): entries beyond it take
+// the slow path, one at a time - the capacity must cover the raw count's spread, not its mean (at B = 256 x 130 k rows,
+// ~6400 expected: 7168 entries cost 50 us where 8192+ cost 36).  big: 91 KB; mid 36 KB (four workgroups per CU, 512
+// threads); small 18.5 KB (eight, 256 threads)
+constexpr int GATHER_ENTRIES = 9216, GATHER_ENTRIES_MID = 3968, GATHER_ENTRIES_SMALL = 1664;
+constexpr int GATHER_THREADS_MID = 512;
 
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
@@ -629,12 +678,19 @@ __device__ __forceinline__ int wave_append_pos(int* counter, bool want) {
   return base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
 }
 
-template <int THREADS, int LDS_KEYS, int RAW_ENTRIES>
-__global__ __launch_bounds__(THREADS) void gather_select_kernel(GatherArgs a, SelectArgs sa) {
-  __shared__ SelectSharedT<THREADS, LDS_KEYS> sh;
-  __shared__ uint2 raw[RAW_ENTRIES];  // {score bits, premise row}
+template <int THREADS, int RAW_ENTRIES, int SEL_CAP>
+__global__ __launch_bounds__(THREADS, THREADS <= 512 ? 8 : 4) void gather_select_kernel(GatherArgs a, SelectArgs sa) {
+  __shared__ SelectSharedT<THREADS, SEL_CAP> sh;
+  // One buffer for two lists: keys [0, LDS_KEYS) from the front (the sample's top keys, then what passes), raw entries
+  // {score bits, premise row} from slot SEL_CAP on.  The key list never passes the raw entries still to be read: it holds
+  // at most n_sample <= SEL_CAP keys + one per entry processed, and phase B loads a whole round of entries into registers
+  // (barrier) before it appends that round's keys.
+  constexpr int LDS_KEYS = SEL_CAP + RAW_ENTRIES;
+  __shared__ uint64_t ubuf[LDS_KEYS];
+  uint64_t* const staged = ubuf;
+  uint2* const raw = reinterpret_cast<uint2*>(ubuf + SEL_CAP);
   __shared__ int s_wave_tot[THREADS / 64];
-  __shared__ int s_out;
+  __shared__ int s_out, s_spill;
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qt = q >> 8, qloc = q & 255;
   const uint64_t thr = a.thr[q];
@@ -643,14 +699,18 @@ __global__ __launch_bounds__(THREADS) void gather_select_kernel(GatherArgs a, Se
   const int64_t qk = a.file_of ? a.q_key[q] : 0;
   uint64_t* out = a.cand + (size_t)q * a.cap;  // global copy of the key list (read back only when LDS is too small)
   const int n_sample = a.count[(size_t)q * SIM_COUNT_STRIDE];
-  for (int i = tid; i < n_sample; i += THREADS) sh.staged[i] = out[i];  // n_sample <= k <= SIM_MAX_K
-  if (tid == 0) s_out = n_sample;
+  for (int i = tid; i < n_sample; i += THREADS) staged[i] = out[i];  // n_sample <= k <= SEL_CAP
+  if (tid == 0) {
+    s_out = n_sample;
+    s_spill = 0;
+  }
   auto accessible = [&](int32_t f, uint32_t word, int p) {
     return ((word >> (q & 31)) & 1u) || (f == own && a.end_key[p] <= qk);
   };
+  bool spill = false;  // set after phase A: keys went straight to the global list, whose positions the LDS bound does not cover
   auto put_key = [&](uint64_t key, int pos) {
     if (pos < (int)a.cap) out[pos] = key;  // beyond the capacity: counted, not stored (reported as overflow below)
-    if (pos < LDS_KEYS) sh.staged[pos] = key;
+    if (!spill && pos < LDS_KEYS) staged[pos] = key;
   };
   // ---- phase A: runs -> raw list (one thread per filter block)
   const i32x4* cnt4 = reinterpret_cast<const i32x4*>(a.scnt + (size_t)q * a.filter_blocks * 4);
@@ -697,7 +757,11 @@ __global__ __launch_bounds__(THREADS) void gather_select_kernel(GatherArgs a, Se
           ok = accessible(f, a.bits_t[(size_t)f * a.bits_words + (q >> 5)], p);
         }
         const uint64_t key = make_key(__uint_as_float(en.x), p + a.id_offset);
-        if (ok && key > thr && key < upper) put_key(key, atomicAdd(&s_out, 1));
+        if (ok && key > thr && key < upper) {  // global copy only (the LDS slot may still hold a raw entry): the select reads it
+          const int kp = atomicAdd(&s_out, 1);
+          if (kp < (int)a.cap) out[kp] = key;
+          s_spill = 1;
+        }
       }
       ++pos;
     };
@@ -717,6 +781,7 @@ __global__ __launch_bounds__(THREADS) void gather_select_kernel(GatherArgs a, Se
   }
   __syncthreads();
   // ---- phase B: entry-parallel predicate; every gather level of a thread's entries is issued before the next
+  spill = s_spill != 0;
   const int nraw = (a.debug & 32) ? 0 : min(raw_base, RAW_ENTRIES);
   constexpr int U = 4;
   for (int e0 = 0; e0 < nraw; e0 += U * THREADS) {
@@ -732,6 +797,7 @@ __global__ __launch_bounds__(THREADS) void gather_select_kernel(GatherArgs a, Se
       if (!live[u]) en[u].y = 0;
       f[u] = a.file_of ? a.file_of[en[u].y] : 0;
     }
+    __syncthreads();  // this round's entries are in registers: their slots may be overwritten by keys
 #pragma unroll
     for (int u = 0; u < U; ++u) word[u] = a.file_of ? a.bits_t[(size_t)f[u] * a.bits_words + (q >> 5)] : 0xffffffffu;
 #pragma unroll
@@ -747,7 +813,10 @@ __global__ __launch_bounds__(THREADS) void gather_select_kernel(GatherArgs a, Se
   __syncthreads();
   const bool overflow = s_out > (int)a.cap;  // out_count = -1: the caller repeats the search with the dense plan
   const int n = min(s_out, (int)a.cap);
-  select_body(sa, q, KeySrc{out, sh.staged, n <= LDS_KEYS}, n, overflow, sh);
+  const KeySrc src{out, staged, n <= LDS_KEYS && !spill};
+  select_body(sa, q, [&](auto&& f) {
+    for (int i = tid; i < n; i += THREADS) f(src[i]);
+  }, overflow, sh);
 }
 
 // (scores, ids, counts)[R, B, k] -> keys[B, R*k]
@@ -797,15 +866,17 @@ __global__ __launch_bounds__(256) void build_file_bits_kernel(const uint64_t* __
 }
 
 // many queries with short lists: the small shape (four workgroups per CU)
-static bool select_small(int B, int64_t list_bound) { return B >= 512 && list_bound <= SELECT_LDS_KEYS_SMALL; }
+static bool select_small(int B, int64_t list_bound) {
+  return B >= 512 && list_bound <= SELECT_KPT_SMALL * SELECT_THREADS_SMALL;
+}
 
 static void launch_select(const SelectArgs& a, int B, hipStream_t stream) {
   ProfScope ps(stream, RP_K_SELECT);
   if (select_small(B, a.counts ? (int64_t)a.cap : (int64_t)a.n_fixed))
-    hipLaunchKernelGGL((select_kernel<SELECT_THREADS_SMALL, SELECT_LDS_KEYS_SMALL>), dim3(B), dim3(SELECT_THREADS_SMALL), 0,
+    hipLaunchKernelGGL((select_kernel<SELECT_THREADS_SMALL, SELECT_KPT_SMALL>), dim3(B), dim3(SELECT_THREADS_SMALL), 0,
                        stream, a);
   else
-    hipLaunchKernelGGL((select_kernel<SELECT_THREADS, SELECT_LDS_KEYS>), dim3(B), dim3(SELECT_THREADS), 0, stream, a);
+    hipLaunchKernelGGL((select_kernel<SELECT_THREADS, SELECT_KPT>), dim3(B), dim3(SELECT_THREADS), 0, stream, a);
 }
 
 struct SimPlan {
@@ -1112,14 +1183,18 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   sb.out_count = out_count;
   if (p.new_filter) {  // runs -> predicate -> key list -> select, one kernel
     ProfScope ps(stream, RP_K_SELECT);
-    // ~k * stride keys lie above the sampled bound, ~3 x that before the accessibility predicate: the small shape when
-    // that fits its raw list and many queries share the chip (longer lists stay correct - they spill to the slow path)
-    if (B >= 512 && (int64_t)k * p.stride * 4 <= GATHER_LDS_ENTRIES_SMALL)
-      hipLaunchKernelGGL((gather_select_kernel<SELECT_THREADS_SMALL, GATHER_LDS_KEYS_SMALL, GATHER_LDS_ENTRIES_SMALL>),
-                         dim3(B), dim3(SELECT_THREADS_SMALL), 0, stream, ga, sb);
+    // ~k * stride keys lie above the sampled bound, ~3 x that before the accessibility predicate: the smallest shape whose
+    // raw list holds that when many queries share the chip (longer lists stay correct - they spill to the slow path)
+    const int64_t raw_bound = (int64_t)k * p.stride * 4;
+    if (B >= 512 && k <= SELECT_SMALL_MAX_K && raw_bound <= GATHER_ENTRIES_SMALL)
+      hipLaunchKernelGGL((gather_select_kernel<SELECT_THREADS_SMALL, GATHER_ENTRIES_SMALL, SELECT_SMALL_MAX_K>), dim3(B),
+                         dim3(SELECT_THREADS_SMALL), 0, stream, ga, sb);
+    else if (B >= 512 && k <= SELECT_SMALL_MAX_K && raw_bound <= GATHER_ENTRIES_MID)
+      hipLaunchKernelGGL((gather_select_kernel<GATHER_THREADS_MID, GATHER_ENTRIES_MID, SELECT_SMALL_MAX_K>), dim3(B),
+                         dim3(GATHER_THREADS_MID), 0, stream, ga, sb);
     else
-      hipLaunchKernelGGL((gather_select_kernel<SELECT_THREADS, SELECT_LDS_KEYS, GATHER_LDS_ENTRIES>), dim3(B),
-                         dim3(SELECT_THREADS), 0, stream, ga, sb);
+      hipLaunchKernelGGL((gather_select_kernel<SELECT_THREADS, GATHER_ENTRIES, SIM_MAX_K>), dim3(B), dim3(SELECT_THREADS), 0,
+                         stream, ga, sb);
   } else {
     launch_select(sb, B, stream);
   }

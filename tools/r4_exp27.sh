@@ -1,0 +1,9 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export PYTHONUNBUFFERED=1 TMPDIR=/tmp; mkdir -p gpurun_out
+for shape in "256 130000" "512 65000"; do
+set -- $shape
+echo "== B=$1 N=$2"
+rm -rf gpurun_out/prof_shard
+N=$2 BS=$1 FP8=0 IMPLS=0 DENSE=0 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_shard -o s --output-format csv -- python tools/scan_bench.py 2>&1 | grep -v amdgpu.ids | grep -E "B=|us|ms" | head -5
+python tools/prof_summary.py gpurun_out/prof_shard 2>&1 | head -6
+done
