@@ -393,6 +393,8 @@ struct SelectArgs {
   float* out_scores;   // [B, k]
   int32_t* out_ids;    // [B, k]
   int32_t* out_count;  // [B]
+  int debug;           // timing only (scan_no_epilogue): 256 = return once the list is loaded, 512 = after the first barrier,
+                       // 1024 = after the radix passes, 2048 = after the sort
 };
 
 // Per-query stages: what bounds them is LATENCY (a chain of ~10 dependent global / LDS round trips per query), so what they
@@ -412,7 +414,7 @@ constexpr int SELECT_SMALL_MAX_K = 128;
 template <int THREADS, int SEL_CAP>
 struct SelectSharedT {
   uint64_t sel[SEL_CAP];
-  unsigned long long s_or[THREADS / 64], s_and[THREADS / 64];
+  uint32_t s_or[THREADS / 64], s_and[THREADS / 64];
   int s_cntw[THREADS / 64];
   int hist[3][256];  // radix pass p counts into hist[p % 3] (see select_body)
   int s_cnt;
@@ -444,19 +446,19 @@ __device__ __forceinline__ void select_body(const SelectArgs& a, int q, Each eac
   if (tid == 0) sh.s_cnt = 0;
   {
     int c = 0;
-    unsigned long long vo = 0ull, va = ~0ull;
+    uint32_t vo = 0u, va = ~0u;  // over the score words (the keys' upper halves)
     each([&](uint64_t key) {
       if (key != 0ull) {
         ++c;
-        vo |= key;
-        va &= key;
+        vo |= (uint32_t)(key >> 32);
+        va &= (uint32_t)(key >> 32);
       }
     });
     c = (int)wave_sum((float)c);  // exact: c <= 2^24 per wave
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      vo |= __shfl_xor(vo, o, 64);
-      va &= __shfl_xor(va, o, 64);
+      vo |= (uint32_t)__shfl_xor((int)vo, o, 64);
+      va &= (uint32_t)__shfl_xor((int)va, o, 64);
     }
     if (lane == 0) {
       sh.s_cntw[tid >> 6] = c;
@@ -466,7 +468,7 @@ __device__ __forceinline__ void select_body(const SelectArgs& a, int q, Each eac
   }
   __syncthreads();
   int nvalid = 0;
-  unsigned long long all_or = 0ull, all_and = ~0ull;
+  uint32_t all_or = 0u, all_and = ~0u;
 #pragma unroll
   for (int w = 0; w < THREADS / 64; ++w) {
     nvalid += sh.s_cntw[w];
@@ -474,67 +476,91 @@ __device__ __forceinline__ void select_body(const SelectArgs& a, int q, Each eac
     all_and &= sh.s_and[w];
   }
   const int kk = min(a.k, nvalid);
+  if (a.debug & 512) return;
+
+  // The passes are what this stage costs (every key of the list is looked at in each, and a CU's instruction issue is
+  // shared by every query resident on it), so they work on 32-bit words: first the score word alone; the id word only if
+  // the kk-th score is tied.  One pass refines the bucket (word >> shift) == prefix by up to 8 more bits: counts into
+  // hist[pass % 3] and clears hist[(pass + 1) % 3] for the next pass while it counts - that buffer's last readers were
+  // the scans of pass - 2, which every wave finished before it arrived at the barrier of pass - 1.
+  int pass = 0;
+  auto refine = [&](auto&& word_of, int& shift, uint32_t& prefix, int& need, int& bucket) {
+    const int new_shift = max(shift - 8, 0);
+    const int width = shift - new_shift;
+    const uint32_t dmask = (1u << width) - 1u;
+    int* const h = sh.hist[pass % 3];
+    if (tid < 256) sh.hist[(pass + 1) % 3][tid] = 0;
+    each([&](uint64_t key) {
+      uint32_t w;
+      const bool member = word_of(key, w);
+      if (member && (shift >= 32 || (w >> shift) == prefix)) atomicAdd(&h[(int)((w >> new_shift) & dmask)], 1);
+    });
+    __syncthreads();
+    ++pass;
+    // every wave: lane l owns digits 255-4l .. 252-4l (descending)
+    const int d0 = 255 - 4 * lane;
+    const int h0 = h[d0], h1 = h[d0 - 1], h2 = h[d0 - 2], h3 = h[d0 - 3];
+    const int mine = h0 + h1 + h2 + h3;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    const int excl = incl - mine;
+    const bool crossing = excl < need && incl >= need;  // the need-th word from the top lies in this lane's 4 digits
+    int d = d0, take = need - excl, hsel = h0;
+    {
+      const int hs[4] = {h0, h1, h2, h3};
+      int before = excl;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {  // the first digit whose cumulative count reaches `need`
+        if (before < need && before + hs[t] >= need) {
+          d = d0 - t;
+          hsel = hs[t];
+          take = need - before;
+        }
+        before += hs[t];
+      }
+    }
+    const unsigned long long cm = __ballot(crossing);  // exactly one lane: the bucket holds at least `need` words
+    const int src_lane = (int)__builtin_ctzll(cm);
+    prefix = (shift >= 32 ? 0u : (prefix << width)) | (uint32_t)__shfl(d, src_lane, 64);
+    shift = new_shift;
+    need = __shfl(take, src_lane, 64);      // how many to take inside the chosen bucket
+    bucket = __shfl(hsel, src_lane, 64);    // ... of how many: equal = the whole bucket is taken, no need to refine further
+  };
+  auto top_shift = [](uint32_t diff) { return diff ? 32 - (int)__builtin_clz(diff) : 0; };
 
   uint64_t T = ~0ull;  // keys >= T are selected
   if (kk > 0) {
-    const unsigned long long diff = all_or ^ all_and;
-    // keys agree above bit known_shift - 1; known_prefix = key >> known_shift of the bucket being refined
-    int known_shift = diff ? 64 - __builtin_clzll(diff) : 0;
-    uint64_t known_prefix = known_shift >= 64 ? 0ull : (all_and >> known_shift);
-    int need = kk;
-    bool done = known_shift == 0;  // a single distinct key
-    // Pass p counts into hist[p % 3] and clears hist[(p + 1) % 3] for the next pass while it counts: that buffer's last
-    // readers were the scans of pass p - 2, which every wave finished before it arrived at the barrier of pass p - 1.
-    for (int p = 0; !done; ++p) {
-      const int new_shift = max(known_shift - 8, 0);
-      const int width = known_shift - new_shift;
-      const uint32_t dmask = (1u << width) - 1u;
-      int* const h = sh.hist[p % 3];
-      if (tid < 256) sh.hist[(p + 1) % 3][tid] = 0;
-      each([&](uint64_t key) {
-        const bool in = key != 0ull && (known_shift >= 64 || (key >> known_shift) == known_prefix);
-        if (in) atomicAdd(&h[(int)((uint32_t)(key >> new_shift) & dmask)], 1);
-      });
-      __syncthreads();
-      // every wave: lane l owns digits 255-4l .. 252-4l (descending)
-      const int d0 = 255 - 4 * lane;
-      const int h0 = h[d0], h1 = h[d0 - 1], h2 = h[d0 - 2], h3 = h[d0 - 3];
-      const int mine = h0 + h1 + h2 + h3;
-      int incl = mine;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-      }
-      const int excl = incl - mine;
-      const bool crossing = excl < need && incl >= need;  // the need-th key from the top lies in this lane's 4 digits
-      int d = d0, take = need - excl, hsel = h0;
-      {
-        const int hs[4] = {h0, h1, h2, h3};
-        int before = excl;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {  // the first digit whose cumulative count reaches `need`
-          if (before < need && before + hs[t] >= need) {
-            d = d0 - t;
-            hsel = hs[t];
-            take = need - before;
-          }
-          before += hs[t];
-        }
-      }
-      const unsigned long long cm = __ballot(crossing);  // exactly one lane: the bucket holds at least `need` keys
-      const int src_lane = (int)__builtin_ctzll(cm);
-      const int digit = __shfl(d, src_lane, 64);
-      const int need_in = __shfl(take, src_lane, 64);      // how many to take inside the chosen bucket
-      const int bucket = __shfl(hsel, src_lane, 64);
-      known_prefix = (known_prefix << width) | (uint64_t)digit;
-      known_shift = new_shift;
-      need = need_in;
-      done = bucket == need_in || new_shift == 0;  // whole bucket taken: no need to refine further
+    // score words agree above bit shift - 1; prefix = word >> shift of the bucket being refined
+    int shift = top_shift(all_or ^ all_and), need = kk, bucket = nvalid;
+    uint32_t prefix = shift >= 32 ? 0u : (all_and >> shift);
+    auto score_word = [](uint64_t key, uint32_t& w) {
+      w = (uint32_t)(key >> 32);
+      return key != 0ull;
+    };
+    while (bucket != need && shift > 0) refine(score_word, shift, prefix, need, bucket);
+    if (bucket == need) {
+      T = (uint64_t)(shift >= 32 ? 0u : (prefix << shift)) << 32;
+      if (T == 0ull) T = 1ull;
+    } else {
+      // `bucket` keys share the kk-th score word exactly: the `need` largest id words among them (= smallest ids)
+      const uint32_t score = prefix;
+      int shift2 = 32, need2 = need, bucket2 = bucket;
+      uint32_t prefix2 = 0u;
+      auto id_word = [score](uint64_t key, uint32_t& w) {
+        w = (uint32_t)key;
+        return (uint32_t)(key >> 32) == score && key != 0ull;
+      };
+      while (bucket2 != need2 && shift2 > 0) refine(id_word, shift2, prefix2, need2, bucket2);
+      T = ((uint64_t)score << 32) | (shift2 >= 32 ? 0u : (prefix2 << shift2));
+      if (T == 0ull) T = 1ull;
     }
-    T = known_shift >= 64 ? 0ull : (known_prefix << known_shift);
   }
 
+  if (a.debug & 1024) return;
   // collect the kk selected keys (the list was zeroed above: padded to a power of two for the sort), sort descending
   int P = 1;
   while (P < kk) P <<= 1;
@@ -593,6 +619,7 @@ __device__ __forceinline__ void select_body(const SelectArgs& a, int q, Each eac
     }
   }
 
+  if (a.debug & 2048) return;
   if (a.out_keys) {
     for (int i = tid; i < kk; i += THREADS) a.out_keys[(size_t)q * a.out_ld + i] = sh.sel[i];
     if (tid == 0) {
@@ -630,6 +657,13 @@ __global__ __launch_bounds__(THREADS, THREADS <= 512 ? 8 : 4) void select_kernel
     for (int j = 0; j < KPT; ++j) {
       const int i = j * THREADS + tid;
       keys[j] = i < n ? gsrc[i] : 0ull;
+    }
+    if (a.debug & 256) {  // (keep the loads alive)
+      uint64_t x = 0ull;
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) x |= keys[j];
+      if (x == 0x123456789abcdefull) a.out_thr[q] = x;
+      return;
     }
     select_body(a, q, [&](auto&& f) {
 #pragma unroll
@@ -698,6 +732,7 @@ __global__ __launch_bounds__(THREADS, THREADS <= 512 ? 8 : 4) void gather_select
   const int32_t own = a.file_of ? a.own_file[q] : -1;
   const int64_t qk = a.file_of ? a.q_key[q] : 0;
   uint64_t* out = a.cand + (size_t)q * a.cap;  // global copy of the key list (read back only when LDS is too small)
+  if (a.debug & 8) return;
   const int n_sample = a.count[(size_t)q * SIM_COUNT_STRIDE];
   for (int i = tid; i < n_sample; i += THREADS) staged[i] = out[i];  // n_sample <= k <= SEL_CAP
   if (tid == 0) {
@@ -706,6 +741,9 @@ __global__ __launch_bounds__(THREADS, THREADS <= 512 ? 8 : 4) void gather_select
   }
   auto accessible = [&](int32_t f, uint32_t word, int p) {
     return ((word >> (q & 31)) & 1u) || (f == own && a.end_key[p] <= qk);
+  };
+  auto accessible_ek = [&](int32_t f, uint32_t word, int64_t ek) {  // (the row's end key already loaded)
+    return ((word >> (q & 31)) & 1u) || (f == own && ek <= qk);
   };
   bool spill = false;  // set after phase A: keys went straight to the global list, whose positions the LDS bound does not cover
   auto put_key = [&](uint64_t key, int pos) {
@@ -773,11 +811,21 @@ __global__ __launch_bounds__(THREADS, THREADS <= 512 ? 8 : 4) void gather_select
           const uint4 v = line[2 * e + (part >> 1)];
           emit((part & 1) ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y), part);
         }
+    // longer runs (a loose bound: few rows per shard, many queries): one 128-byte line = entries e0 .. e0 + 3 of the four
+    // parts per round trip, not one entry
     const int nmax = max(max(n4[0], n4[1]), max(n4[2], n4[3]));
-    for (int e = 4; e < nmax; ++e)
+    for (int e0 = 4; e0 < nmax; e0 += 4) {
 #pragma unroll
-      for (int part = 0; part < 4; ++part)
-        if (e < n4[part]) emit(base[e * 4 + part], part);
+      for (int w = 0; w < 8; ++w) line[w] = reinterpret_cast<const uint4*>(base + e0 * 4)[w];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int part = 0; part < 4; ++part)
+          if (e0 + e < n4[part]) {
+            const uint4 v = line[2 * e + (part >> 1)];
+            emit((part & 1) ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y), part);
+          }
+    }
   }
   __syncthreads();
   // ---- phase B: entry-parallel predicate; every gather level of a thread's entries is issued before the next
@@ -787,6 +835,7 @@ __global__ __launch_bounds__(THREADS, THREADS <= 512 ? 8 : 4) void gather_select
   for (int e0 = 0; e0 < nraw; e0 += U * THREADS) {
     uint2 en[U];
     int32_t f[U];
+    int64_t ek[U];  // requested with the file (its address does not depend on it): two gather levels, not three
     uint32_t word[U];
     bool live[U];
 #pragma unroll
@@ -796,6 +845,7 @@ __global__ __launch_bounds__(THREADS, THREADS <= 512 ? 8 : 4) void gather_select
       live[u] = e < nraw && (int)en[u].y < a.N;  // padding rows of the last block never qualify
       if (!live[u]) en[u].y = 0;
       f[u] = a.file_of ? a.file_of[en[u].y] : 0;
+      ek[u] = a.file_of ? a.end_key[en[u].y] : 0;
     }
     __syncthreads();  // this round's entries are in registers: their slots may be overwritten by keys
 #pragma unroll
@@ -803,7 +853,7 @@ __global__ __launch_bounds__(THREADS, THREADS <= 512 ? 8 : 4) void gather_select
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       bool ok = live[u];
-      if (a.file_of && ok) ok = accessible(f[u], word[u], (int)en[u].y);
+      if (a.file_of && ok) ok = accessible_ek(f[u], word[u], ek[u]);
       const uint64_t key = make_key(__uint_as_float(en[u].x), (int32_t)en[u].y + a.id_offset);
       ok = ok && key > thr && key < upper;
       const int pos = wave_append_pos(&s_out, ok);
@@ -813,6 +863,7 @@ __global__ __launch_bounds__(THREADS, THREADS <= 512 ? 8 : 4) void gather_select
   __syncthreads();
   const bool overflow = s_out > (int)a.cap;  // out_count = -1: the caller repeats the search with the dense plan
   const int n = min(s_out, (int)a.cap);
+  if (a.debug & 64) return;
   const KeySrc src{out, staged, n <= LDS_KEYS && !spill};
   select_body(sa, q, [&](auto&& f) {
     for (int i = tid; i < n; i += THREADS) f(src[i]);
@@ -1048,6 +1099,7 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
 
   RpStatus st;
   SelectArgs sa;
+  sa.debug = 0;
   sa.keys = dense;
   sa.ld = p.dense_ld;
   sa.counts = nullptr;
@@ -1093,6 +1145,7 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   sa.out_scores = nullptr;
   sa.out_ids = nullptr;
   sa.out_count = nullptr;
+  sa.debug = g_scan_no_epilogue;
   launch_select(sa, B, stream);
   RP_CHECK_LAUNCH();
   // pass 1: remaining blocks, keep only keys above each query's bound
@@ -1181,6 +1234,7 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   sb.out_scores = out_scores;
   sb.out_ids = out_ids;
   sb.out_count = out_count;
+  sb.debug = g_scan_no_epilogue;
   if (p.new_filter) {  // runs -> predicate -> key list -> select, one kernel
     ProfScope ps(stream, RP_K_SELECT);
     // ~k * stride keys lie above the sampled bound, ~3 x that before the accessibility predicate: the smallest shape whose
@@ -1544,6 +1598,7 @@ static RpStatus topk_merge_impl(const float* scores, const int32_t* ids, const i
                        k, keys);
   RP_CHECK_LAUNCH();
   SelectArgs sa;
+  sa.debug = 0;
   sa.keys = keys;
   sa.ld = (size_t)R * k;
   sa.counts = nullptr;
