@@ -1131,8 +1131,14 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
     return RP_OK;
   }
   // pass 0: dense keys of the sampled blocks (4 sub-tiles of 64 rows each), k best of the sample -> bound
+  // (many queries - a shard under the queries of an 8-GPU step: the sample is a quarter of the rows there, MFMA-bound, and
+  // the dense pass's 256-query x 128-row tile runs it faster than the 128 x 64 one - 45 vs 52 us, e4m3 34 vs 44 - once its
+  // tiles fill the chip; with fewer it is slower: 41 vs 29 us at 1024 queries x 32.5 k rows)
   const int n_sub = p.sample_blocks * (SIM_PB / SimCfgSample::BN);
-  st = fp8 ? launch_scan_cfg<SimCfg8Sample>(qop, eop, D2, n_sub, p.stride, epi, stream)
+  const bool big_sample_tile = ((B + 255) / 256) * p.sample_blocks * (SIM_PB / SimCfgQ256::BN) >= 256;  // fills the chip
+  st = big_sample_tile ? (fp8 ? launch_scan_cfg<SimCfg8Q256>(qop, eop, D2, p.sample_blocks * (SIM_PB / SimCfg8Q256::BN), p.stride, epi, stream)
+                         : launch_scan_cfg<SimCfgQ256>(qop, eop, D2, p.sample_blocks * (SIM_PB / SimCfgQ256::BN), p.stride, epi, stream))
+       : fp8 ? launch_scan_cfg<SimCfg8Sample>(qop, eop, D2, n_sub, p.stride, epi, stream)
        : (g_scan_sample_cfg == 0 && D2 % 64 == 0)
            ? launch_scan_cfg<SimCfgSampleK64>(qop, eop, D2, n_sub, p.stride, epi, stream)
            : launch_scan_cfg<SimCfgSample>(qop, eop, D2, n_sub, p.stride, epi, stream);  // (D % 64 != 0: 32-wide K slices)
