@@ -50,6 +50,8 @@ typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 1, 0, 1> SimCfg8FilterTail;
 // one (32 KB) - the premise operand streams from HBM, not from L2 like an encoder GEMM's weights
 typedef GemmCfg<256, 256, 32, 2, 2, 4, 1> SimCfgFilterK32;
 typedef GemmCfg<128, 64, 64, 2, 2, 3> SimCfgSampleK64;
+// the sample pass when MANY queries share few rows (its 256 x 128 tiles fill the chip): MFMA-bound there, on the pipelined loop
+typedef GemmCfg<256, 128, 64, 4, 2, 2, 1> SimCfgSampleBig;
 // default: the premise stream (read once, by one CU) carries the nt cache policy: -7 % filter time
 typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 0, 2> SimCfgFilterNt;
 constexpr int SIM_FILTER_META_BYTES = 3072;  // per-tile metadata behind the ring (EpiSimFilter::prologue)
@@ -217,7 +219,10 @@ __global__ __launch_bounds__(C::THREADS) void sim_scan_kernel(GemmOperand Qop, G
   epi.smem = smem;
   epi.tile_q0 = qt * C::BM;
   epi.bm = C::BM;
-  gemm_tile<C>(Qop, Eop, K, qt, pt, epi, smem);
+  if constexpr (C::PIPE != 0)
+    gemm_tile_pipe<C>(Qop, Eop, K, qt, pt, epi, smem);
+  else
+    gemm_tile<C>(Qop, Eop, K, qt, pt, epi, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1137,7 +1142,9 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   const int n_sub = p.sample_blocks * (SIM_PB / SimCfgSample::BN);
   const bool big_sample_tile = ((B + 255) / 256) * p.sample_blocks * (SIM_PB / SimCfgQ256::BN) >= 256;  // fills the chip
   st = big_sample_tile ? (fp8 ? launch_scan_cfg<SimCfg8Q256>(qop, eop, D2, p.sample_blocks * (SIM_PB / SimCfg8Q256::BN), p.stride, epi, stream)
-                         : launch_scan_cfg<SimCfgQ256>(qop, eop, D2, p.sample_blocks * (SIM_PB / SimCfgQ256::BN), p.stride, epi, stream))
+                         : (D2 % 64 == 0)
+                             ? launch_scan_cfg<SimCfgSampleBig>(qop, eop, D2, p.sample_blocks * (SIM_PB / SimCfgSampleBig::BN), p.stride, epi, stream)
+                             : launch_scan_cfg<SimCfgQ256>(qop, eop, D2, p.sample_blocks * (SIM_PB / SimCfgQ256::BN), p.stride, epi, stream))
        : fp8 ? launch_scan_cfg<SimCfg8Sample>(qop, eop, D2, n_sub, p.stride, epi, stream)
        : (g_scan_sample_cfg == 0 && D2 % 64 == 0)
            ? launch_scan_cfg<SimCfgSampleK64>(qop, eop, D2, n_sub, p.stride, epi, stream)
