@@ -578,6 +578,31 @@ __device__ __forceinline__ void select_body(const SelectArgs& a, int q, Each eac
     });
   }
   __syncthreads();
+  if (a.out_keys && !a.out_scores) {
+    // sample stage: what follows needs the SET of the kk best keys (they join the candidates, which are selected again) and
+    // the smallest of them as the bound - no order: one wave's minimum instead of a sort
+    if (a.debug & 2048) return;
+    for (int i = tid; i < kk; i += THREADS) a.out_keys[(size_t)q * a.out_ld + i] = sh.sel[i];
+    if (tid < 64) {
+      uint64_t m = ~0ull;
+      for (int i = lane; i < kk; i += 64) m = sh.sel[i] < m ? sh.sel[i] : m;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)m, o, 64);
+        const uint32_t ohi = (uint32_t)__shfl_xor((int)(uint32_t)(m >> 32), o, 64);
+        const uint64_t x = ((uint64_t)ohi << 32) | olo;
+        m = x < m ? x : m;
+      }
+      if (lane == 0) {
+        a.out_cnt[(size_t)q * SIM_COUNT_STRIDE] = kk;
+        const uint64_t th = (kk == a.k) ? m : 0ull;
+        a.out_thr[q] = th;
+        // keys > th have ordered(score) >= th.hi, i.e. score >= ord2f(th.hi)
+        if (a.out_tau) a.out_tau[q] = th ? ord2f((uint32_t)(th >> 32)) : -INFINITY;
+      }
+    }
+    return;
+  }
   if (P <= 128) {
     // the common case (k <= 128): ONE wave sorts the list in registers, two keys per lane (element e = lane + 64 r), the
     // same bitonic network through lane exchanges - 28 stages without a workgroup barrier each (with 1024 threads a
