@@ -11,7 +11,7 @@ import ctypes as C
 import json
 import os
 from types import SimpleNamespace
-from typing import Dict, Optional, Sequence, Tuple
+from typing import Dict, Optional
 
 import numpy as np
 import torch

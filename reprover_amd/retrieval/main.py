@@ -21,7 +21,6 @@ import torch
 import yaml
 
 from .datamodule import RetrievalDataModule
-from .evaluate import recall_and_mrr
 from .model import PremiseRetriever
 
 

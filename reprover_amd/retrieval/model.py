@@ -20,7 +20,6 @@ import os
 import pickle
 from typing import Any, Dict, List, Optional, Tuple, Union
 
-import numpy as np
 import torch
 
 from ..common import Context, Corpus, Fp8Index, IndexedCorpus, Pos, Premise, load_index, zip_strict

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import json
 import zlib
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Sequence, Tuple
 
 import numpy as np
 import torch

@@ -10,7 +10,7 @@ tests/golden/g1_tokenizer.json.
 from __future__ import annotations
 
 import re
-from typing import Dict, List, Sequence, Tuple
+from typing import List, Sequence, Tuple
 
 import numpy as np
 import torch
