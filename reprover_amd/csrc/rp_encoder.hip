@@ -39,9 +39,14 @@ int g_gemm_variant_wo = 26;   // FFN-out (+ residual)
 int g_gemm_variant_o = -1;    // attention output (+ residual); -1 = by pass size: two 128 x 128 blocks per CU, or - from 57 k
                               // tokens - the 8-wave 256 x 256 tile (A/B inside the 70 k-token step: 2.553 -> 2.470 ms per 12
                               // launches, three pairs; in isolation the two alternate below that size, tools/gemm_bench.py)
-int g_gemm_rs_lds = 1;      // big tiles: the RMSNorm statistic is reduced in the consuming GEMM from slot rows DMA'd into LDS (RowScaleLds)
+int g_gemm_rs_lds = 0;      // 1: big tiles reduce the RMSNorm statistic in the consuming GEMM from slot rows DMA'd into LDS (RowScaleLds:
+                            // 24 launches per pass fewer, the same bits).  Round 5 A/B inside the 70 k-token step, two boxes: the
+                            // rowscale launches + a 4-byte global read per token in the epilogue are FASTER than the LDS form, by
+                            // 0.48 ms per step with every lane summing its tokens' slots (round 4's form: 92 LDS reads + adds per
+                            // lane and tile) and still by 0.12 ms with one thread per token summing once per tile (reduce())
 int g_gemm_small_pipe = 1;  // few-token passes: the 64 x 128 x 64 tile on the software-pipelined loop (variant 17) instead of the plain one (16)
 int g_gemm_helpers = 64;      // few-token launches: up to this many surplus workgroups prefetch the weight rows (0 = off)
+int g_gemm_persist = 9;   // persistent workgroups (gemm_tiles_persist) per projection: 1 QKV, 4 attention-out, 8 FFN-in, 16 FFN-out
 int g_gemm_tail_split = 1;  // big passes: last partial round of 256 x 256 tiles as one round of 128 x 128 tiles
 int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 int g_gemm_skinny = 1;
@@ -147,6 +152,10 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   }
   if (!strcmp(name, "gemm_rs_lds")) {
     g_gemm_rs_lds = value != 0;
+    return RP_OK;
+  }
+  if (!strcmp(name, "gemm_persist")) {
+    g_gemm_persist = value;
     return RP_OK;
   }
   if (!strcmp(name, "gemm_tail_split")) {

@@ -12,7 +12,7 @@ namespace rp {
 
 // tuning knobs (defined in rp_encoder.hip, set through rp_set_option)
 extern int g_gemm_group_m, g_gemm_variant, g_gemm_variant_qkv, g_gemm_variant_wo, g_gemm_variant_o, g_gemm_tail_split,
-    g_debug_skip_ffn, g_gemm_skinny, g_gemm_skinny_variant, g_gemm_rs_lds, g_gemm_small_pipe, g_gemm_helpers;
+    g_debug_skip_ffn, g_gemm_skinny, g_gemm_skinny_variant, g_gemm_rs_lds, g_gemm_small_pipe, g_gemm_helpers, g_gemm_persist;
 extern int g_gemm_stagger_us[RP_K_COUNT];
 
 // ------------------------------------------------------------------------------------------
@@ -209,29 +209,37 @@ struct RowScaleLds {
   const float* ssp;  // [np, ld] slot-major partial sums of squares
   int np, ld;
   float inv_d, eps;
-  const float* lds = nullptr;  // set by prologue()
+  float* lds = nullptr;  // set by prologue()
   int n0 = 0;
   __device__ __forceinline__ void prologue(char* extra, int wave, int lane, int tok0) {
-    lds = reinterpret_cast<const float*>(extra);
+    lds = reinterpret_cast<float*>(extra);
     n0 = tok0;
     const int nw = (int)blockDim.x >> 6;
     for (int p = wave; p < np; p += nw)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ssp + (size_t)p * ld + tok0 + lane * 4), (lds_ptr_t)(extra + p * 1024), 16,
                                        0, 0);
   }
-  __device__ __forceinline__ float get(int token) const {
-    const float* p = lds + (token - n0);
-    float s = 0.f;  // slots in index order, as rowscale_kernel (whose zero padding beyond np adds exactly nothing)
+  // After the main loop (the rows have landed, every wave is past the barrier): ONE thread per token sums its np slots in
+  // index order - rowscale_kernel's chain, whose zero padding beyond np adds exactly nothing - and leaves rs in row 0.
+  // (Round 5: until then every lane summed the slots of its own four tokens in the epilogue, 8 x redundantly across the
+  // workgroup: 92 LDS reads + adds per lane, 0.5 ms per step.)  The caller puts a barrier behind it.
+  __device__ __forceinline__ void reduce(int tid) {
+    if (tid < 256) {
+      float* p = lds + tid;
+      float s = 0.f;
 #pragma unroll 4
-    for (int i = 0; i < np; ++i) s += p[i * 256];
-    return rsqrtf(s * inv_d + eps);
+      for (int i = 0; i < np; ++i) s += p[i * 256];
+      p[0] = rsqrtf(s * inv_d + eps);
+    }
   }
+  __device__ __forceinline__ float get(int token) const { return lds[token - n0]; }
 };
 // an epilogue whose row scale has a prologue of its own exposes it to gemm_tile_pipe
 template <class Base>
 struct WithRsPrologue : Base {
   static constexpr int EXTRA_LDS = decltype(Base::rs)::EXTRA_LDS;
   __device__ __forceinline__ void prologue(char* extra, int wave, int lane, int n0) { this->rs.prologue(extra, wave, lane, n0); }
+  __device__ __forceinline__ void reduce(int tid) { this->rs.reduce(tid); }
 };
 template <class E, class = void>
 struct epi_extra_lds : std::integral_constant<int, 0> {};
@@ -336,11 +344,16 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const size_t off = (size_t)(n_base + j * 32 + c * 8 + rr) * ldx + f;
+#ifdef RP_ABL_NOLOAD  // probe builds: the residual epilogue without the reads of the old planes
+        xh[p][c] = make_uint4((uint32_t)off, 0u, 0u, 0u);
+        xl[p][c] = make_uint4(0u, 0u, 0u, 0u);
+#else
         if constexpr (SPLIT_IN)
           xh[p][c] = *reinterpret_cast<const uint4*>(xhi_in + off);
         else
           xh[p][c] = *reinterpret_cast<const uint4*>(xhi + off);
         xl[p][c] = *reinterpret_cast<const uint4*>(xlo + off);
+#endif
       }
     };
 #pragma unroll
@@ -385,8 +398,12 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
           hilo_update2(h.y, l.y, d0.z, d0.w, oh.y, ol.y, ss);
           hilo_update2(h.z, l.z, d1.x, d1.y, oh.z, ol.z, ss);
           hilo_update2(h.w, l.w, d1.z, d1.w, oh.w, ol.w, ss);
+#ifdef RP_ABL_NOSTORE
+          asm volatile("" ::"v"(oh.x), "v"(oh.y), "v"(oh.z), "v"(oh.w), "v"(ol.x), "v"(ol.y), "v"(ol.z), "v"(ol.w));
+#else
           *reinterpret_cast<uint4*>(xhi + off) = oh;
           *reinterpret_cast<uint4*>(xlo + off) = ol;
+#endif
         }
         if (ssp) {  // fixed shuffle tree over the 8 lanes of the token's 64 features
           ss += __shfl_xor(ss, 1, 64);
@@ -431,7 +448,11 @@ struct EpiGegluBf16T {  // W rows interleaved 32 gate / 32 up: even row-fragment
             float y[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
+#ifdef RP_ABL_NOGELU  // probe builds: the epilogue without the activation's arithmetic
+              y[e] = acc[i][jb + jj][4 * g + e] * acc[i + 1][jb + jj][4 * g + e];
+#else
               y[e] = gelu_new(acc[i][jb + jj][4 * g + e] * sc) * (acc[i + 1][jb + jj][4 * g + e] * sc);
+#endif
             uint2 v;
             v.x = pack_bf2(y[0], y[1]);
             v.y = pack_bf2(y[2], y[3]);
@@ -444,7 +465,11 @@ struct EpiGegluBf16T {  // W rows interleaved 32 gate / 32 up: even row-fragment
         const int t = t0 + rr;
         if (t < nrows) {
           const uint4 v = *reinterpret_cast<const uint4*>(stage + t * EPI_ROW_BYTES + sub * 16);
+#ifdef RP_ABL_NOSTORE  // probe builds: the epilogue without its global stores
+          asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#else
           if (2 * f < n_valid) *reinterpret_cast<uint4*>(out + (size_t)(n_base + jb * 32 + t) * ldo + f) = v;
+#endif
         }
       }
     }
@@ -484,10 +509,9 @@ __device__ __forceinline__ void gemm_prefetch_helper(const GemmOperand& A, int K
 }
 
 template <class C, class Epi>
-__global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOperand W, int K, int tiles_m,
-                                                          int tiles_n, int group_m, int stagger_ticks,
-                                                          const int32_t* __restrict__ t_dev, Epi epi, int n_helpers) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gemm_kernel_body(GemmOperand A, GemmOperand W, int K, int tiles_m,
+                                                  int tiles_n, int group_m, int stagger_ticks,
+                                                  const int32_t* __restrict__ t_dev, Epi& epi, int n_helpers, char* smem) {
 #ifdef RP_EXPERIMENTS  // first-round stagger of the big GEMMs (measured neutral): probe builds only
   if (stagger_ticks > 0 && blockIdx.x < 256) {
     // first round only (later workgroups inherit their CU's phase): phase = position among the 256 CUs, uniform
@@ -522,12 +546,77 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOpe
     gemm_tile<C>(A, W, K, tm, tn, epi, smem);
 }
 
+template <class C, class Epi>
+__global__ __launch_bounds__(C::THREADS) void gemm_kernel(GemmOperand A, GemmOperand W, int K, int tiles_m,
+                                                          int tiles_n, int group_m, int stagger_ticks,
+                                                          const int32_t* __restrict__ t_dev, Epi epi, int n_helpers) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_kernel_body<C>(A, W, K, tiles_m, tiles_n, group_m, stagger_ticks, t_dev, epi, n_helpers, smem);
+}
+// the same kernel held to 256 registers per lane so that two 4-wave workgroups share a CU (GemmCfg::OCC = 2)
+template <class C, class Epi>
+__global__ __launch_bounds__(C::THREADS, 2) void gemm_kernel_occ2(GemmOperand A, GemmOperand W, int K, int tiles_m,
+                                                                  int tiles_n, int group_m, int stagger_ticks,
+                                                                  const int32_t* __restrict__ t_dev, Epi epi, int n_helpers) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_kernel_body<C>(A, W, K, tiles_m, tiles_n, group_m, stagger_ticks, t_dev, epi, n_helpers, smem);
+}
+
+// One workgroup per CU walking its share of the tiles (gemm_tiles_persist).  Workgroup b runs on XCD b % 8 (observed, speed
+// only) and takes the tiles j, j + 32, j + 64, ... of that XCD's contiguous range of logical tile ids (j = b / 8): at any
+// moment the 32 workgroups of an XCD sit on 32 consecutive logical ids, exactly as the one-tile-per-workgroup launch has them.
+template <class C, class Epi>
+__global__ __launch_bounds__(C::THREADS) void gemm_kernel_persist(GemmOperand A, GemmOperand W, int K, int tiles_m,
+                                                                  int tiles_n, int group_m,
+                                                                  const int32_t* __restrict__ t_dev, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int nwg = tiles_m * tiles_n;
+  if (t_dev) {  // rp_encode_padded: the token count is known on the device only (see gemm_kernel_body)
+    const int t_live = *t_dev;
+    tiles_n = (t_live + C::BN - 1) / C::BN;
+    nwg = tiles_m * tiles_n;
+    W.rows = max(1, min(W.rows, t_live));
+  }
+  const int xcd = blockIdx.x & 7, per = (int)gridDim.x >> 3;  // (the grid is a multiple of 8)
+  const int q = nwg >> 3, r = nwg & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, cnt = q + (xcd < r ? 1 : 0);
+  int i = blockIdx.x >> 3;
+  auto next_tile = [&](int& tm, int& tn) {
+    if (i >= cnt) return false;
+    tile_coords(base + i, tiles_n, tiles_m, group_m, tn, tm);  // token tiles grouped, feature tiles inside
+    i += per;
+    return true;
+  };
+  gemm_tiles_persist<C>(A, W, K, next_tile, epi, smem);
+}
+// an epilogue with metadata behind the ring (RowScaleLds) has 24 KiB for it in the persistent layout
+template <class Epi>
+static bool epi_fits_persist(const Epi& epi) {
+  if constexpr (epi_extra_lds<Epi>::value != 0)
+    return epi.rs.np * 1024 <= PERSIST_LDS_BYTES - PERSIST_META_OFF;
+  else
+    return true;
+}
+template <class C>
+constexpr bool persist_capable() {
+  return C::PIPE != 0 && C::FP8 == 0 && C::KTAIL == 0 && C::NSTAGE == 2 && C::STAGE_BYTES == 64 * 1024 && C::NWAVES == 8 && C::OCC == 0;
+}
+
+template <class C, class Epi>
+static auto pick_gemm_kernel() {
+  if constexpr (C::OCC == 2)
+    return gemm_kernel_occ2<C, Epi>;
+  else
+    return gemm_kernel<C, Epi>;
+}
+
 // `w` = weight matrix [n_rows_w, K] (row operand: tile rows = output features, clamped at the edge),
 // `a` = activations [M, K] (column operand: tile cols = tokens, M a multiple of the token tile).
 template <class C, class Epi>
 static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hipStream_t stream,
                                 int prof_class, int tokens_valid, const int32_t* t_dev) {
-  auto kern = gemm_kernel<C, Epi>;
+  auto kern = pick_gemm_kernel<C, Epi>();
+  static_assert(C::OCC == 0 || (C::OCC == 2 && C::THREADS == 256), "OCC: two 4-wave workgroups per CU");
   constexpr int LDS = (epi_extra_lds<Epi>::value ? C::RING_BYTES : C::LDS_BYTES) + epi_extra_lds<Epi>::value;
   static_assert(epi_extra_lds<Epi>::value == 0 || (C::PIPE != 0 && C::RING_BYTES >= C::NWAVES * EPI_STAGE_BYTES),
                 "metadata behind the ring: pipelined tiles only");
@@ -552,6 +641,18 @@ static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hi
   // token rows beyond the valid count are read as copies of the last valid row (the operand clamps at `rows`): the 27
   // padding rows of a 101-token state cost one cache line per DMA piece instead of eight
   a.rows = rows_needed;
+  if constexpr (persist_capable<C>()) {
+    // more tiles than CUs: one persistent workgroup per CU instead of one workgroup per tile
+    const int slots = n_cus & ~7;
+    if (((g_gemm_persist >> (prof_class - RP_K_GEMM_QKV)) & 1) && n_helpers == 0 && n_grid > slots && epi_fits_persist(epi)) {
+      auto pk = gemm_kernel_persist<C, Epi>;
+      static LdsAttrOnce pattr;
+      RP_HIP(pattr.ensure((const void*)pk, PERSIST_LDS_BYTES));
+      hipLaunchKernelGGL(pk, dim3(slots), dim3(C::THREADS), PERSIST_LDS_BYTES, stream, w, a, K, tiles_f, tiles_t, group, t_dev, epi);
+      RP_CHECK_LAUNCH();
+      return RP_OK;
+    }
+  }
   hipLaunchKernelGGL(kern, dim3(n_grid + n_helpers), dim3(C::THREADS), LDS, stream, w, a, K, tiles_f, tiles_t, group,
                      stagger_ticks, t_dev, epi, n_helpers);
   RP_CHECK_LAUNCH();
@@ -595,6 +696,7 @@ inline bool small_variant(int v) { return v == 0 || (v >= 15 && v <= 17); }
 
 // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages[, pipelined]>:
 //   20 / 26  pipelined 256 x 256 x 64, 4 / 8 waves     (the encoder's big GEMMs)
+//   27 / 28  (RP_EXPERIMENTS builds) pipelined 256 x 128 x 32 / 128 x 256 x 32 (features x tokens), 3 stages, 4 waves, TWO workgroups per CU
 //   9        plain 256 x 256 x 32, 3 stages             (K % 64 != 0)
 //   0        plain 128 x 128 x 32, 3 stages, 2 blocks/CU (attention-out; token counts not a multiple of 256)
 //   17       64 x 128 x 64, 4 stages, pipelined loop    (up to ~1024 tokens: single-state queries)
@@ -612,6 +714,10 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
       case 20: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
       case 26: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
       case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
+#ifdef RP_EXPERIMENTS  // round 5, measured and rejected (profiles/r05_epilogue_overlap.md): FFN-in / FFN-out +17 % time
+      case 27: return launch_gemm_cfg<GemmCfg<256, 128, 32, 2, 2, 3, 1, 0, 0, 0, 2>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
+      case 28: return launch_gemm_cfg<GemmCfg<128, 256, 32, 2, 2, 3, 1, 0, 0, 0, 2>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
+#endif
       case 12: return launch_gemm_cfg<GemmCfg<64, 256, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
       default: break;
     }

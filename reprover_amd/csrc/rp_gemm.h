@@ -55,8 +55,13 @@ __device__ unsigned long long g_handover_ts[8 * 64 * 3];
 __device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 // Tile configuration: block tile BM x BN x BK, WM x WN waves, NSTAGE-deep LDS ring.
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSTAGE_, int PIPE_ = 0, int FP8_ = 0, int AAUX_ = 0, int KTAIL_ = 0>
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSTAGE_, int PIPE_ = 0, int FP8_ = 0, int AAUX_ = 0, int KTAIL_ = 0,
+          int OCC_ = 0>
 struct GemmCfg {
+  // OCC = 2: TWO workgroups of this configuration are meant to share a CU (4 waves each, one per SIMD and workgroup, at most
+  // 256 registers per lane, at most 80 KiB of LDS): the hardware scheduler then runs one workgroup's main loop under the
+  // other's prologue / hand-over stalls / epilogue.  0: whatever the register allocation allows.
+  static constexpr int OCC = OCC_;
   // KTAIL = 1 (gemm_tile_pipe): K may end half a k-tile early (K % BK == BK / 2).  The last tile then carries only its
   // first half: the lanes whose 16-byte chunk lies in the missing half fetch the chunk BK/2 earlier instead (a duplicate,
   // never multiplied, never out of bounds) and the tile runs half its k-steps.
@@ -111,6 +116,13 @@ template <class E, class = void>
 struct has_prologue : std::false_type {};
 template <class E>
 struct has_prologue<E, std::void_t<decltype(&E::prologue)>> : std::true_type {};
+
+// ... and `void reduce(int tid)`: called once the main loop is over (the metadata has landed and every wave is past the
+// barrier), followed by a barrier - turns the metadata into what the epilogue reads.
+template <class E, class = void>
+struct has_reduce : std::false_type {};
+template <class E>
+struct has_reduce<E, std::void_t<decltype(&E::reduce)>> : std::true_type {};
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -511,10 +523,231 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
   tile_body(kt, I0(), I0());  // (a half tile skips its upper k-steps inside the body: no second set of MFMA code)
   __syncthreads();
   RP_TS(2);
+  if constexpr (has_reduce<Epilogue>::value) {  // per-tile metadata -> what the epilogue reads (one pass, then visible to all)
+    epi.reduce(tid);
+    __syncthreads();
+  }
 
   epi.template run<FM, FN>(acc, tile_m * C::BM + wave_row * (FM * 32), tile_n * C::BN + wave_col * (FN * 32), lane,
                            smem + wave * EPI_STAGE_BYTES);
   RP_TS(3);
+}
+
+// PERSISTENT form of gemm_tile_pipe (bf16 operands, 2-stage ring, no K tail): ONE workgroup per CU walks a list of tiles
+// (`next_tile(tm, tn)` hands out the workgroup's next tile, false when it has none left).  Two things a launch with one
+// workgroup per tile pays per tile are gone (tools/probes/gemm_phase.py, round 5: of 45.6 us per FFN-in tile 1.8 us are the
+// prologue - the wait for the first k-tile with nothing else to do - and ~3 us the turn-over of the CU from one workgroup
+// to the next):
+//   * no workgroup turn-over between tiles;
+//   * the first k-tile of tile t+1 is requested BEFORE the epilogue of tile t and lands under it.  LDS (all 160 KiB):
+//       [0, 64 K)      ring slot 0 - free once the main loop is over: tile t+1's first k-tile goes there
+//       [64 K, 136 K)  the epilogue's per-wave staging areas (8 x 9 KiB; over ring slot 1, which is dead by then)
+//       [136 K, 160 K) per-tile metadata of an epilogue with a prologue() hook (<= 24 slot rows of 1 KiB)
+//     After the epilogue one raw barrier frees the staging area; the metadata and the second k-tile of tile t+1 are
+//     requested and the main loop starts on a k-tile that has already landed.
+// The queue of a wave at that point, oldest first: [slot 0 of t+1] [epilogue stores of t] [metadata] [slot 1 of t+1];
+// the first counted wait leaves only the youngest DPS operations outstanding, as in the one-tile form.
+// Every output element is the same K-ascending chain of MFMA steps: not a bit differs from gemm_tile_pipe.
+constexpr int PERSIST_EPI_OFF = 64 * 1024, PERSIST_META_OFF = 136 * 1024, PERSIST_LDS_BYTES = 160 * 1024;
+template <class C, class Epilogue, class NextTile>
+__device__ __forceinline__ void gemm_tiles_persist(const GemmOperand A, const GemmOperand W, int K, NextTile next_tile,
+                                                   Epilogue& epi, char* smem) {
+  static_assert(C::PIPE != 0 && C::FP8 == 0 && C::KTAIL == 0 && C::NSTAGE == 2 && C::STAGE_BYTES == 64 * 1024 &&
+                    C::NWAVES * EPI_STAGE_BYTES <= PERSIST_META_OFF - PERSIST_EPI_OFF,
+                "persistent form: the pipelined 256 x 256 x 64 bf16 tile");
+  constexpr int BK = C::BK, FM = C::FM, FN = C::FN, KS = BK / 16, NSTAGE = 2, DPS = C::A_DMA + C::W_DMA;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_row = wave / C::WN, wave_col = wave % C::WN;
+  const int hi = lane >> 5;
+  int tile_m, tile_n;
+  if (!next_tile(tile_m, tile_n)) return;
+
+  const bf16_t* a_src[C::A_DMA];
+  const bf16_t* w_src[C::W_DMA];
+  auto set_src = [&](int tm, int tn) {
+#pragma unroll
+    for (int d = 0; d < C::A_DMA; ++d) {
+      const int row = (wave * C::A_DMA + d) * C::ROWS_PER_DMA + lane / C::SLOTS;
+      const int kc = (lane % C::SLOTS) ^ C::swz(row);
+      a_src[d] = A.ptr + A.row_off(tm * C::BM + row, kc);
+    }
+#pragma unroll
+    for (int d = 0; d < C::W_DMA; ++d) {
+      const int row = (wave * C::W_DMA + d) * C::ROWS_PER_DMA + lane / C::SLOTS;
+      const int kc = (lane % C::SLOTS) ^ C::swz(row);
+      w_src[d] = W.ptr + W.row_off(tn * C::BN + row, kc);
+    }
+  };
+  const int nk = K / BK;
+  auto stage_half = [&](int kt, int buf, int half) {
+    char* base = smem + buf * C::STAGE_BYTES;
+    if (half == 0) {
+#pragma unroll
+      for (int d = 0; d < C::A_DMA; ++d)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + A.k_off(kt, BK)), (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024),
+                                         16, 0, 0);
+    } else {
+#pragma unroll
+      for (int d = 0; d < C::W_DMA; ++d)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[d] + W.k_off(kt, BK)),
+                                         (lds_ptr_t)(base + C::A_BYTES + (wave * C::W_DMA + d) * 1024), 16, 0, 0);
+    }
+  };
+  auto stage = [&](int kt, int buf) {
+    stage_half(kt, buf, 0);
+    stage_half(kt, buf, 1);
+  };
+  int a_off[FM][KS], b_off[FN][KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int slot = ks * 2 + hi;
+#pragma unroll
+    for (int f = 0; f < FM; ++f) a_off[f][ks] = C::off(wave_row * (FM * 32) + f * 32 + (lane & 31), slot);
+#pragma unroll
+    for (int f = 0; f < FN; ++f) b_off[f][ks] = C::A_BYTES + C::off(wave_col * (FN * 32) + f * 32 + (lane & 31), slot);
+  }
+  f32x16 acc[FM][FN];
+  bf16x8 af[2][FM], bfr[2][FN];
+  auto read_frags = [&](const char* st, int ks, int p) {
+#pragma unroll
+    for (int f = 0; f < FM; ++f) af[p][f] = *reinterpret_cast<const bf16x8*>(st + a_off[f][ks]);
+#pragma unroll
+    for (int f = 0; f < FN; ++f) bfr[p][f] = *reinterpret_cast<const bf16x8*>(st + b_off[f][ks]);
+  };
+  auto mma = [&](int p) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[p][i], bfr[p][j], acc[i][j], 0, 0, 0);
+  };
+  auto hint_order = [](auto nread_tag, auto ndma_tag) {
+    constexpr int NREAD = decltype(nread_tag)::value, NDMA = decltype(ndma_tag)::value, NM = FM * FN;
+    constexpr int PER = (NREAD + NDMA + NM - 1) / NM;
+    int rd = NREAD, dm = NDMA;
+#pragma unroll
+    for (int n = 0; n < NM; ++n) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        if (rd > 0) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+          --rd;
+        } else if (dm > 0) {
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (LDS-DMA)
+          --dm;
+        }
+      }
+    }
+  };
+  using NoDma = std::integral_constant<int, 0>;
+  using Reads = std::integral_constant<int, FM + FN>;
+  int buf = 0;
+  auto tile_body = [&](int kt, auto mode_tag, auto pend_tag) {  // as in gemm_tile_pipe
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool PEND = decltype(pend_tag)::value != 0;
+    const char* st = smem + buf * C::STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < KS - 1; ++ks) {
+      read_frags(st, ks + 1, (ks + 1) & 1);
+      if (PEND && ks == 0) stage_half(kt - 1 + NSTAGE, buf == 0 ? NSTAGE - 1 : buf - 1, 1);
+      mma(ks & 1);
+      if (PEND && ks == 0)
+        hint_order(Reads(), std::integral_constant<int, C::W_DMA>());
+      else
+        hint_order(Reads(), NoDma());
+    }
+    if (MODE >= 1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wait_vmcnt<0>();  // (NSTAGE - 2) * DPS = 0: this wave's share of tile kt+1 has landed
+      __builtin_amdgcn_s_barrier();
+      const int freed = buf;
+      if (++buf == NSTAGE) buf = 0;
+      read_frags(smem + buf * C::STAGE_BYTES, 0, 0);
+      if (MODE == 2) stage_half(kt + NSTAGE, freed, 0);
+    }
+    mma((KS - 1) & 1);
+    if (MODE == 2)
+      hint_order(Reads(), std::integral_constant<int, C::A_DMA>());
+    else if (MODE == 1)
+      hint_order(Reads(), NoDma());
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+
+  set_src(tile_m, tile_n);
+  stage(0, 0);  // the workgroup's first tile: both slots requested here; later tiles find slot 0 requested already
+#ifdef RP_PHASE_PROBE  // per workgroup SUMS over its tiles: [prologue, main loop, epilogue + end barrier, tiles] (100 MHz ticks)
+  unsigned long long p_t0 = 0, p_t1 = 0, p_t2 = 0;
+#define RP_PTS(v) v = wall_clock64()
+#else
+#define RP_PTS(v) \
+  do {            \
+  } while (0)
+#endif
+  for (;;) {
+    RP_PTS(p_t0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if constexpr (has_prologue<Epilogue>::value) epi.prologue(smem + PERSIST_META_OFF, wave, lane, tile_n * C::BN);
+    stage(1, 1);
+    wait_vmcnt<DPS>();  // everything older than slot 1's requests: slot 0 (and the last epilogue's stores, the metadata)
+    __builtin_amdgcn_s_barrier();
+    buf = 0;
+    RP_PTS(p_t1);
+    read_frags(smem, 0, 0);
+    int kt = 0;
+    if (nk > NSTAGE) {
+      tile_body(0, I2(), I0());
+      for (kt = 1; kt + NSTAGE < nk; ++kt) tile_body(kt, I2(), I1());
+      tile_body(kt, I1(), I1());
+      ++kt;
+    }
+    for (; kt + 1 < nk; ++kt) tile_body(kt, I1(), I0());
+    tile_body(kt, I0(), I0());
+    __syncthreads();  // every wave is done with the ring (nothing of this wave's is in flight here)
+    if constexpr (has_reduce<Epilogue>::value) epi.reduce(tid);  // (the barrier behind it: below, after the next tile's requests)
+    RP_PTS(p_t2);
+    int nm, nn;
+    const bool more = next_tile(nm, nn);
+    const int em = tile_m * C::BM + wave_row * (FM * 32), en = tile_n * C::BN + wave_col * (FN * 32);
+    if (more) {
+      set_src(nm, nn);
+      stage(0, 0);  // lands under the epilogue
+      tile_m = nm;
+      tile_n = nn;
+    }
+    if constexpr (has_reduce<Epilogue>::value) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // the reduced metadata is visible to every wave (raw: the requests above stay in flight)
+    }
+    epi.template run<FM, FN>(acc, em, en, lane, smem + PERSIST_EPI_OFF + wave * EPI_STAGE_BYTES);
+#ifdef RP_PHASE_PROBE
+    if (more) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+      const unsigned long long p_t3 = wall_clock64();
+      g_phase_ts[blockIdx.x * 4 + 0] += p_t1 - p_t0;
+      g_phase_ts[blockIdx.x * 4 + 1] += p_t2 - p_t1;
+      g_phase_ts[blockIdx.x * 4 + 2] += p_t3 - p_t2;
+      g_phase_ts[blockIdx.x * 4 + 3] += 1;
+    }
+    if (!more) break;
+#else
+    if (!more) break;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the staging areas (over ring slot 1) and the metadata rows are free
+#endif
+  }
+#undef RP_PTS
 }
 
 // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (observed, speed only), so consecutive

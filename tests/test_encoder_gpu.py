@@ -157,27 +157,33 @@ def test_bf16_output_and_chunked_passes_agree(small, golden_dir):
     assert torch.equal(out_bf, ref.to(torch.bfloat16))
 
 
-def test_big_pass_statistic_in_the_consuming_gemm_is_the_same_bits(small):
-    """Passes on the 256 x 256 tiles reduce the RMSNorm statistic inside the consuming GEMM (slot rows DMA'd into LDS
-    behind the operand ring, summed in index order: RowScaleLds) instead of in a rowscale launch per sub-layer.  The same
-    sums in the same order: the embeddings of a 17 k-token pass must not differ by a bit from the rowscale form."""
+def test_big_pass_launch_forms_are_the_same_bits(small):
+    """Passes on the 256 x 256 tiles have four launch forms of the row-scaled projections: the RMSNorm statistic from a
+    rowscale launch per sub-layer (the default since round 5) or reduced inside the consuming GEMM (slot rows DMA'd into LDS
+    behind the operand ring, one thread per token summing them in index order: RowScaleLds), each with one workgroup per
+    tile or with persistent workgroups (gemm_tiles_persist: one per CU, the next tile's first k-tile requested under the
+    epilogue).  The same sums in the same order, the same K-ascending MFMA chain per output element: the embeddings of a
+    70 k-token pass (more tiles than CUs in every projection) must not differ by a bit between any two of them."""
     from reprover_amd import _lib
 
     lib = _lib.load()
     rng = np.random.default_rng(11)
-    lens = synth.synth_lengths(rng, 64, "mix", lo=16, hi=2048)
+    lens = synth.synth_lengths(rng, 256, "mix", lo=16, hi=2048)
     texts = [synth.synth_state(rng, int(n) - 1) for n in lens]
     ids, cu = small.tokenizer.packed(texts, small.max_seq_len)
-    assert int(cu[-1]) > 8192  # big-tile territory for every projection
+    assert int(cu[-1]) > 65536  # 274 token tiles x >= 5 feature tiles: several tiles per persistent workgroup
     outs = []
     try:
-        for on in (1, 0):
-            _lib.check(lib.rp_set_option(b"gemm_rs_lds", on), "opt")
+        for rs_lds, persist in ((0, 9), (0, 0), (1, 0), (1, 29), (0, 29)):
+            _lib.check(lib.rp_set_option(b"gemm_rs_lds", rs_lds), "opt")
+            _lib.check(lib.rp_set_option(b"gemm_persist", persist), "opt")
             out = torch.empty((len(texts), small.embedding_size), dtype=torch.float32, device="cuda:0")
             small.encoder.encode_packed(ids, cu, out)
             torch.cuda.synchronize()
             outs.append(out)
     finally:
-        _lib.check(lib.rp_set_option(b"gemm_rs_lds", 1), "opt")
-    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+        _lib.check(lib.rp_set_option(b"gemm_rs_lds", 0), "opt")
+        _lib.check(lib.rp_set_option(b"gemm_persist", 9), "opt")
+    for o in outs[1:]:
+        assert torch.equal(outs[0].view(torch.int32), o.view(torch.int32))
     assert torch.isfinite(outs[0]).all() and (outs[0].norm(dim=1) - 1).abs().max().item() < 1e-5

@@ -7,7 +7,8 @@ lib = _lib.load()
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 variants = [int(v) for v in os.environ.get("VARIANTS", "26,20,9,0").split(",")]
 groups = [int(v) for v in os.environ.get("GROUP_M", "8").split(",")]
-staggers = [int(v) for v in os.environ.get("STAGGER", "0").split(",")]  # gemm_stagger_us_* values (first-round spread)
+staggers = [int(v) for v in os.environ.get("STAGGER", "0").split(",")]
+persists = [int(v) for v in os.environ.get("PERSIST", "0").split(",")]  # gemm_persist masks (29 = every projection)  # gemm_stagger_us_* values (first-round spread)
 OPT = {"wi": b"gemm_stagger_us_wi", "wo": b"gemm_stagger_us_wo", "qk": b"gemm_stagger_us_qkv", "o ": b"gemm_stagger_us_o"}
 if os.environ.get("SKINNY") is not None:  # 0: the variant asked for is the variant run, whatever the token count
     _lib.check(lib.rp_set_option(b"gemm_skinny", int(os.environ["SKINNY"])), "opt")
@@ -61,8 +62,9 @@ for name, N, K, epi in shapes:
     errs = {}
     for rnd in range(ROUNDS + 1):  # round 0 = correctness + warm-up; then interleaved timing rounds
         for v in variants:
-            for gm in [(g_, s_) for g_ in groups for s_ in staggers]:
+            for gm in [(g_, s_, p_) for g_ in groups for s_ in staggers for p_ in persists]:
                 _lib.check(lib.rp_set_option(b"gemm_variant_all", v), "opt")
+                _lib.check(lib.rp_set_option(b"gemm_persist", gm[2]), "opt")
                 _lib.check(lib.rp_set_option(b"gemm_group_m", gm[0]), "opt")
                 if gm[1]:  # (the stagger knob exists in RP_EXPERIMENTS builds only)
                     _lib.check(lib.rp_set_option(OPT[name[:2]], gm[1]), "opt")
@@ -90,5 +92,5 @@ for name, N, K, epi in shapes:
                 times.setdefault((v, gm), []).append(e0.elapsed_time(e1) / iters)
     for (v, gm), ts in times.items():
         best, med = min(ts), sorted(ts)[len(ts) // 2]
-        print(f"{name} M={M} N={N} K={K} variant={v:2d} group_m,stagger_us={gm}: best {best:7.3f} ms {2.0*M*N*K/best/1e9:7.1f} TF | "
+        print(f"{name} M={M} N={N} K={K} variant={v:2d} group_m,stagger_us,persist={gm}: best {best:7.3f} ms {2.0*M*N*K/best/1e9:7.1f} TF | "
               f"median {med:7.3f} ms {2.0*M*N*K/med/1e9:7.1f} TF  maxerr {errs[(v, gm)]:.3e}", flush=True)

@@ -12,9 +12,9 @@ sys.path.insert(0, ROOT)
 PROBE = os.path.join(ROOT, "tools", "probes", "_build", "libreprover_probe%s.so" % (("_" + os.environ["ABLATE"]) if os.environ.get("ABLATE") else ""))
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     os.makedirs(os.path.dirname(PROBE), exist_ok=True)
-    src = [os.path.join(ROOT, "reprover_amd", "csrc", f) for f in ("rp_encoder.hip", "rp_retrieval.hip", "rp_train.hip")]
+    src = [os.path.join(ROOT, "reprover_amd", "csrc", f) for f in ("rp_encoder.hip", "rp_retrieval.hip", "rp_train.hip", "rp_comm.hip")]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-DRP_PHASE_PROBE", "-DRP_EXPERIMENTS", *src, "-o", PROBE])
+                           "-DRP_PHASE_PROBE", "-DRP_EXPERIMENTS", *os.environ.get("ABLATE_DEFS", "").split(), *src, "-o", PROBE])
     print("built", PROBE); sys.exit(0)
 import numpy as np, torch
 from reprover_amd import _lib
@@ -33,8 +33,38 @@ for name in os.environ.get("ONLY", "wi,wo").split(","):
     W = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
     out = (torch.zeros(2, M, N, dtype=torch.bfloat16, device=dev) if epi == _lib.RP_EPI_RESID else
            torch.empty(M, N // 2 if epi == _lib.RP_EPI_GEGLU_BF16 else N, dtype=torch.bfloat16, device=dev))
+    persist = int(os.environ.get("PERSIST", "0"))
     for v in [int(x) for x in os.environ.get("VARIANTS", "6,20").split(",")]:
         _lib.check(lib.rp_set_option(b"gemm_variant_all", v), "opt")
+        _lib.check(lib.rp_set_option(b"gemm_persist", persist), "opt")
+        if persist:  # persistent workgroups keep SUMS per workgroup: read them around a batch of launches
+            def launch():
+                if epi == _lib.RP_EPI_RESID:
+                    ssp_ = torch.empty((N + 63) // 64, M, device=dev)
+                    _lib.check(lib.rp_dbg_gemm_fused(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, N, epi, None, 0, 0.0,
+                                                     0.0, None, ssp_.data_ptr(), (N + 63) // 64, _lib.current_stream()), "gemm")
+                else:
+                    _lib.check(lib.rp_dbg_gemm(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, N, epi, _lib.current_stream()), "gemm")
+            for _ in range(3):
+                launch()
+            torch.cuda.synchronize()
+            b = np.zeros(4 * 256, dtype=np.uint64); a_ = np.zeros(4 * 256, dtype=np.uint64)
+            assert lib.rp_probe_read_phase_ts(b.ctypes.data, b.size) == 0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                launch()
+            e1.record(); torch.cuda.synchronize()
+            assert lib.rp_probe_read_phase_ts(a_.ctypes.data, a_.size) == 0
+            d = (a_.astype(np.int64) - b.astype(np.int64)).reshape(256, 4)
+            n = d[:, 3].astype(np.float64)
+            span = e0.elapsed_time(e1) / 10 * 1e3
+            pro, main, ep = d[:, 0] / n / 100.0, d[:, 1] / n / 100.0, d[:, 2] / n / 100.0
+            print(f"{name} variant {v} PERSISTENT: launch {span:.1f} us, tiles per workgroup {n.mean() / 10:.2f}")
+            print(f"   per tile: top-of-loop -> first k-tile ready {pro.mean():6.2f} us | main loop {main.mean():6.2f} us "
+                  f"({main.mean() / (K / 64):.3f} per 64-K step) | epilogue + end barrier {ep.mean():6.2f} us | total {(pro + main + ep).mean():6.2f}")
+            print(f"   sum of tile times / (256 CUs x launch) = {((d[:, 0] + d[:, 1] + d[:, 2]).sum() / 100.0 / 10) / (256 * span):.3f}")
+            continue
         fused = epi == _lib.RP_EPI_RESID
         np_ = (N + 63) // 64
         ssp = torch.empty(np_, M, device=dev) if fused else None
