@@ -410,6 +410,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", choices=("allgather", "alltoall"), default=os.environ.get("RP_BENCH_EXCHANGE", "allgather"),
+                    help="N > 1: how the per-shard top-k lists reach the rank that merges them: ONE packed all-gather "
+                         "(north_star's form, the default) or ONE all-to-all of per-destination slices (1 / N of the bytes)")
     ap.add_argument("--premise-sample", type=int, default=4096, help="premises in the encode-throughput leg")
     ap.add_argument("--no-full-reindex", action="store_true", help="skip the 130,000-premise reindex_corpus leg (~20 s)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step leg")
@@ -539,18 +542,35 @@ def main():
         else:
             dist.all_gather(list(dst.view((world,) + tuple(src.shape)).unbind(0)), src)
 
-    def step():
+    def merge_into_f(g_ids, g_scores, g_counts):  # strided merge of [world, B_STATES, k] views of a receive buffer into f_*
+        _lib.check(lib.rp_topk_merge_strided(g_scores.data_ptr(), g_ids.data_ptr(), g_counts.data_ptr(), g_scores.stride(0), world,
+                                             B_STATES, TOP_K, f_s.data_ptr(), f_i.data_ptr(), f_c.data_ptr(), mws.data_ptr(),
+                                             mws_bytes, _lib.current_stream()), "rp_topk_merge_strided")
+        return f_i, f_s, f_c
+
+    a2a_staging = {}
+
+    def exchange_allgather():
+        gather(g_all, send_block)  # one packed block per rank; every rank receives every rank's lists for ALL queries
+        q0 = rank * B_STATES       # this rank merges its own queries, straight from the receive buffer
+        merge_into_f(g_i.view(world, BQ, TOP_K)[:, q0 : q0 + B_STATES], g_s.view(world, BQ, TOP_K)[:, q0 : q0 + B_STATES],
+                     g_c[:, q0 : q0 + B_STATES])
+
+    def exchange_alltoall():
+        from reprover_amd.dist import sliced_exchange_merge
+
+        n_collectives[0] += 1      # one all-to-all of per-destination slices: a rank receives only its own queries' lists
+        sliced_exchange_merge(out_i, out_s, out_c, None, merge=merge_into_f, staging=a2a_staging)
+
+    exchange = {"allgather": exchange_allgather, "alltoall": exchange_alltoall}
+
+    def step(how=args.exchange):
         enc.encode_packed_device(ids_d, cu_d, B_STATES, T, max_len, q_loc)
         if world > 1:
             gather(q_all, q_loc)
         scan()
         if world > 1:
-            gather(g_all, send_block)  # the step's second and last collective: one packed block per rank
-            q0 = rank * B_STATES       # this rank merges its own queries, straight from the receive buffer
-            _lib.check(lib.rp_topk_merge_strided(g_s.data_ptr() + 4 * q0 * TOP_K, g_i.data_ptr() + 4 * q0 * TOP_K,
-                                                 g_c.data_ptr() + 4 * q0, blk, world, B_STATES, TOP_K, f_s.data_ptr(),
-                                                 f_i.data_ptr(), f_c.data_ptr(), mws.data_ptr(), mws_bytes,
-                                                 _lib.current_stream()), "rp_topk_merge_strided")
+            exchange[how]()  # the step's second and last collective
 
     def barrier():
         if world > 1:
@@ -586,8 +606,9 @@ def main():
         dist.barrier()
     counts_ok = bool(((f_c if world > 1 else out_c).cpu() == TOP_K).all())
     merged_ok = None
+    reference_lists = None
     if world > 1 and rank == 0:
-        # shard + all-gather + merge must equal the single-GPU answer: check rank 0's own queries against a
+        # shard + exchange + merge must equal the single-GPU answer: check rank 0's own queries against a
         # scan of the whole (unsharded) matrix
         fo, eo = torch.from_numpy(corpus.file_of).to(dev), torch.from_numpy(corpus.end_key).to(dev)
         b0, o0, k0 = corpus.query_masks(all_ctx[:B_STATES])
@@ -604,7 +625,60 @@ def main():
                                    r_s.data_ptr(), r_i.data_ptr(), r_c.data_ptr(), wsx.data_ptr(), wb,
                                    _lib.current_stream()), "rp_sim_topk")
         torch.cuda.synchronize()
+        reference_lists = (r_i, r_s)
         merged_ok = bool(torch.equal(r_i, f_i) and torch.equal(r_s, f_s))
+
+    # ---- N > 1: the top-k stage WITH its collective: pre-encoded queries -> rp_sim_topk on the shard ->
+    # the exchange -> the merge, timed together under both exchange forms, the collective alone from events
+    topk_only = None
+    if world > 1:
+        topk_only = {}
+        blk_bytes = BQ * (2 * TOP_K + 1) * 4
+        for how in ("allgather", "alltoall"):
+            for _ in range(3):
+                scan()
+                exchange[how]()
+            barrier()
+            t0 = time.perf_counter()
+            iters = 20
+            for _ in range(iters):
+                scan()
+                exchange[how]()
+            torch.cuda.synchronize()
+            dist.barrier()
+            tdt = time.perf_counter() - t0
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+            for a, b in ev:  # the exchange alone (collective + pack copies + merge) between events on the launch stream
+                scan()
+                a.record()
+                exchange[how]()
+                b.record()
+            torch.cuda.synchronize()
+            ex_us = float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e3
+            tt = torch.tensor([tdt, ex_us], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ok = None
+            if rank == 0:
+                ok = bool(torch.equal(reference_lists[0], f_i) and torch.equal(reference_lists[1], f_s))
+            topk_only[how] = {
+                "qps": BQ * iters / float(tt[0].item()), "ms_per_step": float(tt[0].item()) / iters * 1e3,
+                "exchange_us": float(tt[1].item()),
+                # bytes one rank sends / receives in the collective (ring all-gather: its own block to every peer)
+                "collective_bytes_sent_per_rank": (world - 1) * (blk_bytes if how == "allgather" else blk_bytes // world),
+                "collective_bytes_received_per_rank": (world - 1) * (blk_bytes if how == "allgather" else blk_bytes // world),
+                "bytes_merged_per_rank": blk_bytes,  # world lists of this rank's own B_STATES queries
+                "sharded_merge_equals_single_gpu": ok,
+            }
+        qe = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        for a, b in qe:
+            a.record()
+            gather(q_all, q_loc)
+            b.record()
+        torch.cuda.synchronize()
+        topk_only["query_embedding_allgather_us"] = float(np.median([a.elapsed_time(b) for a, b in qe])) * 1e3
+        topk_only["path"] = ("per step: rp_sim_topk of all N*256 queries on this rank's shard -> the exchange -> "
+                             "rp_topk_merge_strided of the rank's own 256 queries; qps = N*256 queries / max-over-ranks time; "
+                             "exchange_us = collective + (all-to-all: three pack copies) + merge between HIP events")
     ms_per_step = dt / args.steps * 1e3
     qps = BQ * args.steps / dt
 
@@ -885,7 +959,7 @@ def main():
             "index": "row-sharded %d-way, bf16 unit-norm random rows" % world,
             "weights": "random-init ByT5-small (d_model 1472, 12 layers, 6 heads, d_ff 3584)",
             "accessible_premises_first_queries": n_acc.tolist(), "all_counts_eq_k": counts_ok, "sharded_merge_equals_single_gpu": merged_ok,
-            "collectives_per_step": collectives_per_step,
+            "collectives_per_step": collectives_per_step, "exchange": args.exchange if world > 1 else None,
         },
         "premises_per_s": prem_per_s,
         "premises_per_s_incl_host_tokenisation": prem_per_s_host,
@@ -898,6 +972,7 @@ def main():
         "b1_latency_ms": b1,
         "scan_only_qps": scan_only_qps,
         "scan_only_qps_e4m3_index": scan_only_qps_fp8,
+        "topk_only": topk_only,
         "roofline": {
             "kernel": "gemm_kernel<EpiGegluBf16> (FFN wi_0|wi_1 GEMM + gated-GELU epilogue; 58% of encoder FLOPs)",
             "bound": "mfma", "achieved": wi_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

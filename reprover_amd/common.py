@@ -487,8 +487,11 @@ class Corpus:
         masks = (_lib.ptr(file_of), _lib.ptr(end_key), _lib.ptr(d_bits), len(self._files), _lib.ptr(d_own), _lib.ptr(d_qk), 0)
         for lo in range(0, k, P):
             kk = min(P, k - lo)
-            ps, pi = pg_s.view(-1)[: B * kk].view(B, kk), pg_i.view(-1)[: B * kk].view(B, kk)  # the call writes [B, kk] rows
-            outs = (kk, flags, _lib.ptr(ps), _lib.ptr(pi), _lib.ptr(pg_c), _lib.ptr(ws), ws_bytes, _lib.current_stream())
+            # Every page is a call with the FULL page size P (the last one is truncated here, on the host): the plan
+            # (dense / two-pass, sampling stride, tile configurations) depends on k, so equal k means every page scores a
+            # row with the same kernels - "pages concatenate exactly" then never rests on two kernels agreeing to the bit
+            # at a page boundary.
+            outs = (P, flags, _lib.ptr(pg_s), _lib.ptr(pg_i), _lib.ptr(pg_c), _lib.ptr(ws), ws_bytes, _lib.current_stream())
             if fp8:
                 head = (_lib.ptr(Q.codes), _lib.ptr(Q.scale), _lib.ptr(E.codes), _lib.ptr(E.scale), B, N, D)
                 st = (lib.rp_sim_topk_fp8(*head, *masks, *outs) if lo == 0 else
@@ -502,14 +505,13 @@ class Corpus:
                 if dense:
                     raise _lib.HipLibraryError("rp_sim_topk reported an overflow under RP_TOPK_DENSE")
                 return self._nearest_premise_ids_paged(premise_embeddings, batch_context, batch_context_emb, k, True)
-            out_s[:, lo : lo + kk] = ps
-            out_i[:, lo : lo + kk] = pi
-            out_c += pg_c
+            out_s[:, lo : lo + kk] = pg_s[:, :kk]
+            out_i[:, lo : lo + kk] = pg_i[:, :kk]
+            out_c += pg_c.clamp(max=kk)
             # the next page starts behind this page's last entry; a query whose page came back short has nothing left
-            full = pg_c == kk
-            last = (pg_c.clamp(min=1) - 1).long().unsqueeze(1)
-            after_s = torch.where(full, ps.gather(1, last).squeeze(1), torch.full_like(after_s, float("-inf"))).contiguous()
-            after_i = torch.where(full, pi.gather(1, last).squeeze(1), torch.full_like(after_i, 2 ** 31 - 1)).contiguous()
+            full = pg_c == P
+            after_s = torch.where(full, pg_s[:, P - 1], torch.full_like(after_s, float("-inf"))).contiguous()
+            after_i = torch.where(full, pg_i[:, P - 1], torch.full_like(after_i, 2 ** 31 - 1)).contiguous()
             if not bool(full.any()):
                 break
         return out_i, out_s, out_c

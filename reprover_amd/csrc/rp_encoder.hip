@@ -47,6 +47,7 @@ int g_gemm_rs_lds = 0;      // 1: big tiles reduce the RMSNorm statistic in the 
 int g_gemm_small_pipe = 1;  // few-token passes: the 64 x 128 x 64 tile on the software-pipelined loop (variant 17) instead of the plain one (16)
 int g_gemm_helpers = 64;      // few-token launches: up to this many surplus workgroups prefetch the weight rows (0 = off)
 int g_gemm_persist = 9;   // persistent workgroups (gemm_tiles_persist) per projection: 1 QKV, 4 attention-out, 8 FFN-in, 16 FFN-out
+int g_pool_chunk = 64;      // tokens per workgroup of the pooling pass (32 / 64 / 128; round 5 A/B at 70 k tokens: 98 / 100 / 104 us)
 int g_gemm_tail_split = 1;  // big passes: last partial round of 256 x 256 tiles as one round of 128 x 128 tiles
 int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 int g_gemm_skinny = 1;
@@ -152,6 +153,11 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   }
   if (!strcmp(name, "gemm_rs_lds")) {
     g_gemm_rs_lds = value != 0;
+    return RP_OK;
+  }
+  if (!strcmp(name, "pool_chunk")) {
+    RP_REQUIRE(value == 32 || value == 64 || value == 128, "pool_chunk must be 32, 64 or 128");
+    g_pool_chunk = value;
     return RP_OK;
   }
   if (!strcmp(name, "gemm_persist")) {
@@ -353,9 +359,9 @@ Workspace carve(const RpEncoder* e, int T, int batch, char* base) {
   w.qkv = (bf16_t*)take(Tp * 3 * inner * 2);
   w.att = (bf16_t*)take(Tp * inner * 2);
   w.ff = (bf16_t*)take(Tp * F * 2);
-  w.pool = (float*)take((Tp / POOL_CHUNK + (size_t)batch + 1) * D * 4);
+  w.pool = (float*)take((Tp / POOL_CHUNK_MIN + (size_t)batch + 1) * D * 4);
   w.work = (int4*)take((Tp / ATT_Q + (size_t)batch + 1) * sizeof(int4));
-  w.pwork = (int4*)take((Tp / POOL_CHUNK + (size_t)batch + 1) * sizeof(int4));
+  w.pwork = (int4*)take((Tp / POOL_CHUNK_MIN + (size_t)batch + 1) * sizeof(int4));
   w.bytes = off;
   return w;
 }
@@ -431,8 +437,9 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
   }
   RP_CHECK_LAUNCH();
   const dim3 att_grid(H, T / ATT_Q + batch);  // upper bound of the number of 128-query blocks
+  const int pc = g_pool_chunk;
   hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu_seqlens, batch, w.work, (int)att_grid.y, w.pwork,
-                     T / POOL_CHUNK + batch);
+                     T / pc + batch, pc);
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerPacked& L = e->layers[i];
     // attention sub-layer: qkv = rs * (xb Wqkv'^T)  ->  attention  ->  x += att Wo^T  (+ xb, ssp refreshed)
@@ -478,9 +485,10 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
   launch_rowscale(true);  // final RMSNorm statistic (the pooling pass reads rs per token row)
   {
     ProfScope ps(stream, RP_K_POOL);
-    launch_pool_partial(dim3(T / POOL_CHUNK + batch), stream, w.xb, w.xlo, w.rs, (const int4*)w.pwork, w.pool, D);
+    launch_pool_partial(dim3(T / pc + batch), stream, w.xb, w.xlo, w.rs, (const int4*)w.pwork, w.pool, D, pc, e->final_ln, out,
+                        out_dtype == RP_DT_BF16 ? 1 : 0, 1);
     hipLaunchKernelGGL(pool_finish_kernel, dim3(batch), dim3(256), 0, stream, w.pool, e->final_ln, cu_seqlens, out,
-                       out_dtype == RP_DT_BF16 ? 1 : 0, D);
+                       out_dtype == RP_DT_BF16 ? 1 : 0, D, pc, 1);
   }
   RP_CHECK_LAUNCH();
   return RP_OK;
@@ -768,7 +776,7 @@ extern "C" RpStatus rp_dbg_attention(const void* qkv, const int32_t* cu, const f
   const int n_p = rows_total / POOL_CHUNK + batch;
   int4* work = nullptr;
   RP_HIP(hipMallocAsync((void**)&work, ((size_t)grid.y + n_p) * sizeof(int4), stream));
-  hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu, batch, work, (int)grid.y, work + grid.y, n_p);
+  hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu, batch, work, (int)grid.y, work + grid.y, n_p, POOL_CHUNK);
   hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, stream, (const bf16_t*)qkv, (const int4*)work, bias_tab,
                      (bf16_t*)out, H, maxd, (float*)nullptr, 0, Drop{0u, 0u, 1.f}, 0u);
   const hipError_t le = hipGetLastError();

@@ -12,7 +12,7 @@ namespace rp {
 
 // tuning knobs (defined in rp_encoder.hip, set through rp_set_option)
 extern int g_gemm_group_m, g_gemm_variant, g_gemm_variant_qkv, g_gemm_variant_wo, g_gemm_variant_o, g_gemm_tail_split,
-    g_debug_skip_ffn, g_gemm_skinny, g_gemm_skinny_variant, g_gemm_rs_lds, g_gemm_small_pipe, g_gemm_helpers, g_gemm_persist;
+    g_debug_skip_ffn, g_gemm_skinny, g_gemm_skinny_variant, g_gemm_rs_lds, g_gemm_small_pipe, g_gemm_helpers, g_gemm_persist, g_pool_chunk;
 extern int g_gemm_stagger_us[RP_K_COUNT];
 
 // ------------------------------------------------------------------------------------------
@@ -146,7 +146,7 @@ static __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __rest
     hilo_update2(0u, 0u, a.z, a.w, oh.y, ol.y, ss);
     hilo_update2(0u, 0u, b.x, b.y, oh.z, ol.z, ss);
     hilo_update2(0u, 0u, b.z, b.w, oh.w, ol.w, ss);
-    dh[c] = oh;
+    dh[c] = oh;  // (non-temporal stores measured in round 5: 83 us either way)
     dl[c] = ol;
   }
   ss = wave_sum(ss);
@@ -785,12 +785,13 @@ constexpr int AT2_K_BYTES = 64 * 128, AT2_V_BYTES = 64 * 128, AT2_STAGE = AT2_K_
 // tail.  It also replaces the two block-wide counting rounds every workgroup of every layer spent finding its sequence.
 // Entries beyond the live count have length 0.  One workgroup; a counting sort over 64 length buckets in LDS.
 constexpr int ATT_BUCKETS = 64;
-constexpr int POOL_CHUNK = 128;  // tokens per workgroup of the pooling pass (pool_partial_kernel)
+constexpr int POOL_CHUNK = 128;  // tokens per workgroup of the pooling pass (the training step's; the inference pass: g_pool_chunk)
+constexpr int POOL_CHUNK_MIN = 32;  // smallest selectable chunk: sizes the inference workspace
 // The same launch lays out the pooling pass's list: chunk c of sequence b is entry cu[b] / 128 + b + c = {first token,
 // length, c, b} (strictly increasing in b, at most T/128 + B entries; a gap entry has length 0).
 static __global__ __launch_bounds__(1024) void worklist_kernel(const int32_t* __restrict__ cu, int batch,
                                                         int4* __restrict__ work, int n_slots,
-                                                        int4* __restrict__ pwork, int n_pslots) {
+                                                        int4* __restrict__ pwork, int n_pslots, int pool_chunk) {
   __shared__ int s_cnt[ATT_BUCKETS], s_pos[ATT_BUCKETS], s_live;
   const int tid = threadIdx.x;
   // bucket k holds sequences of (k, k+1] * 64 keys; the last one everything longer
@@ -812,10 +813,10 @@ static __global__ __launch_bounds__(1024) void worklist_kernel(const int32_t* __
   // the order INSIDE a bucket is whatever the atomics give: every block's result is independent of its position
   for (int b = tid; b < batch; b += 1024) {
     const int s0 = cu[b], s1 = cu[b + 1], len = s1 - s0;
-    const int pbase = s0 / POOL_CHUNK + b;
-    const int pnext = (b + 1 < batch) ? s1 / POOL_CHUNK + b + 1 : n_pslots;
+    const int pbase = s0 / pool_chunk + b;
+    const int pnext = (b + 1 < batch) ? s1 / pool_chunk + b + 1 : n_pslots;
     int c = 0;
-    for (; c * POOL_CHUNK < len; ++c) pwork[pbase + c] = make_int4(s0, len, c, b);
+    for (; c * pool_chunk < len; ++c) pwork[pbase + c] = make_int4(s0, len, c, b);
     for (int i = pbase + c; i < pnext; ++i) pwork[i] = make_int4(0, 0, 0, 0);
     if (b == 0)
       for (int i = 0; i < pbase; ++i) pwork[i] = make_int4(0, 0, 0, 0);  // cu[0] is 0 in every caller; kept general
@@ -1057,19 +1058,23 @@ static __global__ __launch_bounds__(256, DROP ? 2 : 4) void attention_kernel(con
 // ------------------------------------------------------------------------------------------
 
 // NV = 16-byte pieces (8 features) per lane and plane covering a row (ceil(D / 512)): 3 for d_model 1472 / 1536,
-// 4 up to 2048.  Four token rows of a wave are in flight before the first is consumed (the rows are independent
-// streams: rs comes from rowscale).
-template <int NV>
+// 4 up to 2048.  R token rows of a wave are in flight before the first is consumed (the rows are independent
+// streams: rs comes from rowscale).  `chunk` = tokens per workgroup.  A sequence of ONE chunk is finished here (weight,
+// 1 / len, L2 normalisation, output row): its column sums never travel through `partial`, and pool_finish_kernel skips it.
+template <int NV, int R>
 __global__ __launch_bounds__(256) void pool_partial_kernel(const bf16_t* __restrict__ xhi, const bf16_t* __restrict__ xlo,
                                                            const float* __restrict__ rs,
                                                            const int4* __restrict__ pwork,
-                                                           float* __restrict__ partial, int D) {
+                                                           float* __restrict__ partial, int D, int chunk,
+                                                           const float* __restrict__ w, void* __restrict__ out, int out_bf16,
+                                                           int fuse) {
   __shared__ float red[4][NV * 64 * 8];
+  __shared__ float nrm[4];
   const int4 wk = pwork[blockIdx.x];
   const int s0 = wk.x, len = wk.y, c = wk.z, b = wk.w;
   if (len == 0) return;
-  const int t0 = c * POOL_CHUNK;
-  const int t1 = min(len, t0 + POOL_CHUNK);
+  const int t0 = c * chunk;
+  const int t1 = min(len, t0 + chunk);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = D >> 3;
   float acc[NV][8];
@@ -1078,7 +1083,6 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const bf16_t* __restr
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
   // Tokens are accumulated in index order per wave (w, w+4, w+8, ...), whatever the unrolling.
-  constexpr int R = 4;  // rows in flight per wave
   for (int t = t0 + wave; t < t1; t += 4 * R) {
     uint4 vh[R][NV], vl[R][NV];
     float r[R];
@@ -1120,35 +1124,18 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const bf16_t* __restr
     }
   }
   __syncthreads();
-  float* dst = partial + (size_t)(s0 / POOL_CHUNK + b + c) * D;
-  for (int col = threadIdx.x; col < D; col += 256) dst[col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-}
-
-static void launch_pool_partial(dim3 grid, hipStream_t stream, const bf16_t* xhi, const bf16_t* xlo, const float* rs,
-                                const int4* pwork, float* partial, int D) {
-  if (D <= 3 * 512)
-    hipLaunchKernelGGL(pool_partial_kernel<3>, grid, dim3(256), 0, stream, xhi, xlo, rs, pwork, partial, D);
-  else
-    hipLaunchKernelGGL(pool_partial_kernel<4>, grid, dim3(256), 0, stream, xhi, xlo, rs, pwork, partial, D);
-}
-
-static __global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restrict__ partial,
-                                                          const float* __restrict__ w,
-                                                          const int32_t* __restrict__ cu,
-                                                          void* __restrict__ out, int out_bf16, int D) {
-  __shared__ float nrm[4];
-  const int b = blockIdx.x;
-  const int s0 = cu[b], len = cu[b + 1] - s0;
-  const int nchunk = (len + POOL_CHUNK - 1) / POOL_CHUNK;
-  const float* src = partial + (size_t)(s0 / POOL_CHUNK + b) * D;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (!fuse || len > chunk) {  // one chunk of several (or the training step, whose backward reads every row): to `partial`
+    float* dst = partial + (size_t)(s0 / chunk + b + c) * D;
+    for (int col = threadIdx.x; col < D; col += 256) dst[col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    return;
+  }
+  // the whole sequence: pool_finish_kernel's arithmetic on the sums (0 + sum is sum: the same bits as through `partial`)
   const float inv_len = 1.f / (float)len;
-  float vals[8];
+  float vals[NV * 2];
   float part = 0.f;
   int cnt = 0;
   for (int col = threadIdx.x; col < D; col += 256) {
-    float sum = 0.f;
-    for (int c = 0; c < nchunk; ++c) sum += src[(size_t)c * D + col];
+    const float sum = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
     const float e = sum * inv_len * w[col];
     vals[cnt++] = e;
     part += e * e;
@@ -1165,6 +1152,79 @@ static __global__ __launch_bounds__(256) void pool_finish_kernel(const float* __
       reinterpret_cast<bf16_t*>(out)[(size_t)b * D + col] = f2bf(e);
     else
       reinterpret_cast<float*>(out)[(size_t)b * D + col] = e;
+  }
+}
+
+static void launch_pool_partial(dim3 grid, hipStream_t stream, const bf16_t* xhi, const bf16_t* xlo, const float* rs,
+                                const int4* pwork, float* partial, int D, int chunk, const float* w, void* out, int out_bf16,
+                                int fuse) {
+  if (D <= 3 * 512)
+    hipLaunchKernelGGL((pool_partial_kernel<3, 4>), grid, dim3(256), 0, stream, xhi, xlo, rs, pwork, partial, D, chunk, w, out,
+                       out_bf16, fuse);
+  else
+    hipLaunchKernelGGL((pool_partial_kernel<4, 4>), grid, dim3(256), 0, stream, xhi, xlo, rs, pwork, partial, D, chunk, w, out,
+                       out_bf16, fuse);
+}
+
+// Sequences of more than one chunk: one workgroup per sequence sums its chunks' column sums in chunk order - four chunks'
+// rows requested before the first add (round 4's loop waited for one row at a time: 26 us for the 16 chunks of a
+// 2048-token sequence) - then weight, 1 / len and the L2 normalisation.
+static __global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restrict__ partial,
+                                                          const float* __restrict__ w,
+                                                          const int32_t* __restrict__ cu,
+                                                          void* __restrict__ out, int out_bf16, int D, int chunk,
+                                                          int fuse) {
+  __shared__ float nrm[4];
+  const int b = blockIdx.x;
+  const int s0 = cu[b], len = cu[b + 1] - s0;
+  if (fuse && len <= chunk) return;  // finished by pool_partial_kernel
+  const int nchunk = (len + chunk - 1) / chunk;
+  const float* src = partial + (size_t)(s0 / chunk + b) * D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv_len = 1.f / (float)len;
+  constexpr int NC = RMS_MAX_V4;  // columns per thread: D <= 2048
+  float sum[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) sum[i] = 0.f;
+  for (int c0 = 0; c0 < nchunk; c0 += 4) {
+    float v[4][NC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* row = src + (size_t)min(c0 + u, nchunk - 1) * D;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) v[u][i] = row[min((int)threadIdx.x + 256 * i, D - 1)];  // clamped, unpredicated
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (c0 + u < nchunk) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) sum[i] += v[u][i];  // chunk order per column
+      }
+  }
+  float vals[NC];
+  float part = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int col = threadIdx.x + 256 * i;
+    const float e = (col < D) ? sum[i] * inv_len * w[min(col, D - 1)] : 0.f;
+    vals[i] = e;
+    part += e * e;
+  }
+  part = wave_sum(part);
+  if (lane == 0) nrm[wave] = part;
+  __syncthreads();
+  const float norm = sqrtf((nrm[0] + nrm[1]) + (nrm[2] + nrm[3]));
+  const float sc = 1.f / fmaxf(norm, 1e-12f);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int col = threadIdx.x + 256 * i;
+    if (col < D) {
+      const float e = vals[i] * sc;
+      if (out_bf16)
+        reinterpret_cast<bf16_t*>(out)[(size_t)b * D + col] = f2bf(e);
+      else
+        reinterpret_cast<float*>(out)[(size_t)b * D + col] = e;
+    }
   }
 }
 

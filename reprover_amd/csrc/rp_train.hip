@@ -256,7 +256,7 @@ RpStatus train_forward(RpTrainer* tr, const int32_t* ids, const int32_t* cu, int
   }
   const dim3 att_grid(H, T / ATT_Q + batch);
   hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu, batch, w.work, (int)att_grid.y, w.pwork,
-                     T / POOL_CHUNK + batch);
+                     T / POOL_CHUNK + batch, POOL_CHUNK);
   RP_CHECK_LAUNCH();
   for (int i = 0; i < L; ++i) {
     const LayerPacked& Lw = e->layers[i];
@@ -297,7 +297,8 @@ RpStatus train_forward(RpTrainer* tr, const int32_t* ids, const int32_t* cu, int
     ProfScope ps(stream, RP_K_POOL);
     const dim3 pg(T / POOL_CHUNK + batch);
     if (!drop.thresh)
-      launch_pool_partial(pg, stream, w.xa[L], w.xlo, w.rs_final, (const int4*)w.pwork, w.pool, D);
+      launch_pool_partial(pg, stream, w.xa[L], w.xlo, w.rs_final, (const int4*)w.pwork, w.pool, D, POOL_CHUNK, (const float*)e->final_ln,
+                          (void*)out_emb, 0, 0 /* the backward reads every chunk's sums from `pool` */);
     else if (D <= 3 * 512)
       hipLaunchKernelGGL(pool_partial_train_kernel<3>, pg, dim3(256), 0, stream, (const bf16_t*)w.xa[L], (const bf16_t*)w.xlo,
                          (const float*)w.rs_final, (const int4*)w.pwork, w.pool, D, drop);
@@ -305,7 +306,7 @@ RpStatus train_forward(RpTrainer* tr, const int32_t* ids, const int32_t* cu, int
       hipLaunchKernelGGL(pool_partial_train_kernel<4>, pg, dim3(256), 0, stream, (const bf16_t*)w.xa[L], (const bf16_t*)w.xlo,
                          (const float*)w.rs_final, (const int4*)w.pwork, w.pool, D, drop);
     hipLaunchKernelGGL(pool_finish_kernel, dim3(batch), dim3(256), 0, stream, (const float*)w.pool, (const float*)e->final_ln,
-                       cu, (void*)out_emb, 0, D);
+                       cu, (void*)out_emb, 0, D, POOL_CHUNK, 0);
   }
   RP_CHECK_LAUNCH();
   return RP_OK;
@@ -672,7 +673,7 @@ extern "C" RpStatus rp_dbg_attention_bwd(const void* qkv, const void* att, const
     for (int i = 0; i < ntab; ++i) ident[i] = i;  // identity "buckets": the raw table gradient comes back
     RP_HIP(hipMemcpy(bk, ident.data(), (size_t)ntab * 4, hipMemcpyHostToDevice));
   }
-  hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu, batch, work, (int)grid.y, work + grid.y, n_p);
+  hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, stream, cu, batch, work, (int)grid.y, work + grid.y, n_p, POOL_CHUNK);
   hipLaunchKernelGGL((attention_kernel<true, false>), grid, dim3(256), 0, stream, (const bf16_t*)qkv, (const int4*)work, bias_tab,
                      (bf16_t*)att_out, H, maxd, (float*)lse_out, rows_total, Drop{0u, 0u, 1.f}, 0u);
   const bf16_t* o = att ? (const bf16_t*)att : (const bf16_t*)att_out;

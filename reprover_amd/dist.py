@@ -95,6 +95,11 @@ def hip_local_topk(shard: IndexShard, batch_context: Sequence[Context], query_em
     an explicit value: exactly that plan, launch-only (the caller inspects the counts later)."""
     lib = _lib.load()
     dev = query_emb.device
+    from .common import MAX_K_PER_CALL
+
+    if k > MAX_K_PER_CALL:  # (the single-GPU search pages through rp_sim_topk_after; the sharded step has one exchange)
+        raise ValueError(f"sharded retrieval serves k <= {MAX_K_PER_CALL} per query (got k = {k}): one rp_sim_topk call per "
+                         f"shard, one packed exchange; use the unsharded index for a deeper ranking")
     fp8 = getattr(shard, "fp8", None)
     if fp8 is not None:
         return _hip_local_topk_fp8(shard, fp8, batch_context, query_emb, k, flags)
@@ -218,6 +223,8 @@ class HipComm:
         assert len(unique_id) == 128
         self.rank, self.world = int(rank), int(world)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:  # "cuda" -> the current device, so that the device checks
+            self.device = torch.device("cuda", torch.cuda.current_device())  # below compare like with like (cuda:0 != cuda)
         handle = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().rp_comm_init(C.c_char_p(unique_id), self.rank, self.world, C.byref(handle)), "rp_comm_init")
@@ -332,6 +339,44 @@ def sharded_nearest_premise_ids(
     g_scores = g[:, : B * k].view(torch.float32).view(-1, B, k)      # views of the receive buffer, rank stride B (2k + 1)
     g_ids = g[:, B * k : 2 * B * k].view(-1, B, k)
     g_counts = g[:, 2 * B * k :]
+    return merge(g_ids, g_scores, g_counts)
+
+
+def sliced_exchange_merge(ids: torch.Tensor, scores: torch.Tensor, counts: torch.Tensor, group=None,
+                          merge: Callable[..., TopK] = hip_merge, staging: Optional[dict] = None) -> TopK:
+    """The result exchange of a step in which every rank OWNS a slice of the queries (weak scaling: query q belongs to rank
+    q // Bq, Bq = B_all / world) but has scanned its index shard for all of them: rank r needs, from every rank, only the
+    lists of its own Bq queries.  ONE ``all_to_all`` of per-destination slices ``[scores Bq k | ids Bq k | counts Bq]``
+    (Bq (2k + 1) 4 bytes per peer) instead of the packed all-gather, which delivers every rank's lists for ALL queries -
+    world x the bytes, of which a rank merges 1 / world.  The merge then reads the receive buffer as
+    it lies (rank stride Bq (2k + 1)).  Returns (ids [Bq, k], scores, counts) of this rank's queries.
+    ``staging``: an optional dict the caller keeps between steps (send / receive buffers are allocated once)."""
+    world, rank = _world_rank(group)
+    B_all, k = ids.shape
+    assert B_all % world == 0, "every rank owns the same number of queries"
+    Bq = B_all // world
+    blk = Bq * (2 * k + 1)
+    dev = ids.device
+    st = staging if staging is not None else {}
+    key = ("sliced", world, Bq, k, str(dev))
+    if key not in st:
+        st[key] = (torch.empty((world, blk), dtype=torch.int32, device=dev), torch.empty((world, blk), dtype=torch.int32, device=dev))
+    send, recv = st[key]
+    # per-destination slices: three strided copies (the scan writes [scores | ids | counts] over ALL queries)
+    send[:, : Bq * k].copy_(scores.contiguous().view(torch.int32).view(world, Bq * k))
+    send[:, Bq * k : 2 * Bq * k].copy_(ids.to(torch.int32).contiguous().view(world, Bq * k))
+    send[:, 2 * Bq * k :].copy_(counts.to(torch.int32).contiguous().view(world, Bq))
+    if isinstance(group, HipComm):
+        raise NotImplementedError("the library's communicator carries the all-gather form only (rp_allgather_topk)")
+    if dist.get_backend(group) == "nccl" or not send.is_cuda:
+        dist.all_to_all_single(recv, send, group=group)
+    else:  # functional runs of the N > 1 path on one GPU over gloo: gloo's all-to-all takes host tensors
+        r_h = torch.empty(send.shape, dtype=torch.int32)
+        dist.all_to_all_single(r_h, send.cpu(), group=group)
+        recv.copy_(r_h)
+    g_scores = recv[:, : Bq * k].view(torch.float32).view(world, Bq, k)
+    g_ids = recv[:, Bq * k : 2 * Bq * k].view(world, Bq, k)
+    g_counts = recv[:, 2 * Bq * k :]
     return merge(g_ids, g_scores, g_counts)
 
 

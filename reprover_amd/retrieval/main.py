@@ -37,23 +37,50 @@ def run_predict(model: PremiseRetriever, dm: RetrievalDataModule, log_dir: Optio
     return count
 
 
-def save_fit_checkpoint(model: PremiseRetriever, ckpt_dir: str) -> str:
+def save_fit_checkpoint(model: PremiseRetriever, ckpt_dir: str, loop: Optional[Dict[str, int]] = None) -> str:
     """What Lightning's ModelCheckpoint keeps for the reference, in this engine's forms: ``<ckpt_dir>/`` is a HuggingFace
-    checkpoint directory of the CURRENT weights (``load_hf`` / ``transformers`` read it back) and
+    checkpoint directory of the CURRENT weights (``load_hf`` / ``transformers`` read it back),
     ``<ckpt_dir>/training_state.safetensors`` the flat fp32 masters, both AdamW moments, the step counter and the dropout
-    stream (``HipT5Trainer.load_training_state`` resumes from it)."""
-    os.makedirs(ckpt_dir, exist_ok=True)
-    model.encoder.save_pretrained(ckpt_dir)
-    model.train_engine().save_training_state(os.path.join(ckpt_dir, "training_state.safetensors"))
+    stream (``HipT5Trainer.load_training_state`` resumes from it) and ``<ckpt_dir>/loop_state.json`` the position of the
+    training loop (epoch, batches of it already trained on, the epoch's seed).  Written to ``<ckpt_dir>.tmp`` and renamed
+    into place: a crash in the middle leaves the previous checkpoint (or ``<ckpt_dir>.old``) intact."""
+    import json
+    import shutil
+
+    tmp, old = ckpt_dir.rstrip("/") + ".tmp", ckpt_dir.rstrip("/") + ".old"
+    shutil.rmtree(tmp, ignore_errors=True)
+    os.makedirs(tmp)
+    model.encoder.save_pretrained(tmp)
+    model.train_engine().save_training_state(os.path.join(tmp, "training_state.safetensors"))
+    with open(os.path.join(tmp, "loop_state.json"), "w") as fh:
+        json.dump(loop or {}, fh)
+    shutil.rmtree(old, ignore_errors=True)
+    if os.path.exists(ckpt_dir):
+        os.replace(ckpt_dir, old)
+    os.replace(tmp, ckpt_dir)
+    shutil.rmtree(old, ignore_errors=True)
     return ckpt_dir
 
 
+def _epoch_seed(base_seed: int, epoch: int) -> int:
+    return (int(base_seed) * 1_000_003 + 7919 * int(epoch) + 12345) % (2 ** 63)
+
+
 def run_fit(model: PremiseRetriever, dm: RetrievalDataModule, max_steps: int, val_every: int = 0, log=print,
-            ckpt_dir: Optional[str] = None, ckpt_every: int = 0, resume_from: Optional[str] = None) -> Dict[str, Any]:
+            ckpt_dir: Optional[str] = None, ckpt_every: int = 0, resume_from: Optional[str] = None,
+            seed: int = 3407) -> Dict[str, Any]:
     """The training loop Lightning runs for the reference (model.py:146-181): on_fit_start, then per batch
     training_step (forward + backward) → optimizer.step (clipping, AdamW) → scheduler.step → on_train_batch_end;
     epochs until ``max_steps``; validation every ``val_every`` steps (0: never).  With ``ckpt_dir`` the weights and the
-    optimizer state are written there at the end (and every ``ckpt_every`` steps); ``resume_from`` = such a directory."""
+    optimizer state are written there at the end (and every ``ckpt_every`` steps); ``resume_from`` = such a directory.
+
+    Every epoch's shuffle and negative sampling draw from ``random`` re-seeded with a function of (``seed``, epoch), and
+    a checkpoint records (epoch, batches done): a resumed run re-seeds the epoch and consumes the batches already trained
+    on without stepping - the data continues where it stopped, as Lightning restores its loop position, instead of
+    replaying the start of the epoch."""
+    import json
+    import random
+
     if getattr(dm, "batch_size", 1) <= 0:
         raise ValueError(f"fit needs data.batch_size > 0 (got {dm.batch_size})")
     if dm.ds_train is None:
@@ -62,29 +89,43 @@ def run_fit(model: PremiseRetriever, dm: RetrievalDataModule, max_steps: int, va
     opt = model.configure_optimizers()
     optimizer, scheduler = opt["optimizer"], opt["lr_scheduler"]["scheduler"]
     step, losses = 0, []
+    epoch, skip = 0, 0
     if resume_from:
         model.train_engine().load_training_state(os.path.join(resume_from, "training_state.safetensors"))
         step = model.train_engine().steps
+        lpath = os.path.join(resume_from, "loop_state.json")
+        if os.path.exists(lpath):
+            st = json.load(open(lpath))
+            epoch, skip, seed = int(st.get("epoch", 0)), int(st.get("batches_done", 0)), int(st.get("seed", seed))
     while step < max_steps:
         n_epoch = 0
+        random.seed(_epoch_seed(seed, epoch))
         for batch in dm.train_dataloader():
+            n_epoch += 1
+            if n_epoch <= skip:
+                continue  # trained on before the checkpoint: drawn again (the same draws), not stepped again
             loss = model.training_step(batch, step)
             optimizer.step()
             scheduler.step()
             model.on_train_batch_end(loss, batch, step)
             losses.append(loss)
             step += 1
-            n_epoch += 1
             if val_every and step % val_every == 0:
                 log(f"step {step}: {run_validate(model, dm)}")
             if ckpt_dir and ckpt_every and step % ckpt_every == 0 and step < max_steps:
-                save_fit_checkpoint(model, ckpt_dir)
+                rng_state = random.getstate()  # (validation above may draw nothing; the checkpoint itself must not)
+                save_fit_checkpoint(model, ckpt_dir, {"epoch": epoch, "batches_done": n_epoch, "seed": seed, "step": step})
+                random.setstate(rng_state)
             if step >= max_steps:
                 break
         if n_epoch == 0:
             raise ValueError("the training split yields no full batch (drop_last=True)")
+        if step < max_steps:
+            epoch, skip = epoch + 1, 0
+        else:
+            skip = n_epoch
     if ckpt_dir:
-        save_fit_checkpoint(model, ckpt_dir)
+        save_fit_checkpoint(model, ckpt_dir, {"epoch": epoch, "batches_done": skip, "seed": seed, "step": step})
     return {"steps": step, "losses": [float(x) for x in losses], "checkpoint": ckpt_dir}
 
 
@@ -157,9 +198,10 @@ def main(argv=None) -> None:
             model.dropout_seed = int(seed)  # different seeds, different dropout masks
         if int(d.get("batch_size", 0)) <= 0:
             raise SystemExit("fit: the config's data.batch_size must be a positive integer")
-        log_dir = args.log_dir or tcfg.get("default_root_dir") or os.getcwd()
+        log_dir = args.log_dir or tcfg.get("default_root_dir")  # no directory asked for: no checkpoint is written
         out = run_fit(model, dm, args.max_steps or int(tcfg.get("max_steps", 1)), args.val_every,
-                      ckpt_dir=os.path.join(log_dir, "checkpoint"), ckpt_every=args.ckpt_every, resume_from=args.resume_from)
+                      ckpt_dir=os.path.join(log_dir, "checkpoint") if log_dir else None, ckpt_every=args.ckpt_every,
+                      resume_from=args.resume_from, seed=int(seed) if seed is not None else 3407)
         first = f"{out['losses'][0]:.6f} -> {out['losses'][-1]:.6f}" if out["losses"] else "(no step taken)"
         print(f"fit: {out['steps']} steps, loss {first}; checkpoint {out['checkpoint']}")
     elif args.subcommand == "predict":

@@ -131,7 +131,8 @@ class PremiseRetriever:
         (hi + lo: 16 mantissa bits) - where the reference with ``dtype=float32`` multiplies fp32 operands under
         ``torch.set_float32_matmul_precision("medium")`` (model.py:26), a setting that itself licenses bf16-precision
         products inside fp32 matmuls.  ``retrieve`` / ``num_retrieved`` accept any k, as the reference does (one library call
-        sorts at most 1024 keys per query; beyond that ``Corpus.get_nearest_premises`` pages through ``rp_sim_topk_after``)."""
+        sorts at most 1024 keys per query; beyond that ``Corpus.get_nearest_premises`` pages through ``rp_sim_topk_after``) - on
+        the unsharded index; with ``shard_index_over_ranks`` k is limited to 1024 (``dist.hip_local_topk`` raises ``ValueError``)."""
         return cls(ckpt_path, 0.0, 0, max_seq_len, 100, device=device, dtype=dtype or torch.bfloat16)
 
     @classmethod

@@ -19,6 +19,43 @@ def golden_dir():
     return GOLDEN
 
 
+_PARITY_MARGINS = {}
+
+
+@pytest.fixture(scope="session")
+def parity_margins():
+    """Filled by the end-to-end GPU parity tests (G5 / G7 / G9); written to profiles/r05_parity_margins.json and
+    gpurun_out/parity_margins.json and printed in the terminal summary when the session ends."""
+    return _PARITY_MARGINS
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _PARITY_MARGINS:
+        from oracle.parity_margins import write_margins
+
+        write_margins(_PARITY_MARGINS, ROOT)
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not _PARITY_MARGINS:
+        return
+    w = terminalreporter.write_line
+    w("parity margins vs the reference's fp32 goldens (HF-bf16 on the same inputs in brackets):")
+    for name, m in sorted(_PARITY_MARGINS.items()):
+        if "min_row_cosine" in m and "max_abs_pairwise_score_err" in m:
+            w(f"  {name}: min row cosine {m['min_row_cosine']:.5f} [{m['hf_bf16_min_row_cosine']:.5f}], max |d emb| "
+              f"{m['max_abs_emb_err']:.2e} [{m['hf_bf16_max_abs_emb_err']:.2e}], max |d score| {m['max_abs_pairwise_score_err']:.2e} "
+              f"[{m['hf_bf16_max_abs_pairwise_score_err']:.2e}], written contract met: {m['contract_met']}")
+        elif "min_row_cosine" in m:
+            w(f"  {name}: {m['rows']} rows, min cosine {m['min_row_cosine']:.5f} [{m['hf_bf16_min_row_cosine']:.5f}], mean "
+              f"{m['mean_row_cosine']:.6f}, max |d emb| {m['max_abs_emb_err']:.2e}")
+        else:
+            k = m["k"]
+            w(f"  {name}: max |d score| {m['max_abs_score_err']:.2e} [{m['hf_bf16_max_abs_score_err']:.2e}], gap-rule ranks "
+              f"{m['gap_rule_ranks_checked']} of {m['ranks']} checked / {m['gap_rule_mismatches']} mismatched, top-1 "
+              f"{m['top1_agreement']:.3f}, top-{k} overlap {m[f'top{k}_overlap']:.3f}, written contract met: {m['contract_met']}")
+
+
 @pytest.fixture(scope="session")
 def hip_lib():
     """The C-ABI engine, built in-tree (cross-compiles without a GPU)."""

@@ -188,16 +188,4 @@ def check_topk_against_scores(ids, scores, counts, S, acc, k, tol):
         assert np.all(row_i[ties] < row_i[ties + 1]), f"row {j} tie order"
 
 
-def gap_rule_ids(ours_ids, gold_ids, gold_scores, tol):
-    """ids must agree at every rank whose golden score is separated from both neighbours by more
-    than 2*tol.  Returns (#checked, #mismatched)."""
-    checked = bad = 0
-    for o, g, s in zip(ours_ids, gold_ids, gold_scores):
-        s = np.asarray(s, dtype=np.float64)
-        for r in range(len(g)):
-            left = s[r - 1] - s[r] if r > 0 else np.inf
-            right = s[r] - s[r + 1] if r + 1 < len(g) else 0.0  # the (k+1)-th is unknown: skip the last rank
-            if left > 2 * tol and right > 2 * tol:
-                checked += 1
-                bad += int(o[r] != g[r])
-    return checked, bad
+from oracle.parity_margins import gap_rule_ids  # noqa: E402,F401  (one definition, shared with smoke())

@@ -218,6 +218,24 @@ def test_bench_launches_its_own_ranks():
     assert d["config"]["sharded_merge_equals_single_gpu"] is True
     assert d["config"]["collectives_per_step"] == 2
     assert d["config"]["all_counts_eq_k"] is True
+    # the top-k stage timed WITH its collective, under both exchange forms (packed all-gather = the default and
+    # north_star's form; all-to-all of per-destination slices): both must reproduce the single-GPU lists
+    assert d["config"]["exchange"] == "allgather"
+    t = d["topk_only"]
+    for how in ("allgather", "alltoall"):
+        assert t[how]["sharded_merge_equals_single_gpu"] is True, how
+        assert t[how]["qps"] > 0 and t[how]["exchange_us"] > 0
+    blk = 2 * 256 * (2 * 100 + 1) * 4
+    assert t["allgather"]["collective_bytes_received_per_rank"] == blk
+    assert t["alltoall"]["collective_bytes_received_per_rank"] == blk // 2
+    # ... and the step itself on the sliced exchange
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--headline-only", "--exchange", "alltoall"], env=env, capture_output=True, text=True, timeout=900,
+                         cwd=root)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')][0])
+    assert d["config"]["exchange"] == "alltoall" and d["config"]["collectives_per_step"] == 2
+    assert d["config"]["sharded_merge_equals_single_gpu"] is True and d["config"]["all_counts_eq_k"] is True
 
 
 def test_load_lightning_checkpoint_file(workdir, tmp_path):

@@ -16,7 +16,7 @@ from oracle import common_ref
 from reprover_amd import synth
 from reprover_amd.common import Context, Corpus, Pos
 from reprover_amd.dist import (IndexShard, gather_shards, shard_bounds, sharded_get_nearest_premises,
-                                sharded_nearest_premise_ids)
+                                sharded_nearest_premise_ids, sliced_exchange_merge)
 
 
 def test_shard_bounds_balance_tokens():
@@ -101,6 +101,21 @@ def _worker(rank, world, port, corpus_path, out_dir):
                 wi, ws = common_ref.masked_topk(S[j : j + 1], acc[j : j + 1], n)
                 assert ids[j, :n].tolist() == wi[0].tolist()
                 assert np.allclose(scores[j, :n].numpy(), ws[0])
+        # the sliced exchange (a rank owns queries [rank B/world, (rank + 1) B/world) and receives only their lists): ONE
+        # all-to-all, no all-gather, and the same merged lists as the all-gather form for the rank's own queries
+        l_ids, l_sc, l_cnt = _oracle_local_topk(shard, ctxs, torch.from_numpy(Q), k)
+        calls2 = []
+        real_a2a = dist.all_to_all_single
+        dist.all_to_all_single = lambda *a, **kw: (calls2.append("all_to_all_single"), real_a2a(*a, **kw))[1]
+        dist.all_gather = lambda *a, **kw: (calls2.append("all_gather"), real_ag(*a, **kw))[1]
+        try:
+            s_ids, s_sc, s_cnt = sliced_exchange_merge(l_ids, l_sc, l_cnt, None, merge=_oracle_merge)
+        finally:
+            dist.all_to_all_single, dist.all_gather = real_a2a, real_ag
+        assert calls2 == ["all_to_all_single"], calls2
+        Bq = B // world
+        mine = slice(rank * Bq, (rank + 1) * Bq)
+        assert torch.equal(s_ids, ids[mine]) and torch.equal(s_sc, scores[mine]) and torch.equal(s_cnt, counts[mine])
         # the drop-in wrapper raises ValueError exactly when the reference would
         short = [j for j in range(B) if acc[j].sum() < k]
         ok = [j for j in range(B) if acc[j].sum() >= k]

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import parity_margins as pm
 from oracle import t5_ref
 from reprover_amd import synth
 from reprover_amd.retrieval.model import PremiseRetriever
@@ -97,47 +98,35 @@ def test_padded_entry_point_single_row(tiny, golden_dir):
             tiny._encode(torch.full((1, 4), 70, dtype=torch.int64).cuda(), torch.tensor([bad], dtype=torch.int64).cuda())
 
 
-def test_byt5_small_matches_hf_golden(small, golden_dir):
-    g = np.load(os.path.join(golden_dir, "g5_byt5_small.npz"), allow_pickle=True)
-    texts = list(g["texts"])
-    gold = torch.from_numpy(g["emb"])
-    hf_bf16 = torch.from_numpy(g["emb_hf_bf16"].astype(np.float32))
-    emb = small.encode_texts(texts).cpu()
-    cos, cos_hf = _cos(emb, gold), _cos(hf_bf16, gold)
-    err, err_hf = (emb - gold).abs().max().item(), (hf_bf16 - gold).abs().max().item()
-    print(f"byt5-small: ours min cos {cos.min().item():.6f} max|Δ| {err:.3e};  HF-bf16 min cos "
-          f"{cos_hf.min().item():.6f} max|Δ| {err_hf:.3e}")
+def test_byt5_small_matches_hf_golden(small, golden_dir, parity_margins):
+    m = parity_margins["g5_byt5_small_12_layers"] = pm.g5_margins(small, golden_dir)
+    print(f"byt5-small: {m}")
     # The synthetic weights are deliberately sharp (attention logits std ~4), so even HuggingFace's
     # own bf16 mode -- the reference's GPU numerics -- only reaches cosine 0.996 with its fp32 self;
     # the engine must be at least as close as that on every row, and above an absolute floor.
-    assert cos.min().item() >= max(0.997, cos_hf.min().item())
-    assert (cos >= cos_hf - 1e-4).all(), "a row is further from the oracle than HF-bf16 is"
-    assert err <= err_hf, "further from the fp32 oracle than the reference's own bf16 mode"
+    # (A RELAXATION of the written 0.999 / 1e-2 contract: oracle/parity_margins.py; m["contract_met"] records whether the
+    # written numbers hold as they stand.)
+    assert m["min_row_cosine"] >= max(0.997, m["hf_bf16_min_row_cosine"])
+    assert m["rows_further_from_fp32_than_hf_bf16"] == 0, "a row is further from the oracle than HF-bf16 is"
+    assert m["max_abs_emb_err"] <= m["hf_bf16_max_abs_emb_err"], "further from the fp32 oracle than the reference's own bf16 mode"
     # retrieval scores of these rows against each other: within 1e-2 absolute of the oracle's
-    assert ((emb @ emb.T) - (gold @ gold.T)).abs().max().item() < 1e-2
+    assert m["max_abs_pairwise_score_err"] < 1e-2
 
 
-def test_byt5_base_full_depth_matches_hf_golden(golden_dir):
+def test_byt5_base_full_depth_matches_hf_golden(golden_dir, parity_margins):
     """BASELINE configs[4]'s encoder at its FULL depth (18 layers, d_model 1536, 12 heads, d_ff 3968) against
     the reference + HuggingFace fp32 fixture G9, with the G5 rule: no row further from fp32 than HF-bf16."""
-    g = np.load(os.path.join(golden_dir, "g9_byt5_base.npz"), allow_pickle=True)
     cfg = synth.t5_config("byt5-base")
     assert cfg["num_layers"] == 18
     model = PremiseRetriever.from_state_dict(cfg, synth.synth_state_dict(cfg), 1024, "cuda:0", dtype=torch.float32)
-    texts = list(g["texts"])
-    gold = torch.from_numpy(g["emb"])
-    hf_bf16 = torch.from_numpy(g["emb_hf_bf16"].astype(np.float32))
-    emb = model.encode_texts(texts).cpu()
-    cos, cos_hf = _cos(emb, gold), _cos(hf_bf16, gold)
-    err, err_hf = (emb - gold).abs().max().item(), (hf_bf16 - gold).abs().max().item()
-    print(f"byt5-base x18: ours min cos {cos.min().item():.6f} max|Δ| {err:.3e};  HF-bf16 min cos "
-          f"{cos_hf.min().item():.6f} max|Δ| {err_hf:.3e}")
+    m = parity_margins["g9_byt5_base_18_layers"] = pm.g9_margins(model, golden_dir)
+    print(f"byt5-base x18: {m}")
     # 18 layers of bf16-operand GEMMs on the sharp synthetic weights: HuggingFace's own bf16 mode reaches only
-    # cosine 0.988 here (measured: ours 0.9945, max|Δ| 1.2e-2 vs HF 1.6e-2); the bar is HF-bf16 row by row + a floor
-    assert cos.min().item() >= max(0.99, cos_hf.min().item())
-    assert (cos >= cos_hf - 1e-4).all(), "a row is further from the oracle than HF-bf16 is"
-    assert err <= err_hf, "further from the fp32 oracle than the reference's own bf16 mode"
-    assert ((emb @ emb.T) - (gold @ gold.T)).abs().max().item() < max(1e-2, ((hf_bf16 @ hf_bf16.T) - (gold @ gold.T)).abs().max().item())
+    # cosine 0.988 here (measured: ours 0.9945, max|d| 1.2e-2 vs HF 1.6e-2); the bar is HF-bf16 row by row + a floor
+    assert m["min_row_cosine"] >= max(0.99, m["hf_bf16_min_row_cosine"])
+    assert m["rows_further_from_fp32_than_hf_bf16"] == 0, "a row is further from the oracle than HF-bf16 is"
+    assert m["max_abs_emb_err"] <= m["hf_bf16_max_abs_emb_err"], "further from the fp32 oracle than the reference's own bf16 mode"
+    assert m["max_abs_pairwise_score_err"] < max(1e-2, m["hf_bf16_max_abs_pairwise_score_err"])
 
 
 def test_bf16_output_and_chunked_passes_agree(small, golden_dir):
@@ -187,3 +176,35 @@ def test_big_pass_launch_forms_are_the_same_bits(small):
     for o in outs[1:]:
         assert torch.equal(outs[0].view(torch.int32), o.view(torch.int32))
     assert torch.isfinite(outs[0]).all() and (outs[0].norm(dim=1) - 1).abs().max().item() < 1e-5
+
+
+def _published_checkpoint_dir():
+    """A local copy of kaiyuy/leandojo-lean4-retriever-byt5-small, if this box happens to have one: $RP_REAL_CKPT, or the
+    HuggingFace hub cache.  There is no network here, so normally there is none and the test below is skipped."""
+    import glob
+
+    cands = [os.environ.get("RP_REAL_CKPT", "")]
+    hub = os.environ.get("HF_HOME", os.path.expanduser("~/.cache/huggingface"))
+    cands += sorted(glob.glob(os.path.join(hub, "hub", "models--kaiyuy--leandojo-lean4-retriever-byt5-small", "snapshots", "*")))
+    for c in cands:
+        if c and os.path.exists(os.path.join(c, "config.json")):
+            return c
+    return None
+
+
+@pytest.mark.skipif(_published_checkpoint_dir() is None,
+                    reason="opt-in: needs the published checkpoint kaiyuy/leandojo-lean4-retriever-byt5-small on disk "
+                           "($RP_REAL_CKPT or the HuggingFace cache); unavailable offline")
+def test_readme_known_answer_on_the_published_checkpoint(golden_dir):
+    """The only known-answer data the reference holds for this path (README.md:97-158): one proof state, eight premises,
+    the four the published retriever ranks first.  Fixture G16 = that example's inputs and expected output."""
+    import json
+
+    g = json.load(open(os.path.join(golden_dir, "g16_readme_known_answer.json")))
+    model = PremiseRetriever.load_hf(_published_checkpoint_dir(), 2048, "cuda:0")
+    q = model.encode_texts([g["state"]]).float()
+    P = model.encode_texts(g["premises"]).float()
+    assert torch.allclose(P.norm(dim=1), torch.ones(len(g["premises"]), device=P.device), atol=1e-2)
+    top = (q @ P.T)[0].topk(g["k"]).indices.tolist()
+    assert set(top) == set(g["expected_top_k_indices_in_order"]), top
+    assert top[0] == g["expected_top_k_indices_in_order"][0], top

@@ -13,6 +13,7 @@ import torch
 
 import hip_helpers as hh
 from oracle import common_ref
+from oracle import parity_margins as pm
 from reprover_amd import _lib, synth
 from reprover_amd.common import Context, Corpus, IndexedCorpus, Pos
 from reprover_amd.retrieval.model import PremiseRetriever
@@ -73,7 +74,7 @@ def g7(golden_dir, small_weights):
     return g, z, model, path
 
 
-def test_g7_reindex_corpus(g7):
+def test_g7_reindex_corpus(g7, parity_margins):
     g, z, model, _ = g7
     E = model.corpus_embeddings
     assert E.shape == (g["N"], 1472) and E.dtype == torch.bfloat16 and E.is_cuda
@@ -84,50 +85,30 @@ def test_g7_reindex_corpus(g7):
     # fp32 self on these sharp synthetic weights; the engine must be at least that close.
     assert cos.min().item() >= max(0.997, g["hf_bf16_min_embedding_cosine"])
     # every row against the reference's fp32 matrix (stored as fp16: 5e-4 relative, far below the bar)
-    gold = torch.from_numpy(z["E_all_f16"].astype(np.float32))
-    cos_all = torch.nn.functional.cosine_similarity(Ef, gold, dim=1)
-    err_all = (Ef - gold).abs().max().item()
-    print(f"g7: all {g['N']} rows: min cosine {cos_all.min().item():.5f} (HF-bf16: {g['hf_bf16_min_embedding_cosine']:.5f}), "
-          f"mean {cos_all.mean().item():.6f}, max|Δ| {err_all:.3e}")
-    assert cos_all.min().item() >= g["hf_bf16_min_embedding_cosine"]  # no row further from fp32 than HF-bf16's worst
-    assert cos_all.mean().item() >= 0.998  # bf16 rows (the GPU default dtype): measured 0.9985
-    assert err_all <= 2e-2
+    m = parity_margins["g7_reindex_1005_rows_bf16"] = pm.g7_row_margins(model, g, z)
+    print(f"g7 rows: {m}")
+    assert m["min_row_cosine"] >= g["hf_bf16_min_embedding_cosine"]  # no row further from fp32 than HF-bf16's worst
+    assert m["mean_row_cosine"] >= 0.998  # bf16 rows (the GPU default dtype): measured 0.9985
+    assert m["max_abs_emb_err"] <= 2e-2
 
 
-def test_g7_predict_and_retrieve(g7):
+def test_g7_predict_and_retrieve(g7, parity_margins):
     g, z, model, _ = g7
     k = g["k"]
-    model.num_retrieved = k
-    ctxs = [Context(q["path"], f"thm{j}", Pos(*q["pos"]), q["state"]) for j, q in enumerate(g["queries"])]
     where = {id(p): i for i, p in enumerate(model.corpus.all_premises)}
-    model.predict_step_outputs = []
-    for i in range(0, len(ctxs), g["batch_size"]):
-        batch = ctxs[i : i + g["batch_size"]]
-        tok = model.tokenizer([c.serialize() for c in batch], padding="longest", max_length=g["max_seq_len"],
-                              truncation=True, return_tensors="pt")
-        b = {"context": batch, "context_ids": tok.input_ids.cuda(), "context_mask": tok.attention_mask.cuda()}
-        for key in ("url", "commit", "file_path", "full_name", "start", "tactic_idx", "all_pos_premises"):
-            b[key] = [None] * len(batch)
-        model.predict_step(b, 0)
-    recs = model.predict_step_outputs
+    recs, ids, scores, ctxs, m = pm.g7_predict(model, g)
+    parity_margins["g7_predict_128_states_top10"] = m
+    print(f"g7 predict: {m}")
     assert len(recs) == len(ctxs) and set(recs[0]) == {
         "url", "commit", "file_path", "full_name", "start", "tactic_idx", "context", "all_pos_premises",
         "retrieved_premises", "scores"}
-    ids = [[where[id(p)] for p in r["retrieved_premises"]] for r in recs]
-    scores = np.array([r["scores"] for r in recs])
-    gold_s = np.array(g["scores"])
-    checked, bad = hh.gap_rule_ids(ids, g["ids"], g["scores"], tol=1e-2)
-    overlap = np.mean([len(set(a) & set(b)) / k for a, b in zip(ids, g["ids"])])
-    top1 = np.mean([a[0] == b[0] for a, b in zip(ids, g["ids"])])
-    print(f"g7: max|Δscore| {np.abs(scores - gold_s).max():.3e}; top-{k} overlap {overlap:.3f}; top-1 agreement "
-          f"{top1:.3f}; gap-rule ranks checked {checked}, mismatched {bad}")
     # stated tolerance: 1e-2 abs, or what HuggingFace-bf16 itself needs on these inputs
-    # if that is looser (fixture: the reference re-run in bf16, scores at the golden ids)
-    hf_err = np.abs(np.array(g["hf_bf16_scores_at_gold_ids"]) - gold_s).max()
-    print(f"g7: HF-bf16's own max|Δscore| on the same queries: {hf_err:.3e}")
-    assert np.abs(scores - gold_s).max() <= max(1e-2, hf_err)
-    assert bad == 0
-    assert overlap >= 0.9
+    # if that is looser (fixture: the reference re-run in bf16, scores at the golden ids) - the relaxation
+    # oracle/parity_margins.py labels; m["contract_met"] records whether 1e-2 holds as written
+    hf_err = m["hf_bf16_max_abs_score_err"]
+    assert m["max_abs_score_err"] <= max(1e-2, hf_err)
+    assert m["gap_rule_mismatches"] == 0
+    assert m[f"top{k}_overlap"] >= 0.9
     # single-query path (model.py:338-375)
     for j, single in enumerate(g["retrieve"]):
         c = ctxs[j]
@@ -387,3 +368,68 @@ def test_k_beyond_1024_is_served_in_pages(index_dtype):
     assert n_acc[0] < N  # (a theorem never sees the premises behind it in its own file)
     with pytest.raises(ValueError):
         corpus.get_nearest_premises(operand, [ctxs[0]], Qd[[0]], N)
+
+
+@pytest.mark.parametrize("index_dtype", ["bf16", "fp8"])
+@pytest.mark.parametrize("B", [6, 130])
+def test_paging_through_the_two_pass_plan(index_dtype, B):
+    """k > 1024 on an index of more than 16,384 rows: every page runs the TWO-PASS plan (sample scan -> bound -> filter ->
+    gather / select) with the `after` bound of the page before - the first-generation filter at B <= 128, the
+    second-generation one (private survivor runs, D % 64 == 0) at B > 128, bf16 and e4m3 rows of d_model 1472 (11.5
+    k-tiles of e4m3: the half-tile form).  The concatenated pages must be exactly the oracle's masked ranking on the same
+    operands, exact ties across a page boundary included (the small-index paging test only reaches the dense
+    plan)."""
+    from reprover_amd.common import Fp8Index
+    from oracle import fp8_ref
+
+    files = synth.synth_corpus_records(60, 20000, seed=177, max_imports=10)
+    path = os.path.join(tempfile.mkdtemp(), "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    corpus = Corpus(path)
+    N, D, k = len(corpus), 1472, 2300
+    assert N > 16384
+    rng = np.random.default_rng(178 + B)
+    E = rng.standard_normal((N, D)).astype(np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    Qm = rng.standard_normal((B, D)).astype(np.float32)
+    Qm /= np.linalg.norm(Qm, axis=1, keepdims=True)
+    late = files[-8:]
+    ctxs = [Context(late[j % 8]["path"], f"t{j}", Pos(10_000, 0), f"h{j} ⊢ g") for j in range(B)]
+    acc = np.stack([corpus.accessible_mask(c.path, c.theorem_pos) for c in ctxs])
+    assert (acc.sum(1) >= k).all(), acc.sum(1).min()
+    Ed, Qd = torch.from_numpy(E).cuda(), torch.from_numpy(Qm).cuda()
+    if index_dtype == "bf16":
+        Eb, Qb = _bf16_round(E), _bf16_round(Qm)
+        # exact ties straddling the first page boundary of query 0: twelve copies of its 1020th-best accessible row
+        S0 = Qb[0] @ Eb.T
+        order = np.argsort(-np.where(acc[0], S0, -np.inf), kind="stable")
+        dup = [int(i) for i in order[1019:1031]]
+        E[dup] = E[dup[0]]
+        Ed = torch.from_numpy(E).cuda()
+        Eb = _bf16_round(E)
+        operand = Ed
+        S = Qb.astype(np.float64) @ Eb.astype(np.float64).T
+        S = S.astype(np.float32)
+    else:
+        operand = Fp8Index.quantize(Ed)
+        q8 = Fp8Index.quantize(Qd)
+        S = fp8_ref.scores_fp8(q8.codes.cpu().numpy(), q8.scale.cpu().numpy(), operand.codes.cpu().numpy(),
+                               operand.scale.cpu().numpy())
+    want_i, want_s = common_ref.masked_topk(S, acc, k)
+    ids, scores, counts = corpus.nearest_premise_ids(operand, ctxs, Qd, k)
+    ids, scores, counts = ids.cpu().numpy(), scores.cpu().numpy(), counts.cpu().numpy()
+    assert (counts == k).all()
+    for j in range(B):
+        row = ids[j].tolist()
+        assert len(set(row)) == k, f"query {j}: a row was returned on two pages (or dropped)"
+        assert acc[j][row].all()
+        sc = scores[j]
+        assert all(sc[i] > sc[i + 1] or (sc[i] == sc[i + 1] and row[i] < row[i + 1]) for i in range(k - 1)), j
+    # (the e4m3 scan's scores lie within 2e-6 of the exact value of the quantised dot product, DESIGN.md section 2: its
+    # ranks are compared where the oracle's gap exceeds twice that and more)
+    checked, bad = hh.gap_rule_ids(ids.tolist(), want_i.tolist(), want_s.tolist(), tol=1e-6 if index_dtype == "bf16" else 4e-6)
+    assert bad == 0 and checked > B * k // (20 if index_dtype == "bf16" else 100)
+    assert np.abs(scores - want_s).max() < 1e-5
+    if index_dtype == "bf16":  # the twelve tied rows of query 0 come out in id order, across the page boundary
+        pos = [ids[0].tolist().index(i) for i in sorted(dup)]
+        assert pos == list(range(pos[0], pos[0] + 12)) and pos[0] <= 1023 <= pos[-1] + 12

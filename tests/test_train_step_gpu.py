@@ -152,6 +152,16 @@ def test_product_training_api_learns_and_reindexes(tmp_path):
     out3 = run_fit(from_ckpt, dm, max_steps=7, resume_from=str(tmp_path / "fit" / "checkpoint"))
     assert out3["steps"] == 7 and len(out3["losses"]) == 2  # 5 steps were already taken
     assert from_ckpt.train_engine()._forwards == fresh.train_engine()._forwards + 2  # the dropout stream continued
+    # ... and so did the DATA: the resumed run trains on the batches an uninterrupted run sees at steps 6 and 7 (the loop
+    # position travels in the checkpoint; every epoch's shuffle and negative draws are a function of (seed, epoch)), not on
+    # a replay of the epoch's first batches - same weights, same masks, same batches: the same losses
+    assert json.load(open(tmp_path / "fit" / "checkpoint" / "loop_state.json"))["step"] == 5
+    straight = PremiseRetriever.from_state_dict(cfg, synth.synth_state_dict(cfg, seed=5), 256, "cuda:0")
+    straight.lr, straight.warmup_steps, straight.gradient_clip_val, straight.num_retrieved = 2e-3, 2, 1.0, 10
+    out4 = run_fit(straight, dm, max_steps=7)
+    assert out4["losses"][:5] == out2["losses"]
+    assert np.allclose(out4["losses"][5:], out3["losses"], rtol=0, atol=1e-6), (out4["losses"][5:], out3["losses"])
+    assert not os.path.exists(tmp_path / "fit" / "checkpoint.tmp") and not os.path.exists(tmp_path / "fit" / "checkpoint.old")
     dm.batch_size = 0
     with pytest.raises(ValueError, match="batch_size"):
         run_fit(model, dm, max_steps=1)

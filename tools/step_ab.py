@@ -26,7 +26,7 @@ ids_d, cu_d = torch.from_numpy(ids_np).to(dev), torch.from_numpy(cu_np).to(dev)
 out = torch.empty((B, cfg["d_model"]), dtype=torch.bfloat16, device=dev)
 print(f"{model} B={B} tokens={T}", flush=True)
 
-DEFAULTS = {"gemm_variant_all": -1, "gemm_tail_split": 1, "gemm_group_m": 8, "gemm_persist": 9, "gemm_rs_lds": 0}
+DEFAULTS = {"gemm_variant_all": -1, "gemm_tail_split": 1, "gemm_group_m": 8, "gemm_persist": 9, "gemm_rs_lds": 0, "pool_chunk": 64}
 confs = []
 for a in sys.argv[1:]:
     name, _, rest = a.partition(":")
@@ -76,5 +76,5 @@ apply(DEFAULTS)
 for name, _ in confs:
     ts = sorted(times[name])
     s = split[name]
-    keys = ("gemm_qkv", "gemm_o", "gemm_wi", "gemm_wo", "attention")
+    keys = ("gemm_qkv", "gemm_o", "gemm_wi", "gemm_wo", "attention", "embed", "pool", "rmsnorm")
     print(f"{name:28s} median {ts[len(ts)//2]:7.3f} best {ts[0]:7.3f} ms | " + " ".join(f"{k[5:] if k.startswith('gemm_') else k} {s.get(k, 0):6.3f}" for k in keys), flush=True)
