@@ -701,14 +701,17 @@ def main():
     n_layers = cfg["num_layers"]
     inner = enc.cfg["num_heads"] * 64
     B_ = B_STATES
-    n_chunks = Tp // 128 + B_
+    # chunk rows of the pooling pass that travel through `partial` (64-token chunks; one-chunk sequences are finished in place)
+    n_multi = int(sum(-(-int(n) // 64) for n in np.diff(cu_np) if n > 64))
     hbm_rows = [
         # (kernel, profile class, launches per step, algorithmic bytes per launch)
-        ("embed_kernel (byte-id gather -> two bf16 planes of x + row statistic)", "embed", 1, T * 4 + Tp * D * 4 + Tp * 4),
+        # x = a bf16 plane + an int8 extension plane since round 5: 3 bytes per element read, 3 written
+        ("embed_kernel (byte-id gather -> bf16 plane + int8 extension plane of x + row statistic)", "embed", 1,
+         T * 4 + Tp * D * 3 + Tp * 4),
         ("pool_partial_kernel + pool_finish_kernel (final RMSNorm + masked mean + L2 normalise)", "pool", 1,
-         T * D * 4 + T * 4 + 2 * n_chunks * D * 4 + B_ * D * 2),
-        ("gemm_kernel<EpiResid>, attention-out projection (K = 384: read-modify-write of the two planes of x)", "gemm_o", n_layers,
-         Tp * D * 8 + Tp * inner * 2 + D * inner * 2 + Tp * ((D + 63) // 64) * 4),
+         T * D * 3 + T * 4 + 2 * n_multi * D * 4 + B_ * D * 2),
+        ("gemm_kernel<EpiResid8>, attention-out projection (K = 384: read-modify-write of the 3-byte form of x)", "gemm_o", n_layers,
+         Tp * D * 6 + Tp * inner * 2 + D * inner * 2 + Tp * ((D + 63) // 64) * 4),
     ]
     roofline_hbm = []
     for name, cls_, per_step, nbytes in hbm_rows:

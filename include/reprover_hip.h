@@ -379,7 +379,8 @@ RpStatus rp_profile_read(int32_t kernel_class, double* total_ms, int64_t* launch
  * Kernel-level entry points used by the parity tests (tests/test_kernels_gpu.py) to check each
  * HIP kernel against the oracle in isolation.  Same conventions as above.
  * ------------------------------------------------------------------------------------------- */
-enum { RP_EPI_STORE_BF16 = 0, RP_EPI_RESID = 1, RP_EPI_GEGLU_BF16 = 2 };
+enum { RP_EPI_STORE_BF16 = 0, RP_EPI_RESID = 1, RP_EPI_GEGLU_BF16 = 2,
+       RP_EPI_RESID8 = 3 /* the inference pass's residual stream: out = bf16 plane [M, n_valid], then int8 extension plane [M, n_valid] */ };
 /* C = A[M,K] (bf16) x W[N,K]^T (bf16); M, N multiples of 128 (N may exceed n_valid: only the
  * first n_valid columns are written), K multiple of 32.
  *   STORE_BF16: out bf16 [M, n_valid]

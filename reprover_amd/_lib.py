@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libreprover_hip.so")
 RP_OK = 0
 RP_DT_F32, RP_DT_BF16 = 0, 1
 RP_TOPK_AUTO, RP_TOPK_DENSE = 0, 1
-RP_EPI_STORE_BF16, RP_EPI_RESID, RP_EPI_GEGLU_BF16 = 0, 1, 2
+RP_EPI_STORE_BF16, RP_EPI_RESID, RP_EPI_GEGLU_BF16, RP_EPI_RESID8 = 0, 1, 2, 3
 ABI_VERSION = 4
 KERNEL_CLASSES = ["embed", "rmsnorm", "gemm_qkv", "attention", "gemm_o", "gemm_wi", "gemm_wo", "pool", "scan",
                   "select", "scan_sample", "bwd_dgrad", "bwd_wgrad", "bwd_attention", "bwd_other", "optimizer", "collective"]

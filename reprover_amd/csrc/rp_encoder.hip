@@ -332,7 +332,8 @@ extern "C" void rp_encoder_destroy(RpEncoder* e) {
 
 namespace {
 struct Workspace {
-  bf16_t *xb, *xlo;  // the residual stream's two planes: xb = bf16(x) (A operand of the QKV / FFN-in GEMMs), xlo = x - xb
+  bf16_t *xb, *xlo;  // the residual stream: xb = its bf16 plane (A operand of the QKV / FFN-in GEMMs), xlo = the int8 extension
+                     // plane of the 24-bit form (one byte per element; x24_update2)
   bf16_t *qkv, *att, *ff;
   float* ssp;   // [Tp, ceil(D/64)] per-row partial sums of squares of x
   float* rs;    // [Tp] rsqrt(mean(x^2) + eps)
@@ -353,7 +354,7 @@ Workspace carve(const RpEncoder* e, int T, int batch, char* base) {
     return p;
   };
   w.xb = (bf16_t*)take(Tp * D * 2);
-  w.xlo = (bf16_t*)take(Tp * D * 2);
+  w.xlo = (bf16_t*)take(Tp * D);  // int8 extension plane
   w.ssp = (float*)take(Tp * ((D + 63) / 64) * 4);
   w.rs = (float*)take(Tp * 4);
   w.qkv = (bf16_t*)take(Tp * 3 * inner * 2);
@@ -432,7 +433,7 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
   };
   {
     ProfScope ps(stream, RP_K_EMBED);
-    hipLaunchKernelGGL(embed_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.xb, w.xlo, w.ssp, np, T,
+    hipLaunchKernelGGL(embed_kernel<true>, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.xb, w.xlo, w.ssp, np, T,
                        Tp, D, c.vocab_size, t_dev);
   }
   RP_CHECK_LAUNCH();
@@ -456,7 +457,7 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
       hipLaunchKernelGGL(attention_kernel<false>, att_grid, dim3(256), 0, stream, w.qkv, (const int4*)w.work, e->bias_tab, w.att,
                          H, e->maxd, (float*)nullptr, 0, Drop{0u, 0u, 1.f}, 0u);
     }
-    if ((st = launch_gemm(w.att, inner, Tp, L.wo, inner, D, inner, EpiResid{w.xb, w.xlo, D, D, w.ssp, np, Tp}, stream,
+    if ((st = launch_gemm(w.att, inner, Tp, L.wo, inner, D, inner, EpiResid8{w.xb, w.xlo, D, D, w.ssp, np, Tp}, stream,
                           RP_K_GEMM_O, tv, t_dev)))
       return st;
     if (g_debug_skip_ffn) continue;
@@ -471,13 +472,13 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
     if (st) return st;
     if (wo_main < Tp) {
       const int r1 = wo_main;
-      st = launch_gemm(w.ff, F, r1, L.wo2, F, D, F, EpiResid{w.xb, w.xlo, D, D, w.ssp, np, Tp}, stream, RP_K_GEMM_WO);
+      st = launch_gemm(w.ff, F, r1, L.wo2, F, D, F, EpiResid8{w.xb, w.xlo, D, D, w.ssp, np, Tp}, stream, RP_K_GEMM_WO);
       if (st) return st;
       st = launch_gemm(w.ff + (size_t)r1 * F, F, Tp - r1, L.wo2, F, D, F,
-                       EpiResid{w.xb + (size_t)r1 * D, w.xlo + (size_t)r1 * D, D, D, w.ssp + r1, np, Tp}, stream,
+                       EpiResid8{w.xb + (size_t)r1 * D, (bf16_t*)((uint8_t*)w.xlo + (size_t)r1 * D), D, D, w.ssp + r1, np, Tp}, stream,
                        RP_K_GEMM_WO, std::max(1, tv - r1), nullptr, 0);
     } else {
-      st = launch_gemm(w.ff, F, Tp, L.wo2, F, D, F, EpiResid{w.xb, w.xlo, D, D, w.ssp, np, Tp}, stream, RP_K_GEMM_WO, tv,
+      st = launch_gemm(w.ff, F, Tp, L.wo2, F, D, F, EpiResid8{w.xb, w.xlo, D, D, w.ssp, np, Tp}, stream, RP_K_GEMM_WO, tv,
                        t_dev);
     }
     if (st) return st;
@@ -486,7 +487,7 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
   {
     ProfScope ps(stream, RP_K_POOL);
     launch_pool_partial(dim3(T / pc + batch), stream, w.xb, w.xlo, w.rs, (const int4*)w.pwork, w.pool, D, pc, e->final_ln, out,
-                        out_dtype == RP_DT_BF16 ? 1 : 0, 1);
+                        out_dtype == RP_DT_BF16 ? 1 : 0, 1, true);
     hipLaunchKernelGGL(pool_finish_kernel, dim3(batch), dim3(256), 0, stream, w.pool, e->final_ln, cu_seqlens, out,
                        out_dtype == RP_DT_BF16 ? 1 : 0, D, pc, 1);
   }
@@ -712,6 +713,11 @@ extern "C" RpStatus rp_dbg_gemm(const void* A, const void* W, void* out, int32_t
       return launch_gemm(a, K, M, w, K, N, K,
                          EpiResid{(bf16_t*)out, (bf16_t*)out + (size_t)M * n_valid, n_valid, n_valid, nullptr, 0, 0}, stream,
                          RP_K_GEMM_WO);
+    case RP_EPI_RESID8:  // out = the bf16 plane [M, n_valid], then the int8 extension plane [M, n_valid] (the 24-bit form)
+      RP_REQUIRE(n_valid % 8 == 0, "n_valid=%d", n_valid);
+      return launch_gemm(a, K, M, w, K, N, K,
+                         EpiResid8{(bf16_t*)out, (bf16_t*)out + (size_t)M * n_valid, n_valid, n_valid, nullptr, 0, 0}, stream,
+                         RP_K_GEMM_WO);
     case RP_EPI_GEGLU_BF16:
       return launch_gemm(a, K, M, w, K, N, K, EpiGegluBf16{(bf16_t*)out, n_valid / 2, n_valid, RowScale{nullptr}}, stream,
                          RP_K_GEMM_WI);
@@ -749,6 +755,11 @@ extern "C" RpStatus rp_dbg_gemm_fused(const void* A, const void* W, void* out, i
       RP_REQUIRE(n_valid % 8 == 0, "n_valid=%d", n_valid);
       return launch_gemm(a, K, M, w, K, N, K,
                          EpiResid{(bf16_t*)out, (bf16_t*)out + (size_t)M * n_valid, n_valid, n_valid, ssp_out, np_out, M},
+                         stream, RP_K_GEMM_WO);
+    case RP_EPI_RESID8:
+      RP_REQUIRE(n_valid % 8 == 0, "n_valid=%d", n_valid);
+      return launch_gemm(a, K, M, w, K, N, K,
+                         EpiResid8{(bf16_t*)out, (bf16_t*)out + (size_t)M * n_valid, n_valid, n_valid, ssp_out, np_out, M},
                          stream, RP_K_GEMM_WO);
     case RP_EPI_GEGLU_BF16:
       return launch_gemm(a, K, M, w, K, N, K, EpiGegluBf16{(bf16_t*)out, n_valid / 2, n_valid, rs}, stream,

@@ -114,13 +114,52 @@ __device__ __forceinline__ void hilo_update2(uint32_t h2, uint32_t l2, float d0,
   ss = __fmaf_rn(x1, x1, __fmaf_rn(x0, x0, ss));
 }
 
+// Round 5 - the INFERENCE pass keeps x as a 24-bit word per element instead: hi = the bf16 plane (still the next
+// projection's A operand) and an int8 "extension" plane e, x = float((hi << 16) + (e << 8)) - the fp32 word of x rounded to
+// its top 24 bits (16 significant bits, as the two bf16 planes gave), split so that hi is that word rounded to its top 16
+// bits (half away from zero: differs from nearest-even on exact ties only, 1 value in 256) and e the signed remainder in
+// units of 2^-8 ulp(hi): e is simply bits 8..15 of the rounded word read as int8.  A residual update reads 3 B and writes 3 B per element where the two bf16 planes move 4 + 4: the
+// read-modify-write of x bounds the attention-out projection and the FFN-out epilogue (tools/probes/rmw_probe.hip:
+// 0.144 -> 0.122 ms for [70144, 1472] in 256 x 256 tiles; in the step -0.5 ms).  The training step keeps the bf16 pair.
+// One updated element pair: decode, add, round, re-split; ss accumulates the squares of the values as stored.
+__device__ __forceinline__ void x24_update2(uint32_t h2, int e0, int e1, float d0, float d1, uint32_t& oh, uint32_t& b0,
+                                            uint32_t& b1, float& ss) {
+  const float v0 = __uint_as_float((h2 << 16) + (uint32_t)(e0 << 8)) + d0;
+  const float v1 = __uint_as_float((h2 & 0xffff0000u) + (uint32_t)(e1 << 8)) + d1;
+  const uint32_t r0 = __float_as_uint(v0) + 0x80u, r1 = __float_as_uint(v1) + 0x80u;  // to 24 bits, half away from zero
+  b0 = (r0 >> 8) & 0xffu;
+  b1 = (r1 >> 8) & 0xffu;
+  oh = ((r0 + 0x8000u) >> 16) | ((r1 + 0x8000u) & 0xffff0000u);  // hi = the 24-bit word to 16 bits, half away from zero
+  const float x0 = __uint_as_float(r0 & 0xffffff00u), x1 = __uint_as_float(r1 & 0xffffff00u);
+  ss = __fmaf_rn(x1, x1, __fmaf_rn(x0, x0, ss));  // explicit fma chain: the same rounding sequence for every token
+}
+// (hi by the hardware's nearest-even conversion + an explicit remainder was measured too: the same margins, and 6 % more
+// time in the two residual epilogues - they are VALU-sensitive: two waves per SIMD, 128 elements per lane and tile.)
+// eight elements: h = 8 bf16, l = 8 int8 (element i = byte i), d[0..7] added
+__device__ __forceinline__ void x24_update8(const uint4 h, const uint2 l, const float4 d0, const float4 d1, uint4& oh, uint2& ol,
+                                            float& ss) {
+  uint32_t b[8];
+  x24_update2(h.x, __builtin_amdgcn_sbfe((int)l.x, 0, 8), __builtin_amdgcn_sbfe((int)l.x, 8, 8), d0.x, d0.y, oh.x, b[0], b[1], ss);
+  x24_update2(h.y, __builtin_amdgcn_sbfe((int)l.x, 16, 8), __builtin_amdgcn_sbfe((int)l.x, 24, 8), d0.z, d0.w, oh.y, b[2], b[3], ss);
+  x24_update2(h.z, __builtin_amdgcn_sbfe((int)l.y, 0, 8), __builtin_amdgcn_sbfe((int)l.y, 8, 8), d1.x, d1.y, oh.z, b[4], b[5], ss);
+  x24_update2(h.w, __builtin_amdgcn_sbfe((int)l.y, 16, 8), __builtin_amdgcn_sbfe((int)l.y, 24, 8), d1.z, d1.w, oh.w, b[6], b[7], ss);
+  ol.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+  ol.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+}
+// decode only (the pooling pass): elements 2 j, 2 j + 1 of an 8-element group
+__device__ __forceinline__ void x24_decode2(uint32_t h2, uint32_t lw, int j, float& x0, float& x1) {
+  x0 = __uint_as_float((h2 << 16) + (uint32_t)(__builtin_amdgcn_sbfe((int)lw, 16 * j, 8) << 8));
+  x1 = __uint_as_float((h2 & 0xffff0000u) + (uint32_t)(__builtin_amdgcn_sbfe((int)lw, 16 * j + 8, 8) << 8));
+}
+
 // ------------------------------------------------------------------------------------------
 // K1: byte-token embedding gather  x[t] = embed[ids[t]]   (HF:678); the table (vocab x D fp32,
 //   2.3 MB for ByT5-small) is L2-resident.  Emits the two planes of x (hi = the A operand of the first
 //   projection) and the row's sum of squares (RMSNorm statistic, applied in that GEMM's epilogue).
 //   rows >= T (tile padding) get token 0 so every workspace row stays finite.
 // ------------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ ids,
+template <bool LO8>  // LO8: the extension plane of the 24-bit form (x24_update2) instead of the bf16 lo plane
+__global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ ids,
                                                     const float* __restrict__ table,
                                                     bf16_t* __restrict__ xhi, bf16_t* __restrict__ xlo,
                                                     float* __restrict__ ssp, int np, int T, int Tp, int D,
@@ -138,16 +177,25 @@ static __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __rest
   const float4* src = reinterpret_cast<const float4*>(table + (size_t)id * D);
   uint4* dh = reinterpret_cast<uint4*>(xhi + (size_t)row * D);
   uint4* dl = reinterpret_cast<uint4*>(xlo + (size_t)row * D);
+  uint2* dl8 = reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(xlo) + (size_t)row * D);
   float ss = 0.f;
   for (int c = lane; c < (D >> 3); c += 64) {  // 8 features per lane and step
     const float4 a = src[2 * c], b = src[2 * c + 1];
-    uint4 oh, ol;
-    hilo_update2(0u, 0u, a.x, a.y, oh.x, ol.x, ss);
-    hilo_update2(0u, 0u, a.z, a.w, oh.y, ol.y, ss);
-    hilo_update2(0u, 0u, b.x, b.y, oh.z, ol.z, ss);
-    hilo_update2(0u, 0u, b.z, b.w, oh.w, ol.w, ss);
-    dh[c] = oh;  // (non-temporal stores measured in round 5: 83 us either way)
-    dl[c] = ol;
+    if constexpr (LO8) {
+      uint4 oh;
+      uint2 ol;
+      x24_update8(make_uint4(0u, 0u, 0u, 0u), make_uint2(0u, 0u), a, b, oh, ol, ss);
+      dh[c] = oh;
+      dl8[c] = ol;
+    } else {
+      uint4 oh, ol;
+      hilo_update2(0u, 0u, a.x, a.y, oh.x, ol.x, ss);
+      hilo_update2(0u, 0u, a.z, a.w, oh.y, ol.y, ss);
+      hilo_update2(0u, 0u, b.x, b.y, oh.z, ol.z, ss);
+      hilo_update2(0u, 0u, b.z, b.w, oh.w, ol.w, ss);
+      dh[c] = oh;  // (non-temporal stores measured in round 5: 83 us either way)
+      dl[c] = ol;
+    }
   }
   ss = wave_sum(ss);
   // sum-of-squares partials of the row (see EpiResid): slot 0 carries the whole row here
@@ -310,10 +358,10 @@ struct EpiStoreBf16T {  // out[token, feature] = bf16(acc * rs[token])
 
 // SPLIT_IN (the training forward, rp_train.hip): the old hi plane is read from xhi_in and the new one written to xhi, so
 // the sub-layer's input bf16(x) - an operand of the backward - survives the update at no extra traffic.
-template <bool SPLIT_IN>
+template <bool SPLIT_IN, bool LO8 = false>
 struct EpiResidT {  // x[token, feature] += acc on the two planes of the residual stream (+ ssp partials)
   bf16_t* __restrict__ xhi;  // bf16(x): also the next projection's A operand
-  bf16_t* __restrict__ xlo;  // bf16(x - hi)
+  bf16_t* __restrict__ xlo;  // bf16(x - hi); LO8: the int8 extension plane of the 24-bit form (one byte per element)
   int ldx, n_valid;          // n_valid % 8 == 0
   float* __restrict__ ssp;   // optional: [np, ssp_ld] partial sums of squares, slot = feature / 64; slot-major so
                              // that a workgroup's statistics land in whole cache lines (token-major they were
@@ -337,7 +385,9 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
     // make hipcc drain vmcnt to 0 around it, which serialises the whole epilogue.
     // (wave tiles of 128 x 128 keep their accumulators in AGPRs and have the VGPRs for 3 blocks ahead)
     constexpr int DEPTH = (FM * FN >= 16) ? 4 : 2;
-    uint4 xh[DEPTH][4], xl[DEPTH][4];
+    uint4 xh[DEPTH][4];
+    typename std::conditional<LO8, uint2, uint4>::type xl[DEPTH][4];
+    const uint8_t* xlo8 = reinterpret_cast<const uint8_t*>(xlo);
     auto fetch = [&](int b, int p) {
       const int q = b / FN, j = b % FN;
       const int f = min(m_base + q * 64 + sub * 8, n_valid - 8);
@@ -346,13 +396,16 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
         const size_t off = (size_t)(n_base + j * 32 + c * 8 + rr) * ldx + f;
 #ifdef RP_ABL_NOLOAD  // probe builds: the residual epilogue without the reads of the old planes
         xh[p][c] = make_uint4((uint32_t)off, 0u, 0u, 0u);
-        xl[p][c] = make_uint4(0u, 0u, 0u, 0u);
+        xl[p][c] = {};
 #else
         if constexpr (SPLIT_IN)
           xh[p][c] = *reinterpret_cast<const uint4*>(xhi_in + off);
         else
           xh[p][c] = *reinterpret_cast<const uint4*>(xhi + off);
-        xl[p][c] = *reinterpret_cast<const uint4*>(xlo + off);
+        if constexpr (LO8)
+          xl[p][c] = *reinterpret_cast<const uint2*>(xlo8 + off);
+        else
+          xl[p][c] = *reinterpret_cast<const uint4*>(xlo + off);
 #endif
       }
     };
@@ -392,17 +445,26 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
         float ss = 0.f;
         if (f < n_valid) {
           const size_t off = (size_t)(n_base + j * 32 + t) * ldx + f;
-          const uint4 h = xh[b % DEPTH][c], l = xl[b % DEPTH][c];
-          uint4 oh, ol;
-          hilo_update2(h.x, l.x, d0.x, d0.y, oh.x, ol.x, ss);
-          hilo_update2(h.y, l.y, d0.z, d0.w, oh.y, ol.y, ss);
-          hilo_update2(h.z, l.z, d1.x, d1.y, oh.z, ol.z, ss);
-          hilo_update2(h.w, l.w, d1.z, d1.w, oh.w, ol.w, ss);
+          const uint4 h = xh[b % DEPTH][c];
+          const auto l = xl[b % DEPTH][c];
+          uint4 oh;
+          typename std::conditional<LO8, uint2, uint4>::type ol;
+          if constexpr (LO8) {
+            x24_update8(h, l, d0, d1, oh, ol, ss);
+          } else {
+            hilo_update2(h.x, l.x, d0.x, d0.y, oh.x, ol.x, ss);
+            hilo_update2(h.y, l.y, d0.z, d0.w, oh.y, ol.y, ss);
+            hilo_update2(h.z, l.z, d1.x, d1.y, oh.z, ol.z, ss);
+            hilo_update2(h.w, l.w, d1.z, d1.w, oh.w, ol.w, ss);
+          }
 #ifdef RP_ABL_NOSTORE
-          asm volatile("" ::"v"(oh.x), "v"(oh.y), "v"(oh.z), "v"(oh.w), "v"(ol.x), "v"(ol.y), "v"(ol.z), "v"(ol.w));
+          asm volatile("" ::"v"(oh.x), "v"(oh.y), "v"(oh.z), "v"(oh.w), "v"(ol.x), "v"(ol.y));
 #else
           *reinterpret_cast<uint4*>(xhi + off) = oh;
-          *reinterpret_cast<uint4*>(xlo + off) = ol;
+          if constexpr (LO8)
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(xlo) + off) = ol;
+          else
+            *reinterpret_cast<uint4*>(xlo + off) = ol;
 #endif
         }
         if (ssp) {  // fixed shuffle tree over the 8 lanes of the token's 64 features
@@ -416,7 +478,8 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
   }
 };
 
-typedef EpiResidT<false> EpiResid;
+typedef EpiResidT<false> EpiResid;          // the two bf16 planes (kernel tests; the training step's SPLIT_IN form)
+typedef EpiResidT<false, true> EpiResid8;   // bf16 plane + int8 extension plane: the inference pass
 
 template <class RS>
 struct EpiGegluBf16T {  // W rows interleaved 32 gate / 32 up: even row-fragments gate, odd up
@@ -1061,7 +1124,7 @@ static __global__ __launch_bounds__(256, DROP ? 2 : 4) void attention_kernel(con
 // 4 up to 2048.  R token rows of a wave are in flight before the first is consumed (the rows are independent
 // streams: rs comes from rowscale).  `chunk` = tokens per workgroup.  A sequence of ONE chunk is finished here (weight,
 // 1 / len, L2 normalisation, output row): its column sums never travel through `partial`, and pool_finish_kernel skips it.
-template <int NV, int R>
+template <int NV, int R, bool LO8>
 __global__ __launch_bounds__(256) void pool_partial_kernel(const bf16_t* __restrict__ xhi, const bf16_t* __restrict__ xlo,
                                                            const float* __restrict__ rs,
                                                            const int4* __restrict__ pwork,
@@ -1084,7 +1147,8 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const bf16_t* __restr
     for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
   // Tokens are accumulated in index order per wave (w, w+4, w+8, ...), whatever the unrolling.
   for (int t = t0 + wave; t < t1; t += 4 * R) {
-    uint4 vh[R][NV], vl[R][NV];
+    uint4 vh[R][NV];
+    typename std::conditional<LO8, uint2, uint4>::type vl[R][NV];
     float r[R];
 #pragma unroll
     for (int u = 0; u < R; ++u) {
@@ -1092,12 +1156,14 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const bf16_t* __restr
       const bool live = tu < t1;
       const size_t row = (size_t)(s0 + (live ? tu : t)) * D;
       const uint4* sh = reinterpret_cast<const uint4*>(xhi + row);
-      const uint4* sl = reinterpret_cast<const uint4*>(xlo + row);
       r[u] = live ? rs[s0 + tu] : 0.f;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {  // clamped, unpredicated
         vh[u][i] = sh[min(lane + 64 * i, nv - 1)];
-        vl[u][i] = sl[min(lane + 64 * i, nv - 1)];
+        if constexpr (LO8)
+          vl[u][i] = reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(xlo) + row)[min(lane + 64 * i, nv - 1)];
+        else
+          vl[u][i] = reinterpret_cast<const uint4*>(xlo + row)[min(lane + 64 * i, nv - 1)];
       }
     }
 #pragma unroll
@@ -1105,11 +1171,16 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const bf16_t* __restr
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const uint32_t h[4] = {vh[u][i].x, vh[u][i].y, vh[u][i].z, vh[u][i].w};
-        const uint32_t l[4] = {vl[u][i].x, vl[u][i].y, vl[u][i].z, vl[u][i].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float x0 = __uint_as_float(h[e] << 16) + __uint_as_float(l[e] << 16);
-          const float x1 = __uint_as_float(h[e] & 0xffff0000u) + __uint_as_float(l[e] & 0xffff0000u);
+          float x0, x1;
+          if constexpr (LO8) {
+            x24_decode2(h[e], (e < 2) ? vl[u][i].x : vl[u][i].y, e & 1, x0, x1);
+          } else {
+            const uint32_t l[4] = {vl[u][i].x, vl[u][i].y, vl[u][i].z, vl[u][i].w};
+            x0 = __uint_as_float(h[e] << 16) + __uint_as_float(l[e] << 16);
+            x1 = __uint_as_float(h[e] & 0xffff0000u) + __uint_as_float(l[e] & 0xffff0000u);
+          }
           acc[i][2 * e] = fmaf(x0, r[u], acc[i][2 * e]);
           acc[i][2 * e + 1] = fmaf(x1, r[u], acc[i][2 * e + 1]);
         }
@@ -1157,13 +1228,21 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const bf16_t* __restr
 
 static void launch_pool_partial(dim3 grid, hipStream_t stream, const bf16_t* xhi, const bf16_t* xlo, const float* rs,
                                 const int4* pwork, float* partial, int D, int chunk, const float* w, void* out, int out_bf16,
-                                int fuse) {
-  if (D <= 3 * 512)
-    hipLaunchKernelGGL((pool_partial_kernel<3, 4>), grid, dim3(256), 0, stream, xhi, xlo, rs, pwork, partial, D, chunk, w, out,
+                                int fuse, bool lo8) {
+  if (lo8) {
+    if (D <= 3 * 512)
+      hipLaunchKernelGGL((pool_partial_kernel<3, 4, true>), grid, dim3(256), 0, stream, xhi, xlo, rs, pwork, partial, D, chunk, w, out,
+                         out_bf16, fuse);
+    else
+      hipLaunchKernelGGL((pool_partial_kernel<4, 4, true>), grid, dim3(256), 0, stream, xhi, xlo, rs, pwork, partial, D, chunk, w, out,
+                         out_bf16, fuse);
+  } else if (D <= 3 * 512) {
+    hipLaunchKernelGGL((pool_partial_kernel<3, 4, false>), grid, dim3(256), 0, stream, xhi, xlo, rs, pwork, partial, D, chunk, w, out,
                        out_bf16, fuse);
-  else
-    hipLaunchKernelGGL((pool_partial_kernel<4, 4>), grid, dim3(256), 0, stream, xhi, xlo, rs, pwork, partial, D, chunk, w, out,
+  } else {
+    hipLaunchKernelGGL((pool_partial_kernel<4, 4, false>), grid, dim3(256), 0, stream, xhi, xlo, rs, pwork, partial, D, chunk, w, out,
                        out_bf16, fuse);
+  }
 }
 
 // Sequences of more than one chunk: one workgroup per sequence sums its chunks' column sums in chunk order - four chunks'

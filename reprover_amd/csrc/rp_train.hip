@@ -251,7 +251,7 @@ RpStatus train_forward(RpTrainer* tr, const int32_t* ids, const int32_t* cu, int
       hipLaunchKernelGGL(embed_train_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, (const float*)e->embed, w.xa[0], w.xlo,
                          w.ssp, np, T, Tp, D, c.vocab_size, drop);
     else
-      hipLaunchKernelGGL(embed_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.xa[0], w.xlo, w.ssp, np, T, Tp,
+      hipLaunchKernelGGL(embed_kernel<false>, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.xa[0], w.xlo, w.ssp, np, T, Tp,
                          D, c.vocab_size, (const int32_t*)nullptr);
   }
   const dim3 att_grid(H, T / ATT_Q + batch);
@@ -298,7 +298,7 @@ RpStatus train_forward(RpTrainer* tr, const int32_t* ids, const int32_t* cu, int
     const dim3 pg(T / POOL_CHUNK + batch);
     if (!drop.thresh)
       launch_pool_partial(pg, stream, w.xa[L], w.xlo, w.rs_final, (const int4*)w.pwork, w.pool, D, POOL_CHUNK, (const float*)e->final_ln,
-                          (void*)out_emb, 0, 0 /* the backward reads every chunk's sums from `pool` */);
+                          (void*)out_emb, 0, 0 /* the backward reads every chunk's sums from `pool` */, false);
     else if (D <= 3 * 512)
       hipLaunchKernelGGL(pool_partial_train_kernel<3>, pg, dim3(256), 0, stream, (const bf16_t*)w.xa[L], (const bf16_t*)w.xlo,
                          (const float*)w.rs_final, (const int4*)w.pwork, w.pool, D, drop);

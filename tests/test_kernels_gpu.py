@@ -71,6 +71,47 @@ def test_gemm_residual_two_planes(gen):
     assert (planes[0] != got.to(torch.bfloat16)).float().mean().item() < 1e-2
 
 
+def test_gemm_residual_24_bit_form(gen):
+    """The inference pass's residual stream: a bf16 plane + an int8 extension plane, x = float((hi << 16) + (ext << 8)),
+    i.e. the fp32 word of x rounded to its top 24 bits (x24_update2).  The representation is specified to the bit: the
+    update must equal the host's restatement of it EXACTLY wherever the fp32 sums agree, hi must be the 24-bit word rounded
+    to 16 bits (half away from zero), and the sums of squares must be those of the values as stored."""
+    M, N, K = 256, 1472, 384
+    np_ = (N + 63) // 64
+    A, W = _rand_bf16(gen, M, K), _rand_bf16(gen, N, K, scale=K ** -0.5)
+    x = torch.randn(M, N, generator=gen, device="cuda") * 3.0
+    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 2.0 ** -20, -(2.0 ** 20), 1.0 + 2.0 ** -9, -(1.0 + 2.0 ** -9)], device="cuda")
+    buf, hi, ext = hh.split_x24(x)
+    x0 = hh.merge_x24(hi, ext)
+    assert (x0 - x).abs().max().item() <= 2 ** -16 * x.abs().max().item()  # 16 significant bits
+    assert ((x0 - hi.float()).abs() <= 2 ** -8 * hi.float().abs() + 1e-30).all()
+    delta = A.float() @ W.float().T
+    lib = _lib.load()
+    ssp = torch.full((np_, M), float("nan"), device="cuda")
+    _lib.check(lib.rp_dbg_gemm_fused(A.data_ptr(), W.data_ptr(), buf.data_ptr(), M, N, K, N, _lib.RP_EPI_RESID8, None, 0, 0.0, 0.0,
+                                     None, ssp.data_ptr(), np_, _lib.current_stream()), "fused")
+    torch.cuda.synchronize()
+    got = hh.merge_x24(hi, ext)
+    ref = x0 + delta
+    assert ((got - ref).abs() <= 2 ** -16 * ref.abs() + 2e-6).all()  # 16 significant bits (+ the MFMA's own summation order)
+    # bit-level: re-encoding what the kernel stored reproduces both planes (the stored pair is canonical) ...
+    _, hi2, ext2 = hh.split_x24(got)
+    assert torch.equal(hi2.view(torch.int16), hi.view(torch.int16)) and torch.equal(ext2, ext)
+    # ... and it is the 24-bit rounding of an fp32 sum that agrees with torch's to an ulp or two of fp32 (MFMA order)
+    _, hi3, ext3 = hh.split_x24(ref)
+    same = (hi3.view(torch.int16) == hi.view(torch.int16)) & (ext3 == ext)
+    assert same.float().mean().item() > 0.98
+    assert (hh.merge_x24(hi3, ext3) - got).abs().max().item() <= 2 ** -15 * ref.abs().max().item()
+    want = (got.double() ** 2).view(M, np_, 64).sum(-1).float().T
+    assert not torch.isnan(ssp).any() and (ssp - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+    # the plain entry point (no statistics) stores the same planes
+    buf_b, hi_b, ext_b = hh.split_x24(x)
+    _lib.check(lib.rp_dbg_gemm(A.data_ptr(), W.data_ptr(), buf_b.data_ptr(), M, N, K, N, _lib.RP_EPI_RESID8,
+                               _lib.current_stream()), "rp_dbg_gemm")
+    torch.cuda.synchronize()
+    assert torch.equal(buf_b, buf)
+
+
 def test_gemm_geglu(gen):
     M, F, K = 128, 256, 128
     A = _rand_bf16(gen, M, K)

@@ -10,6 +10,8 @@ import bench
 from reprover_amd import _lib, synth, tokenizer
 from reprover_amd.encoder import HipT5Encoder
 
+if os.environ.get("LIB"):  # another build of the library (A/B of two source states on one box: run the tool twice)
+    _lib.LIB_PATH = os.path.abspath(os.environ["LIB"])
 lib = _lib.load()
 dev = torch.device("cuda", 0)
 model = os.environ.get("MODEL", "byt5-small")
