@@ -3,6 +3,8 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reprover_amd import _lib
+if os.environ.get("LIB"):  # another build of the library (probe builds: tools/probes/gemm_phase.py build)
+    _lib.LIB_PATH = os.path.abspath(os.environ["LIB"])
 lib = _lib.load()
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 variants = [int(v) for v in os.environ.get("VARIANTS", "26,20,9,0").split(",")]

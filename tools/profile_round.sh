@@ -2,7 +2,7 @@
 # rocprofv3 evidence for the bench command: kernel-trace + stats (one run), then PMC passes
 # (separate runs, --kernel-trace only, as the guide prescribes).  Summaries -> gpurun_out/prof_*/
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 timeout -k 5 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$R -o bench --output-format csv -- \
   python bench.py --steps 5 --warmup 2 --no-cpu-baseline --headline-only > gpurun_out/prof_$R.log 2>&1
 tail -1 gpurun_out/prof_$R.log | cut -c1-400
