@@ -1,11 +1,11 @@
 #!/bin/bash
 # Round 5, experiment 9: the residual stream as bf16 plane + int8 extension plane (24-bit form) against the two bf16 planes
-# (the library of the commit before, tools/r5/libreprover_prev.so), alternating processes on one box
+# (the library of the commit before, profiles/r05_raw/scripts/libreprover_prev.so), alternating processes on one box
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/r5_exp9; mkdir -p $O
 export PYTHONUNBUFFERED=1
 timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_encoder_gpu.py -m gpu -q -x 2>&1 | tail -12 | tee $O/pytest.log
 for i in 1 2 3; do
-LIB=tools/r5/libreprover_prev.so ROUNDS=4 STEPS=4 timeout 900 python tools/step_ab.py "two_bf16_planes:" 2>&1 | grep median | tee -a $O/step_ab.log
+LIB=profiles/r05_raw/scripts/libreprover_prev.so ROUNDS=4 STEPS=4 timeout 900 python tools/step_ab.py "two_bf16_planes:" 2>&1 | grep median | tee -a $O/step_ab.log
 ROUNDS=4 STEPS=4 timeout 900 python tools/step_ab.py "bf16+int8_planes:" 2>&1 | grep median | tee -a $O/step_ab.log
 done
