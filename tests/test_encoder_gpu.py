@@ -178,6 +178,21 @@ def test_big_pass_launch_forms_are_the_same_bits(small):
     assert torch.isfinite(outs[0]).all() and (outs[0].norm(dim=1) - 1).abs().max().item() < 1e-5
 
 
+def test_padded_entry_point_at_big_tile_sizes_equals_packed(small):
+    """rp_encode_padded with a token bound in big-tile territory (64 states padded to 2048 = 131 k rows bound, ~17 k live
+    tokens): the grids are sized for the bound, the live tiles are re-numbered on the device (`t_dev`) - also inside the
+    persistent workgroups of the FFN-in / QKV projections, whose tile lists are cut at the live count.  Same bits as the
+    packed entry point."""
+    rng = np.random.default_rng(23)
+    lens = synth.synth_lengths(rng, 64, "mix", lo=16, hi=2048)
+    texts = [synth.synth_state(rng, int(n) - 1) for n in lens]
+    packed = small.encode_texts(texts)
+    tok = small.tokenizer(texts, padding="longest", max_length=2048, truncation=True, return_tensors="pt")
+    assert tok.input_ids.shape[0] * tok.input_ids.shape[1] > 65536
+    padded = small._encode(tok.input_ids.cuda(), tok.attention_mask.cuda())
+    assert torch.equal(padded, packed)
+
+
 def _published_checkpoint_dir():
     """A local copy of kaiyuy/leandojo-lean4-retriever-byt5-small, if this box happens to have one: $RP_REAL_CKPT, or the
     HuggingFace hub cache.  There is no network here, so normally there is none and the test below is skipped."""
