@@ -127,8 +127,8 @@ class PremiseRetriever:
     def load_hf(cls, ckpt_path: str, max_seq_len: int, device, dtype=None) -> "PremiseRetriever":
         """``dtype`` None → bf16, the reference's own choice on a capable GPU (model.py:59-64).  ``dtype`` selects
         the dtype of the embeddings handed back (``corpus_embeddings``, ``_encode``); the arithmetic is the same for
-        both values - bf16 MFMA operands, fp32 accumulation and statistics, the residual stream as two bf16 planes
-        (hi + lo: 16 mantissa bits) - where the reference with ``dtype=float32`` multiplies fp32 operands under
+        both values - bf16 MFMA operands, fp32 accumulation and statistics, the residual stream as a bf16 plane + an int8
+        extension plane (16 significant bits) - where the reference with ``dtype=float32`` multiplies fp32 operands under
         ``torch.set_float32_matmul_precision("medium")`` (model.py:26), a setting that itself licenses bf16-precision
         products inside fp32 matmuls.  ``retrieve`` / ``num_retrieved`` accept any k, as the reference does (one library call
         sorts at most 1024 keys per query; beyond that ``Corpus.get_nearest_premises`` pages through ``rp_sim_topk_after``) - on
