@@ -256,6 +256,10 @@ static RpStatus pack_all(RpEncoder* e, const RpT5Weights* w) {
   if ((st = alloc((size_t)c.vocab_size * D * 4, (void**)&e->embed))) return st;
   hipLaunchKernelGGL((to_f32_kernel<T>), dim3((c.vocab_size * D + 255) / 256), dim3(256), 0, 0, e->embed,
                      w->embed, c.vocab_size * D);
+  if ((st = alloc((size_t)c.vocab_size * D * 2, (void**)&e->embed_hi))) return st;
+  if ((st = alloc((size_t)c.vocab_size * D, (void**)&e->embed_lo))) return st;
+  if ((st = alloc((size_t)c.vocab_size * 4, (void**)&e->embed_ss))) return st;
+  embed_table_x24(e, 0);
   if ((st = alloc((size_t)D * 4, (void**)&e->final_ln))) return st;
   hipLaunchKernelGGL((to_f32_kernel<T>), dim3((D + 255) / 256), dim3(256), 0, 0, e->final_ln, w->final_ln, D);
   e->layers.resize(c.num_layers);
@@ -431,10 +435,14 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
     hipLaunchKernelGGL(rowscale_kernel, dim3((Tp + 63) / 64), dim3(64), 0, stream, w.ssp, w.rs, Tp, np,
                        1.f / (float)D, c.layer_norm_eps);
   };
+  // the first QKV projection's RMSNorm factor straight from the embedding kernel (the table carries every row's sum of
+  // squares) unless a consumer reads the statistic slots itself (few-token passes, the LDS form)
+  const bool embed_rs = !fused_rs && !lds_qkv;
   {
     ProfScope ps(stream, RP_K_EMBED);
-    hipLaunchKernelGGL(embed_kernel<true>, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, e->embed, w.xb, w.xlo, w.ssp, np, T,
-                       Tp, D, c.vocab_size, t_dev);
+    hipLaunchKernelGGL(embed_copy_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, ids, (const bf16_t*)e->embed_hi,
+                       (const uint8_t*)e->embed_lo, (const float*)e->embed_ss, w.xb, reinterpret_cast<uint8_t*>(w.xlo), w.ssp, np,
+                       embed_rs ? w.rs : (float*)nullptr, 1.f / (float)D, c.layer_norm_eps, T, Tp, D, c.vocab_size, t_dev);
   }
   RP_CHECK_LAUNCH();
   const dim3 att_grid(H, T / ATT_Q + batch);  // upper bound of the number of 128-query blocks
@@ -444,7 +452,7 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerPacked& L = e->layers[i];
     // attention sub-layer: qkv = rs * (xb Wqkv'^T)  ->  attention  ->  x += att Wo^T  (+ xb, ssp refreshed)
-    if (!lds_qkv) launch_rowscale();
+    if (!lds_qkv && !(i == 0 && embed_rs)) launch_rowscale();
     st = fused_rs ? launch_gemm<true>(w.xb, D, Tp, L.wqkv, D, 3 * inner, D,
                                       EpiStoreBf16Slots{w.qkv, 3 * inner, 3 * inner, rs_slots}, stream, RP_K_GEMM_QKV, tv, t_dev)
          : lds_qkv ? launch_gemm_big(w.xb, D, Tp, L.wqkv, D, 3 * inner, D,

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ 
     rows = min(Tp, (T + 255) & ~255);
   }
   if (row >= rows) return;
-  int id = (row < T) ? ids[row] : 0;
+  int id = (row < T) ? (ids ? ids[row] : row) : 0;  // ids NULL: row r is token r (embed_table_x24: the table re-encoded)
   id = min(max(id, 0), vocab - 1);
   const float4* src = reinterpret_cast<const float4*>(table + (size_t)id * D);
   uint4* dh = reinterpret_cast<uint4*>(xhi + (size_t)row * D);
@@ -202,7 +202,63 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ 
   for (int p = lane; p < np; p += 64) ssp[(size_t)p * Tp + row] = (p == 0) ? ss : 0.f;
 }
 
-constexpr int RMS_MAX_V4 = 8;  // a row is at most 8 float4 per lane of a wave: d_model <= 2048
+constexpr int RMS_MAX_V4 = 8;
+
+// The inference pass's embedding: the table is kept PRE-ENCODED in the 24-bit form (embed_table_x24: embed_kernel<true> run
+// once over the vocabulary - at create time and whenever the trainer refreshes the fp32 table - so a token's planes and its
+// sum of squares are the bits embed_kernel<true> computes per token), and a pass copies rows: one wave per token row,
+// 16 B of the bf16 plane + 8 B of the int8 plane per lane and step, no arithmetic.  Round 5: the access pattern alone
+// stores the 70 k x 1472 stream in 45 us (tools/probes/stream_probe.hip); embed_kernel<true> took 63-67 (it re-reads the
+// fp32 table row - 413 MB through L2 per pass - encodes, and scatters 23 four-byte statistic slots per row).
+// rs_out given: the row's RMSNorm factor is written directly (rowscale_kernel's arithmetic on slot 0 + zeros: the same
+// bits) and the pass skips the first rowscale launch; else the statistic goes to the slots as embed_kernel writes it.
+static __global__ __launch_bounds__(256) void embed_copy_kernel(const int32_t* __restrict__ ids, const bf16_t* __restrict__ thi,
+                                                         const uint8_t* __restrict__ tlo, const float* __restrict__ tss,
+                                                         bf16_t* __restrict__ xhi, uint8_t* __restrict__ xlo,
+                                                         float* __restrict__ ssp, int np, float* __restrict__ rs_out,
+                                                         float inv_d, float eps, int T, int Tp, int D, int vocab,
+                                                         const int32_t* __restrict__ t_dev) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int rows = Tp;
+  if (t_dev) {  // token count known on the device only (rp_encode_padded): T / Tp are upper bounds
+    T = *t_dev;
+    rows = min(Tp, (T + 255) & ~255);
+  }
+  if (row >= rows) return;
+  int id = (row < T) ? ids[row] : 0;
+  id = min(max(id, 0), vocab - 1);
+  const uint4* sh = reinterpret_cast<const uint4*>(thi + (size_t)id * D);
+  const uint2* sl = reinterpret_cast<const uint2*>(tlo + (size_t)id * D);
+  uint4* dh = reinterpret_cast<uint4*>(xhi + (size_t)row * D);
+  uint2* dl = reinterpret_cast<uint2*>(xlo + (size_t)row * D);
+  const int nv = D >> 3;
+  constexpr int NV = RMS_MAX_V4 / 2;  // up to 4 steps of 64 lanes x 8 features: d_model <= 2048
+  uint4 vh[NV];
+  uint2 vl[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {  // every load of the row requested before the first store
+    const int c = min(lane + 64 * i, nv - 1);
+    vh[i] = sh[c];
+    vl[i] = sl[c];
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      dh[c] = vh[i];
+      dl[c] = vl[i];
+    }
+  }
+  const float ss = tss[id];
+  if (rs_out) {
+    if (lane == 0) rs_out[row] = rsqrtf(ss * inv_d + eps);
+  } else {
+    for (int p = lane; p < np; p += 64) ssp[(size_t)p * Tp + row] = (p == 0) ? ss : 0.f;
+  }
+}
+
+  // a row is at most 8 float4 per lane of a wave: d_model <= 2048
 
 // ------------------------------------------------------------------------------------------
 // K3/K6/K7/K8: GEMM epilogues
@@ -1326,8 +1382,21 @@ struct RpEncoder {
   int inner;
   int maxd;
   float* embed;        // [V, D] f32
+  rp::bf16_t* embed_hi = nullptr;   // the table in the inference pass's 24-bit form: bf16 plane [V, D],
+  uint8_t* embed_lo = nullptr;  //   int8 extension plane [V, D],
+  float* embed_ss = nullptr;    //   sum of squares of every row as stored [V]   (embed_table_x24)
   float* final_ln;     // [D]
   float* bias_tab;     // [H, 2*maxd+1]
   std::vector<rp::LayerPacked> layers;
   std::vector<void*> allocs;
 };
+
+namespace rp {
+// (Re-)encode the embedding table into the 24-bit form: embed_kernel<true> over the vocabulary (token r = row r), the row
+// statistic into embed_ss (slot 0 of a one-slot layout).  Launch-only; e->embed_* are allocated by rp_encoder_create.
+inline void embed_table_x24(RpEncoder* e, hipStream_t stream) {
+  const int V = e->cfg.vocab_size, D = e->cfg.d_model;
+  hipLaunchKernelGGL(embed_kernel<true>, dim3((V + 3) / 4), dim3(256), 0, stream, (const int32_t*)nullptr, (const float*)e->embed,
+                     e->embed_hi, reinterpret_cast<bf16_t*>(e->embed_lo), e->embed_ss, 1, V, V, D, V, (const int32_t*)nullptr);
+}
+}  // namespace rp

@@ -578,6 +578,7 @@ extern "C" RpStatus rp_trainer_load_params(RpTrainer* tr, const float* params, v
   const int D = c.d_model, F = c.d_ff, inner = e->inner, H = c.num_heads;
   ProfScope ps(stream, RP_K_OPTIMIZER);
   RP_HIP(hipMemcpyAsync(e->embed, params + lay.embed(), (size_t)c.vocab_size * D * 4, hipMemcpyDeviceToDevice, stream));
+  embed_table_x24(e, stream);  // the inference pass's pre-encoded copy of the table follows the masters
   RP_HIP(hipMemcpyAsync(e->final_ln, params + lay.final_ln(), (size_t)D * 4, hipMemcpyDeviceToDevice, stream));
   const int ntab = 2 * e->maxd + 1;
   hipLaunchKernelGGL(bias_table_kernel, dim3((H * ntab + 255) / 256), dim3(256), 0, stream, params + lay.rel_bias(),
