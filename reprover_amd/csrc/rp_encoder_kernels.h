@@ -440,6 +440,7 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
     // unconditional, from a clamped address: a predicated load would sit in its own basic block and
     // make hipcc drain vmcnt to 0 around it, which serialises the whole epilogue.
     // (wave tiles of 128 x 128 keep their accumulators in AGPRs and have the VGPRs for 3 blocks ahead)
+    // (round 5, 24-bit form on the 8-wave tile: 3 / 4 blocks in flight measured 2 / 5 % SLOWER than 2 on the attention-out projection)
     constexpr int DEPTH = (FM * FN >= 16) ? 4 : 2;
     uint4 xh[DEPTH][4];
     typename std::conditional<LO8, uint2, uint4>::type xl[DEPTH][4];
@@ -833,7 +834,9 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
       case 20: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
       case 26: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
       case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
-#ifdef RP_EXPERIMENTS  // round 5, measured and rejected (profiles/r05_epilogue_overlap.md): FFN-in / FFN-out +17 % time
+#ifdef RP_EXPERIMENTS  // round 5, measured and rejected (profiles/r05_epilogue_overlap.md): FFN-in / FFN-out +17 % time; 29 = two
+      // pipelined 128 x 128 x 64 workgroups per CU for the attention-out projection: 2.46 vs 2.29 ms per step
+      case 29: return launch_gemm_cfg<GemmCfg<128, 128, 64, 2, 2, 2, 1, 0, 0, 0, 2>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
       case 27: return launch_gemm_cfg<GemmCfg<256, 128, 32, 2, 2, 3, 1, 0, 0, 0, 2>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
       case 28: return launch_gemm_cfg<GemmCfg<128, 256, 32, 2, 2, 3, 1, 0, 0, 0, 2>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
 #endif
