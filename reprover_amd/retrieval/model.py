@@ -467,7 +467,16 @@ class PremiseRetriever:
         self.embeddings_staled = False
 
     # -- prediction (model.py:274-336) --------------------------------------------------------------
-    def on_predict_start(self, corpus: Corpus, eval_batch_size: int) -> None:
+    def on_predict_start(self, corpus: Optional[Corpus] = None, eval_batch_size: Optional[int] = None) -> None:
+        """model.py:274-279.  The reference's hook takes no arguments and reads ``self.trainer.datamodule.corpus`` /
+        ``.eval_batch_size``: called that way (a Lightning-style ``trainer`` attribute attached to the object) it does the
+        same here; this package's own driver (``retrieval/main.py``) passes the two values."""
+        if corpus is None or eval_batch_size is None:
+            dm = getattr(getattr(self, "trainer", None), "datamodule", None)
+            if dm is None:
+                raise TypeError("on_predict_start() needs (corpus, eval_batch_size) or an attached trainer.datamodule")
+            corpus = dm.corpus if corpus is None else corpus
+            eval_batch_size = dm.eval_batch_size if eval_batch_size is None else eval_batch_size
         self.corpus = corpus
         self._drop_derived()
         self.corpus_embeddings = None

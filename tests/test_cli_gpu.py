@@ -113,6 +113,24 @@ def test_predict_validate_and_evaluate(workdir):
     assert abs(m["MRR"] - mrr) < 1e-9 and np.allclose([m[f"Recall@{j + 1}_val"] for j in range(10)], rec, atol=1e-9)
 
 
+def test_on_predict_start_reads_an_attached_trainer(workdir):
+    """The reference's ``on_predict_start(self)`` takes no arguments and reads ``self.trainer.datamodule`` (model.py:274-279):
+    a caller that attaches a Lightning-style trainer object gets the same behaviour here."""
+    import types
+
+    from reprover_amd.retrieval.datamodule import RetrievalDataModule
+
+    d, ckpt, cpath, sdir, splits, cfg, sd = workdir
+    model = PremiseRetriever.load_hf(ckpt, 256, "cuda:0")
+    dm = RetrievalDataModule(sdir, cpath, 16, 256, model.tokenizer)
+    with pytest.raises(TypeError):
+        model.on_predict_start()
+    model.trainer = types.SimpleNamespace(datamodule=dm)
+    model.on_predict_start()
+    assert model.corpus is dm.corpus and not model.embeddings_staled
+    assert model.corpus_embeddings.shape == (len(dm.corpus), cfg["d_model"]) and model.predict_step_outputs == []
+
+
 def test_native_index_directory_via_cli(workdir):
     d, ckpt, cpath, sdir, splits, cfg, sd = workdir
     out = os.path.join(d, "native.rpidx")
