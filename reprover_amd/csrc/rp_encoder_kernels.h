@@ -764,7 +764,9 @@ static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hi
   if constexpr (persist_capable<C>()) {
     // more tiles than CUs: one persistent workgroup per CU instead of one workgroup per tile
     const int slots = n_cus & ~7;
-    if (((g_gemm_persist >> (prof_class - RP_K_GEMM_QKV)) & 1) && n_helpers == 0 && n_grid > slots && epi_fits_persist(epi)) {
+    // (K >= two k-tiles: the persistent loop requests ring slot 1 unconditionally)
+    if (prof_class >= RP_K_GEMM_QKV && prof_class <= RP_K_GEMM_WO && ((g_gemm_persist >> (prof_class - RP_K_GEMM_QKV)) & 1) &&
+        n_helpers == 0 && n_grid > slots && K >= 2 * C::BK && epi_fits_persist(epi)) {
       auto pk = gemm_kernel_persist<C, Epi>;
       static LdsAttrOnce pattr;
       RP_HIP(pattr.ensure((const void*)pk, PERSIST_LDS_BYTES));
