@@ -933,6 +933,34 @@ def main():
                                    "host, packed varlen encode on the GPU; BASELINE configs[3] at N = 1"}
                 del r2
 
+    # ---- box calibration: what this box's matrix pipes sustain under load (boxes of one pool differ by several per cent) ----
+    box = None
+    if rank == 0:
+        with _Leg("box_calibration", leg_errors):
+            sink = torch.zeros(4, dtype=torch.float32, device=dev)
+            waves_per_cu, mfmas = 8, 32768
+
+            def probe():
+                _lib.check(lib.rp_dbg_mfma_probe(waves_per_cu, mfmas, sink.data_ptr(), _lib.current_stream()), "rp_dbg_mfma_probe")
+
+            probe()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                probe()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            flops = 256.0 * waves_per_cu * mfmas * 32768.0
+            tf = flops / (float(np.median(ts)) * 1e-3) / 1e12
+            box = {"mfma_probe_tflops": tf, "mfma_probe_frac_of_peak": tf / PEAK_BF16_TFLOPS,
+                   "step_gemm_tflops_over_probe": all_gemm_tf / tf if tf else None,
+                   "what": "v_mfma_f32_32x32x16_bf16 from registers, 8 waves per CU, pseudo-random bf16 operands, no memory "
+                           "traffic (rp_dbg_mfma_probe): the matrix-pipe rate THIS box sustains under load, median of 5 launches "
+                           "of ~1 ms; the chip clocks to its power budget, so step times of different boxes compare through it"}
+
     # ---- N = 1 only: the training step at the reference's training configuration -------------
     train = None
     if world == 1 and not args.headline_only and not args.no_train_step:
@@ -999,6 +1027,7 @@ def main():
         "shard_call_us": shard_call_us,
         "train_step": train,
         "all_encoder_gemms_tflops": all_gemm_tf,
+        "box_calibration": box,
         "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
     }
     traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")

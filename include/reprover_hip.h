@@ -401,6 +401,11 @@ RpStatus rp_dbg_gemm_fused(const void* A, const void* W, void* out, int32_t M, i
                            float eps, void* xb_out, float* ssp_out, int32_t np_out, void* stream);
 /* The T5 RMSNorm statistic as the product computes it (there is no separate normalisation pass): rs[row] =
  * rsqrt(sum_p ssp[p, row] * inv_d + eps) from the slot-major partial sums of squares the residual epilogues emit. */
+/* Box calibration for the bench line: `waves_per_cu` x 256 CUs waves each issue `mfmas` v_mfma_f32_32x32x16_bf16 from
+ * registers (pseudo-random bf16 operands, eight accumulators per wave, no memory traffic): 32768 FLOP per instruction.
+ * The achieved rate is what THIS box's matrix pipes sustain under load (the chip clocks to its power budget: boxes of one
+ * pool differ by several per cent), against which a step time can be read.  `sink` (>= 4 bytes) keeps the result live. */
+RpStatus rp_dbg_mfma_probe(int32_t waves_per_cu, int32_t mfmas, float* sink, void* stream);
 RpStatus rp_dbg_rowscale(const float* ssp /* [np, rows] */, float* rs /* [rows] */, int32_t rows, int32_t np,
                          float inv_d, float eps, void* stream);
 RpStatus rp_dbg_attention(const void* qkv_bf16, const int32_t* cu_seqlens, const float* bias_tab,

@@ -188,6 +188,7 @@ SIGNATURES = {
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
          C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p],
     ),
+    "rp_dbg_mfma_probe": (C.c_int32, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "rp_dbg_rowscale": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
     "rp_dbg_attention": (
         C.c_int32,

@@ -776,6 +776,44 @@ extern "C" RpStatus rp_dbg_gemm_fused(const void* A, const void* W, void* out, i
   return fail(RP_E_INVALID, "unknown epilogue %d", epilogue);
 }
 
+// Matrix-pipe rate of this box under load: MFMAs from registers only (include/reprover_hip.h).
+namespace rp {
+__global__ __launch_bounds__(256) void mfma_probe_kernel(int mfmas, float* __restrict__ sink) {
+  const uint32_t seed = (uint32_t)(blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+  bf16x8 a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {  // bf16 values in [-2, 2) with random mantissas and signs
+      const uint32_t h = (seed + 40503u * (uint32_t)(i * 8 + e)) * 2246822519u;
+      a[i][e] = (short)(0x3f00 | (h & 0x80ff) | ((h >> 9) & 0x0080));
+      b[i][e] = (short)(0x3f00 | ((h >> 16) & 0x80ff) | ((h >> 3) & 0x0080));
+    }
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  for (int it = 0; it < mfmas; it += 32) {  // (operand registers indexed by compile-time constants only)
+#pragma unroll
+    for (int rot = 0; rot < 4; ++rot)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 3], b[(i + rot) & 3], acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][15];
+  if (s == 12345.678f) sink[0] = s;  // (never true: keeps the accumulators live)
+}
+}  // namespace rp
+extern "C" RpStatus rp_dbg_mfma_probe(int32_t waves_per_cu, int32_t mfmas, float* sink, void* stream_) {
+  RP_REQUIRE(sink && waves_per_cu >= 4 && waves_per_cu % 4 == 0 && mfmas >= 32 && mfmas % 32 == 0, "waves_per_cu=%d mfmas=%d",
+             waves_per_cu, mfmas);
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(256 * (waves_per_cu / 4)), dim3(256), 0, (hipStream_t)stream_, mfmas, sink);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
 extern "C" RpStatus rp_dbg_rowscale(const float* ssp, float* rs, int32_t rows, int32_t np, float inv_d, float eps,
                                     void* stream_) {
   RP_REQUIRE(ssp && rs && rows > 0 && np > 0 && np <= 32, "rows=%d np=%d", rows, np);

@@ -124,8 +124,8 @@ __device__ __forceinline__ void hilo_update2(uint32_t h2, uint32_t l2, float d0,
 // One updated element pair: decode, add, round, re-split; ss accumulates the squares of the values as stored.
 __device__ __forceinline__ void x24_update2(uint32_t h2, int e0, int e1, float d0, float d1, uint32_t& oh, uint32_t& b0,
                                             uint32_t& b1, float& ss) {
-  const float v0 = __uint_as_float((h2 << 16) + (uint32_t)(e0 << 8)) + d0;
-  const float v1 = __uint_as_float((h2 & 0xffff0000u) + (uint32_t)(e1 << 8)) + d1;
+  const float v0 = __uint_as_float((h2 << 16) + ((uint32_t)e0 << 8)) + d0;  // (e sign-extended: the add borrows from hi)
+  const float v1 = __uint_as_float((h2 & 0xffff0000u) + ((uint32_t)e1 << 8)) + d1;
   const uint32_t r0 = __float_as_uint(v0) + 0x80u, r1 = __float_as_uint(v1) + 0x80u;  // to 24 bits, half away from zero
   b0 = (r0 >> 8) & 0xffu;
   b1 = (r1 >> 8) & 0xffu;
@@ -148,8 +148,8 @@ __device__ __forceinline__ void x24_update8(const uint4 h, const uint2 l, const 
 }
 // decode only (the pooling pass): elements 2 j, 2 j + 1 of an 8-element group
 __device__ __forceinline__ void x24_decode2(uint32_t h2, uint32_t lw, int j, float& x0, float& x1) {
-  x0 = __uint_as_float((h2 << 16) + (uint32_t)(__builtin_amdgcn_sbfe((int)lw, 16 * j, 8) << 8));
-  x1 = __uint_as_float((h2 & 0xffff0000u) + (uint32_t)(__builtin_amdgcn_sbfe((int)lw, 16 * j + 8, 8) << 8));
+  x0 = __uint_as_float((h2 << 16) + ((uint32_t)__builtin_amdgcn_sbfe((int)lw, 16 * j, 8) << 8));
+  x1 = __uint_as_float((h2 & 0xffff0000u) + ((uint32_t)__builtin_amdgcn_sbfe((int)lw, 16 * j + 8, 8) << 8));
 }
 
 // ------------------------------------------------------------------------------------------

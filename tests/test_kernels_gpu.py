@@ -561,3 +561,15 @@ def test_candidate_overflow_contract_through_the_product(gen):
         assert np.allclose(got_single[1], ref_single[1], atol=1e-6)
     finally:
         _lib.check(lib.rp_set_option(b"scan_cap", 0), "opt")
+
+
+def test_mfma_probe_runs_and_validates_its_arguments():
+    """rp_dbg_mfma_probe (the bench line's box calibration): launches, touches nothing but its sink, rejects bad shapes."""
+    lib = _lib.load()
+    sink = torch.zeros(4, device="cuda")
+    _lib.check(lib.rp_dbg_mfma_probe(8, 64, sink.data_ptr(), _lib.current_stream()), "rp_dbg_mfma_probe")
+    torch.cuda.synchronize()
+    assert float(sink.abs().sum()) == 0.0
+    assert lib.rp_dbg_mfma_probe(6, 64, sink.data_ptr(), _lib.current_stream()) != 0
+    assert lib.rp_dbg_mfma_probe(8, 40, sink.data_ptr(), _lib.current_stream()) != 0
+    assert lib.rp_dbg_mfma_probe(8, 64, None, _lib.current_stream()) != 0
