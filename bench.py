@@ -955,11 +955,28 @@ def main():
                 ts.append(e0.elapsed_time(e1))
             flops = 256.0 * waves_per_cu * mfmas * 32768.0
             tf = flops / (float(np.median(ts)) * 1e-3) / 1e12
+            # ... and its memory side: a 1-GiB device-to-device copy (read + write counted), median of 5
+            src = torch.empty(1 << 29, dtype=torch.bfloat16, device=dev).normal_()
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            torch.cuda.synchronize()
+            cs = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dst.copy_(src)
+                e1.record()
+                torch.cuda.synchronize()
+                cs.append(e0.elapsed_time(e1))
+            copy_gbs = 2.0 * src.numel() * 2 / (float(np.median(cs)) * 1e-3) / 1e9
+            del src, dst
             box = {"mfma_probe_tflops": tf, "mfma_probe_frac_of_peak": tf / PEAK_BF16_TFLOPS,
+                   "hbm_copy_gbs": copy_gbs, "hbm_copy_frac_of_peak": copy_gbs / PEAK_HBM_GBS,
                    "step_gemm_tflops_over_probe": all_gemm_tf / tf if tf else None,
                    "what": "v_mfma_f32_32x32x16_bf16 from registers, 8 waves per CU, pseudo-random bf16 operands, no memory "
                            "traffic (rp_dbg_mfma_probe): the matrix-pipe rate THIS box sustains under load, median of 5 launches "
-                           "of ~1 ms; the chip clocks to its power budget, so step times of different boxes compare through it"}
+                           "of ~1 ms; hbm_copy_gbs = a 1-GiB device-to-device copy (torch, read + write bytes); boxes of one pool differ by "
+                           "several per cent in either, and step times from different boxes compare through them"}
 
     # ---- N = 1 only: the training step at the reference's training configuration -------------
     train = None
