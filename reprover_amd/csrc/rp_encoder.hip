@@ -48,6 +48,9 @@ int g_gemm_small_pipe = 1;  // few-token passes: the 64 x 128 x 64 tile on the s
 int g_gemm_helpers = 64;      // few-token launches: up to this many surplus workgroups prefetch the weight rows (0 = off)
 int g_gemm_persist = 9;   // persistent workgroups (gemm_tiles_persist) per projection: 1 QKV, 4 attention-out, 8 FFN-in, 16 FFN-out
 int g_pool_chunk = 64;      // tokens per workgroup of the pooling pass (32 / 64 / 128; round 5 A/B at 70 k tokens: 98 / 100 / 104 us)
+int g_gemm_edge_layout = 1;  // big tiles: the last feature tile of 1152 / 1472 features on a wave grid over its valid features only
+int g_gemm_mixed = 20;  // full and half tiles in ONE launch (gemm_kernel_mixed) per projection: 1 QKV, 4 attention-out, 16 FFN-out
+int g_gemm_tail_variant = 30;  // tile configuration of that tail round: 30 = 256 x 128 x 64 half tiles, 0 = 128 x 128 x 32 quarter tiles
 int g_gemm_tail_split = 1;  // big passes: last partial round of 256 x 256 tiles as one round of 128 x 128 tiles
 int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 int g_gemm_skinny = 1;
@@ -162,6 +165,20 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   }
   if (!strcmp(name, "gemm_persist")) {
     g_gemm_persist = value;
+    return RP_OK;
+  }
+  if (!strcmp(name, "gemm_edge_layout")) {
+    g_gemm_edge_layout = value != 0;
+    return RP_OK;
+  }
+  if (!strcmp(name, "gemm_mixed")) {
+    RP_REQUIRE(value >= 0 && value <= 31, "gemm_mixed: bit mask 0..31");
+    g_gemm_mixed = value;
+    return RP_OK;
+  }
+  if (!strcmp(name, "gemm_tail_variant")) {
+    RP_REQUIRE(value == 0 || value == 30, "gemm_tail_variant: 0 or 30");
+    g_gemm_tail_variant = value;
     return RP_OK;
   }
   if (!strcmp(name, "gemm_tail_split")) {
@@ -412,6 +429,7 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
   }
   auto main_rows = [&](int prof_class, int n_features, int K) -> int {
     if (!g_gemm_tail_split || t_dev) return Tp;  // (token count known on the device only: one launch)
+    if ((g_gemm_mixed >> (prof_class - RP_K_GEMM_QKV)) & 1) return Tp;  // the mixed launch carries its own half tiles
     const int v = pick_gemm_variant(prof_class, Tp, n_features, K, tv);
     if (v != 20 && v != 26) return Tp;
     const int tiles_f = (n_features + 255) / 256, tiles_t = Tp / 256;
@@ -425,7 +443,9 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
     const int t1 = tiles_t / unit * unit, rest = tiles_t - t1;
     if (t1 == 0 || rest == 0) return Tp;
     if (rest * tiles_f > (7 * n_cus) / 10) return Tp;                      // the last round is nearly full anyway
-    if (rest * 2 * ((n_features + 127) / 128) > 2 * n_cus) return Tp;      // the small tiles would not fit one round
+    if (g_gemm_tail_variant == 30 ? rest * 2 * tiles_f > n_cus             // the half tiles (one per CU) ...
+                                  : rest * 2 * ((n_features + 127) / 128) > 2 * n_cus)  // ... the quarter tiles (two per CU)
+      return Tp;                                                           // would not fit one round
     return t1 * 256;
   };
   const int wo_main = main_rows(RP_K_GEMM_WO, D, F);
@@ -484,7 +504,7 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
       if (st) return st;
       st = launch_gemm(w.ff + (size_t)r1 * F, F, Tp - r1, L.wo2, F, D, F,
                        EpiResid8{w.xb + (size_t)r1 * D, (bf16_t*)((uint8_t*)w.xlo + (size_t)r1 * D), D, D, w.ssp + r1, np, Tp}, stream,
-                       RP_K_GEMM_WO, std::max(1, tv - r1), nullptr, 0);
+                       RP_K_GEMM_WO, std::max(1, tv - r1), nullptr, g_gemm_tail_variant);
     } else {
       st = launch_gemm(w.ff, F, Tp, L.wo2, F, D, F, EpiResid8{w.xb, w.xlo, D, D, w.ssp, np, Tp}, stream, RP_K_GEMM_WO, tv,
                        t_dev);

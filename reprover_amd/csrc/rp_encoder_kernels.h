@@ -12,7 +12,7 @@ namespace rp {
 
 // tuning knobs (defined in rp_encoder.hip, set through rp_set_option)
 extern int g_gemm_group_m, g_gemm_variant, g_gemm_variant_qkv, g_gemm_variant_wo, g_gemm_variant_o, g_gemm_tail_split,
-    g_debug_skip_ffn, g_gemm_skinny, g_gemm_skinny_variant, g_gemm_rs_lds, g_gemm_small_pipe, g_gemm_helpers, g_gemm_persist, g_pool_chunk;
+    g_debug_skip_ffn, g_gemm_skinny, g_gemm_skinny_variant, g_gemm_rs_lds, g_gemm_small_pipe, g_gemm_helpers, g_gemm_persist, g_pool_chunk, g_gemm_edge_layout, g_gemm_tail_variant, g_gemm_mixed;
 extern int g_gemm_stagger_us[RP_K_COUNT];
 
 // ------------------------------------------------------------------------------------------
@@ -366,6 +366,7 @@ static __global__ __launch_bounds__(64) void rowscale_kernel(const float* __rest
 
 template <class RS>
 struct EpiStoreBf16T {  // out[token, feature] = bf16(acc * rs[token])
+  static constexpr bool any_layout = true;
   bf16_t* out;
   int ldo, n_valid;  // n_valid = number of real output features (multiple of 8)
   RS rs;
@@ -416,6 +417,7 @@ struct EpiStoreBf16T {  // out[token, feature] = bf16(acc * rs[token])
 // the sub-layer's input bf16(x) - an operand of the backward - survives the update at no extra traffic.
 template <bool SPLIT_IN, bool LO8 = false>
 struct EpiResidT {  // x[token, feature] += acc on the two planes of the residual stream (+ ssp partials)
+  static constexpr bool any_layout = true;
   bf16_t* __restrict__ xhi;  // bf16(x): also the next projection's A operand
   bf16_t* __restrict__ xlo;  // bf16(x - hi); LO8: the int8 extension plane of the 24-bit form (one byte per element)
   int ldx, n_valid;          // n_valid % 8 == 0
@@ -628,6 +630,34 @@ __device__ __forceinline__ void gemm_prefetch_helper(const GemmOperand& A, int K
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(tmp)::"memory");
 }
 
+// epilogues that take any wave layout with an even number of 32-feature fragments per wave declare `any_layout`
+template <class E, class = void>
+struct epi_any_layout : std::false_type {};
+template <class E>
+struct epi_any_layout<E, std::void_t<decltype(E::any_layout)>> : std::true_type {};
+template <class C, class Epi>
+__host__ __device__ constexpr bool edge_layouts() {
+  return C::PIPE != 0 && C::FP8 == 0 && C::BM == 256 && C::BN == 256 && C::NWAVES == 8 && C::OCC == 0 && epi_any_layout<Epi>::value;
+}
+
+// One pipelined tile; the last feature tile of an extent that ends inside it runs on a wave grid over the valid features
+// only (rp_gemm.h WaveLayout).  128 of 256 (QKV, 1152 features): half the MFMA steps; 192 (d_model = 1472): three quarters.
+template <class C, class Epi>
+__device__ __forceinline__ void pipe_tile_edge(const GemmOperand& A, const GemmOperand& W, int K, int tm, int tn, Epi& epi,
+                                               char* smem, bool edge_on) {
+  if constexpr (edge_layouts<C, Epi>()) {
+    const int vf = __builtin_amdgcn_readfirstlane(A.rows - tm * C::BM);
+    if (edge_on && vf <= 192) {
+      if (vf <= 128)
+        gemm_tile_pipe<C, Epi, WaveLayout<2, 4, 2, 2>>(A, W, K, tm, tn, epi, smem);
+      else
+        gemm_tile_pipe<C, Epi, WaveLayout<1, 8, 6, 1>>(A, W, K, tm, tn, epi, smem);
+      return;
+    }
+  }
+  gemm_tile_pipe<C>(A, W, K, tm, tn, epi, smem);
+}
+
 template <class C, class Epi>
 __device__ __forceinline__ void gemm_kernel_body(GemmOperand A, GemmOperand W, int K, int tiles_m,
                                                   int tiles_n, int group_m, int stagger_ticks,
@@ -661,7 +691,7 @@ __device__ __forceinline__ void gemm_kernel_body(GemmOperand A, GemmOperand W, i
   int tm, tn;
   tile_coords(logical, tiles_n, tiles_m, group_m, tn, tm);  // token tiles grouped, feature tiles inside
   if constexpr (C::PIPE != 0)
-    gemm_tile_pipe<C>(A, W, K, tm, tn, epi, smem);
+    pipe_tile_edge<C>(A, W, K, tm, tn, epi, smem, stagger_ticks >= 0);  // (stagger_ticks < 0: the option gemm_edge_layout = 0)
   else
     gemm_tile<C>(A, W, K, tm, tn, epi, smem);
 }
@@ -682,12 +712,59 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_kernel_occ2(GemmOperand A,
   gemm_kernel_body<C>(A, W, K, tiles_m, tiles_n, group_m, stagger_ticks, t_dev, epi, n_helpers, smem);
 }
 
+// FULL and HALF tiles in one launch (MixedPlan below).  The token rows that make whole rounds of 256 x 256 tiles are the
+// full tiles; the rest are half tiles (CH: the same features x 128 tokens), some handed out FIRST and the others LAST:
+//   blocks [0, nh1)  half tiles | [nh1, nh1_pad) exit | [nh1_pad, nh1_pad + n_full)  full tiles | then the last half tiles.
+// About half the CUs start on a half tile, so the chip runs as two groups half a tile period apart from then on: the
+// read-modify-write epilogues (a burst of 100 MB when all 256 CUs reach them together: HBM-bound for ~20 us while the
+// MFMA pipes idle) of one group fall under the main loops of the other.  The group that started on full tiles finishes
+// them half a period early and takes the last half tiles: both end together, as the separate tail round had it.
+// Same K-ascending chains per output element: not a bit changes.
+template <class C, class CH, class Epi>
+__global__ __launch_bounds__(C::THREADS) void gemm_kernel_mixed(GemmOperand A, GemmOperand W, int K, int tiles_m,
+                                                                int full_rows, int nh1, int nh1_pad, int group_m,
+                                                                int edge_on, Epi epi) {
+  static_assert(CH::BM == C::BM && 2 * CH::BN == C::BN && CH::THREADS == C::THREADS && CH::PIPE != 0 && C::PIPE != 0, "half tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x, n_full = full_rows * tiles_m;
+  if (b >= nh1_pad && b < nh1_pad + n_full) {
+    const int logical = xcd_remap(b - nh1_pad, n_full);  // (nh1_pad % 8 == 0: block b - nh1_pad runs on XCD (b - nh1_pad) % 8)
+    int tm, tn;
+    tile_coords(logical, full_rows, tiles_m, group_m, tn, tm);
+    pipe_tile_edge<C>(A, W, K, tm, tn, epi, smem, edge_on != 0);
+  } else if (b < nh1 || b >= nh1_pad + n_full) {
+    const int h = b < nh1 ? b : b - (nh1_pad + n_full) + nh1;  // feature tiles fastest: neighbours share the token rows
+    gemm_tile_pipe<CH>(A, W, K, h % tiles_m, 2 * full_rows + h / tiles_m, epi, smem);
+  }
+}
+struct MixedPlan {
+  int full_rows = 0, half_first = 0, half_last = 0;  // token tiles of 256 | rows of 128 tokens handed out first | last
+};
+// tiles_f feature tiles x tiles_t token tiles of 256 on n_cus CUs; nothing (full_rows = 0) when the full tiles make whole
+// rounds anyway, when the last round is nearly full, or when the half tiles would not fit one round
+inline MixedPlan plan_mixed(int tiles_f, int tiles_t, int n_cus) {
+  MixedPlan p;
+  int g = tiles_f, b = n_cus;
+  while (b) {
+    const int t = g % b;
+    g = b;
+    b = t;
+  }
+  const int unit = n_cus / g;  // token tiles per whole number of rounds
+  const int t1 = tiles_t / unit * unit, rest = tiles_t - t1;
+  if (t1 == 0 || rest == 0 || rest * tiles_f > (7 * n_cus) / 10 || 2 * rest * tiles_f > n_cus) return p;
+  p.full_rows = t1;
+  p.half_first = std::min(2 * rest, (n_cus / 2) / tiles_f);
+  p.half_last = 2 * rest - p.half_first;
+  return p;
+}
+
 // One workgroup per CU walking its share of the tiles (gemm_tiles_persist).  Workgroup b runs on XCD b % 8 (observed, speed
 // only) and takes the tiles j, j + 32, j + 64, ... of that XCD's contiguous range of logical tile ids (j = b / 8): at any
 // moment the 32 workgroups of an XCD sit on 32 consecutive logical ids, exactly as the one-tile-per-workgroup launch has them.
 template <class C, class Epi>
 __global__ __launch_bounds__(C::THREADS) void gemm_kernel_persist(GemmOperand A, GemmOperand W, int K, int tiles_m,
-                                                                  int tiles_n, int group_m,
+                                                                  int tiles_n, int group_m, int edge_on,
                                                                   const int32_t* __restrict__ t_dev, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int nwg = tiles_m * tiles_n;
@@ -707,7 +784,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel_persist(GemmOperand A,
     i += per;
     return true;
   };
-  gemm_tiles_persist<C>(A, W, K, next_tile, epi, smem);
+  gemm_tiles_persist<C, edge_layouts<C, Epi>()>(A, W, K, next_tile, epi, smem, edge_on != 0);
 }
 // an epilogue with metadata behind the ring (RowScaleLds) has 24 KiB for it in the persistent layout
 template <class Epi>
@@ -749,7 +826,7 @@ static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hi
   // tile order: feature tiles fastest inside groups of `group` token tiles (shared activation panels)
   const int group = max(1, g_gemm_group_m * 128 / C::BN);
   ProfScope ps(stream, prof_class);
-  const int stagger_ticks = (C::PIPE != 0 && tiles_f * tiles_t > 512) ? g_gemm_stagger_us[prof_class] * 100 : 0;
+  const int stagger_ticks = !g_gemm_edge_layout ? -1 : (C::PIPE != 0 && tiles_f * tiles_t > 512) ? g_gemm_stagger_us[prof_class] * 100 : 0;
   // few-token launches (one group of token tiles, well under one round of the chip) on weights worth prefetching: the idle
   // CUs become prefetch helpers (above)
   int n_grid = tiles_f * tiles_t, n_helpers = 0;
@@ -761,6 +838,23 @@ static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hi
   // token rows beyond the valid count are read as copies of the last valid row (the operand clamps at `rows`): the 27
   // padding rows of a 101-token state cost one cache line per DMA piece instead of eight
   a.rows = rows_needed;
+  if constexpr (edge_layouts<C, Epi>() && epi_extra_lds<Epi>::value == 0) {
+    if (prof_class >= RP_K_GEMM_QKV && prof_class <= RP_K_GEMM_WO && ((g_gemm_mixed >> (prof_class - RP_K_GEMM_QKV)) & 1) &&
+        n_helpers == 0 && !t_dev && K >= 2 * C::BK) {
+      const MixedPlan mp = plan_mixed(tiles_f, tiles_t, n_cus);
+      if (mp.full_rows) {
+        using CH = GemmCfg<C::BM, C::BN / 2, C::BK, C::WM, C::WN, C::NSTAGE, C::PIPE>;
+        auto mk = gemm_kernel_mixed<C, CH, Epi>;
+        static LdsAttrOnce mattr;
+        RP_HIP(mattr.ensure((const void*)mk, C::LDS_BYTES));
+        const int nh1 = mp.half_first * tiles_f, nh1_pad = (nh1 + 7) & ~7;
+        hipLaunchKernelGGL(mk, dim3(nh1_pad + mp.full_rows * tiles_f + mp.half_last * tiles_f), dim3(C::THREADS), C::LDS_BYTES,
+                           stream, w, a, K, tiles_f, mp.full_rows, nh1, nh1_pad, group, g_gemm_edge_layout, epi);
+        RP_CHECK_LAUNCH();
+        return RP_OK;
+      }
+    }
+  }
   if constexpr (persist_capable<C>()) {
     // more tiles than CUs: one persistent workgroup per CU instead of one workgroup per tile
     const int slots = n_cus & ~7;
@@ -770,7 +864,8 @@ static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hi
       auto pk = gemm_kernel_persist<C, Epi>;
       static LdsAttrOnce pattr;
       RP_HIP(pattr.ensure((const void*)pk, PERSIST_LDS_BYTES));
-      hipLaunchKernelGGL(pk, dim3(slots), dim3(C::THREADS), PERSIST_LDS_BYTES, stream, w, a, K, tiles_f, tiles_t, group, t_dev, epi);
+      hipLaunchKernelGGL(pk, dim3(slots), dim3(C::THREADS), PERSIST_LDS_BYTES, stream, w, a, K, tiles_f, tiles_t, group,
+                         g_gemm_edge_layout, t_dev, epi);
       RP_CHECK_LAUNCH();
       return RP_OK;
     }
@@ -819,6 +914,7 @@ inline bool small_variant(int v) { return v == 0 || (v >= 15 && v <= 17); }
 // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages[, pipelined]>:
 //   20 / 26  pipelined 256 x 256 x 64, 4 / 8 waves     (the encoder's big GEMMs)
 //   27 / 28  (RP_EXPERIMENTS builds) pipelined 256 x 128 x 32 / 128 x 256 x 32 (features x tokens), 3 stages, 4 waves, TWO workgroups per CU
+//   30       pipelined 256 x 128 x 64, 8 waves          (the FFN-out projection's tail round: half tiles, one per CU)
 //   9        plain 256 x 256 x 32, 3 stages             (K % 64 != 0)
 //   0        plain 128 x 128 x 32, 3 stages, 2 blocks/CU (attention-out; token counts not a multiple of 256)
 //   17       64 x 128 x 64, 4 stages, pipelined loop    (up to ~1024 tokens: single-state queries)
@@ -836,6 +932,7 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
       case 20: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
       case 26: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
       case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
+      case 30: return launch_gemm_cfg<GemmCfg<256, 128, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
 #ifdef RP_EXPERIMENTS  // round 5, measured and rejected (profiles/r05_epilogue_overlap.md): FFN-in / FFN-out +17 % time; 29 = two
       // pipelined 128 x 128 x 64 workgroups per CU for the attention-out projection: 2.46 vs 2.29 ms per step
       case 29: return launch_gemm_cfg<GemmCfg<128, 128, 64, 2, 2, 2, 1, 0, 0, 0, 2>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);

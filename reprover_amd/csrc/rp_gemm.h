@@ -91,6 +91,14 @@ struct GemmCfg {
   __device__ static __forceinline__ int off(int row, int kc) { return row * ROW_BYTES + ((kc ^ swz(row)) << 4); }
 };
 
+// A wave grid WM x WN with FM x FN accumulator fragments per wave that covers only the first WM * FM * 32 rows of the
+// block tile's M side: for the last tile of an M extent that ends inside it (1152 = 4.5 tiles, 1472 = 5.75 tiles of 256)
+// the rows beyond are never multiplied instead of multiplied and thrown away.
+template <int WM_, int WN_, int FM_, int FN_>
+struct WaveLayout {
+  static constexpr int WM = WM_, WN = WN_, FM = FM_, FN = FN_;
+};
+
 // Per-wave LDS staging area the epilogues may use after the main loop (the ring is dead by then) to
 // turn the accumulator layout (lane = column) into row-contiguous 16-B-per-lane global accesses:
 // up to 64 rows of 128 B + 16 B pad.
@@ -277,12 +285,16 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
 // software-pipelined by hand: the fragments of k-step s+1 are read while the MFMAs of k-step s
 // issue, and the tile hand-over (counted wait, barrier, next DMA issue, first fragment read of the
 // next tile) sits in front of the last k-step's MFMAs.
-template <class C, class Epilogue>
+// L: how the waves split the block tile (WaveLayout below; default: the configuration's own WM x WN grid).  The LDS
+// image, the DMA split and the k loop do not depend on it, and every output element is the same K-ascending chain of
+// MFMA steps under every layout.
+template <class C, class Epilogue, class L = C>
 __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOperand W, int K, int tile_m,
                                                int tile_n, Epilogue& epi, char* smem) {
+  static_assert(L::WM * L::WN == C::NWAVES && L::WM * L::FM * 32 <= C::BM && L::WN * L::FN * 32 <= C::BN, "wave layout");
   // bf16: one MFMA k-step = 16 values = two 16-B slots of a row (one per lane half); e4m3: one k-step =
   // 64 values = four slots (two per lane half), so a 128-B row holds 4 bf16 or 2 e4m3 k-steps.
-  constexpr int BK = C::BK, FM = C::FM, FN = C::FN, KS = C::FP8 ? C::ROW_BYTES / 64 : BK / 16;
+  constexpr int BK = C::BK, FM = L::FM, FN = L::FN, KS = C::FP8 ? C::ROW_BYTES / 64 : BK / 16;
   constexpr int RPF = C::FP8 ? 2 : 1;  // ds_read_b128 per fragment
   using frag_t = std::conditional_t<C::FP8 != 0, i32x8, bf16x8>;
   RP_TS(0);
@@ -290,7 +302,7 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_row = wave / C::WN, wave_col = wave % C::WN;
+  const int wave_row = wave / L::WN, wave_col = wave % L::WN;
   const int hi = lane >> 5;
 
   f32x16 acc[FM][FN];
@@ -549,17 +561,16 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
 // the first counted wait leaves only the youngest DPS operations outstanding, as in the one-tile form.
 // Every output element is the same K-ascending chain of MFMA steps: not a bit differs from gemm_tile_pipe.
 constexpr int PERSIST_EPI_OFF = 64 * 1024, PERSIST_META_OFF = 136 * 1024, PERSIST_LDS_BYTES = 160 * 1024;
-template <class C, class Epilogue, class NextTile>
+template <class C, bool EDGE = false, class Epilogue, class NextTile>
 __device__ __forceinline__ void gemm_tiles_persist(const GemmOperand A, const GemmOperand W, int K, NextTile next_tile,
-                                                   Epilogue& epi, char* smem) {
+                                                   Epilogue& epi, char* smem, bool edge_on = false) {
   static_assert(C::PIPE != 0 && C::FP8 == 0 && C::KTAIL == 0 && C::NSTAGE == 2 && C::STAGE_BYTES == 64 * 1024 &&
                     C::NWAVES * EPI_STAGE_BYTES <= PERSIST_META_OFF - PERSIST_EPI_OFF,
                 "persistent form: the pipelined 256 x 256 x 64 bf16 tile");
-  constexpr int BK = C::BK, FM = C::FM, FN = C::FN, KS = BK / 16, NSTAGE = 2, DPS = C::A_DMA + C::W_DMA;
+  constexpr int BK = C::BK, KS = BK / 16, NSTAGE = 2, DPS = C::A_DMA + C::W_DMA;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_row = wave / C::WN, wave_col = wave % C::WN;
   const int hi = lane >> 5;
   int tile_m, tile_n;
   if (!next_tile(tile_m, tile_n)) return;
@@ -599,86 +610,9 @@ __device__ __forceinline__ void gemm_tiles_persist(const GemmOperand A, const Ge
     stage_half(kt, buf, 0);
     stage_half(kt, buf, 1);
   };
-  int a_off[FM][KS], b_off[FN][KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const int slot = ks * 2 + hi;
-#pragma unroll
-    for (int f = 0; f < FM; ++f) a_off[f][ks] = C::off(wave_row * (FM * 32) + f * 32 + (lane & 31), slot);
-#pragma unroll
-    for (int f = 0; f < FN; ++f) b_off[f][ks] = C::A_BYTES + C::off(wave_col * (FN * 32) + f * 32 + (lane & 31), slot);
-  }
-  f32x16 acc[FM][FN];
-  bf16x8 af[2][FM], bfr[2][FN];
-  auto read_frags = [&](const char* st, int ks, int p) {
-#pragma unroll
-    for (int f = 0; f < FM; ++f) af[p][f] = *reinterpret_cast<const bf16x8*>(st + a_off[f][ks]);
-#pragma unroll
-    for (int f = 0; f < FN; ++f) bfr[p][f] = *reinterpret_cast<const bf16x8*>(st + b_off[f][ks]);
-  };
-  auto mma = [&](int p) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[p][i], bfr[p][j], acc[i][j], 0, 0, 0);
-  };
-  auto hint_order = [](auto nread_tag, auto ndma_tag) {
-    constexpr int NREAD = decltype(nread_tag)::value, NDMA = decltype(ndma_tag)::value, NM = FM * FN;
-    constexpr int PER = (NREAD + NDMA + NM - 1) / NM;
-    int rd = NREAD, dm = NDMA;
-#pragma unroll
-    for (int n = 0; n < NM; ++n) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-#pragma unroll
-      for (int q = 0; q < PER; ++q) {
-        if (rd > 0) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-          --rd;
-        } else if (dm > 0) {
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (LDS-DMA)
-          --dm;
-        }
-      }
-    }
-  };
-  using NoDma = std::integral_constant<int, 0>;
-  using Reads = std::integral_constant<int, FM + FN>;
-  int buf = 0;
-  auto tile_body = [&](int kt, auto mode_tag, auto pend_tag) {  // as in gemm_tile_pipe
-    constexpr int MODE = decltype(mode_tag)::value;
-    constexpr bool PEND = decltype(pend_tag)::value != 0;
-    const char* st = smem + buf * C::STAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < KS - 1; ++ks) {
-      read_frags(st, ks + 1, (ks + 1) & 1);
-      if (PEND && ks == 0) stage_half(kt - 1 + NSTAGE, buf == 0 ? NSTAGE - 1 : buf - 1, 1);
-      mma(ks & 1);
-      if (PEND && ks == 0)
-        hint_order(Reads(), std::integral_constant<int, C::W_DMA>());
-      else
-        hint_order(Reads(), NoDma());
-    }
-    if (MODE >= 1) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      wait_vmcnt<0>();  // (NSTAGE - 2) * DPS = 0: this wave's share of tile kt+1 has landed
-      __builtin_amdgcn_s_barrier();
-      const int freed = buf;
-      if (++buf == NSTAGE) buf = 0;
-      read_frags(smem + buf * C::STAGE_BYTES, 0, 0);
-      if (MODE == 2) stage_half(kt + NSTAGE, freed, 0);
-    }
-    mma((KS - 1) & 1);
-    if (MODE == 2)
-      hint_order(Reads(), std::integral_constant<int, C::A_DMA>());
-    else if (MODE == 1)
-      hint_order(Reads(), NoDma());
-  };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
-
-  set_src(tile_m, tile_n);
-  stage(0, 0);  // the workgroup's first tile: both slots requested here; later tiles find slot 0 requested already
 #ifdef RP_PHASE_PROBE  // per workgroup SUMS over its tiles: [prologue, main loop, epilogue + end barrier, tiles] (100 MHz ticks)
   unsigned long long p_t0 = 0, p_t1 = 0, p_t2 = 0;
 #define RP_PTS(v) v = wall_clock64()
@@ -687,7 +621,80 @@ __device__ __forceinline__ void gemm_tiles_persist(const GemmOperand A, const Ge
   do {            \
   } while (0)
 #endif
-  for (;;) {
+
+  // One tile under wave layout L (WaveLayout; the configuration's own grid by default) up to and including its epilogue;
+  // returns whether the workgroup has another tile (whose first k-tile is then on its way into ring slot 0).
+  auto do_tile = [&](auto layout_tag, const auto& a_off, const auto& b_off) -> bool {
+    using L = decltype(layout_tag);
+    static_assert(L::WM * L::WN == C::NWAVES && L::WM * L::FM * 32 <= C::BM && L::WN * L::FN * 32 <= C::BN, "wave layout");
+    constexpr int FM = L::FM, FN = L::FN;
+    const int wave_row = wave / L::WN, wave_col = wave % L::WN;
+    f32x16 acc[FM][FN];
+    bf16x8 af[2][FM], bfr[2][FN];
+    auto read_frags = [&](const char* st, int ks, int p) {
+#pragma unroll
+      for (int f = 0; f < FM; ++f) af[p][f] = *reinterpret_cast<const bf16x8*>(st + a_off[f][ks]);
+#pragma unroll
+      for (int f = 0; f < FN; ++f) bfr[p][f] = *reinterpret_cast<const bf16x8*>(st + b_off[f][ks]);
+    };
+    auto mma = [&](int p) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[p][i], bfr[p][j], acc[i][j], 0, 0, 0);
+    };
+    auto hint_order = [](auto nread_tag, auto ndma_tag) {
+      constexpr int NREAD = decltype(nread_tag)::value, NDMA = decltype(ndma_tag)::value, NM = FM * FN;
+      constexpr int PER = (NREAD + NDMA + NM - 1) / NM;
+      int rd = NREAD, dm = NDMA;
+#pragma unroll
+      for (int n = 0; n < NM; ++n) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+          if (rd > 0) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+            --rd;
+          } else if (dm > 0) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (LDS-DMA)
+            --dm;
+          }
+        }
+      }
+    };
+    using NoDma = std::integral_constant<int, 0>;
+    using Reads = std::integral_constant<int, FM + FN>;
+    int buf = 0;
+    auto tile_body = [&](int kt, auto mode_tag, auto pend_tag) {  // as in gemm_tile_pipe
+      constexpr int MODE = decltype(mode_tag)::value;
+      constexpr bool PEND = decltype(pend_tag)::value != 0;
+      const char* st = smem + buf * C::STAGE_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < KS - 1; ++ks) {
+        read_frags(st, ks + 1, (ks + 1) & 1);
+        if (PEND && ks == 0) stage_half(kt - 1 + NSTAGE, buf == 0 ? NSTAGE - 1 : buf - 1, 1);
+        mma(ks & 1);
+        if (PEND && ks == 0)
+          hint_order(Reads(), std::integral_constant<int, C::W_DMA>());
+        else
+          hint_order(Reads(), NoDma());
+      }
+      if (MODE >= 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_vmcnt<0>();  // (NSTAGE - 2) * DPS = 0: this wave's share of tile kt+1 has landed
+        __builtin_amdgcn_s_barrier();
+        const int freed = buf;
+        if (++buf == NSTAGE) buf = 0;
+        read_frags(smem + buf * C::STAGE_BYTES, 0, 0);
+        if (MODE == 2) stage_half(kt + NSTAGE, freed, 0);
+      }
+      mma((KS - 1) & 1);
+      if (MODE == 2)
+        hint_order(Reads(), std::integral_constant<int, C::A_DMA>());
+      else if (MODE == 1)
+        hint_order(Reads(), NoDma());
+    };
+
     RP_PTS(p_t0);
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -699,7 +706,6 @@ __device__ __forceinline__ void gemm_tiles_persist(const GemmOperand A, const Ge
     stage(1, 1);
     wait_vmcnt<DPS>();  // everything older than slot 1's requests: slot 0 (and the last epilogue's stores, the metadata)
     __builtin_amdgcn_s_barrier();
-    buf = 0;
     RP_PTS(p_t1);
     read_frags(smem, 0, 0);
     int kt = 0;
@@ -728,6 +734,51 @@ __device__ __forceinline__ void gemm_tiles_persist(const GemmOperand A, const Ge
       __builtin_amdgcn_s_barrier();  // the reduced metadata is visible to every wave (raw: the requests above stay in flight)
     }
     epi.template run<FM, FN>(acc, em, en, lane, smem + PERSIST_EPI_OFF + wave * EPI_STAGE_BYTES);
+    return more;
+  };
+
+  // LDS offsets of a wave's fragments under layout L
+  auto fill_offs = [&](auto layout_tag, auto& a_off, auto& b_off, int ln) {
+    using L = decltype(layout_tag);
+    const int wave_row = wave / L::WN, wave_col = wave % L::WN;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int slot = ks * 2 + (ln >> 5);
+#pragma unroll
+      for (int f = 0; f < L::FM; ++f) a_off[f][ks] = C::off(wave_row * (L::FM * 32) + f * 32 + (ln & 31), slot);
+#pragma unroll
+      for (int f = 0; f < L::FN; ++f) b_off[f][ks] = C::A_BYTES + C::off(wave_col * (L::FN * 32) + f * 32 + (ln & 31), slot);
+    }
+  };
+  // an edge tile computes its table when it comes up (a few dozen VALU operations; the empty asm keeps the compiler from
+  // hoisting all three tables out of the tile loop, where they would be live across it and spill)
+  auto edge_tile = [&](auto layout_tag) -> bool {
+    using L = decltype(layout_tag);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    int a_off[L::FM][KS], b_off[L::FN][KS];
+    fill_offs(layout_tag, a_off, b_off, ln);
+    return do_tile(layout_tag, a_off, b_off);
+  };
+  int a_off0[C::FM][KS], b_off0[C::FN][KS];
+  fill_offs(C(), a_off0, b_off0, lane);
+
+  set_src(tile_m, tile_n);
+  stage(0, 0);  // the workgroup's first tile: both slots requested here; later tiles find slot 0 requested already
+  for (;;) {
+    bool more;
+    if constexpr (EDGE) {
+      // the last feature tile of an extent that ends inside it: a wave grid over the valid features only (WaveLayout)
+      const int vf = __builtin_amdgcn_readfirstlane(A.rows - tile_m * C::BM);
+      if (edge_on && vf <= 128)
+        more = edge_tile(WaveLayout<2, 4, 2, 2>());
+      else if (edge_on && vf <= 192)
+        more = edge_tile(WaveLayout<1, 8, 6, 1>());
+      else
+        more = do_tile(C(), a_off0, b_off0);
+    } else {
+      more = do_tile(C(), a_off0, b_off0);
+    }
 #ifdef RP_PHASE_PROBE
     if (more) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -151,8 +151,11 @@ def test_big_pass_launch_forms_are_the_same_bits(small):
     rowscale launch per sub-layer (the default since round 5) or reduced inside the consuming GEMM (slot rows DMA'd into LDS
     behind the operand ring, one thread per token summing them in index order: RowScaleLds), each with one workgroup per
     tile or with persistent workgroups (gemm_tiles_persist: one per CU, the next tile's first k-tile requested under the
-    epilogue).  The same sums in the same order, the same K-ascending MFMA chain per output element: the embeddings of a
-    70 k-token pass (more tiles than CUs in every projection) must not differ by a bit between any two of them."""
+    epilogue).  Round 5 added, on both forms: the last feature tile of 1152 / 1472 features on a wave grid over its valid
+    features only (`gemm_edge_layout`), the FFN-out / attention-out projections' half tiles inside the main launch
+    (`gemm_mixed`: gemm_kernel_mixed) or as a tail round of half / quarter tiles (`gemm_tail_variant` 30 / 0).  The same sums
+    in the same order, the same K-ascending MFMA chain per output element: the embeddings of a 70 k-token pass (more
+    tiles than CUs in every projection) must not differ by a bit between any two of them."""
     from reprover_amd import _lib
 
     lib = _lib.load()
@@ -163,16 +166,21 @@ def test_big_pass_launch_forms_are_the_same_bits(small):
     assert int(cu[-1]) > 65536  # 274 token tiles x >= 5 feature tiles: several tiles per persistent workgroup
     outs = []
     try:
-        for rs_lds, persist in ((0, 9), (0, 0), (1, 0), (1, 29), (0, 29)):
-            _lib.check(lib.rp_set_option(b"gemm_rs_lds", rs_lds), "opt")
-            _lib.check(lib.rp_set_option(b"gemm_persist", persist), "opt")
+        #                rs_lds persist edge mixed tail
+        for forms in ((0, 9, 1, 20, 30),   # the defaults
+                      (0, 0, 0, 0, 0),     # round 4's launches: one workgroup per tile, every tile on the full wave grid, quarter-tile tail
+                      (1, 0, 1, 0, 30), (1, 29, 0, 0, 30), (0, 29, 1, 0, 0),
+                      (0, 0, 1, 21, 30),   # QKV, attention-out and FFN-out as mixed launches
+                      (0, 9, 1, 0, 30)):
+            for name, v in zip((b"gemm_rs_lds", b"gemm_persist", b"gemm_edge_layout", b"gemm_mixed", b"gemm_tail_variant"), forms):
+                _lib.check(lib.rp_set_option(name, v), "opt")
             out = torch.empty((len(texts), small.embedding_size), dtype=torch.float32, device="cuda:0")
             small.encoder.encode_packed(ids, cu, out)
             torch.cuda.synchronize()
             outs.append(out)
     finally:
-        _lib.check(lib.rp_set_option(b"gemm_rs_lds", 0), "opt")
-        _lib.check(lib.rp_set_option(b"gemm_persist", 9), "opt")
+        for name, v in ((b"gemm_rs_lds", 0), (b"gemm_persist", 9), (b"gemm_edge_layout", 1), (b"gemm_mixed", 20), (b"gemm_tail_variant", 30)):
+            _lib.check(lib.rp_set_option(name, v), "opt")
     for o in outs[1:]:
         assert torch.equal(outs[0].view(torch.int32), o.view(torch.int32))
     assert torch.isfinite(outs[0]).all() and (outs[0].norm(dim=1) - 1).abs().max().item() < 1e-5
