@@ -1141,10 +1141,14 @@ static __global__ __launch_bounds__(256, DROP ? 2 : 4) void attention_kernel(con
     if (!active) continue;
     const char* sb = smem + (kt & 1) * AT2_STAGE;
     const int k0 = kt * ATT_KV;
+    // the tile's second 32-key block lies wholly beyond the sequence (its last tile, len % 64 in 1..32): every score of it
+    // would be masked to -inf, p = 0 - the block is not multiplied, not exponentiated, not summed (+0 everywhere: same bits)
+    const bool two = k0 + 32 < len;  // (wave-uniform)
     // ---- S^T = K Q^T
     f32x16 s[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      if (kb == 1 && !two) break;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
@@ -1158,6 +1162,7 @@ static __global__ __launch_bounds__(256, DROP ? 2 : 4) void attention_kernel(con
     //   the table index is base + compile-time offset, no clamp, no mask), general.
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      if (kb == 1 && !two) break;
       const int c0 = k0 + kb * 32;
       const bool all_real = (c0 + 32 <= len);
       if (c0 - (wq0 + 31) >= maxd && all_real) {
@@ -1172,6 +1177,17 @@ static __global__ __launch_bounds__(256, DROP ? 2 : 4) void attention_kernel(con
         const float* tp = tab + (c0 - qi + maxd + TAB_PAD + 4 * hi);
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kb][r] += tp[(r & 3) + 8 * (r >> 2)];
+      } else if (c0 - (wq0 + 31) >= maxd) {  // the sequence's last block, saturated: one constant + the key mask
+        const float bb = tab[2 * maxd + TAB_PAD];
+        const int jn = len - c0 - 4 * hi;  // keys (r & 3) + 8 (r >> 2) < jn are real
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = ((r & 3) + 8 * (r >> 2) < jn) ? s[kb][r] + bb : -INFINITY;
+      } else if (c0 + 31 - wq0 >= -maxd - 2) {  // ... every offset >= -maxd - 64, inside the padded table (always so here: a block with
+                                                // masked keys ends beyond len > wq0): unclamped index + the key mask
+        const float* tp = tab + (c0 - qi + maxd + TAB_PAD + 4 * hi);
+        const int jn = len - c0 - 4 * hi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = ((r & 3) + 8 * (r >> 2) < jn) ? s[kb][r] + tp[(r & 3) + 8 * (r >> 2)] : -INFINITY;
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1184,22 +1200,26 @@ static __global__ __launch_bounds__(256, DROP ? 2 : 4) void attention_kernel(con
     // ---- online softmax in the exp2 domain: p = 2^((s - m) * log2 e)
     float mx = s[0][0];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+    if (two) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
     const float LOG2E = 1.4426950408889634f;
     const float mneg = -m_new * LOG2E;
     float psum = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < 2; ++kb) {
+      if (kb == 1 && !two) break;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], LOG2E, mneg));
         s[kb][r] = p;
         psum += p;
       }
+    }
     if (__any(m_new != m_run)) {  // rescale only when some row's running max moved (exact: alpha = 1 otherwise)
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);  // m_run = -inf first -> 0
       l_run *= alpha;
@@ -1215,13 +1235,14 @@ static __global__ __launch_bounds__(256, DROP ? 2 : 4) void attention_kernel(con
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
+          for (int r = 0; r < 16 && (kb == 0 || two); ++r)
             s[kb][r] *= drop_mul(drop, drop_site, (uint32_t)(s0 + qi), ((uint32_t)h << 20) | (uint32_t)(k0 + kb * 32 + mfma32_row(r, hi)));
       }
     }
     // ---- O^T += V^T P^T over four 16-key slabs
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) {
+      if (sl == 2 && !two) break;
       const int kb = sl >> 1, sub = sl & 1;
       bf16x8 pf;
       {

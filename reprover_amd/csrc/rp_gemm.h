@@ -571,7 +571,6 @@ __device__ __forceinline__ void gemm_tiles_persist(const GemmOperand A, const Ge
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5;
   int tile_m, tile_n;
   if (!next_tile(tile_m, tile_n)) return;
 

@@ -54,7 +54,7 @@ typedef GemmCfg<128, 64, 64, 2, 2, 3> SimCfgSampleK64;
 typedef GemmCfg<256, 128, 64, 4, 2, 2, 1> SimCfgSampleBig;
 // default: the premise stream (read once, by one CU) carries the nt cache policy: -7 % filter time
 typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 0, 2> SimCfgFilterNt;
-constexpr int SIM_FILTER_META_BYTES = 3072;  // per-tile metadata behind the ring (EpiSimFilter::prologue)
+constexpr int SIM_FILTER_META_BYTES = 5120;  // per-tile metadata behind the ring (EpiSimFilter::prologue)
 int g_scan_cfg = 0;   // 0: auto; 1: force 128-query tiles in the dense path
 int g_scan_impl = 0;  // 0: auto (pipelined filter kernel when the shape allows); 1: first-generation filter kernel
 int g_scan_impl_force_new = 0;  // experiments: second-generation filter for every batch size
@@ -249,12 +249,19 @@ __global__ __launch_bounds__(C::THREADS) void sim_scan_kernel(GemmOperand Qop, G
 constexpr int SLOT_RUN = 64;                         // slots per (query, tile, part) = scores per lane and column fragment
 constexpr int SLOTS_PER_TILE = 256 * 4 * SLOT_RUN;   // uint2 entries per workgroup tile (512 KB)
 
-template <int FP8>
+// PAGED (rp_sim_topk_after): the page's upper bound joins the float pre-test - score <= after_score[q] (ties go on to the exact
+// key test in gather_select_kernel) - so the rows already returned on earlier pages never enter the runs (without it every
+// page re-admitted them: ~1024 more entries per query and page for the one-at-a-time path behind the raw list), and an
+// exhausted query (bound (-inf, INT_MAX)) admits nothing instead of every row of the index.  A separate instantiation:
+// the first page's kernel carries no second compare.
+template <int FP8, bool PAGED = false>
 struct EpiSimFilter {
   int N, B;
   const float* q_scale;  // FP8: score = (acc * q_scale[query]) * e_scale[premise]
   const float* e_scale;
   const float* tau;      // [B] score of the sampled k-th key (-inf when the sample held fewer than k)
+  const float* after_score = nullptr;  // PAGED: [B] the paging bound, as EpiSim
+  const int32_t* after_id = nullptr;
   uint2* slots;          // [workgroup tiles][256][4][64]
   int32_t* scnt;         // [tiles_q * 256][filter_blocks][4]
   int filter_blocks;
@@ -265,7 +272,7 @@ struct EpiSimFilter {
   int wg_tile, fb;
   int debug_drop_all;
 
-  static constexpr int M_TAU = 0, M_QS = 1024, M_ES = 2048;  // metadata layout (bytes from meta_off)
+  static constexpr int M_TAU = 0, M_QS = 1024, M_ES = 2048, M_AS = 3072, M_AI = 4096;  // metadata layout (bytes from meta_off)
 
   __device__ __forceinline__ void prologue(char* meta, int wave, int lane, int /*n0*/) {
     auto dma4 = [&](const void* g, char* dst) {
@@ -277,6 +284,10 @@ struct EpiSimFilter {
     if constexpr (FP8 != 0) {
       dma4(q_scale + q, meta + M_QS + wave * 256);
       dma4(e_scale + p, meta + M_ES + wave * 256);
+    }
+    if constexpr (PAGED) {
+      dma4(after_score + q, meta + M_AS + wave * 256);
+      dma4(after_id + q, meta + M_AI + wave * 256);
     }
   }
 
@@ -291,13 +302,18 @@ struct EpiSimFilter {
     const int pl0 = m_base - p0, ql0 = n_base - q0;  // this wave's first premise / query inside the tile
     const int part = (pl0 >> 7) * 2 + hi;
 
-    float tauv[FN], qsv[FN];
+    float tauv[FN], qsv[FN], upv[FN];
     uint2* run_ptr[FN];
     int n[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int ql = ql0 + j * 32 + cl;
       tauv[j] = (debug_drop_all & 1) ? INFINITY : s_tau[ql];
+      upv[j] = INFINITY;
+      if constexpr (PAGED) {  // (after_id < 0: no bound for this query)
+        const float as = reinterpret_cast<const float*>(meta + M_AS)[ql];
+        if (reinterpret_cast<const int*>(meta + M_AI)[ql] >= 0) upv[j] = as;
+      }
       qsv[j] = FP8 ? s_qs[ql] : 1.f;
       run_ptr[j] = slots + ((size_t)wg_tile * 256 + ql) * (4 * SLOT_RUN) + part;
       n[j] = 0;
@@ -318,7 +334,7 @@ struct EpiSimFilter {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float sc = FP8 ? (acc[i][j][r] * qsv[j]) * esv[r] : acc[i][j][r];
-          if (sc >= tauv[j]) {
+          if (sc >= tauv[j] && (!PAGED || sc <= upv[j])) {
             run_ptr[j][n[j]] = make_uint2(__float_as_uint(sc), (uint32_t)(i * 16 + r));
             n[j] += 4;  // entry stride: the four parts of a query interleave
           }
@@ -331,9 +347,9 @@ struct EpiSimFilter {
   }
 };
 
-template <class C>
+template <class C, bool PAGED>
 __global__ __launch_bounds__(C::THREADS) void sim_filter_kernel(GemmOperand Eop, GemmOperand Qop, int K, int tiles_q,
-                                                                int stride, EpiSimFilter<C::FP8> epi) {
+                                                                int stride, EpiSimFilter<C::FP8, PAGED> epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(C::BM == SIM_PB && C::BN == 256 && C::NWAVES == 4, "filter tile geometry");
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -1045,16 +1061,16 @@ static RpStatus launch_scan_cfg(GemmOperand q, GemmOperand e, int D2, int n_tile
   return RP_OK;
 }
 
-template <class C>
+template <class C, bool PAGED>
 static RpStatus launch_filter_cfg(GemmOperand e, GemmOperand q, int D2, int n_blocks, int stride,
-                                  const EpiSimFilter<C::FP8>& epi, hipStream_t stream) {
+                                  const EpiSimFilter<C::FP8, PAGED>& epi, hipStream_t stream) {
   if (n_blocks <= 0) return RP_OK;
   constexpr int LDS = C::RING_BYTES + SIM_FILTER_META_BYTES;
   static LdsAttrOnce attr;
-  RP_HIP(attr.ensure((const void*)sim_filter_kernel<C>, LDS));
+  RP_HIP(attr.ensure((const void*)sim_filter_kernel<C, PAGED>, LDS));
   const int tiles_q = (epi.B + C::BN - 1) / C::BN;
   ProfScope ps(stream, RP_K_SCAN);
-  hipLaunchKernelGGL((sim_filter_kernel<C>), dim3(tiles_q * n_blocks), dim3(C::THREADS), LDS, stream, e, q, D2, tiles_q,
+  hipLaunchKernelGGL((sim_filter_kernel<C, PAGED>), dim3(tiles_q * n_blocks), dim3(C::THREADS), LDS, stream, e, q, D2, tiles_q,
                      stride, epi);
   RP_CHECK_LAUNCH();
   return RP_OK;
@@ -1202,22 +1218,35 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
       ef.p0 = ef.q0 = ef.wg_tile = ef.fb = 0;
       ef.debug_drop_all = g_scan_no_epilogue;
     };
-    if (fp8) {
+    if (fp8 && after_id) {  // a later page: the bound joins the pre-test (EpiSimFilter<., PAGED>)
+      EpiSimFilter<1, true> ef;
+      fill(ef);
+      ef.after_score = after_score;
+      ef.after_id = after_id;
+      st = (D2 % 64 == 0) ? launch_filter_cfg<SimCfg8Filter, true>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
+                          : launch_filter_cfg<SimCfg8FilterTail, true>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+    } else if (fp8) {
       EpiSimFilter<1> ef;
       fill(ef);
-      st = (D2 % 64 == 0) ? launch_filter_cfg<SimCfg8Filter>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
-                          : launch_filter_cfg<SimCfg8FilterTail>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+      st = (D2 % 64 == 0) ? launch_filter_cfg<SimCfg8Filter, false>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
+                          : launch_filter_cfg<SimCfg8FilterTail, false>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+    } else if (after_id) {
+      EpiSimFilter<0, true> ef;
+      fill(ef);
+      ef.after_score = after_score;
+      ef.after_id = after_id;
+      st = launch_filter_cfg<SimCfgFilterNt, true>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
     } else {
       EpiSimFilter<0> ef;
       fill(ef);
 #ifdef RP_EXPERIMENTS  // alternatives measured and rejected: only a probe build (RP_EXPERIMENTS=1) carries them
       if (g_scan_filter_cfg == 1)
-        st = launch_filter_cfg<SimCfgFilterK32>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+        st = launch_filter_cfg<SimCfgFilterK32, false>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
       else if (g_scan_filter_cfg == 2)
-        st = launch_filter_cfg<SimCfgFilter>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+        st = launch_filter_cfg<SimCfgFilter, false>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
       else
 #endif
-        st = launch_filter_cfg<SimCfgFilterNt>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+        st = launch_filter_cfg<SimCfgFilterNt, false>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
     }
   } else {
     epi.filter = 1;

@@ -371,6 +371,60 @@ def test_k_beyond_1024_is_served_in_pages(index_dtype):
 
 
 @pytest.mark.parametrize("index_dtype", ["bf16", "fp8"])
+def test_paging_with_queries_that_run_out_of_premises(index_dtype):
+    """Later pages when some queries are already exhausted (bound (-inf, INT_MAX): the second-generation filter's PAGED
+    pre-test `score <= after_score` admits none of their rows) and others come back with a short last page:
+    130 theorems spread over the corpus's files, from ones that see a few hundred premises to ones that see nearly all 20 k.
+    Every query's list is its whole masked ranking up to k, in (score desc, id asc) order; counts = min(k, accessible)."""
+    from reprover_amd.common import Fp8Index
+    from oracle import fp8_ref
+
+    files = synth.synth_corpus_records(60, 20000, seed=179, max_imports=10)
+    path = os.path.join(tempfile.mkdtemp(), "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    corpus = Corpus(path)
+    N, D, k, B = len(corpus), 1472, 2300, 130
+    rng = np.random.default_rng(180)
+    E = rng.standard_normal((N, D)).astype(np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    Qm = rng.standard_normal((B, D)).astype(np.float32)
+    Qm /= np.linalg.norm(Qm, axis=1, keepdims=True)
+    ctxs = [Context(files[(j * 7) % len(files)]["path"], f"t{j}", Pos(10_000, 0), f"h{j} ⊢ g") for j in range(B)]
+    acc = np.stack([corpus.accessible_mask(c.path, c.theorem_pos) for c in ctxs])
+    n_acc = acc.sum(1)
+    assert (n_acc < 1024).any() and ((n_acc > 1024) & (n_acc < k)).any() and (n_acc >= k).any(), sorted(n_acc.tolist())[::13]
+    Ed, Qd = torch.from_numpy(E).cuda(), torch.from_numpy(Qm).cuda()
+    if index_dtype == "bf16":
+        operand = Ed
+        S = (_bf16_round(Qm).astype(np.float64) @ _bf16_round(E).astype(np.float64).T).astype(np.float32)
+        tol = 1e-6
+    else:
+        operand = Fp8Index.quantize(Ed)
+        q8 = Fp8Index.quantize(Qd)
+        S = fp8_ref.scores_fp8(q8.codes.cpu().numpy(), q8.scale.cpu().numpy(), operand.codes.cpu().numpy(),
+                               operand.scale.cpu().numpy())
+        tol = 4e-6
+    ids, scores, counts = corpus.nearest_premise_ids(operand, ctxs, Qd, k)
+    ids, scores, counts = ids.cpu().numpy(), scores.cpu().numpy(), counts.cpu().numpy()
+    assert (counts == np.minimum(k, n_acc)).all()
+    want_i, want_s = [], []
+    for j in range(B):
+        n = int(counts[j])
+        row, sc = ids[j, :n].tolist(), scores[j, :n]
+        assert len(set(row)) == n and acc[j][row].all()
+        assert all(sc[i] > sc[i + 1] or (sc[i] == sc[i + 1] and row[i] < row[i + 1]) for i in range(n - 1)), j
+        cand = np.flatnonzero(acc[j])
+        order = cand[np.lexsort((cand, -S[j, cand]))][:n]
+        assert np.abs(sc - S[j, order]).max() < 1e-5
+        if n < k:  # an exhausted query returned EVERY accessible premise
+            assert set(row) == set(cand.tolist())
+        want_i.append(order.tolist())
+        want_s.append(S[j, order].tolist())
+    checked, bad = hh.gap_rule_ids([ids[j, : int(counts[j])].tolist() for j in range(B)], want_i, want_s, tol=tol)
+    assert bad == 0 and checked > 1000
+
+
+@pytest.mark.parametrize("index_dtype", ["bf16", "fp8"])
 @pytest.mark.parametrize("B", [6, 130])
 def test_paging_through_the_two_pass_plan(index_dtype, B):
     """k > 1024 on an index of more than 16,384 rows: every page runs the TWO-PASS plan (sample scan -> bound -> filter ->
