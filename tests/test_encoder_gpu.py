@@ -186,6 +186,40 @@ def test_big_pass_launch_forms_are_the_same_bits(small):
     assert torch.isfinite(outs[0]).all() and (outs[0].norm(dim=1) - 1).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("n_states", [132, 368])
+def test_mixed_and_edge_forms_at_other_pass_sizes(small, n_states):
+    """The mixed launch plans its half tiles from the token-tile count: 36 k tokens (142 token tiles: 128 whole-round tiles + 28 half
+    rows, 21 handed out first) and 103 k (402 = 384 + 18 token tiles) beside the 70 k-token pass of the test above.  Shipped
+    forms vs one workgroup per tile on the full wave grid with no half tiles: the same bits."""
+    from reprover_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(31 + n_states)
+    lens = synth.synth_lengths(rng, n_states, "mix", lo=16, hi=2048)
+    texts = [synth.synth_state(rng, int(n) - 1) for n in lens]
+    ids, cu = small.tokenizer.packed(texts, small.max_seq_len)
+    tiles = (int(cu[-1]) + 255) // 256
+    assert tiles > 128 and 0 < tiles % 128 <= 21, tiles  # (a remainder the mixed plan takes)
+    names = (b"gemm_persist", b"gemm_edge_layout", b"gemm_mixed", b"gemm_tail_split")
+    outs = []
+    old = small.encoder.max_tokens_per_pass
+    small.encoder.max_tokens_per_pass = 1 << 20  # one pass whatever the size
+    try:
+        for forms in ((9, 1, 20, 1), (0, 0, 0, 0)):
+            for name, v in zip(names, forms):
+                _lib.check(lib.rp_set_option(name, v), "opt")
+            out = torch.empty((len(texts), small.embedding_size), dtype=torch.float32, device="cuda:0")
+            small.encoder.encode_packed(ids, cu, out)
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        small.encoder.max_tokens_per_pass = old
+        for name, v in zip(names, (9, 1, 20, 1)):
+            _lib.check(lib.rp_set_option(name, v), "opt")
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    assert torch.isfinite(outs[0]).all() and (outs[0].norm(dim=1) - 1).abs().max().item() < 1e-5
+
+
 def test_padded_entry_point_at_big_tile_sizes_equals_packed(small):
     """rp_encode_padded with a token bound in big-tile territory (64 states padded to 2048 = 131 k rows bound, ~17 k live
     tokens): the grids are sized for the bound, the live tiles are re-numbered on the device (`t_dev`) - also inside the
