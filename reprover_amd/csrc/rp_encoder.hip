@@ -51,7 +51,7 @@ int g_pool_chunk = 64;      // tokens per workgroup of the pooling pass (32 / 64
 int g_gemm_edge_layout = 1;  // big tiles: the last feature tile of 1152 / 1472 features on a wave grid over its valid features only
 int g_gemm_mixed = 20;  // full and half tiles in ONE launch (gemm_kernel_mixed) per projection: 1 QKV, 4 attention-out, 16 FFN-out
 int g_gemm_tail_variant = 30;  // tile configuration of that tail round: 30 = 256 x 128 x 64 half tiles, 0 = 128 x 128 x 32 quarter tiles
-int g_gemm_tail_split = 1;  // big passes: last partial round of 256 x 256 tiles as one round of 128 x 128 tiles
+int g_gemm_tail_split = 1;  // big passes without a mixed launch: the last partial round of 256 x 256 tiles as one round of smaller tiles
 int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 int g_gemm_skinny = 1;
 int g_gemm_skinny_variant = 12;
@@ -416,10 +416,13 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
   const bool lds_qkv = !fused_rs && g_gemm_rs_lds && np <= 32 && big_variant(pick_gemm_variant(RP_K_GEMM_QKV, Tp, 3 * inner, D, tv));
   const bool lds_wi = !fused_rs && g_gemm_rs_lds && np <= 32 && big_variant(pick_gemm_variant(RP_K_GEMM_WI, Tp, 2 * F, D, tv));
   // Tail of the FFN-out launch.  1644 tiles of 256 x 256 on 256 CUs are 6.42 rounds: the seventh runs 108 tiles
-  // while 148 CUs idle (70 k tokens).  The token rows that make whole rounds go to the big tiles; the rest (18 token
-  // tiles here) runs as ONE round of 128 x 128 tiles, two workgroups per CU.  Same K-ascending chains per output
-  // element: not a bit changes.  Measured 9.28 -> 9.04 ms per step; the same split of the QKV projection (5.35
-  // rounds) gained nothing (3.11 -> 3.14 ms: its short K loop leaves the tail round cheap already).
+  // while 148 CUs idle (70 k tokens).  Since round 5 the projection runs as a MIXED launch (gemm_kernel_mixed, option
+  // gemm_mixed: the token rows beyond the whole rounds are half tiles inside the same launch) and main_rows() returns Tp.
+  // With that option off this is rounds 3 - 4's form: the token rows that make whole rounds go to the big tiles in
+  // one launch, the rest (18 token tiles here) runs as ONE more round - of 256 x 128 half tiles (gemm_tail_variant 30,
+  // one per CU) or 128 x 128 quarter tiles (0, two per CU).  Same K-ascending chains per output element: not a bit
+  // changes.  Measured 9.28 -> 9.04 ms per step in round 3; the same split of the QKV projection (5.35 rounds) gained
+  // nothing (3.11 -> 3.14 ms: its short K loop leaves the tail round cheap already).
   int n_cus = 256;
   {
     int dev = 0, v = 0;  // an attribute query, not the (slow) property struct: this runs once per pass

@@ -15,7 +15,11 @@
 // Two main loops:
 //   gemm_tile       the plain loop (compiler-scheduled): small tiles with several blocks per CU, the
 //                   few-token configurations, the similarity scan (bf16 or e4m3 operands);
-//   gemm_tile_pipe  the hand-software-pipelined loop of the encoder's big GEMMs (GemmCfg<..., PIPE=1>).
+//   gemm_tile_pipe  the hand-software-pipelined loop of the encoder's big GEMMs (GemmCfg<..., PIPE=1>);
+//   gemm_tiles_persist  the same loop for ONE workgroup per CU walking a list of tiles (next tile's first k-tile
+//                   requested under the epilogue).
+// Both pipelined forms take a WaveLayout: how the waves split the block tile.  The last tile of an M extent that ends
+// inside it runs on a wave grid over its valid rows only (the LDS image, the DMA split and the k loop do not change).
 //
 // The epilogue is a functor so the same core serves the encoder GEMMs (bf16 store, fp32
 // residual add, gated-GELU) and the similarity scan (accessibility mask + top-k filter).
