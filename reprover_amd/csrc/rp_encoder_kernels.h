@@ -418,6 +418,8 @@ struct EpiStoreBf16T {  // out[token, feature] = bf16(acc * rs[token])
 template <bool SPLIT_IN, bool LO8 = false>
 struct EpiResidT {  // x[token, feature] += acc on the two planes of the residual stream (+ ssp partials)
   static constexpr bool any_layout = true;
+  // (no main_layout: the 2 x 4 wave grid that pays for the gated-GELU store was measured here too - QKV's store epilogue: no
+  // difference, it writes whole lines already; this one: attention-out +3 %, FFN-out +2 % - round 5, exp30)
   bf16_t* __restrict__ xhi;  // bf16(x): also the next projection's A operand
   bf16_t* __restrict__ xlo;  // bf16(x - hi); LO8: the int8 extension plane of the 24-bit form (one byte per element)
   int ldx, n_valid;          // n_valid % 8 == 0
@@ -542,6 +544,10 @@ typedef EpiResidT<false, true> EpiResid8;   // bf16 plane + int8 extension plane
 
 template <class RS>
 struct EpiGegluBf16T {  // W rows interleaved 32 gate / 32 up: even row-fragments gate, odd up
+  // full tiles of the 8-wave 256 x 256 configuration run as 2 x 4 waves of 128 features x 64 tokens: a wave's 64 outputs per
+  // token are ONE 128-byte line of ff.  On the configuration's own 4 x 2 grid (64 x 128 per wave) two waves wrote the two
+  // halves of every line: FFN-in 14.99 - 15.10 -> 14.81 ms per step (round 5, exp30).  Same MFMA chain per element.
+  using main_layout = WaveLayout<2, 4, 4, 2>;
   bf16_t* out;         // [tokens, n_valid/2]
   int ldo, n_valid;    // n_valid counts interleaved rows (= 2 * d_ff)
   RS rs;
@@ -635,6 +641,15 @@ template <class E, class = void>
 struct epi_any_layout : std::false_type {};
 template <class E>
 struct epi_any_layout<E, std::void_t<decltype(E::any_layout)>> : std::true_type {};
+// an epilogue may name the wave grid it wants for FULL tiles of the 8-wave 256 x 256 configuration (`main_layout`)
+template <class E, class C, class = void>
+struct epi_main_layout {
+  using type = C;
+};
+template <class E, class C>
+struct epi_main_layout<E, C, std::void_t<typename E::main_layout>> {
+  using type = std::conditional_t<C::BM == 256 && C::BN == 256 && C::NWAVES == 8, typename E::main_layout, C>;
+};
 template <class C, class Epi>
 __host__ __device__ constexpr bool edge_layouts() {
   return C::PIPE != 0 && C::FP8 == 0 && C::BM == 256 && C::BN == 256 && C::NWAVES == 8 && C::OCC == 0 && epi_any_layout<Epi>::value;
@@ -655,7 +670,7 @@ __device__ __forceinline__ void pipe_tile_edge(const GemmOperand& A, const GemmO
       return;
     }
   }
-  gemm_tile_pipe<C>(A, W, K, tm, tn, epi, smem);
+  gemm_tile_pipe<C, Epi, typename epi_main_layout<Epi, C>::type>(A, W, K, tm, tn, epi, smem);
 }
 
 template <class C, class Epi>
@@ -784,7 +799,8 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel_persist(GemmOperand A,
     i += per;
     return true;
   };
-  gemm_tiles_persist<C, edge_layouts<C, Epi>()>(A, W, K, next_tile, epi, smem, edge_on != 0);
+  // full tiles: the epilogue's preferred wave grid when it names one (main_layout), else the configuration's own
+  gemm_tiles_persist<C, edge_layouts<C, Epi>(), typename epi_main_layout<Epi, C>::type>(A, W, K, next_tile, epi, smem, edge_on != 0);
 }
 // an epilogue with metadata behind the ring (RowScaleLds) has 24 KiB for it in the persistent layout
 template <class Epi>

@@ -565,7 +565,7 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
 // the first counted wait leaves only the youngest DPS operations outstanding, as in the one-tile form.
 // Every output element is the same K-ascending chain of MFMA steps: not a bit differs from gemm_tile_pipe.
 constexpr int PERSIST_EPI_OFF = 64 * 1024, PERSIST_META_OFF = 136 * 1024, PERSIST_LDS_BYTES = 160 * 1024;
-template <class C, bool EDGE = false, class Epilogue, class NextTile>
+template <class C, bool EDGE = false, class L0 = C, class Epilogue, class NextTile>
 __device__ __forceinline__ void gemm_tiles_persist(const GemmOperand A, const GemmOperand W, int K, NextTile next_tile,
                                                    Epilogue& epi, char* smem, bool edge_on = false) {
   static_assert(C::PIPE != 0 && C::FP8 == 0 && C::KTAIL == 0 && C::NSTAGE == 2 && C::STAGE_BYTES == 64 * 1024 &&
@@ -763,8 +763,8 @@ __device__ __forceinline__ void gemm_tiles_persist(const GemmOperand A, const Ge
     fill_offs(layout_tag, a_off, b_off, ln);
     return do_tile(layout_tag, a_off, b_off);
   };
-  int a_off0[C::FM][KS], b_off0[C::FN][KS];
-  fill_offs(C(), a_off0, b_off0, lane);
+  int a_off0[L0::FM][KS], b_off0[L0::FN][KS];  // L0: the wave layout of a full tile (the configuration's own grid by default)
+  fill_offs(L0(), a_off0, b_off0, lane);
 
   set_src(tile_m, tile_n);
   stage(0, 0);  // the workgroup's first tile: both slots requested here; later tiles find slot 0 requested already
@@ -778,9 +778,9 @@ __device__ __forceinline__ void gemm_tiles_persist(const GemmOperand A, const Ge
       else if (edge_on && vf <= 192)
         more = edge_tile(WaveLayout<1, 8, 6, 1>());
       else
-        more = do_tile(C(), a_off0, b_off0);
+        more = do_tile(L0(), a_off0, b_off0);
     } else {
-      more = do_tile(C(), a_off0, b_off0);
+      more = do_tile(L0(), a_off0, b_off0);
     }
 #ifdef RP_PHASE_PROBE
     if (more) {
