@@ -43,7 +43,7 @@ enum {
 enum { RP_DT_F32 = 0, RP_DT_BF16 = 1 };
 
 /* ABI / build identification; bumps when a signature changes. */
-int32_t rp_abi_version(void);   /* 4 */
+int32_t rp_abi_version(void);   /* 6 */
 /* Message of the last error returned on this thread ("" if none). */
 const char* rp_last_error(void);
 

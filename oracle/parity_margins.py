@@ -2,13 +2,16 @@
 fixtures the reference + HuggingFace produced in fp32 (tests/golden/g5, g7, g9; made by tests/golden/make_golden.py),
 beside what HuggingFace's own bf16 mode - the reference's GPU numerics, retrieval/model.py:59-64 - reaches on the same
 inputs.  One place computes them; the `-m gpu` tests assert on the numbers and write them to
-profiles/r05_parity_margins.json (+ gpurun_out/), `__graft_entry__.smoke()` prints them.
+profiles/r06_parity_margins.json (+ gpurun_out/), `__graft_entry__.smoke()` prints them.
 
 The written contract: scores within 1e-2 absolute of the fp32 oracle, embeddings
-cosine >= 0.999, ids equal wherever the oracle's gap to both neighbours exceeds 2 x tol.  On these deliberately sharp
-synthetic weights HF-bf16 itself misses the first two, so the tests enforce a RELAXATION of the contract, labelled as such
-wherever parity is quoted: "no row further from fp32 than HF-bf16 is" + absolute floors (see the tests).  `contract_met`
-below says, per fixture, whether the written numbers hold as they stand."""
+cosine >= 0.999, ids equal wherever the oracle's gap to both neighbours exceeds 2 x tol, no worse than HF-bf16 on the same
+inputs.  Two fixture families (reprover_amd/synth.py::synth_state_dict):
+  * **G5h / G7h / G9h** - weights at exactly HF's init scales, the recipe SURVEY.md 8c gives for G5 and the one the
+    contract's numbers were derived on.  The GPU tests assert the contract on them AS WRITTEN (`assert_written_contract`).
+  * G5 / G7 / G9 - the deliberately sharp stress family (q 4x, position table 38x HF's scale), on which HF-bf16 itself
+    misses 0.999 / 1e-2; there the tests enforce "no further from fp32 than HF-bf16 on any metric" + absolute floors, and
+    `contract_met` records whether the written numbers happen to hold."""
 import json
 import os
 
@@ -48,21 +51,54 @@ def embedding_margins(emb: torch.Tensor, gold: torch.Tensor, hf_bf16: torch.Tens
     }
     d["contract_met"] = bool(d["min_row_cosine"] >= 0.999 and d["max_abs_pairwise_score_err"] <= 1e-2)
     d["hf_bf16_meets_contract"] = bool(d["hf_bf16_min_row_cosine"] >= 0.999 and d["hf_bf16_max_abs_pairwise_score_err"] <= 1e-2)
+    d["no_worse_than_hf_bf16"] = bool(d["rows_further_from_fp32_than_hf_bf16"] == 0
+                                      and d["max_abs_emb_err"] <= d["hf_bf16_max_abs_emb_err"]
+                                      and d["max_abs_pairwise_score_err"] <= d["hf_bf16_max_abs_pairwise_score_err"])
     return d
 
 
-def g5_margins(model, golden_dir) -> dict:
-    """`model`: PremiseRetriever of the synthetic ByT5-small (fp32 outputs).  Fixture G5: 16 texts, 8 ... 2048 bytes."""
-    g = np.load(os.path.join(golden_dir, "g5_byt5_small.npz"), allow_pickle=True)
+def assert_written_contract(m: dict) -> None:
+    """The floating-point contract of BASELINE.md section 2 / SURVEY.md 8c exactly as written - no max(.., HF) escape, no
+    lowered floor.  For embedding fixtures: every row's cosine >= 0.999, pairwise scores within 1e-2, and no metric worse
+    than HF-bf16's on the same inputs.  For predict fixtures: max |d score| <= 1e-2, zero mismatches under the id gap rule,
+    and the score error no larger than HF-bf16's."""
+    if "min_row_cosine" in m and "max_abs_pairwise_score_err" in m:
+        assert m["min_row_cosine"] >= 0.999, m
+        assert m["max_abs_pairwise_score_err"] <= 1e-2, m
+        assert m["rows_further_from_fp32_than_hf_bf16"] == 0, m
+        assert m["max_abs_emb_err"] <= m["hf_bf16_max_abs_emb_err"], m
+        assert m["max_abs_pairwise_score_err"] <= m["hf_bf16_max_abs_pairwise_score_err"], m
+    elif "min_row_cosine" in m:
+        assert m["min_row_cosine"] >= 0.999 and m["min_row_cosine"] >= m["hf_bf16_min_row_cosine"], m
+    else:
+        assert m["max_abs_score_err"] <= 1e-2 and m["gap_rule_mismatches"] == 0, m
+        assert m["max_abs_score_err"] <= m["hf_bf16_max_abs_score_err"], m
+    assert m["contract_met"], m
+
+
+def g5_margins(model, golden_dir, fixture: str = "g5_byt5_small.npz") -> dict:
+    """`model`: PremiseRetriever of the synthetic ByT5-small (fp32 outputs).  Fixture G5 (or "g5h_byt5_small.npz", the
+    HF-init-scale family): 16 texts, 8 ... 2048 bytes."""
+    g = np.load(os.path.join(golden_dir, fixture), allow_pickle=True)
     emb = model.encode_texts(list(g["texts"])).float().cpu()
     return embedding_margins(emb, torch.from_numpy(g["emb"]), torch.from_numpy(g["emb_hf_bf16"].astype(np.float32)))
 
 
-def g9_margins(model, golden_dir) -> dict:
-    """`model`: PremiseRetriever of the synthetic ByT5-base, all 18 layers.  Fixture G9: 8 texts."""
-    g = np.load(os.path.join(golden_dir, "g9_byt5_base.npz"), allow_pickle=True)
+def g9_margins(model, golden_dir, fixture: str = "g9_byt5_base.npz") -> dict:
+    """`model`: PremiseRetriever of the synthetic ByT5-base, all 18 layers.  Fixture G9 (or "g9h_byt5_base.npz"): 8 texts."""
+    g = np.load(os.path.join(golden_dir, fixture), allow_pickle=True)
     emb = model.encode_texts(list(g["texts"])).float().cpu()
     return embedding_margins(emb, torch.from_numpy(g["emb"]), torch.from_numpy(g["emb_hf_bf16"].astype(np.float32)))
+
+
+def g7_corpus_records(g: dict):
+    """The corpus.jsonl records of a G7-style fixture, regenerated from its seeds (G7: independent bodies; G7h: families)."""
+    from reprover_amd import synth
+
+    if g.get("corpus") == "family":
+        return synth.synth_family_corpus_records(g["n_files"], g["n_premises"], seed=g["corpus_seed"],
+                                                 code_bytes=tuple(g["code_bytes"]), family_size=g["family_size"])[0]
+    return synth.synth_corpus_records(g["n_files"], g["n_premises"], seed=g["corpus_seed"], code_bytes=tuple(g["code_bytes"]))
 
 
 def g7_row_margins(model, g, z) -> dict:
@@ -107,24 +143,31 @@ def g7_predict(model, g):
         "top1_agreement": float(np.mean([a[0] == b[0] for a, b in zip(ids, g["ids"])])),
         f"top{k}_overlap": float(np.mean([len(set(a) & set(b)) / k for a, b in zip(ids, g["ids"])])),
     }
+    if "hf_bf16_predict_ids" in g:  # what the reference's own GPU mode (HF-bf16 + bf16 similarity matrix) retrieves
+        hf_ids = g["hf_bf16_predict_ids"]
+        _, hf_bad = gap_rule_ids(hf_ids, g["ids"], g["scores"], tol=1e-2)
+        m["hf_bf16_top1_agreement"] = float(np.mean([a[0] == b[0] for a, b in zip(hf_ids, g["ids"])]))
+        m[f"hf_bf16_top{k}_overlap"] = float(np.mean([len(set(a) & set(b)) / k for a, b in zip(hf_ids, g["ids"])]))
+        m["hf_bf16_gap_rule_mismatches"] = int(hf_bad)
     m["contract_met"] = bool(m["max_abs_score_err"] <= 1e-2 and bad == 0)
     m["hf_bf16_meets_contract"] = bool(hf_err <= 1e-2)
     return recs, ids, scores, ctxs, m
 
 
 def write_margins(margins: dict, root: str) -> None:
-    """profiles/r05_parity_margins.json (tracked) and gpurun_out/parity_margins.json (what travels back from the GPU box)."""
+    """profiles/r06_parity_margins.json (tracked) and gpurun_out/parity_margins.json (what travels back from the GPU box)."""
     doc = {
         "what": "end-to-end parity margins of the HIP engine vs the fp32 goldens of the reference + HuggingFace "
                 "(tests/golden), beside HF-bf16's own error on the same inputs; written by `pytest -m gpu`",
         "written_contract": "scores within 1e-2 abs, embedding cosine >= 0.999, ids equal where the oracle's rank gap > 2e-2 "
                             "(BASELINE.md section 2)",
-        "enforced_bar": "a RELAXATION where HF-bf16 itself misses the contract on these sharp synthetic weights: no row "
-                        "further from fp32 than HF-bf16, max |d score| <= max(1e-2, HF-bf16's), cosine floors 0.997 (12 "
-                        "layers) / 0.99 (18 layers), gap-rule mismatches = 0",
+        "enforced_bar": "fixtures g5h / g7h / g9h (weights at HF's init scales, SURVEY.md 8c's recipe): the written contract "
+                        "as it stands + no metric worse than HF-bf16's.  Fixtures g5 / g7 / g9 (sharp stress family, on which "
+                        "HF-bf16 itself misses 0.999 / 1e-2): no row and no metric further from fp32 than HF-bf16, max |d score| "
+                        "<= max(1e-2, HF-bf16's), cosine floors 0.997 (12 layers) / 0.99 (18 layers), gap-rule mismatches = 0",
         **margins,
     }
-    for path in (os.path.join(root, "profiles", "r05_parity_margins.json"), os.path.join(root, "gpurun_out", "parity_margins.json")):
+    for path in (os.path.join(root, "profiles", "r06_parity_margins.json"), os.path.join(root, "gpurun_out", "parity_margins.json")):
         try:
             os.makedirs(os.path.dirname(path), exist_ok=True)
             with open(path, "w") as fh:

@@ -882,6 +882,90 @@ def load_indexed_corpus_pickle(path: str):
     return corpus, obj.embeddings
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# ... and the other direction: an index file the REFERENCE loads.  Its prover unpickles `common.IndexedCorpus`
+# (prover/tactic_generator.py:273-276 -> retrieval/model.py:81-85), so the stream must name the reference's own
+# classes - `common.{IndexedCorpus, Corpus, File, Premise}`, `lean_dojo.data_extraction.lean.Pos` - and hold what their
+# instances hold: `Corpus.{all_premises, transitive_dep_graph (a networkx DiGraph of the closure, node attribute
+# "file"), imported_premises_cache}` (common.py:181-224, 264-278).  The objects below are attribute-for-attribute
+# stand-ins pickled under those names (plain `object.__reduce_ex__` state, which is also how the reference's
+# dataclasses pickle); while the stream is written the names resolve to the stand-ins, afterwards `sys.modules` is as
+# it was.  tests/golden/make_golden.py (g17) loads such a file with the imported reference's plain `pickle.load` and runs
+# its `retrieve` on it.
+# ----------------------------------------------------------------------------------------------------------------
+REFERENCE_POS_MODULE = "lean_dojo.data_extraction.lean"  # where lean_dojo defines Pos (`from lean_dojo import Pos`)
+
+
+def _reference_standins() -> Dict[str, type]:
+    def make(module, name):
+        return type(name, (), {"__module__": module, "__qualname__": name})
+
+    return {"IndexedCorpus": make("common", "IndexedCorpus"), "Corpus": make("common", "Corpus"),
+            "File": make("common", "File"), "Premise": make("common", "Premise"), "Pos": make(REFERENCE_POS_MODULE, "Pos")}
+
+
+def save_reference_pickle(path: str, corpus: "Corpus", embeddings: torch.Tensor) -> None:
+    """Write ``IndexedCorpus(corpus, fp32 CPU embeddings)`` as the reference's OWN pickle (retrieval/index.py:37-40):
+    its ``pickle.load`` - with ``common``, ``lean_dojo`` and ``networkx`` importable, as in the reference's environment -
+    returns a ``common.IndexedCorpus`` that ``PremiseRetriever.load_corpus`` / the prover use as they use their own."""
+    import sys
+    import types
+
+    try:
+        import networkx as nx
+    except ImportError as e:  # the reference's Corpus IS a networkx graph; without the package its state cannot be written
+        raise ImportError("save_reference_pickle needs networkx (the reference's Corpus holds a networkx.DiGraph)") from e
+    emb = embeddings.detach().to(torch.float32).cpu().contiguous()
+    if len(emb) != len(corpus):
+        raise ValueError(f"{len(emb)} embedding rows for {len(corpus)} premises")
+    cls = _reference_standins()
+
+    def obj(kind, **state):
+        o = cls[kind].__new__(cls[kind])
+        o.__dict__.update(state)
+        return o
+
+    def pos(p):
+        return obj("Pos", line_nb=int(p.line_nb), column_nb=int(p.column_nb))
+
+    graph = nx.DiGraph()
+    prem_of: Dict[int, Any] = {}
+    files = []
+    for f in corpus._files:
+        prem = []
+        for p in f.premises:
+            q = prem_of[id(p)] = obj("Premise", path=p.path, full_name=p.full_name, start=pos(p.start), end=pos(p.end), code=p.code)
+            prem.append(q)
+        files.append(obj("File", path=f.path, premises=prem))
+        graph.add_node(f.path, file=files[-1])
+    for i, f in enumerate(corpus._files):  # the graph IS the transitive closure (common.py:216)
+        for g in corpus._reach_ids(i):
+            graph.add_edge(f.path, corpus._files[int(g)].path)
+    cache = {f.path: [q for g in corpus._reach_ids(i) for q in files[int(g)].premises] for i, f in enumerate(corpus._files)}
+    ref_corpus = obj("Corpus", all_premises=[prem_of[id(p)] for p in corpus.all_premises], transitive_dep_graph=graph,
+                     imported_premises_cache=cache)
+    indexed = obj("IndexedCorpus", corpus=ref_corpus, embeddings=emb)
+
+    names = ["common", "lean_dojo", "lean_dojo.data_extraction", REFERENCE_POS_MODULE]
+    saved = {n: sys.modules.get(n) for n in names}
+    try:
+        common_mod = types.ModuleType("common")
+        for n in ("IndexedCorpus", "Corpus", "File", "Premise"):
+            setattr(common_mod, n, cls[n])
+        sys.modules["common"] = common_mod
+        for n in names[1:]:
+            sys.modules[n] = types.ModuleType(n)
+        sys.modules[REFERENCE_POS_MODULE].Pos = cls["Pos"]
+        with open(path, "wb") as fh:
+            pickle.dump(indexed, fh, protocol=4)
+    finally:
+        for n, m in saved.items():
+            if m is None:
+                sys.modules.pop(n, None)
+            else:
+                sys.modules[n] = m
+
+
 def get_all_pos_premises(annot_tac, corpus: Corpus) -> List[Premise]:
     """Premises used by an annotated tactic: each provenance ``{def_path, def_pos}`` is resolved with
     ``corpus.locate_premise``; unresolvable ones are skipped (common.py:341-354)."""

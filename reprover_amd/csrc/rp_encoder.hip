@@ -97,7 +97,7 @@ void prof_end(hipStream_t stream) {
 
 using namespace rp;
 
-extern "C" int32_t rp_abi_version(void) { return 4; }
+extern "C" int32_t rp_abi_version(void) { return 6; }
 extern "C" const char* rp_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
@@ -423,19 +423,17 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
   // one per CU) or 128 x 128 quarter tiles (0, two per CU).  Same K-ascending chains per output element: not a bit
   // changes.  Measured 9.28 -> 9.04 ms per step in round 3; the same split of the QKV projection (5.35 rounds) gained
   // nothing (3.11 -> 3.14 ms: its short K loop leaves the tail round cheap already).
-  int n_cus = 256;
-  {
-    int dev = 0, v = 0;  // an attribute query, not the (slow) property struct: this runs once per pass
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      n_cus = v;
-  }
+  const int n_cus = device_cu_count();
   auto main_rows = [&](int prof_class, int n_features, int K) -> int {
     if (!g_gemm_tail_split || t_dev) return Tp;  // (token count known on the device only: one launch)
-    if ((g_gemm_mixed >> (prof_class - RP_K_GEMM_QKV)) & 1) return Tp;  // the mixed launch carries its own half tiles
     const int v = pick_gemm_variant(prof_class, Tp, n_features, K, tv);
     if (v != 20 && v != 26) return Tp;
     const int tiles_f = (n_features + 255) / 256, tiles_t = Tp / 256;
+    // The mixed launch carries its own half tiles - when launch_gemm_cfg actually takes it: the 8-wave 256 x 256
+    // configuration (26; the 4-wave form 20 has no edge layouts), at least two k-tiles, and a plan (plan_mixed, the SAME
+    // function and CU count launch_gemm_cfg uses).  Declined there, the tail split below still applies.
+    if (((g_gemm_mixed >> (prof_class - RP_K_GEMM_QKV)) & 1) && v == 26 && K >= 128 && plan_mixed(tiles_f, tiles_t, n_cus).full_rows)
+      return Tp;
     int g = tiles_f, b = n_cus;  // gcd
     while (b) {
       const int t = g % b;

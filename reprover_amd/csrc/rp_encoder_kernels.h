@@ -752,6 +752,22 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel_mixed(GemmOperand A, G
     gemm_tile_pipe<CH>(A, W, K, h % tiles_m, 2 * full_rows + h / tiles_m, epi, smem);
   }
 }
+// CUs of the current device: an attribute query (not the slow property struct), cached per device.  ONE source for the
+// planners below and for encode_pass's main_rows(): plans computed in two places must agree on a part that does not have
+// 256 CUs.
+inline int device_cu_count() {
+  static int cached_dev = -1, cached = 256;
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (dev == cached_dev) return cached;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) {
+    cached_dev = dev;
+    cached = v;
+    return v;
+  }
+  return 256;
+}
+
 struct MixedPlan {
   int full_rows = 0, half_first = 0, half_last = 0;  // token tiles of 256 | rows of 128 tokens handed out first | last
 };
@@ -846,7 +862,7 @@ static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hi
   // few-token launches (one group of token tiles, well under one round of the chip) on weights worth prefetching: the idle
   // CUs become prefetch helpers (above)
   int n_grid = tiles_f * tiles_t, n_helpers = 0;
-  const int n_cus = 256;
+  const int n_cus = device_cu_count();
   if (g_gemm_helpers && n_grid <= n_cus / 2 && tiles_t <= group && (size_t)w.rows * K * 2 >= ((size_t)2 << 20)) {
     n_grid = (n_grid + 7) & ~7;
     n_helpers = std::min(g_gemm_helpers, (n_cus - n_grid) & ~7);

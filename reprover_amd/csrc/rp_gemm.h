@@ -564,6 +564,16 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
 // The queue of a wave at that point, oldest first: [slot 0 of t+1] [epilogue stores of t] [metadata] [slot 1 of t+1];
 // the first counted wait leaves only the youngest DPS operations outstanding, as in the one-tile form.
 // Every output element is the same K-ascending chain of MFMA steps: not a bit differs from gemm_tile_pipe.
+//
+// ORDERING ASSUMPTION.  `wait_vmcnt<DPS>` is read as "everything older than the youngest DPS vector-memory
+// operations of this wave has completed" across THREE kinds of operation in one queue: LDS-DMA loads (slot 0 of tile t+1),
+// the epilogue's global STORES, and the metadata DMA.  That holds on the gfx9 family this file is written for - gfx942 /
+// gfx950 keep loads and stores on ONE vmcnt counter that retires in issue order (the ISA has no separate vscnt; gfx10+
+// split stores off into vscnt, where a store would no longer hold younger loads' count back and this wait would have to
+// become a load-only count).  The guard below refuses to compile the persistent form for anything else.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "gemm_tiles_persist relies on gfx942/gfx950 vmcnt semantics (loads and stores retire in order on one counter)"
+#endif
 constexpr int PERSIST_EPI_OFF = 64 * 1024, PERSIST_META_OFF = 136 * 1024, PERSIST_LDS_BYTES = 160 * 1024;
 template <class C, bool EDGE = false, class L0 = C, class Epilogue, class NextTile>
 __device__ __forceinline__ void gemm_tiles_persist(const GemmOperand A, const GemmOperand W, int K, NextTile next_tile,

@@ -342,6 +342,9 @@ def sharded_nearest_premise_ids(
     return merge(g_ids, g_scores, g_counts)
 
 
+_default_sliced_staging: dict = {}  # send / receive buffers of sliced_exchange_merge calls that pass no `staging`
+
+
 def sliced_exchange_merge(ids: torch.Tensor, scores: torch.Tensor, counts: torch.Tensor, group=None,
                           merge: Callable[..., TopK] = hip_merge, staging: Optional[dict] = None) -> TopK:
     """The result exchange of a step in which every rank OWNS a slice of the queries (weak scaling: query q belongs to rank
@@ -351,13 +354,15 @@ def sliced_exchange_merge(ids: torch.Tensor, scores: torch.Tensor, counts: torch
     world x the bytes, of which a rank merges 1 / world.  The merge then reads the receive buffer as
     it lies (rank stride Bq (2k + 1)).  Returns (ids [Bq, k], scores, counts) of this rank's queries.
     ``staging``: an optional dict the caller keeps between steps (send / receive buffers are allocated once)."""
+    if isinstance(group, HipComm):  # (before anything is packed or allocated)
+        raise NotImplementedError("the library's communicator carries the all-gather form only (rp_allgather_topk)")
     world, rank = _world_rank(group)
     B_all, k = ids.shape
     assert B_all % world == 0, "every rank owns the same number of queries"
     Bq = B_all // world
     blk = Bq * (2 * k + 1)
     dev = ids.device
-    st = staging if staging is not None else {}
+    st = staging if staging is not None else _default_sliced_staging  # (a caller without its own dict still allocates once)
     key = ("sliced", world, Bq, k, str(dev))
     if key not in st:
         st[key] = (torch.empty((world, blk), dtype=torch.int32, device=dev), torch.empty((world, blk), dtype=torch.int32, device=dev))
@@ -366,8 +371,6 @@ def sliced_exchange_merge(ids: torch.Tensor, scores: torch.Tensor, counts: torch
     send[:, : Bq * k].copy_(scores.contiguous().view(torch.int32).view(world, Bq * k))
     send[:, Bq * k : 2 * Bq * k].copy_(ids.to(torch.int32).contiguous().view(world, Bq * k))
     send[:, 2 * Bq * k :].copy_(counts.to(torch.int32).contiguous().view(world, Bq))
-    if isinstance(group, HipComm):
-        raise NotImplementedError("the library's communicator carries the all-gather form only (rp_allgather_topk)")
     if dist.get_backend(group) == "nccl" or not send.is_cuda:
         dist.all_to_all_single(recv, send, group=group)
     else:  # functional runs of the N > 1 path on one GPU over gloo: gloo's all-to-all takes host tensors

@@ -28,6 +28,9 @@ def main(argv=None) -> None:
     parser.add_argument("--corpus-path", type=str, required=True)
     parser.add_argument("--output-path", type=str, required=True)
     parser.add_argument("--batch-size", type=int, default=64)
+    parser.add_argument("--reference-pickle", action="store_true",
+                        help="write the pickle under the REFERENCE's class names (common.IndexedCorpus, networkx closure, "
+                             "lean_dojo Pos) so that the reference's prover / load_corpus can load it; needs networkx")
     args = parser.parse_args(argv)
     logger.info(args)
 
@@ -75,6 +78,10 @@ def main(argv=None) -> None:
 
             fp8 = Fp8Index.quantize(model.corpus_embeddings, device)
         save_index(args.output_path, args.corpus_path, model.corpus_embeddings, corpus=model.corpus, fp8=fp8)
+    elif args.reference_pickle:  # ... under the reference's own class identities (prover/tactic_generator.py:273-276 loads it)
+        from ..common import save_reference_pickle
+
+        save_reference_pickle(args.output_path, model.corpus, model.corpus_embeddings)
     else:  # the reference's format: pickled IndexedCorpus with fp32 CPU embeddings (index.py:37-40)
         with open(args.output_path, "wb") as oup:
             pickle.dump(IndexedCorpus(model.corpus, model.corpus_embeddings.to(torch.float32).cpu()), oup)

@@ -91,12 +91,33 @@ def run_fit(model: PremiseRetriever, dm: RetrievalDataModule, max_steps: int, va
     step, losses = 0, []
     epoch, skip = 0, 0
     if resume_from:
+        if not os.path.isdir(resume_from) and os.path.isdir(resume_from.rstrip("/") + ".old"):
+            # a crash between the two renames of save_fit_checkpoint leaves only <dir>.old (+ <dir>.tmp): the last
+            # COMPLETE checkpoint is the .old one
+            log(f"fit: {resume_from} is missing, resuming from {resume_from.rstrip('/')}.old")
+            resume_from = resume_from.rstrip("/") + ".old"
         model.train_engine().load_training_state(os.path.join(resume_from, "training_state.safetensors"))
         step = model.train_engine().steps
         lpath = os.path.join(resume_from, "loop_state.json")
         if os.path.exists(lpath):
             st = json.load(open(lpath))
-            epoch, skip, seed = int(st.get("epoch", 0)), int(st.get("batches_done", 0)), int(st.get("seed", seed))
+            epoch, skip = int(st.get("epoch", 0)), int(st.get("batches_done", 0))
+            if int(st.get("seed", seed)) != int(seed):
+                log(f"fit: the checkpoint's data seed {st['seed']} overrides the configured {seed} "
+                    "(the resumed epoch must redraw the batches it already trained on)")
+            seed = int(st.get("seed", seed))
+    caller_rng = random.getstate()  # the loop re-seeds the global `random` per epoch (the dataset draws from it, as upstream)
+    try:
+        return _fit_loop(model, dm, max_steps, val_every, log, ckpt_dir, ckpt_every, seed, optimizer, scheduler,
+                         step, losses, epoch, skip)
+    finally:
+        random.setstate(caller_rng)  # ... and hands the caller's stream back untouched
+
+
+def _fit_loop(model, dm, max_steps, val_every, log, ckpt_dir, ckpt_every, seed, optimizer, scheduler, step, losses,
+              epoch, skip) -> Dict[str, Any]:
+    import random
+
     while step < max_steps:
         n_epoch = 0
         random.seed(_epoch_seed(seed, epoch))
@@ -198,9 +219,13 @@ def main(argv=None) -> None:
             model.dropout_seed = int(seed)  # different seeds, different dropout masks
         if int(d.get("batch_size", 0)) <= 0:
             raise SystemExit("fit: the config's data.batch_size must be a positive integer")
-        log_dir = args.log_dir or tcfg.get("default_root_dir")  # no directory asked for: no checkpoint is written
+        # Lightning's Trainer defaults default_root_dir to the working directory and always keeps a checkpoint under it
+        # (<cwd>/lightning_logs/version_N/checkpoints): a run from a reference-style YAML without a root dir must not
+        # train for max_steps and then discard the weights
+        log_dir = args.log_dir or tcfg.get("default_root_dir") or os.path.join(os.getcwd(), "lightning_logs")
+        print(f"fit: checkpoints go to {os.path.join(log_dir, 'checkpoint')}", flush=True)
         out = run_fit(model, dm, args.max_steps or int(tcfg.get("max_steps", 1)), args.val_every,
-                      ckpt_dir=os.path.join(log_dir, "checkpoint") if log_dir else None, ckpt_every=args.ckpt_every,
+                      ckpt_dir=os.path.join(log_dir, "checkpoint"), ckpt_every=args.ckpt_every,
                       resume_from=args.resume_from, seed=int(seed) if seed is not None else 3407)
         first = f"{out['losses'][0]:.6f} -> {out['losses'][-1]:.6f}" if out["losses"] else "(no step taken)"
         print(f"fit: {out['steps']} steps, loss {first}; checkpoint {out['checkpoint']}")

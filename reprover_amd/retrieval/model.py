@@ -113,6 +113,10 @@ class PremiseRetriever:
         # (the reference's eval batch is 64 states; a 256-state pass costs 10 % less GPU time per state).  0 = every
         # batch is its own pass.  Records keep their order; they are complete when ``predict_step_outputs`` is read.
         self.predict_coalesce_states = 256
+        # False = the reference's synchronous semantics (model.py:281-290 + common.py:323-324): predict_step finishes
+        # ITS OWN batch before it returns - records appended, ValueError raised in the call that submitted the batch,
+        # nothing queued or in flight afterwards.  True (default): the one-pass-deep pipeline described at predict_step.
+        self.predict_pipeline = True
         self._predict_stash: List[Dict[str, Any]] = []
         # training (lazily built by training_step / configure_optimizers: fp32 masters, gradients, AdamW moments)
         self._trainer = None
@@ -523,7 +527,16 @@ class PremiseRetriever:
         (encode, masked top-k, copy to pinned memory); the records of the PREVIOUS pass are completed afterwards, so the
         host-side mapping - and whatever the caller does between calls: collating the next batch - overlaps GPU work.
         Consequence: a ``ValueError`` (fewer than k accessible premises; a mask that is not right-padded) surfaces later
-        than in the reference - at the latest when ``predict_step_outputs`` is read or the epoch ends."""
+        than in the reference - at the latest when ``predict_step_outputs`` is read or the epoch ends.
+
+        ``predict_pipeline = False`` is the STRICT form: no gathering, no overlap - the call encodes, searches and maps
+        its own batch and raises the reference's ``ValueError`` itself, exactly where model.py:281-290 does."""
+        if not self.predict_pipeline:
+            self._launch_predict(self._take_predict_stash())  # (batches queued before the switch was flipped)
+            self._finish_pending_predict()
+            self._launch_predict([batch])
+            self._finish_pending_predict()
+            return
         host = not batch["context_ids"].is_cuda and not batch["context_mask"].is_cuda
         if host and self.predict_coalesce_states > len(batch["context"]):
             self._predict_stash.append(batch)

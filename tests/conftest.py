@@ -24,7 +24,7 @@ _PARITY_MARGINS = {}
 
 @pytest.fixture(scope="session")
 def parity_margins():
-    """Filled by the end-to-end GPU parity tests (G5 / G7 / G9); written to profiles/r05_parity_margins.json and
+    """Filled by the end-to-end GPU parity tests (G5 / G7 / G9 and G5h / G7h / G9h); written to profiles/r06_parity_margins.json and
     gpurun_out/parity_margins.json and printed in the terminal summary when the session ends."""
     return _PARITY_MARGINS
 
@@ -45,7 +45,8 @@ def pytest_terminal_summary(terminalreporter):
         if "min_row_cosine" in m and "max_abs_pairwise_score_err" in m:
             w(f"  {name}: min row cosine {m['min_row_cosine']:.5f} [{m['hf_bf16_min_row_cosine']:.5f}], max |d emb| "
               f"{m['max_abs_emb_err']:.2e} [{m['hf_bf16_max_abs_emb_err']:.2e}], max |d score| {m['max_abs_pairwise_score_err']:.2e} "
-              f"[{m['hf_bf16_max_abs_pairwise_score_err']:.2e}], written contract met: {m['contract_met']}")
+              f"[{m['hf_bf16_max_abs_pairwise_score_err']:.2e}], written contract met: {m['contract_met']}, no worse than "
+              f"HF-bf16 on any metric: {m['no_worse_than_hf_bf16']}")
         elif "min_row_cosine" in m:
             w(f"  {name}: {m['rows']} rows, min cosine {m['min_row_cosine']:.5f} [{m['hf_bf16_min_row_cosine']:.5f}], mean "
               f"{m['mean_row_cosine']:.6f}, max |d emb| {m['max_abs_emb_err']:.2e}")
@@ -53,7 +54,10 @@ def pytest_terminal_summary(terminalreporter):
             k = m["k"]
             w(f"  {name}: max |d score| {m['max_abs_score_err']:.2e} [{m['hf_bf16_max_abs_score_err']:.2e}], gap-rule ranks "
               f"{m['gap_rule_ranks_checked']} of {m['ranks']} checked / {m['gap_rule_mismatches']} mismatched, top-1 "
-              f"{m['top1_agreement']:.3f}, top-{k} overlap {m[f'top{k}_overlap']:.3f}, written contract met: {m['contract_met']}")
+              f"{m['top1_agreement']:.3f}" + (f" [{m['hf_bf16_top1_agreement']:.3f}]" if "hf_bf16_top1_agreement" in m else "") +
+              f", top-{k} overlap {m[f'top{k}_overlap']:.3f}" +
+              (f" [{m[f'hf_bf16_top{k}_overlap']:.3f}]" if f"hf_bf16_top{k}_overlap" in m else "") +
+              f", written contract met: {m['contract_met']}")
 
 
 @pytest.fixture(scope="session")
@@ -72,6 +76,16 @@ def small_weights():
 
     cfg = synth.t5_config("byt5-small")
     return cfg, synth.synth_state_dict(cfg)
+
+
+@pytest.fixture(scope="session")
+def small_weights_hf():
+    """ByT5-small weights at exactly HF's init scales (SURVEY.md 8c's G5 recipe): fixtures G5h / G7h, on which the written
+    floating-point contract is asserted un-relaxed."""
+    from reprover_amd import synth
+
+    cfg = synth.t5_config("byt5-small")
+    return cfg, synth.synth_state_dict(cfg, scale="hf")
 
 
 @pytest.fixture(scope="session")

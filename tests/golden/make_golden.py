@@ -202,11 +202,13 @@ def g4_tiny():
     print("g4 ok")
 
 
-def g5_small():
+def g5_small(scale="sharp"):
+    """scale="sharp": fixture G5 (the stress family of synth.synth_state_dict); scale="hf": fixture G5h - the same 16
+    texts on weights at exactly HF's init scales, SURVEY.md section 8c's recipe, on which the written contract holds."""
     cfg = synth.t5_config("byt5-small")
     t0 = time.time()
-    sd = synth.synth_state_dict(cfg)
-    print(f"g5: weights generated in {time.time() - t0:.1f}s")
+    sd = synth.synth_state_dict(cfg, scale=scale)
+    print(f"g5[{scale}]: weights generated in {time.time() - t0:.1f}s")
     model = H.offline_retriever(rm, hf_cfg(cfg), sd, max_seq_len=2048)
     n_par = sum(p.numel() for p in model.encoder.parameters())
     print("g5: encoder params", n_par)
@@ -229,13 +231,14 @@ def g5_small():
     print(f"g5: HF bf16 vs fp32 max|Δemb| = {(emb_bf - emb).abs().max().item():.2e}; "
           f"min cos = {torch.nn.functional.cosine_similarity(emb_bf, emb).min().item():.5f} ({time.time() - t0:.1f}s)")
     np.savez_compressed(
-        os.path.join(OUT, "g5_byt5_small.npz"),
+        os.path.join(OUT, "g5_byt5_small.npz" if scale == "sharp" else "g5h_byt5_small.npz"),
         texts=np.array(texts, dtype=object),
         emb=emb.numpy(),
         emb_hf_bf16=emb_bf.numpy().astype(np.float16),
         seed=np.int64(synth.SEED),
+        **({} if scale == "sharp" else {"weight_scale": np.array(scale)}),
     )
-    print("g5 ok")
+    print(f"g5[{scale}] ok")
 
 
 # ----------------------------------------------------------------------------------------------
@@ -317,14 +320,46 @@ def g6_nearest():
 
 
 # ----------------------------------------------------------------------------------------------
-def g7_predict():
+def _g7_run_predict(model, ctxs, where, max_len):
+    """The reference's predict_step (model.py:281-327) over the states in eval batches of 64 (retrieval/confs/*.yaml);
+    returns (ids, scores) per state."""
+    ids_all, sc_all = [], []
+    for i in range(0, len(ctxs), 64):
+        batch = ctxs[i : i + 64]
+        tok = model.tokenizer([c.serialize() for c in batch], padding="longest", max_length=max_len,
+                              truncation=True, return_tensors="pt")  # datamodule.py:130-144
+        model.predict_step_outputs = []
+        b = {"context": batch, "context_ids": tok.input_ids, "context_mask": tok.attention_mask}
+        for key in ("url", "commit", "file_path", "full_name", "start", "tactic_idx", "all_pos_premises"):
+            b[key] = [None] * len(batch)
+        with torch.no_grad():
+            model.predict_step(b, 0)
+        for rec in model.predict_step_outputs:
+            ids_all.append([where[id(p)] for p in rec["retrieved_premises"]])
+            sc_all.append([float(x) for x in rec["scores"]])
+    return ids_all, sc_all
+
+
+def g7_predict(scale="sharp"):
     """BASELINE config 1: 1k synthetic premises, 128 states, top-10 through the reference's
     reindex_corpus + predict_step logic (Lightning is stubbed; the hooks' bodies are the
-    reference's)."""
+    reference's).
+
+    scale="sharp": fixture G7 (stress-family weights, independent random premise bodies).
+    scale="hf": fixture **G7h** - weights at HF's init scales (the family the written contract was derived on) and the
+    FAMILY corpus of synth.synth_family_corpus_records, 15 of every 16 states built from a family's base text:
+    the fp32 scores of a state's top-10 then step down by several 1e-2 per rank, so the id comparison ("equal wherever
+    the oracle's gap to both neighbours exceeds 2 x tol") has hundreds of ranks to check instead of a few dozen."""
+    hf = scale == "hf"
+    tag = "g7h" if hf else "g7"
     cfg = synth.t5_config("byt5-small")
-    sd = synth.synth_state_dict(cfg)
+    sd = synth.synth_state_dict(cfg, scale=scale)
     model = H.offline_retriever(rm, hf_cfg(cfg), sd, max_seq_len=1024)
-    files = synth.synth_corpus_records(60, 1000, seed=71, code_bytes=(24, 96))
+    corpus_seed = 171 if hf else 71
+    if hf:
+        files, families = synth.synth_family_corpus_records(60, 1000, seed=corpus_seed, code_bytes=(24, 96))
+    else:
+        files, families = synth.synth_corpus_records(60, 1000, seed=corpus_seed, code_bytes=(24, 96)), []
     td = tempfile.mkdtemp()
     path = os.path.join(td, "corpus.jsonl")
     synth.write_corpus_jsonl(path, files)
@@ -332,38 +367,39 @@ def g7_predict():
     N = len(model.corpus)
     t0 = time.time()
     model.reindex_corpus(batch_size=64)
-    print(f"g7: reference reindex_corpus of {N} premises took {time.time() - t0:.1f}s")
+    print(f"{tag}: reference reindex_corpus of {N} premises took {time.time() - t0:.1f}s")
     E = model.corpus_embeddings
-    rng = np.random.default_rng(72)
+    rng = np.random.default_rng(172 if hf else 72)
     B = 128
     ctxs, qmeta = [], []
     for j in range(B):
         while True:  # the reference raises ValueError when < k premises are accessible
             f = int(rng.integers(30, 60))
             pos = (int(rng.integers(1, 300)), int(rng.integers(0, 40)))
-            if len(model.corpus.get_accessible_premises(files[f]["path"], H.Pos(*pos))) >= 12:
+            acc = model.corpus.get_accessible_premises(files[f]["path"], H.Pos(*pos))
+            if len(acc) >= 12:
                 break
         state = synth.synth_state(rng, int(rng.integers(40, 200)))
+        if hf and j % 16 != 15:
+            # a family all of whose members this state may use (own file before pos, or an imported file)
+            names = {(p.path, p.full_name) for p in acc}
+            ok = [g for g in families if all((files[g["file"]]["path"], n) in names for n in g["members"])
+                  and len(g["members"]) >= 10]
+            if ok:
+                base = ok[int(rng.integers(len(ok)))]["base"]
+                base = synth.corrupt_text(rng, base, 0.04)
+                h = int(rng.integers(len(base) // 4, 3 * len(base) // 4))
+                state = base[:h] + " ⊢" + base[h:]
         ctxs.append(common.Context(files[f]["path"], f"thm{j}", H.Pos(*pos), state))
         qmeta.append({"path": files[f]["path"], "pos": list(pos), "state": state})
     where = {id(p): i for i, p in enumerate(model.corpus.all_premises)}
     model.num_retrieved = 10  # BASELINE config 1: top-10 (the hook reads self.num_retrieved, model.py:288)
-    ids_all, sc_all = [], []
     t0 = time.time()
-    for i in range(0, B, 64):  # eval_batch_size 64 (retrieval/confs/*.yaml)
-        batch = ctxs[i : i + 64]
-        tok = model.tokenizer([c.serialize() for c in batch], padding="longest", max_length=1024,
-                              truncation=True, return_tensors="pt")  # datamodule.py:130-144
-        model.predict_step_outputs = []
-        b = {"context": batch, "context_ids": tok.input_ids, "context_mask": tok.attention_mask}
-        for key in ("url", "commit", "file_path", "full_name", "start", "tactic_idx", "all_pos_premises"):
-            b[key] = [None] * len(batch)
-        with torch.no_grad():
-            model.predict_step(b, 0)  # model.py:281-327
-        for rec in model.predict_step_outputs:
-            ids_all.append([where[id(p)] for p in rec["retrieved_premises"]])
-            sc_all.append(rec["scores"])
-    print(f"g7: reference predict of {B} states took {time.time() - t0:.1f}s")
+    ids_all, sc_all = _g7_run_predict(model, ctxs, where, 1024)
+    print(f"{tag}: reference predict of {B} states took {time.time() - t0:.1f}s")
+    from oracle.parity_margins import gap_rule_ids
+    checked, _ = gap_rule_ids(ids_all, ids_all, sc_all, tol=1e-2)
+    print(f"{tag}: ranks the gap rule (2 x 1e-2 to both neighbours) can check: {checked} of {B * 10}")
     # single-query retrieve() (model.py:338-375) on the first 4 states
     single = []
     for j in range(4):
@@ -372,7 +408,8 @@ def g7_predict():
         single.append({"ids": [where[id(p)] for p in prem], "scores": sc})
         assert single[-1]["ids"] == ids_all[j]
     # The reference's own GPU numerics (model.py:59-64: everything bf16) on the same inputs: how far
-    # HuggingFace-bf16 lands from its fp32 self, measured at the golden ids (the tolerance envelope).
+    # HuggingFace-bf16 lands from its fp32 self, measured at the golden ids (the tolerance envelope), and the ids its
+    # own predict_step returns (bf16 embeddings, bf16 similarity matrix: common.py:307-308 as the GPU mode runs it).
     t0 = time.time()
     E32 = E.clone()
     model_bf = model.to(torch.bfloat16)
@@ -388,20 +425,29 @@ def g7_predict():
             qbf = model_bf._encode(tok.input_ids, tok.attention_mask).float()
         for j in range(len(batch)):
             hf_bf16_scores.append((Ebf[ids_all[i + j]] @ qbf[j]).tolist())
+    hf_ids, hf_sc = _g7_run_predict(model_bf, ctxs, where, 1024)
+    _, hf_bad = gap_rule_ids(hf_ids, ids_all, sc_all, tol=1e-2)
+    hf_top1 = float(np.mean([a[0] == b[0] for a, b in zip(hf_ids, ids_all)]))
+    hf_top10 = float(np.mean([len(set(a) & set(b)) / 10 for a, b in zip(hf_ids, ids_all)]))
     d_hf = np.abs(np.array(hf_bf16_scores) - np.array(sc_all))
     cos_hf = torch.nn.functional.cosine_similarity(Ebf, E32, dim=1)
-    print(f"g7: HF-bf16 vs fp32: max|Δscore| at golden ids {d_hf.max():.3e}, mean {d_hf.mean():.3e}; "
-          f"min embedding cosine {cos_hf.min().item():.5f} ({time.time() - t0:.0f}s)")
+    print(f"{tag}: HF-bf16 vs fp32: max|Δscore| at golden ids {d_hf.max():.3e}, mean {d_hf.mean():.3e}; "
+          f"min embedding cosine {cos_hf.min().item():.5f}; its own predict: top-1 agreement {hf_top1:.3f}, top-10 overlap "
+          f"{hf_top10:.3f}, gap-rule mismatches {hf_bad} ({time.time() - t0:.0f}s)")
     E = E32
     probe = np.random.default_rng(73).standard_normal((E.shape[1], 4)).astype(np.float32)
-    json.dump({"corpus_seed": 71, "n_files": 60, "n_premises": 1000, "code_bytes": [24, 96], "N": N,
-               "queries": qmeta, "k": 10, "ids": ids_all, "scores": sc_all, "retrieve": single,
-               "max_seq_len": 1024, "batch_size": 64, "hf_bf16_scores_at_gold_ids": hf_bf16_scores,
-               "hf_bf16_min_embedding_cosine": float(cos_hf.min())},
-              open(os.path.join(OUT, "g7_predict.json"), "w"), ensure_ascii=False)
-    np.savez_compressed(os.path.join(OUT, "g7_predict.npz"), E_probe=(E @ torch.from_numpy(probe)).numpy(),
+    doc = {"corpus_seed": corpus_seed, "n_files": 60, "n_premises": 1000, "code_bytes": [24, 96], "N": N,
+           "queries": qmeta, "k": 10, "ids": ids_all, "scores": sc_all, "retrieve": single,
+           "max_seq_len": 1024, "batch_size": 64, "hf_bf16_scores_at_gold_ids": hf_bf16_scores,
+           "hf_bf16_min_embedding_cosine": float(cos_hf.min()),
+           "hf_bf16_predict_ids": hf_ids, "hf_bf16_predict_scores": hf_sc,
+           "gap_rule_ranks_checkable": int(checked)}
+    if hf:
+        doc.update({"weight_scale": "hf", "corpus": "family", "family_size": 12})
+    json.dump(doc, open(os.path.join(OUT, f"{tag}_predict.json"), "w"), ensure_ascii=False)
+    np.savez_compressed(os.path.join(OUT, f"{tag}_predict.npz"), E_probe=(E @ torch.from_numpy(probe)).numpy(),
                         probe_seed=np.int64(73), E_head=E[:16].numpy(), E_all_f16=E.numpy().astype(np.float16))
-    print("g7 ok")
+    print(f"{tag} ok")
 
 
 # ----------------------------------------------------------------------------------------------
@@ -466,14 +512,15 @@ def g8_eval_data():
 
 
 # ----------------------------------------------------------------------------------------------
-def g9_base_full_depth():
-    """BASELINE configs[4]'s encoder at FULL depth: ByT5-base geometry (d_model 1536, 12 heads, d_ff 3968,
+def g9_base_full_depth(scale="sharp"):
+    """(scale="hf": fixture G9h, the same texts on HF-init-scale weights.)
+    BASELINE configs[4]'s encoder at FULL depth: ByT5-base geometry (d_model 1536, 12 heads, d_ff 3968,
     18 layers) through the reference's tokenise -> _encode with HuggingFace fp32, plus HF-bf16 (the
     reference's GPU numerics) for the tolerance envelope.  8 short texts keep the fp32 CPU run short."""
     cfg = synth.t5_config("byt5-base")
     t0 = time.time()
-    sd = synth.synth_state_dict(cfg)
-    print(f"g9: weights generated in {time.time() - t0:.1f}s")
+    sd = synth.synth_state_dict(cfg, scale=scale)
+    print(f"g9[{scale}]: weights generated in {time.time() - t0:.1f}s")
     model = H.offline_retriever(rm, hf_cfg(cfg), sd, max_seq_len=1024)
     assert model.encoder.config.num_layers == 18
     rng = np.random.default_rng(9)
@@ -491,9 +538,11 @@ def g9_base_full_depth():
     emb_bf = _ref_encode(model_bf, texts, 1024, 4).float()
     print(f"g9: HF bf16 vs fp32 max|Δemb| = {(emb_bf - emb).abs().max().item():.2e}; "
           f"min cos = {torch.nn.functional.cosine_similarity(emb_bf, emb).min().item():.5f}")
-    np.savez_compressed(os.path.join(OUT, "g9_byt5_base.npz"), texts=np.array(texts, dtype=object), emb=emb.numpy(),
-                        emb_hf_bf16=emb_bf.numpy().astype(np.float16), seed=np.int64(synth.SEED))
-    print("g9 ok")
+    np.savez_compressed(os.path.join(OUT, "g9_byt5_base.npz" if scale == "sharp" else "g9h_byt5_base.npz"),
+                        texts=np.array(texts, dtype=object), emb=emb.numpy(),
+                        emb_hf_bf16=emb_bf.numpy().astype(np.float16), seed=np.int64(synth.SEED),
+                        **({} if scale == "sharp" else {"weight_scale": np.array(scale)}))
+    print(f"g9[{scale}] ok")
 
 
 # ----------------------------------------------------------------------------------------------
@@ -771,6 +820,65 @@ def g14_reference_indexed_corpus():
     print(f"g14 ok: {len(model.corpus)} premises, pickle {os.path.getsize(out_pickle)} bytes")
 
 
+def g17_reference_loads_our_pickle():
+    """The other direction of G14: an index file written by THIS package under the reference's class names
+    (reprover_amd.common.save_reference_pickle, `retrieval/index.py --reference-pickle`) is loaded by the imported
+    reference with plain pickle (retrieval/model.py:81-85, as prover/tactic_generator.py:273-276 does) and its
+    ``retrieve`` must return, from that file, exactly what it returns from the index it built itself.  Asserted here
+    (authoring container); the JSON records the queries and the reference's answers from OUR file, and the CPU suite
+    re-reads a freshly written file with the package's own loader against them."""
+    import pickle
+
+    from reprover_amd import common as our_common
+
+    cfg = synth.t5_config("tiny")
+    sd = synth.synth_state_dict(cfg, seed=14)
+    model = H.offline_retriever(rm, hf_cfg(cfg), sd, max_seq_len=512)
+    files = synth.synth_corpus_records(12, 120, seed=171, max_imports=4, code_bytes=(20, 90))
+    td = tempfile.mkdtemp()
+    path = os.path.join(td, "corpus.jsonl")
+    synth.write_corpus_jsonl(path, files)
+    model.load_corpus(path)
+    model.reindex_corpus(batch_size=32)
+    E = model.corpus_embeddings.to(torch.float32).cpu()
+    ours = os.path.join(td, "ours_for_the_reference.pickle")
+    our_common.save_reference_pickle(ours, our_common.Corpus(path), E)
+    with open(ours, "rb") as fh:
+        loaded = pickle.load(fh)  # plain pickle: resolves common.* to the REFERENCE's classes, Pos to the harness' lean_dojo
+    assert type(loaded) is common.IndexedCorpus and type(loaded.corpus) is common.Corpus
+    assert type(loaded.corpus.all_premises[0]) is common.Premise and type(loaded.corpus.all_premises[0].start) is H.Pos
+    assert [(p.path, p.full_name, tuple(p.start), tuple(p.end), p.code) for p in loaded.corpus.all_premises] == \
+        [(p.path, p.full_name, tuple(p.start), tuple(p.end), p.code) for p in model.corpus.all_premises]
+    g_ref, g_our = model.corpus.transitive_dep_graph, loaded.corpus.transitive_dep_graph
+    assert list(g_ref.nodes) == list(g_our.nodes) and set(g_ref.edges) == set(g_our.edges)
+    model2 = H.offline_retriever(rm, hf_cfg(cfg), sd, max_seq_len=512)
+    model2.load_corpus(ours)  # retrieval/model.py:81-85
+    assert not model2.embeddings_staled and torch.equal(model2.corpus_embeddings, E)
+    where = {(p.path, p.full_name, tuple(p.start)): i for i, p in enumerate(model.corpus.all_premises)}
+    rng = np.random.default_rng(172)
+    queries = []
+    for j in range(8):
+        while True:
+            f = int(rng.integers(6, 12))
+            pos = (int(rng.integers(1, 300)), int(rng.integers(0, 40)))
+            if len(model.corpus.get_accessible_premises(files[f]["path"], H.Pos(*pos))) >= 8:
+                break
+        state = synth.synth_state(rng, int(rng.integers(40, 160)))
+        prem, sc = model.retrieve(state, files[f]["path"], f"thm{j}", H.Pos(*pos), 5)
+        prem2, sc2 = model2.retrieve(state, files[f]["path"], f"thm{j}", H.Pos(*pos), 5)
+        ids = [where[(p.path, p.full_name, tuple(p.start))] for p in prem]
+        assert ids == [where[(p.path, p.full_name, tuple(p.start))] for p in prem2] and sc == sc2, j
+        assert len(model.corpus.get_accessible_premises(files[f]["path"], H.Pos(*pos))) == \
+            len(model2.corpus.get_accessible_premises(files[f]["path"], H.Pos(*pos)))
+        queries.append({"path": files[f]["path"], "pos": list(pos), "state": state, "ids": ids, "scores": sc})
+    json.dump({"corpus_seed": 171, "n_files": 12, "n_premises": 120, "max_imports": 4, "code_bytes": [20, 90],
+               "weight_seed": 14, "N": len(model.corpus), "queries": queries, "k": 5,
+               "checked": "the imported reference unpickled a file written by reprover_amd.common.save_reference_pickle with "
+                          "plain pickle.load, load_corpus()ed it and retrieve()d these answers - identical to its own index"},
+              open(os.path.join(OUT, "g17_reference_loads_our_pickle.json"), "w"), ensure_ascii=False)
+    print(f"g17 ok: the reference loaded our pickle ({os.path.getsize(ours)} bytes) and retrieved identically")
+
+
 def g12_train_small_width():
     """The training step at ByT5-small WIDTH (d_model 1472, 6 heads, d_ff 3584; 2 layers): the reference's
     ``loss.backward()`` and three AdamW steps as in G11, on a batch whose sequences span several 128-token blocks.  36 M
@@ -904,10 +1012,13 @@ def g15_augmented_state():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15",
+                             "g5h", "g7h", "g9h", "g17"]
     torch.manual_seed(0)
     for name in which:
         {"g1": g1_tokenizer, "g2": g2_serialize, "g3": g3_buckets, "g4": g4_tiny, "g5": g5_small,
          "g6": g6_nearest, "g7": g7_predict, "g8": g8_eval_data, "g9": g9_base_full_depth, "g10": g10_train_forward, "g11": g11_train_backward,
          "g12": g12_train_small_width, "g13": g13_train_examples,
-         "g14": g14_reference_indexed_corpus, "g15": g15_augmented_state}[name]()
+         "g14": g14_reference_indexed_corpus, "g15": g15_augmented_state,
+         "g17": g17_reference_loads_our_pickle,
+         "g5h": lambda: g5_small("hf"), "g7h": lambda: g7_predict("hf"), "g9h": lambda: g9_base_full_depth("hf")}[name]()

@@ -68,6 +68,8 @@ class _LightningModule(torch.nn.Module):
 def install():
     """Install the stand-in modules and import the reference. Returns (common, retrieval.model)."""
     _mod("lean_dojo", Pos=Pos, LeanGitRepo=object)
+    _mod("lean_dojo.data_extraction")
+    _mod("lean_dojo.data_extraction.lean", Pos=Pos)  # the module lean_dojo defines Pos in (what a pickle of it names)
     _mod("loguru", logger=_Quiet())
     _mod("pytorch_lightning", LightningModule=_LightningModule, LightningDataModule=object, Trainer=object)
     _mod("pytorch_lightning.utilities")

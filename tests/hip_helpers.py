@@ -163,23 +163,7 @@ def topk_merge(scores, ids, counts):
     return out_i, out_s, out_c
 
 
-def synth_masks(rng, N, B, F, density=0.3):
-    """Random accessibility operands + the boolean [B, N] predicate they encode."""
-    cuts = np.sort(rng.choice(np.arange(1, N), size=F - 1, replace=False)) if F > 1 else np.array([], dtype=int)
-    file_of = np.zeros(N, dtype=np.int32)
-    file_of[cuts] = 1
-    file_of = np.cumsum(file_of).astype(np.int32)
-    end_key = rng.integers(0, 1 << 30, size=N).astype(np.int64)
-    own = rng.integers(0, F, size=B).astype(np.int32)
-    qk = rng.integers(0, 1 << 30, size=B).astype(np.int64)
-    imp = rng.random((B, F)) < density
-    imp[np.arange(B), own] = False
-    words = (B + 31) // 32
-    padded = np.zeros((F, words * 32), dtype=np.uint8)
-    padded[:, :B] = imp.T
-    bits_t = np.packbits(padded, axis=1, bitorder="little").view(np.uint32).reshape(F, words)
-    acc = imp[:, file_of] | ((file_of[None, :] == own[:, None]) & (end_key[None, :] <= qk[:, None]))
-    return (file_of, end_key, bits_t, own, qk), acc
+from reprover_amd.synth import synth_masks  # noqa: E402,F401  (moved: bench.py --config c5 draws the same operands)
 
 
 def masks_to_device(m, device):

@@ -290,6 +290,34 @@ def test_load_lightning_checkpoint_file(workdir, tmp_path):
     assert torch.equal(c.encode_texts(texts), b.encode_texts(texts))
 
 
+def test_fit_cli_keeps_a_checkpoint_without_a_log_dir(workdir, tmp_path, monkeypatch):
+    """`fit` from a reference-style YAML that names no root directory (Lightning's Trainer then defaults
+    default_root_dir to the working directory and always keeps a checkpoint): the weights must not be discarded
+    (ADVICE r05).  And a resume whose directory is missing falls back to the `.old` copy a crash between the two
+    renames of the checkpoint swap leaves behind."""
+    import yaml
+
+    d, ckpt, cpath, sdir, splits, cfg, sd = workdir
+    conf = {"seed_everything": 3407, "trainer": {"max_steps": 2, "gradient_clip_val": 1.0},
+            "model": {"model_name": ckpt, "num_retrieved": 10, "lr": 1e-4, "warmup_steps": 1},
+            "data": {"data_path": sdir, "corpus_path": cpath, "eval_batch_size": 16, "max_seq_len": 256,
+                     "batch_size": 4, "num_negatives": 1, "num_in_file_negatives": 0}}
+    cpath_yaml = str(tmp_path / "fit.yaml")
+    yaml.safe_dump(conf, open(cpath_yaml, "w"))
+    monkeypatch.chdir(tmp_path)
+    main_cli.main(["fit", "--config", cpath_yaml])
+    ck = tmp_path / "lightning_logs" / "checkpoint"
+    assert (ck / "training_state.safetensors").exists() and (ck / "loop_state.json").exists()
+    reloaded = PremiseRetriever.load_hf(str(ck), 256, "cuda:0")  # an HF directory of the trained weights
+    base = PremiseRetriever.load_hf(ckpt, 256, "cuda:0")
+    texts = ["theorem foo : a = b"]
+    assert not torch.equal(reloaded.encode_texts(texts), base.encode_texts(texts))
+    os.replace(ck, str(ck) + ".old")  # what a crash inside save_fit_checkpoint's swap leaves
+    main_cli.main(["fit", "--config", cpath_yaml, "--max-steps", "3", "--resume-from", str(ck), "--log-dir", str(tmp_path / "second")])
+    import json as _json
+    assert _json.load(open(tmp_path / "second" / "checkpoint" / "loop_state.json"))["step"] == 3
+
+
 def test_validation_hooks_on_the_class(workdir):
     """on_validation_start / validation_step as methods of PremiseRetriever (reference retrieval/model.py:212-268), called
     the way Lightning calls them, give the epoch metrics run_validate reports (the oracle's Recall@k / MRR)."""

@@ -35,6 +35,12 @@ def small(small_weights):
     return PremiseRetriever.from_state_dict(cfg, sd, 2048, "cuda:0", dtype=torch.float32)
 
 
+@pytest.fixture(scope="module")
+def small_hf(small_weights_hf):
+    cfg, sd = small_weights_hf
+    return PremiseRetriever.from_state_dict(cfg, sd, 2048, "cuda:0", dtype=torch.float32)
+
+
 def test_tiny_encoder_matches_hf_golden(tiny, golden_dir):
     g = np.load(os.path.join(golden_dir, "g4_tiny.npz"), allow_pickle=True)
     texts = list(g["texts"])
@@ -109,8 +115,20 @@ def test_byt5_small_matches_hf_golden(small, golden_dir, parity_margins):
     assert m["min_row_cosine"] >= max(0.997, m["hf_bf16_min_row_cosine"])
     assert m["rows_further_from_fp32_than_hf_bf16"] == 0, "a row is further from the oracle than HF-bf16 is"
     assert m["max_abs_emb_err"] <= m["hf_bf16_max_abs_emb_err"], "further from the fp32 oracle than the reference's own bf16 mode"
-    # retrieval scores of these rows against each other: within 1e-2 absolute of the oracle's
+    # retrieval scores of these rows against each other: within 1e-2 absolute of the oracle's, and no further from them
+    # than HF-bf16's are (the score-side half of "no worse than the reference's GPU mode")
     assert m["max_abs_pairwise_score_err"] < 1e-2
+    assert m["max_abs_pairwise_score_err"] <= m["hf_bf16_max_abs_pairwise_score_err"], \
+        "pairwise scores further from the fp32 oracle than the reference's own bf16 mode"
+
+
+def test_byt5_small_hf_init_scales_meets_the_written_contract(small_hf, golden_dir, parity_margins):
+    """Fixture G5h: the 16 texts of G5 on weights at exactly HF's init scales (SURVEY.md 8c's G5 recipe; q ~ (D dk)^-1/2,
+    position table ~ D^-1/2).  The contract AS WRITTEN, nothing relaxed: every row's cosine with the reference's fp32
+    embedding >= 0.999, pairwise scores within 1e-2, and the engine no worse than HF-bf16 on any metric."""
+    m = parity_margins["g5h_byt5_small_12_layers_hf_init"] = pm.g5_margins(small_hf, golden_dir, "g5h_byt5_small.npz")
+    print(f"byt5-small, HF-init scales: {m}")
+    pm.assert_written_contract(m)
 
 
 def test_byt5_base_full_depth_matches_hf_golden(golden_dir, parity_margins):
@@ -127,6 +145,17 @@ def test_byt5_base_full_depth_matches_hf_golden(golden_dir, parity_margins):
     assert m["rows_further_from_fp32_than_hf_bf16"] == 0, "a row is further from the oracle than HF-bf16 is"
     assert m["max_abs_emb_err"] <= m["hf_bf16_max_abs_emb_err"], "further from the fp32 oracle than the reference's own bf16 mode"
     assert m["max_abs_pairwise_score_err"] < max(1e-2, m["hf_bf16_max_abs_pairwise_score_err"])
+    assert m["max_abs_pairwise_score_err"] <= m["hf_bf16_max_abs_pairwise_score_err"], \
+        "pairwise scores further from the fp32 oracle than the reference's own bf16 mode"
+
+
+def test_byt5_base_full_depth_hf_init_scales_meets_the_written_contract(golden_dir, parity_margins):
+    """Fixture G9h: BASELINE configs[4]'s encoder (18 layers) on HF-init-scale weights - the written contract un-relaxed."""
+    cfg = synth.t5_config("byt5-base")
+    model = PremiseRetriever.from_state_dict(cfg, synth.synth_state_dict(cfg, scale="hf"), 1024, "cuda:0", dtype=torch.float32)
+    m = parity_margins["g9h_byt5_base_18_layers_hf_init"] = pm.g9_margins(model, golden_dir, "g9h_byt5_base.npz")
+    print(f"byt5-base x18, HF-init scales: {m}")
+    pm.assert_written_contract(m)
 
 
 def test_bf16_output_and_chunked_passes_agree(small, golden_dir):
@@ -217,6 +246,43 @@ def test_mixed_and_edge_forms_at_other_pass_sizes(small, n_states):
         for name, v in zip(names, (9, 1, 20, 1)):
             _lib.check(lib.rp_set_option(name, v), "opt")
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    assert torch.isfinite(outs[0]).all() and (outs[0].norm(dim=1) - 1).abs().max().item() < 1e-5
+
+
+def test_launch_forms_are_the_same_bits_at_byt5_base_width():
+    """The persistent / mixed / edge launch forms against one workgroup per tile at ByT5-BASE shapes: d_model
+    1536 = 6 exact feature tiles (no edge tile; 24 statistic slots instead of 23), QKV 2304 = 9 tiles, FFN 2 x 3968 = 31
+    tiles - other tile counts per XCD range, other metadata sizes behind the ring than ByT5-small's.  Two layers keep
+    the test short; a 45 k-token pass gives every projection more tiles than CUs."""
+    from reprover_amd import _lib
+
+    lib = _lib.load()
+    cfg = synth.t5_config("byt5-base")
+    cfg["num_layers"] = 2
+    model = PremiseRetriever.from_state_dict(cfg, synth.synth_state_dict(cfg, seed=9), 2048, "cuda:0", dtype=torch.float32)
+    rng = np.random.default_rng(41)
+    lens = synth.synth_lengths(rng, 170, "mix", lo=16, hi=2048)
+    texts = [synth.synth_state(rng, int(n) - 1) for n in lens]
+    ids, cu = model.tokenizer.packed(texts, model.max_seq_len)
+    assert int(cu[-1]) > 36000
+    names = (b"gemm_rs_lds", b"gemm_persist", b"gemm_edge_layout", b"gemm_mixed", b"gemm_tail_split")
+    outs = []
+    old = model.encoder.max_tokens_per_pass
+    model.encoder.max_tokens_per_pass = 1 << 20
+    try:
+        for forms in ((0, 9, 1, 20, 1), (0, 0, 0, 0, 0), (1, 29, 1, 21, 1), (1, 0, 0, 0, 1)):
+            for name, v in zip(names, forms):
+                _lib.check(lib.rp_set_option(name, v), "opt")
+            out = torch.empty((len(texts), model.embedding_size), dtype=torch.float32, device="cuda:0")
+            model.encoder.encode_packed(ids, cu, out)
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        model.encoder.max_tokens_per_pass = old
+        for name, v in zip(names, (0, 9, 1, 20, 1)):
+            _lib.check(lib.rp_set_option(name, v), "opt")
+    for o in outs[1:]:
+        assert torch.equal(outs[0].view(torch.int32), o.view(torch.int32))
     assert torch.isfinite(outs[0]).all() and (outs[0].norm(dim=1) - 1).abs().max().item() < 1e-5
 
 
