@@ -532,6 +532,88 @@ def run_c5(args):
     }), flush=True)
 
 
+def run_plumbing_only(args, world, rank, local, exchange_how):
+    """`--plumbing-only`: everything of the N-rank run that is not GPU work, on the host (gloo): the rendezvous from the
+    launcher's environment, the one-builder-per-node barrier, this rank's row shard, the two collectives of a step on CPU
+    blocks of the step's shapes (query embeddings; the packed [scores | ids | counts] block as all-gather and as sliced
+    all-to-all, merged by a host merge and checked against the unsharded answer), the barrier-bracketed max-over-ranks clock,
+    ONE JSON line from rank 0.  No kernel runs and nothing is measured: the line says so."""
+    from reprover_amd.dist import sliced_exchange_merge
+
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo")
+        if local == 0:
+            build.build()  # (cross-compiles without a GPU; a no-op when the shipped .so is current)
+        dist.barrier()
+    else:
+        build.build()
+    _lib.load()
+    N, D, k, Bq = 4096, 64, 10, 8  # small stand-ins: the plumbing does not depend on the sizes
+    bounds = np.linspace(0, N, world + 1).astype(int)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    BQ = Bq * world
+    g = torch.Generator().manual_seed(synth.SEED)
+    E = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=1)
+    q_all_ref = torch.nn.functional.normalize(torch.randn(BQ, D, generator=g), dim=1)
+    q_loc = q_all_ref[rank * Bq : (rank + 1) * Bq].contiguous()
+    q_all = torch.empty((BQ, D))
+    n_coll = 0
+
+    def gather(dst, src):
+        nonlocal n_coll
+        n_coll += 1
+        if world > 1:
+            dist.all_gather(list(dst.view((world,) + tuple(src.shape)).unbind(0)), src)
+        else:
+            dst.copy_(src.view_as(dst))
+
+    def host_merge(g_ids, g_scores, g_counts):  # [world, B, k] lists -> top-k per query (ties to the lower id)
+        W, B, _ = g_scores.shape
+        s = g_scores.permute(1, 0, 2).reshape(B, W * k)
+        i = g_ids.permute(1, 0, 2).reshape(B, W * k)
+        key = torch.argsort(-s.double() + i.double() * 1e-12, dim=1)[:, :k]
+        return torch.gather(i, 1, key), torch.gather(s, 1, key), g_counts.sum(0).clamp(max=k)
+
+    t0 = time.perf_counter()
+    gather(q_all, q_loc)  # collective 1: query embeddings
+    S = q_all @ E[lo:hi].T
+    sc, ix = torch.topk(S, k, dim=1)
+    ids = (ix + lo).to(torch.int32)
+    cnt = torch.full((BQ,), k, dtype=torch.int32)
+    blk = BQ * (2 * k + 1)
+    send = torch.cat([sc.contiguous().view(torch.int32).reshape(-1), ids.reshape(-1), cnt])
+    recv = torch.empty((world, blk), dtype=torch.int32)
+    gather(recv, send)  # collective 2, all-gather form: the packed block
+    g_s = recv[:, : BQ * k].view(torch.float32).view(world, BQ, k)
+    g_i = recv[:, BQ * k : 2 * BQ * k].view(world, BQ, k)
+    g_c = recv[:, 2 * BQ * k :]
+    mine = slice(rank * Bq, (rank + 1) * Bq)
+    ag = host_merge(g_i[:, mine], g_s[:, mine], g_c[:, mine])
+    a2a = sliced_exchange_merge(ids, sc, cnt, None, merge=host_merge) if world > 1 else ag
+    want_s, want_i = torch.topk(q_loc @ E.T, k, dim=1)
+    ok = bool(torch.equal(ag[0], want_i.to(torch.int32)) and torch.equal(a2a[0], want_i.to(torch.int32))
+              and torch.allclose(ag[1], want_s) and torch.equal(q_all, q_all_ref))
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        tt = torch.tensor([dt, float(ok)], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dmin = torch.tensor([float(ok)], dtype=torch.float64)
+        dist.all_reduce(dmin, op=dist.ReduceOp.MIN)
+        dt, ok = float(tt[0]), bool(dmin[0] == 1.0)
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing only (no GPU work, nothing measured)", "plumbing_only": True, "value": None,
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
+                          "config": {"exchange": exchange_how if world > 1 else None, "collectives_per_step": 2 if world > 1 else 0,
+                                     "shard_rows": [int(b) for b in bounds], "backend": "gloo",
+                                     "sharded_merge_equals_single_gpu": ok},
+                          "max_over_ranks_s": dt}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", choices=("c2", "c5"), default="c2",
@@ -541,9 +623,18 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exchange", choices=("allgather", "alltoall"), default=os.environ.get("RP_BENCH_EXCHANGE", "allgather"),
+    ap.add_argument("--exchange", choices=("auto", "allgather", "alltoall"), default=os.environ.get("RP_BENCH_EXCHANGE", "auto"),
                     help="N > 1: how the per-shard top-k lists reach the rank that merges them: ONE packed all-gather "
-                         "(north_star's form, the default) or ONE all-to-all of per-destination slices (1 / N of the bytes)")
+                         "(north_star's form) or ONE all-to-all of per-destination slices (1 / N of the bytes: in this step a rank "
+                         "merges only its OWN 256 queries).  auto (default): by bytes - the all-gather below 4 ranks, the "
+                         "all-to-all from 4 ranks on (at N = 8 the all-gather delivers 11.5 MB per rank of which 1.4 MB are "
+                         "merged); `topk_only` reports both forms either way, and the product's replicated-query predict keeps "
+                         "the all-gather (every rank needs every list there)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="run ONLY the multi-rank plumbing of this script on the host - argument checks, the self-launch of the "
+                         "N ranks, rendezvous, the one-builder-per-node barrier, shard bounds, one packed all-gather + one sliced "
+                         "all-to-all of CPU blocks, the max-over-ranks clock - and print a line marked plumbing_only (no GPU, no "
+                         "measurement; tests/test_dist_cpu.py drives it at N = 8 under gloo)")
     ap.add_argument("--premise-sample", type=int, default=4096, help="premises in the encode-throughput leg")
     ap.add_argument("--no-full-reindex", action="store_true", help="skip the 130,000-premise reindex_corpus leg (~20 s)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step leg")
@@ -571,6 +662,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus})")
+    if args.exchange == "auto":
+        args.exchange = "alltoall" if world >= 4 else "allgather"
+        exchange_how = f"{args.exchange} (auto: {'>= 4 ranks' if world >= 4 else '< 4 ranks'})"
+    else:
+        exchange_how = args.exchange
+    if args.plumbing_only:
+        return run_plumbing_only(args, world, rank, local, exchange_how)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     # RP_BENCH_SHARE_GPU=1 + RP_BENCH_BACKEND=gloo: functional smoke run of the N > 1 code path on a
     # single-GPU box (every rank on device 0; not a measurement).
@@ -1157,7 +1255,7 @@ def main():
             "index": "row-sharded %d-way, bf16 unit-norm random rows" % world,
             "weights": "random-init ByT5-small (d_model 1472, 12 layers, 6 heads, d_ff 3584)",
             "accessible_premises_first_queries": n_acc.tolist(), "all_counts_eq_k": counts_ok, "sharded_merge_equals_single_gpu": merged_ok,
-            "collectives_per_step": collectives_per_step, "exchange": args.exchange if world > 1 else None,
+            "collectives_per_step": collectives_per_step, "exchange": exchange_how if world > 1 else None,
         },
         "premises_per_s": prem_per_s,
         "premises_per_s_incl_host_tokenisation": prem_per_s_host,

@@ -48,6 +48,10 @@ def embedding_margins(emb: torch.Tensor, gold: torch.Tensor, hf_bf16: torch.Tens
         "max_abs_pairwise_score_err": float(((emb @ emb.T) - (gold @ gold.T)).abs().max()),
         "hf_bf16_max_abs_pairwise_score_err": float(((hf_bf16 @ hf_bf16.T) - (gold @ gold.T)).abs().max()),
         "rows_further_from_fp32_than_hf_bf16": int((cos < cos_hf - 1e-4).sum()),
+        # the maximum over n (n - 1) / 2 pairs is a noisy statistic (it moves by +-10 % with any change of rounding order);
+        # the root-mean-square over the same pairs is the robust form of "no further from fp32 than HF-bf16 on scores"
+        "rms_pairwise_score_err": float(((emb @ emb.T) - (gold @ gold.T)).double().pow(2).mean().sqrt()),
+        "hf_bf16_rms_pairwise_score_err": float(((hf_bf16 @ hf_bf16.T) - (gold @ gold.T)).double().pow(2).mean().sqrt()),
     }
     d["contract_met"] = bool(d["min_row_cosine"] >= 0.999 and d["max_abs_pairwise_score_err"] <= 1e-2)
     d["hf_bf16_meets_contract"] = bool(d["hf_bf16_min_row_cosine"] >= 0.999 and d["hf_bf16_max_abs_pairwise_score_err"] <= 1e-2)

@@ -45,7 +45,8 @@ def pytest_terminal_summary(terminalreporter):
         if "min_row_cosine" in m and "max_abs_pairwise_score_err" in m:
             w(f"  {name}: min row cosine {m['min_row_cosine']:.5f} [{m['hf_bf16_min_row_cosine']:.5f}], max |d emb| "
               f"{m['max_abs_emb_err']:.2e} [{m['hf_bf16_max_abs_emb_err']:.2e}], max |d score| {m['max_abs_pairwise_score_err']:.2e} "
-              f"[{m['hf_bf16_max_abs_pairwise_score_err']:.2e}], written contract met: {m['contract_met']}, no worse than "
+              f"[{m['hf_bf16_max_abs_pairwise_score_err']:.2e}] rms {m['rms_pairwise_score_err']:.2e} "
+              f"[{m['hf_bf16_rms_pairwise_score_err']:.2e}], written contract met: {m['contract_met']}, no worse than "
               f"HF-bf16 on any metric: {m['no_worse_than_hf_bf16']}")
         elif "min_row_cosine" in m:
             w(f"  {name}: {m['rows']} rows, min cosine {m['min_row_cosine']:.5f} [{m['hf_bf16_min_row_cosine']:.5f}], mean "

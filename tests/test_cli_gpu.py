@@ -238,7 +238,7 @@ def test_bench_launches_its_own_ranks():
     assert d["config"]["all_counts_eq_k"] is True
     # the top-k stage timed WITH its collective, under both exchange forms (packed all-gather = the default and
     # north_star's form; all-to-all of per-destination slices): both must reproduce the single-GPU lists
-    assert d["config"]["exchange"] == "allgather"
+    assert d["config"]["exchange"].startswith("allgather")  # auto: by bytes, the all-gather below 4 ranks
     t = d["topk_only"]
     for how in ("allgather", "alltoall"):
         assert t[how]["sharded_merge_equals_single_gpu"] is True, how

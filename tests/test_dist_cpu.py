@@ -14,6 +14,8 @@ import torch.multiprocessing as mp
 
 from oracle import common_ref
 from reprover_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from reprover_amd.common import Context, Corpus, Pos
 from reprover_amd.dist import (IndexShard, gather_shards, shard_bounds, sharded_get_nearest_premises,
                                 sharded_nearest_premise_ids, sliced_exchange_merge)
@@ -148,3 +150,44 @@ def test_sharded_retrieval_world2_gloo():
     mp.start_processes(_worker, args=(2, port, path, d), nprocs=2, join=True, start_method="spawn")
     spans = [tuple(map(int, open(os.path.join(d, f"ok{r}")).read().split())) for r in range(2)]
     assert spans[0][0] == 0 and spans[0][1] == spans[1][0] and spans[1][1] > spans[1][0]
+
+
+def _run_bench(cmd, env):
+    import subprocess
+
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, res.stdout[-2000:]  # ONE line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_eight_rank_plumbing_under_gloo():
+    """`bench.py --gpus 8` as the driver's scaling run starts it, minus the GPU work (`--plumbing-only`, gloo, CPU blocks):
+    (a) the script launching its own 8 ranks, (b) the driver's launcher command line (`python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...`) - rendezvous, the
+    one-builder barrier, 8 row shards, the two collectives of a step in both exchange forms with the merge equal to the
+    unsharded answer on every rank, the max-over-ranks clock, one JSON line; a --gpus / WORLD_SIZE mismatch is refused."""
+    import socket
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    d = _run_bench([sys.executable, bench, "--gpus", "8", "--steps", "3", "--warmup", "1", "--plumbing-only"], env)
+    assert d["plumbing_only"] is True and d["n_gpus"] == 8 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["config"]["sharded_merge_equals_single_gpu"] is True and d["config"]["collectives_per_step"] == 2
+    assert d["config"]["exchange"].startswith("alltoall (auto")  # by bytes: all-to-all from 4 ranks on
+    assert len(d["config"]["shard_rows"]) == 9 and d["config"]["shard_rows"][0] == 0
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    d = _run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                    "127.0.0.1", "--master-port", str(port), bench, "--gpus", "8", "--steps", "2", "--warmup", "1",
+                    "--plumbing-only", "--exchange", "allgather"], env)
+    assert d["n_gpus"] == 8 and d["config"]["exchange"] == "allgather" and d["config"]["sharded_merge_equals_single_gpu"] is True
+    d = _run_bench([sys.executable, bench, "--gpus", "2", "--plumbing-only"], env)
+    assert d["config"]["exchange"].startswith("allgather (auto")
+    bad = subprocess.run([sys.executable, bench, "--gpus", "4", "--plumbing-only"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
