@@ -309,6 +309,38 @@ def shard_shape_call_us(lib, corpus, E_full, dev):
         e1.record()
         torch.cuda.synchronize()
         out[f"{n}_gpus_{BQ}q_x_{rows}rows"] = e0.elapsed_time(e1) / 20 * 1e3
+        if n > 1:
+            # ... and the merge behind the exchange at that world size, on this one GPU: n sorted lists (the shard call's own
+            # output, replicated with disjoint id ranges) of a rank's OWN 256 queries -> rp_topk_merge_strided, as the step runs it
+            blk = B_STATES * (2 * TOP_K + 1)
+            recv = torch.empty((n, blk), dtype=torch.int32, device=dev)
+            g_s = recv[:, : B_STATES * TOP_K].view(torch.float32).view(n, B_STATES, TOP_K)
+            g_i = recv[:, B_STATES * TOP_K : 2 * B_STATES * TOP_K].view(n, B_STATES, TOP_K)
+            g_c = recv[:, 2 * B_STATES * TOP_K :]
+            for r in range(n):
+                g_s[r].copy_(o_s[:B_STATES])
+                g_i[r].copy_(o_i[:B_STATES] + r * rows)
+                g_c[r].copy_(o_c[:B_STATES])
+            mwb = lib.rp_topk_merge_workspace_bytes(n, B_STATES, TOP_K)
+            mws = torch.empty(mwb, dtype=torch.uint8, device=dev)
+            f_s = torch.empty((B_STATES, TOP_K), dtype=torch.float32, device=dev)
+            f_i = torch.empty((B_STATES, TOP_K), dtype=torch.int32, device=dev)
+            f_c = torch.empty((B_STATES,), dtype=torch.int32, device=dev)
+
+            def merge():
+                _lib.check(lib.rp_topk_merge_strided(g_s.data_ptr(), g_i.data_ptr(), g_c.data_ptr(), g_s.stride(0), n, B_STATES, TOP_K,
+                                                     f_s.data_ptr(), f_i.data_ptr(), f_c.data_ptr(), mws.data_ptr(), mwb,
+                                                     _lib.current_stream()), "rp_topk_merge_strided")
+
+            for _ in range(3):
+                merge()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(20):
+                merge()
+            e1.record()
+            torch.cuda.synchronize()
+            out[f"{n}_gpus_merge_of_{n}_lists_us"] = e0.elapsed_time(e1) / 20 * 1e3
     return out
 
 
@@ -388,6 +420,8 @@ def kernel_source_hash() -> str:
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "reprover_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
+        if os.path.isdir(os.path.join(csrc, name)):  # csrc/probes/: bodies of probe builds, never part of the product library
+            continue
         with open(os.path.join(csrc, name), "rb") as fh:
             h.update(name.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]

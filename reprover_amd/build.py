@@ -29,7 +29,7 @@ def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not os.path.isdir(os.path.join(CSRC, f))]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "reprover_hip.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 

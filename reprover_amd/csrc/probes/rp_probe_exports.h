@@ -1,0 +1,8 @@
+// PROBE BUILDS ONLY (-DRP_PHASE_PROBE): copy the per-workgroup phase timestamps (probes/rp_probe_hooks.h) to the host.
+#pragma once
+extern "C" int rp_probe_read_phase_ts(unsigned long long* host_out, int n_words) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(rp::g_phase_ts), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int rp_probe_read_handover_ts(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(rp::g_handover_ts), sizeof(rp::g_handover_ts), 0, hipMemcpyDeviceToHost);
+}

@@ -54,7 +54,7 @@ int g_gemm_tail_variant = 30;  // tile configuration of that tail round: 30 = 25
 int g_gemm_tail_split = 1;  // big passes without a mixed launch: the last partial round of 256 x 256 tiles as one round of smaller tiles
 int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
 int g_gemm_skinny = 1;
-int g_gemm_skinny_variant = 12;
+int g_gemm_skinny_variant = 0;  // 15: few-token passes forced onto variant 15 (a test); 0: the measured table of pick_gemm_variant
 // Experiment knob: spread the first round of workgroups of the big GEMMs over this many microseconds (0 = off).
 // All 256 CUs otherwise reach their epilogues at the same moment, round after round (tiles take equal time), and
 // the epilogue traffic arrives in bursts.  Indexed by kernel class (RP_K_GEMM_*).
@@ -141,7 +141,7 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     return RP_OK;
   }
   if (!strcmp(name, "gemm_skinny_variant")) {
-    RP_REQUIRE(value == 12 || value == 15, "gemm_skinny_variant must be 12 or 15");
+    RP_REQUIRE(value == 0 || value == 15, "gemm_skinny_variant must be 0 or 15");
     g_gemm_skinny_variant = value;
     return RP_OK;
   }
@@ -863,12 +863,6 @@ extern "C" RpStatus rp_dbg_attention(const void* qkv, const int32_t* cu, const f
   return RP_OK;
 }
 
-#ifdef RP_PHASE_PROBE
-// probe build only (tools/probes/gemm_phase.py): copy the per-workgroup phase timestamps to the host
-extern "C" int rp_probe_read_phase_ts(unsigned long long* host_out, int n_words) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(rp::g_phase_ts), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
-}
-extern "C" int rp_probe_read_handover_ts(unsigned long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(rp::g_handover_ts), sizeof(rp::g_handover_ts), 0, hipMemcpyDeviceToHost);
-}
+#ifdef RP_PHASE_PROBE  // probe builds only (tools/probes/gemm_phase.py): the host-side readers of the phase timestamps
+#include "probes/rp_probe_exports.h"
 #endif

@@ -455,9 +455,8 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const size_t off = (size_t)(n_base + j * 32 + c * 8 + rr) * ldx + f;
-#ifdef RP_ABL_NOLOAD  // probe builds: the residual epilogue without the reads of the old planes
-        xh[p][c] = make_uint4((uint32_t)off, 0u, 0u, 0u);
-        xl[p][c] = {};
+#ifdef RP_ABL_NOLOAD  // (probe builds only; body in probes/rp_probe_hooks.h)
+        RP_ABL_NOLOAD_BODY(xh[p][c], xl[p][c], off);
 #else
         if constexpr (SPLIT_IN)
           xh[p][c] = *reinterpret_cast<const uint4*>(xhi_in + off);
@@ -518,8 +517,8 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
             hilo_update2(h.z, l.z, d1.x, d1.y, oh.z, ol.z, ss);
             hilo_update2(h.w, l.w, d1.z, d1.w, oh.w, ol.w, ss);
           }
-#ifdef RP_ABL_NOSTORE
-          asm volatile("" ::"v"(oh.x), "v"(oh.y), "v"(oh.z), "v"(oh.w), "v"(ol.x), "v"(ol.y));
+#ifdef RP_ABL_NOSTORE  // (probe builds only)
+          RP_ABL_KEEP6(oh.x, oh.y, oh.z, oh.w, ol.x, ol.y);
 #else
           *reinterpret_cast<uint4*>(xhi + off) = oh;
           if constexpr (LO8)
@@ -576,8 +575,8 @@ struct EpiGegluBf16T {  // W rows interleaved 32 gate / 32 up: even row-fragment
             float y[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-#ifdef RP_ABL_NOGELU  // probe builds: the epilogue without the activation's arithmetic
-              y[e] = acc[i][jb + jj][4 * g + e] * acc[i + 1][jb + jj][4 * g + e];
+#ifdef RP_ABL_NOGELU  // (probe builds only)
+              y[e] = RP_ABL_NOGELU_BODY(acc[i][jb + jj][4 * g + e], acc[i + 1][jb + jj][4 * g + e]);
 #else
               y[e] = gelu_new(acc[i][jb + jj][4 * g + e] * sc) * (acc[i + 1][jb + jj][4 * g + e] * sc);
 #endif
@@ -593,8 +592,8 @@ struct EpiGegluBf16T {  // W rows interleaved 32 gate / 32 up: even row-fragment
         const int t = t0 + rr;
         if (t < nrows) {
           const uint4 v = *reinterpret_cast<const uint4*>(stage + t * EPI_ROW_BYTES + sub * 16);
-#ifdef RP_ABL_NOSTORE  // probe builds: the epilogue without its global stores
-          asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#ifdef RP_ABL_NOSTORE  // (probe builds only)
+          RP_ABL_KEEP4(v.x, v.y, v.z, v.w);
 #else
           if (2 * f < n_valid) *reinterpret_cast<uint4*>(out + (size_t)(n_base + jb * 32 + t) * ldo + f) = v;
 #endif
@@ -931,11 +930,11 @@ static int pick_gemm_variant(int prof_class, int M, int n_rows_w, int K, int tok
   if (g_gemm_skinny && m256) {
     const int tv = (tokens_valid > 0 && tokens_valid < M) ? tokens_valid : M;
     const bool few_tiles = ((n_rows_w + 255) / 256) * (M / 256) < 96;
-    if (few_tiles && g_gemm_skinny_variant != 12) v = g_gemm_skinny_variant;  // forced by a test
+    if (few_tiles && g_gemm_skinny_variant != 0) v = g_gemm_skinny_variant;  // forced by a test (15)
     else if (prof_class == RP_K_GEMM_WI) v = (tv <= 256) ? 16 : (few_tiles || tv <= 1024) ? 0 : v;
     else if (few_tiles) v = (tv <= 1024) ? 16 : 0;
   }
-  if ((v == 20 || v == 26) && !k64) v = 9;  // 64-wide K tiles need K % 64 == 0
+  if (v == 26 && !k64) v = 9;  // 64-wide K tiles need K % 64 == 0
   if (v == 16 && !k64) v = 15;
   if (v == 16 && g_gemm_small_pipe) v = 17;  // the same tile on the software-pipelined loop
   if (v >= 5 && !m256) v = 0;
@@ -944,14 +943,14 @@ static int pick_gemm_variant(int prof_class, int M, int n_rows_w, int K, int tok
 inline bool small_variant(int v) { return v == 0 || (v >= 15 && v <= 17); }
 
 // GemmCfg<feature tile, token tile, BK, waves over features, waves over tokens, stages[, pipelined]>:
-//   20 / 26  pipelined 256 x 256 x 64, 4 / 8 waves     (the encoder's big GEMMs)
+//   26       pipelined 256 x 256 x 64, 8 waves          (the encoder's big GEMMs; the 4-wave form 20 - 128 x 128 per wave,
+//            accumulators in AGPRs - lost the in-step A/B of round 3 and left the sources in round 6, as did 12 = 64 x 256 x 32)
 //   27 / 28  (RP_EXPERIMENTS builds) pipelined 256 x 128 x 32 / 128 x 256 x 32 (features x tokens), 3 stages, 4 waves, TWO workgroups per CU
 //   30       pipelined 256 x 128 x 64, 8 waves          (the FFN-out projection's tail round: half tiles, one per CU)
 //   9        plain 256 x 256 x 32, 3 stages             (K % 64 != 0)
 //   0        plain 128 x 128 x 32, 3 stages, 2 blocks/CU (attention-out; token counts not a multiple of 256)
 //   17       64 x 128 x 64, 4 stages, pipelined loop    (up to ~1024 tokens: single-state queries)
 //   16 / 15  the same on the plain loop / x 32, 7 stages (16: kept selectable; 15: K % 64 != 0)
-//   12       64 x 256 x 32, 7 stages                    (on request only)
 // SMALL_ONLY: the epilogue type exists for the small configurations only (pick_gemm_variant said so).
 template <bool SMALL_ONLY = false, class Epi>
 static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, int ldw, int n_rows_w,
@@ -961,7 +960,6 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
   const int v = force_variant >= 0 ? force_variant : pick_gemm_variant(prof_class, M, n_rows_w, K, tokens_valid);
   if constexpr (!SMALL_ONLY) {
     switch (v) {
-      case 20: return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
       case 26: return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
       case 9: return launch_gemm_cfg<GemmCfg<256, 256, 32, 4, 2, 3>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
       case 30: return launch_gemm_cfg<GemmCfg<256, 128, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
@@ -971,7 +969,6 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
       case 27: return launch_gemm_cfg<GemmCfg<256, 128, 32, 2, 2, 3, 1, 0, 0, 0, 2>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
       case 28: return launch_gemm_cfg<GemmCfg<128, 256, 32, 2, 2, 3, 1, 0, 0, 0, 2>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
 #endif
-      case 12: return launch_gemm_cfg<GemmCfg<64, 256, 32, 1, 4, 7>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
       default: break;
     }
   } else {
@@ -985,7 +982,7 @@ static RpStatus launch_gemm(const bf16_t* A, int lda, int M, const bf16_t* W, in
   }
 }
 
-inline bool big_variant(int v) { return v == 20 || v == 26; }
+inline bool big_variant(int v) { return v == 26; }
 // epilogues that exist for the pipelined 256 x 256 tiles only (metadata behind the ring)
 template <class Epi>
 static RpStatus launch_gemm_big(const bf16_t* A, int lda, int M, const bf16_t* W, int ldw, int n_rows_w, int K, Epi epi,
@@ -993,7 +990,6 @@ static RpStatus launch_gemm_big(const bf16_t* A, int lda, int M, const bf16_t* W
   GemmOperand a{A, lda, M}, w{W, ldw, n_rows_w};
   const int v = pick_gemm_variant(prof_class, M, n_rows_w, K, tokens_valid);
   RP_REQUIRE(big_variant(v), "tile configuration %d has no LDS row-scale form", v);
-  if (v == 20) return launch_gemm_cfg<GemmCfg<256, 256, 64, 2, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
   return launch_gemm_cfg<GemmCfg<256, 256, 64, 4, 2, 2, 1>>(w, a, K, epi, stream, prof_class, tokens_valid, t_dev);
 }
 

@@ -29,30 +29,21 @@
 
 namespace rp {
 
-// tools/probes/gemm_phase.py builds a second copy of the library with -DRP_PHASE_PROBE: thread 0 of
-// every workgroup then records the 100 MHz wall clock at four points of its tile (start, first
-// K-tile landed, main loop done, epilogue done).  The product build compiles none of this.
+// Timing probes (tools/probes/gemm_phase.py builds a second copy of the library with -DRP_PHASE_PROBE, optionally with
+// -DRP_PROBE_NO_DMA / _HALF_DMA / _SAME_TILE / _NO_READS and -DRP_ABL_*): their bodies live in probes/rp_probe_hooks.h, which
+// the product build never includes - here every hook is an empty statement.
 #ifdef RP_PHASE_PROBE
-__device__ unsigned long long g_phase_ts[4 * 16384];
-#define RP_TS(slot)                                                                          \
-  do {                                                                                       \
-    if (threadIdx.x == 0 && blockIdx.x < 16384) g_phase_ts[blockIdx.x * 4 + (slot)] = wall_clock64(); \
-  } while (0)
-// hand-over detail of workgroup 1000, every wave: [wave][kt][0..2] = shader clock before the waits,
-// after the counted vmcnt wait, after the barrier
-__device__ unsigned long long g_handover_ts[8 * 64 * 3];
-#define RP_HTS(kt, which)                                                                         \
-  do {                                                                                            \
-    if (blockIdx.x == 1000 && (threadIdx.x & 63) == 0 && (kt) < 64)                                \
-      g_handover_ts[((threadIdx.x >> 6) * 64 + (kt)) * 3 + (which)] = clock64();                  \
-  } while (0)
+#include "probes/rp_probe_hooks.h"
 #else
-#define RP_HTS(kt, which) \
-  do {                    \
-  } while (0)
-#define RP_TS(slot) \
-  do {              \
-  } while (0)
+#define RP_TS(slot) ((void)0)
+#define RP_HTS(kt, which) ((void)0)
+#define RP_PROBE_STAGE_FILTER(kt, half) ((void)0)
+#define RP_PROBE_READS_DECL ((void)0)
+#define RP_PROBE_READS_GATE ((void)0)
+#define RP_PROBE_READS_PRIME(read_frags, smem) ((void)0)
+#define RP_PTS_DECL ((void)0)
+#define RP_PTS(v) ((void)0)
+#define RP_PROBE_PERSIST_TILE_END(more) ((void)0)
 #endif
 
 // C/D layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -219,9 +210,7 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
     else
       wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // every wave's share of tile kt is in LDS; tile kt-1 fully consumed
-#ifdef RP_PHASE_PROBE
     if (kt == 0) RP_TS(1);
-#endif
     if (kt + NSTAGE - 1 < nk) {
       int nb = buf + NSTAGE - 1;
       if (nb >= NSTAGE) nb -= NSTAGE;
@@ -342,15 +331,7 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
   // half 0: the A image of a stage, half 1: the W image (issued one k-step apart, see tile_body)
   auto stage_half = [&](int kt, int buf, int half) {
     char* base = smem + buf * C::STAGE_BYTES;
-#if defined(RP_PHASE_PROBE) && defined(RP_PROBE_NO_DMA)
-    if (kt > 1) return;
-#endif
-#if defined(RP_PHASE_PROBE) && defined(RP_PROBE_HALF_DMA)
-    if (kt > 1 && half == 1) return;  // timing only: half the bytes
-#endif
-#if defined(RP_PHASE_PROBE) && defined(RP_PROBE_SAME_TILE)
-    kt = kt & 1;  // timing only: every refill re-reads the first two K-tiles (L2 hits)
-#endif
+    RP_PROBE_STAGE_FILTER(kt, half);
     const int fix_mask = (C::KTAIL != 0 && has_tail && kt == nk - 1) ? -1 : 0;  // (scalar)
     if (half == 0) {
 #pragma unroll
@@ -388,13 +369,9 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
   }
 
   frag_t af[2][FM], bfr[2][FN];  // double-buffered fragments, parity = k-step & 1
-#if defined(RP_PHASE_PROBE) && defined(RP_PROBE_NO_READS)
-  bool probe_reads_on = true;
-#endif
+  RP_PROBE_READS_DECL;
   auto read_frags = [&](const char* st, int ks, int p) {
-#if defined(RP_PHASE_PROBE) && defined(RP_PROBE_NO_READS)
-    if (!probe_reads_on) return;  // keep what the prologue read
-#endif
+    RP_PROBE_READS_GATE;
     if constexpr (C::FP8 != 0) {
 #pragma unroll
       for (int f = 0; f < FM; ++f) {
@@ -448,10 +425,7 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
   __builtin_amdgcn_s_barrier();
   RP_TS(1);
   read_frags(smem, 0, 0);
-#if defined(RP_PHASE_PROBE) && defined(RP_PROBE_NO_READS)
-  read_frags(smem, 1, 1);
-  probe_reads_on = false;
-#endif
+  RP_PROBE_READS_PRIME(read_frags, smem);
 
   // Tile kt lives in ring slot kt % NSTAGE.  MODE 2: hand over to tile kt+1 and refill this slot with
   // tile kt+NSTAGE; 1: hand over only (tail of the K loop); 0: last tile.  A refill is issued in two
@@ -626,14 +600,7 @@ __device__ __forceinline__ void gemm_tiles_persist(const GemmOperand A, const Ge
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
-#ifdef RP_PHASE_PROBE  // per workgroup SUMS over its tiles: [prologue, main loop, epilogue + end barrier, tiles] (100 MHz ticks)
-  unsigned long long p_t0 = 0, p_t1 = 0, p_t2 = 0;
-#define RP_PTS(v) v = wall_clock64()
-#else
-#define RP_PTS(v) \
-  do {            \
-  } while (0)
-#endif
+  RP_PTS_DECL;  // (probe builds: per-workgroup phase sums over its tiles)
 
   // One tile under wave layout L (WaveLayout; the configuration's own grid by default) up to and including its epilogue;
   // returns whether the workgroup has another tile (whose first k-tile is then on its way into ring slot 0).
@@ -792,26 +759,11 @@ __device__ __forceinline__ void gemm_tiles_persist(const GemmOperand A, const Ge
     } else {
       more = do_tile(L0(), a_off0, b_off0);
     }
-#ifdef RP_PHASE_PROBE
-    if (more) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-    if (threadIdx.x == 0 && blockIdx.x < 4096) {
-      const unsigned long long p_t3 = wall_clock64();
-      g_phase_ts[blockIdx.x * 4 + 0] += p_t1 - p_t0;
-      g_phase_ts[blockIdx.x * 4 + 1] += p_t2 - p_t1;
-      g_phase_ts[blockIdx.x * 4 + 2] += p_t3 - p_t2;
-      g_phase_ts[blockIdx.x * 4 + 3] += 1;
-    }
-    if (!more) break;
-#else
+    RP_PROBE_PERSIST_TILE_END(more);
     if (!more) break;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // the staging areas (over ring slot 1) and the metadata rows are free
-#endif
   }
-#undef RP_PTS
 }
 
 // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (observed, speed only), so consecutive

@@ -409,7 +409,7 @@ def test_shard_merge_equals_single_shot(gen):
     assert torch.equal(mi, ids) and torch.equal(ms, sc) and torch.equal(mc, cnt)
 
 
-@pytest.mark.parametrize("variant", [20, 26, 17, 16, 15, 12, 0, 9])
+@pytest.mark.parametrize("variant", [26, 17, 16, 15, 0, 9, 30])
 @pytest.mark.parametrize("M", [256, 768])
 def test_gemm_fused_rmsnorm_pieces_all_variants(gen, variant, M):
     """Residual epilogue on the two planes + per-64-feature sums of squares, and the row-scaled
