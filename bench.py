@@ -845,7 +845,8 @@ def main():
 
     exchange = {"allgather": exchange_allgather, "alltoall": exchange_alltoall}
 
-    def step(how=args.exchange):
+    def step(how=None):
+        how = how or args.exchange
         enc.encode_packed_device(ids_d, cu_d, B_STATES, T, max_len, q_loc)
         if world > 1:
             gather(q_all, q_loc)
@@ -859,9 +860,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
+    try:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+    except RuntimeError as e:  # a backend without the sliced all-to-all: the all-gather (north_star's form) always exists
+        if world > 1 and args.exchange == "alltoall":
+            print(f"[bench] rank {rank}: all-to-all exchange failed ({e}); falling back to the packed all-gather", file=sys.stderr)
+            args.exchange, exchange_how = "allgather", "allgather (the all-to-all form failed on this backend)"
+            for _ in range(args.warmup):
+                step("allgather")
+            barrier()
+        else:
+            raise
     n_collectives[0] = 0
     step()  # (untimed) count the collectives one step issues: 2 at N > 1 (query embeddings, packed result block), 0 at N = 1
     collectives_per_step = n_collectives[0]
@@ -917,10 +928,14 @@ def main():
         topk_only = {}
         blk_bytes = BQ * (2 * TOP_K + 1) * 4
         for how in ("allgather", "alltoall"):
-            for _ in range(3):
-                scan()
-                exchange[how]()
-            barrier()
+            try:  # (a backend that lacks one form must not cost the line: every rank fails the same call together)
+                for _ in range(3):
+                    scan()
+                    exchange[how]()
+                barrier()
+            except RuntimeError as e:
+                topk_only[how] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                continue
             t0 = time.perf_counter()
             iters = 20
             for _ in range(iters):
