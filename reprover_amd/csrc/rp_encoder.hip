@@ -46,7 +46,6 @@ int g_gemm_rs_lds = 0;      // 1: big tiles reduce the RMSNorm statistic in the 
                             // lane and tile) and still by 0.12 ms with one thread per token summing once per tile (reduce())
 int g_gemm_small_pipe = 1;  // few-token passes: the 64 x 128 x 64 tile on the software-pipelined loop (variant 17) instead of the plain one (16)
 int g_gemm_helpers = 64;      // few-token launches: up to this many surplus workgroups prefetch the weight rows (0 = off)
-int g_gemm_o_pingpong = 0;  // attention-out projection as ping-pong halves (gemm_kernel_pingpong): one half multiplies while the other moves its tile
 int g_gemm_persist = 9;   // persistent workgroups (gemm_tiles_persist) per projection: 1 QKV, 4 attention-out, 8 FFN-in, 16 FFN-out
 int g_pool_chunk = 64;      // tokens per workgroup of the pooling pass (32 / 64 / 128; round 5 A/B at 70 k tokens: 98 / 100 / 104 us)
 int g_gemm_edge_layout = 1;  // big tiles: the last feature tile of 1152 / 1472 features on a wave grid over its valid features only
@@ -162,10 +161,6 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   if (!strcmp(name, "pool_chunk")) {
     RP_REQUIRE(value == 32 || value == 64 || value == 128, "pool_chunk must be 32, 64 or 128");
     g_pool_chunk = value;
-    return RP_OK;
-  }
-  if (!strcmp(name, "gemm_o_pingpong")) {
-    g_gemm_o_pingpong = value;
     return RP_OK;
   }
   if (!strcmp(name, "gemm_persist")) {

@@ -12,7 +12,7 @@ namespace rp {
 
 // tuning knobs (defined in rp_encoder.hip, set through rp_set_option)
 extern int g_gemm_group_m, g_gemm_variant, g_gemm_variant_qkv, g_gemm_variant_wo, g_gemm_variant_o, g_gemm_tail_split,
-    g_debug_skip_ffn, g_gemm_skinny, g_gemm_skinny_variant, g_gemm_rs_lds, g_gemm_small_pipe, g_gemm_helpers, g_gemm_persist, g_pool_chunk, g_gemm_edge_layout, g_gemm_tail_variant, g_gemm_mixed, g_gemm_o_pingpong;
+    g_debug_skip_ffn, g_gemm_skinny, g_gemm_skinny_variant, g_gemm_rs_lds, g_gemm_small_pipe, g_gemm_helpers, g_gemm_persist, g_pool_chunk, g_gemm_edge_layout, g_gemm_tail_variant, g_gemm_mixed;
 extern int g_gemm_stagger_us[RP_K_COUNT];
 
 // ------------------------------------------------------------------------------------------
@@ -415,13 +415,6 @@ struct EpiStoreBf16T {  // out[token, feature] = bf16(acc * rs[token])
 
 // SPLIT_IN (the training forward, rp_train.hip): the old hi plane is read from xhi_in and the new one written to xhi, so
 // the sub-layer's input bf16(x) - an operand of the backward - survives the update at no extra traffic.
-// a pacing hook (EpiPhased) may ask for a deeper prefetch of the old planes: only half the workgroup's waves are in the
-// epilogue at a time there, so each must keep twice the bytes in flight
-template <class H, class = void>
-struct hook_depth : std::integral_constant<int, 0> {};
-template <class H>
-struct hook_depth<H, std::void_t<decltype(H::DEPTH)>> : std::integral_constant<int, H::DEPTH> {};
-
 template <bool SPLIT_IN, bool LO8 = false>
 struct EpiResidT {  // x[token, feature] += acc on the two planes of the residual stream (+ ssp partials)
   static constexpr bool any_layout = true;
@@ -437,16 +430,8 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
   const bf16_t* __restrict__ xhi_in = nullptr;  // SPLIT_IN only
   Drop drop = {0u, 0u, 1.f};                    // SPLIT_IN only: dropout on the sub-layer's output before the add (HF:140, 400)
   uint32_t drop_site = 0;
-  struct NoHook {
-    __device__ __forceinline__ void operator()(int, int) const {}
-  };
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
-    run_hooked<FM, FN>(acc, m_base, n_base, lane, stage, NoHook{});
-  }
-  // hook(b, NB) is called after block b of NB (gemm_kernel_pingpong: the workgroup barriers that pace the OTHER half's main loop)
-  template <int FM, int FN, class Hook>
-  __device__ __forceinline__ void run_hooked(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage, Hook hook) {
     static_assert(FM % 2 == 0, "one statistic slot per 64 features (two row fragments)");
     const int hi = lane >> 5, cl = lane & 31;
     // Blocks of 64 features x 32 tokens.  8 lanes x 16 B cover one token's 64 features = 128 contiguous bytes of
@@ -460,7 +445,7 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
     // make hipcc drain vmcnt to 0 around it, which serialises the whole epilogue.
     // (wave tiles of 128 x 128 keep their accumulators in AGPRs and have the VGPRs for 3 blocks ahead)
     // (round 5, 24-bit form on the 8-wave tile: 3 / 4 blocks in flight measured 2 / 5 % SLOWER than 2 on the attention-out projection)
-    constexpr int DEPTH = hook_depth<Hook>::value > 0 ? hook_depth<Hook>::value : (FM * FN >= 16) ? 4 : 2;
+    constexpr int DEPTH = (FM * FN >= 16) ? 4 : 2;
     uint4 xh[DEPTH][4];
     typename std::conditional<LO8, uint2, uint4>::type xl[DEPTH][4];
     const uint8_t* xlo8 = reinterpret_cast<const uint8_t*>(xlo);
@@ -548,31 +533,8 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
           ss += __shfl_xor(ss, 4, 64);
           if (sub == 0 && slot < np) ssp[(size_t)slot * ssp_ld + n_base + j * 32 + t] = ss;
         }
-        hook(b * 4 + c, NB * 4);
       }
     }
-  }
-};
-
-// An epilogue paced by workgroup barriers (gemm_kernel_pingpong): `nbar` raw s_barriers spread over its blocks - as many as
-// a main loop of the same K executes - so that the other half of the workgroup, which is in its main loop meanwhile and
-// shares those barriers, advances k-tile by k-tile beside it.  Raw barriers: the epilogue's loads and stores stay in flight.
-template <class E>
-struct EpiPhased {
-  static constexpr bool any_layout = false;
-  E e;
-  int nbar;
-  struct Pace {
-    static constexpr int DEPTH = 3;
-    int nbar;
-    __device__ __forceinline__ void operator()(int b, int NB) const {
-      const int lo = (int)((long long)nbar * b / NB), hi = (int)((long long)nbar * (b + 1) / NB);
-      for (int i = lo; i < hi; ++i) __builtin_amdgcn_s_barrier();
-    }
-  };
-  template <int FM, int FN>
-  __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
-    e.template run_hooked<FM, FN>(acc, m_base, n_base, lane, stage, Pace{nbar});
   }
 };
 
@@ -789,78 +751,6 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel_mixed(GemmOperand A, G
     gemm_tile_pipe<CH>(A, W, K, h % tiles_m, 2 * full_rows + h / tiles_m, epi, smem);
   }
 }
-// PING-PONG form of a projection whose epilogue is a read-modify-write of the residual stream and whose K is short
-// (round 6: the attention-out projection, K = 384: per 256 x 256 tile ~10 us of main loop, then ~15 us of epilogue during
-// which the CU's matrix pipes idle - and while the main loop runs its memory path idles).  ONE workgroup of 8 waves per
-// CU runs as two HALVES of 4 waves, each a complete 256-feature x 128-token x 32 tile pipeline (CH: own LDS ring,
-// own DMA split, own accumulators; gemm_tile_pipe as it stands), half a period apart:
-//
-//     half 0:  M0 E0 M1 E1 ...  Mn-1 En-1 (D)         M = main loop, E = epilogue, D = barriers only
-//     half 1:  (D) M0 E0 M1 E1 ...  Mn-1 En-1
-//
-// so that at any time one half multiplies while the other moves its tile through HBM, on the same SIMDs (one wave of each
-// half per SIMD).  The two halves share the workgroup barrier: every phase executes exactly nbar = K / BK + 1 of them - the
-// main loop its own (prologue, one per hand-over, the closing one), the epilogue the same number spread over its blocks
-// (EpiPhased) - so a barrier of one half's k-tile hand-over is also a pacing point of the other half's epilogue, and the
-// counts match by construction whatever a half has to do (a half without a tile executes the barriers alone).
-// Tiles: workgroup b takes pairs of consecutive half-tile ids of XCD (b % 8)'s contiguous range (features fastest inside a
-// 128-token row: the two halves usually share the token rows' activation panel).  Every output element is the same
-// K-ascending chain of 32x32x16 MFMA steps and the same epilogue arithmetic as under every other launch form: same bits.
-template <class CH, class E>
-__global__ __launch_bounds__(2 * CH::THREADS) void gemm_kernel_pingpong(GemmOperand A, GemmOperand W, int K, int tiles_m,
-                                                                        int tiles_n, E epi0) {
-  static_assert(CH::PIPE != 0 && CH::FP8 == 0 && CH::KTAIL == 0 && 2 * CH::LDS_BYTES <= 160 * 1024, "two halves in one CU's LDS");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / CH::THREADS));
-  char* my = smem + half * CH::LDS_BYTES;
-  const int nbar = K / CH::BK + 1;
-  EpiPhased<E> epi{epi0, nbar};
-  const int n_all = tiles_m * tiles_n;
-  const int xcd = blockIdx.x & 7, per = (int)gridDim.x >> 3;  // (the grid is a multiple of 8)
-  const int q = n_all >> 3, r = n_all & 7;
-  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, cnt = q + (xcd < r ? 1 : 0);
-  const int j = blockIdx.x >> 3;
-  auto barriers_only = [&] {
-    for (int i = 0; i < nbar; ++i) __builtin_amdgcn_s_barrier();
-  };
-  if (half == 1) barriers_only();
-  for (int p = j; 2 * p < cnt; p += per) {
-    const int id = 2 * p + half;
-    if (id < cnt) {
-      const int g = base + id;
-      gemm_tile_pipe<CH>(A, W, K, g % tiles_m, g / tiles_m, epi, my);  // M (nbar barriers) then E (nbar barriers)
-    } else {
-      barriers_only();
-      barriers_only();
-    }
-  }
-  if (half == 0) barriers_only();
-}
-
-// DUO form (experiment, round 6): the same half tiles as gemm_kernel_pingpong but as TWO independent persistent 4-wave
-// workgroups per CU (no shared barriers), the second one (odd workgroup slot of the CU, HW_ID.TG_ID) starting half a
-// tile period late, so that one is in its epilogue while the other multiplies.
-template <class CH, class E>
-__global__ __launch_bounds__(CH::THREADS, 2) void gemm_kernel_duo(GemmOperand A, GemmOperand W, int K, int tiles_m, int tiles_n,
-                                                                  E epi0, int offset_ticks) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  EpiPhased<E> epi{epi0, 0};  // (no pacing barriers; the deeper prefetch of the old planes)
-  const int n_all = tiles_m * tiles_n;
-  const int xcd = blockIdx.x & 7, per = (int)gridDim.x >> 3;
-  const int q = n_all >> 3, r = n_all & 7;
-  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, cnt = q + (xcd < r ? 1 : 0);
-  const unsigned hw_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 16 << 6 | 4);  // HW_ID[19:16] = TG_ID: the workgroup's slot on its CU
-  if ((hw_id & 1u) && offset_ticks > 0) {
-    const unsigned long long until = wall_clock64() + (unsigned long long)offset_ticks;  // 100 MHz
-    while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
-  }
-  for (int id = blockIdx.x >> 3; id < cnt; id += per) {
-    const int g = base + id;
-    gemm_tile_pipe<CH>(A, W, K, g % tiles_m, g / tiles_m, epi, smem);
-    __syncthreads();  // the staging areas are the next tile's ring
-  }
-}
-
 // CUs of the current device: an attribute query (not the slow property struct), cached per device.  ONE source for the
 // planners below and for encode_pass's main_rows(): plans computed in two places must agree on a part that does not have
 // 256 CUs.
@@ -979,29 +869,6 @@ static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hi
   // token rows beyond the valid count are read as copies of the last valid row (the operand clamps at `rows`): the 27
   // padding rows of a 101-token state cost one cache line per DMA piece instead of eight
   a.rows = rows_needed;
-  if constexpr (std::is_same<Epi, EpiResid8>::value && C::PIPE != 0 && C::BM == 256 && C::BN == 256 && C::NWAVES == 8) {
-    // the attention-out projection as ping-pong halves (gemm_kernel_pingpong): one workgroup per CU, more tiles than CUs
-    using CH = GemmCfg<256, 128, 32, 2, 2, 3, 1>;
-    const int slots = n_cus & ~7;
-    if (prof_class == RP_K_GEMM_O && g_gemm_o_pingpong && n_helpers == 0 && !t_dev && K % CH::BK == 0 && K / CH::BK >= CH::NSTAGE &&
-        2 * tiles_f * tiles_t > 2 * slots) {
-      if (g_gemm_o_pingpong >= 2) {  // the duo form: offset in units of 0.5 us = (g_gemm_o_pingpong - 2)
-        auto dk = gemm_kernel_duo<CH, Epi>;
-        static LdsAttrOnce dattr;
-        RP_HIP(dattr.ensure((const void*)dk, CH::LDS_BYTES));
-        hipLaunchKernelGGL(dk, dim3(2 * slots), dim3(CH::THREADS), CH::LDS_BYTES, stream, w, a, K, tiles_f, 2 * tiles_t, epi,
-                           (g_gemm_o_pingpong - 2) * 50);
-        RP_CHECK_LAUNCH();
-        return RP_OK;
-      }
-      auto pk = gemm_kernel_pingpong<CH, Epi>;
-      static LdsAttrOnce ppattr;
-      RP_HIP(ppattr.ensure((const void*)pk, 2 * CH::LDS_BYTES));
-      hipLaunchKernelGGL(pk, dim3(slots), dim3(2 * CH::THREADS), 2 * CH::LDS_BYTES, stream, w, a, K, tiles_f, 2 * tiles_t, epi);  // (the same token rows as the 256-token tiling)
-      RP_CHECK_LAUNCH();
-      return RP_OK;
-    }
-  }
   if constexpr (edge_layouts<C, Epi>() && epi_extra_lds<Epi>::value == 0) {
     if (prof_class >= RP_K_GEMM_QKV && prof_class <= RP_K_GEMM_WO && ((g_gemm_mixed >> (prof_class - RP_K_GEMM_QKV)) & 1) &&
         n_helpers == 0 && !t_dev && K >= 2 * C::BK) {

@@ -292,9 +292,7 @@ __device__ __forceinline__ void gemm_tile_pipe(const GemmOperand A, const GemmOp
   using frag_t = std::conditional_t<C::FP8 != 0, i32x8, bf16x8>;
   RP_TS(0);
   static_assert(KS % 2 == 0 && KS >= 2, "even number of k-steps (fragment double-buffer parity)");
-  // (masked: a kernel may run TWO such tiles side by side in one 2 x C::THREADS workgroup, each half with its own LDS
-  // region and wave numbers 0 .. NWAVES - 1: gemm_kernel_pingpong)
-  const int tid = threadIdx.x & (C::THREADS - 1);
+  const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_row = wave / L::WN, wave_col = wave % L::WN;
