@@ -528,9 +528,12 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
 #endif
         }
         if (ssp) {  // fixed shuffle tree over the 8 lanes of the token's 64 features
-          ss += __shfl_xor(ss, 1, 64);
-          ss += __shfl_xor(ss, 2, 64);
-          ss += __shfl_xor(ss, 4, 64);
+          // (round 6: DPP instead of __shfl_xor - 3 instructions instead of ~15 per token slice.  The third step takes the
+          // value of lane 7 - i instead of lane i ^ 4: after two steps the four lanes of a quad hold the same bits, and both
+          // lanes lie in the OTHER quad of the 8, so the sum and its rounding sequence are the ones of the xor tree)
+          ss += dpp_f32<0xB1>(ss);
+          ss += dpp_f32<0x4E>(ss);
+          ss += dpp_f32<0x141>(ss);
           if (sub == 0 && slot < np) ssp[(size_t)slot * ssp_ld + n_base + j * 32 + t] = ss;
         }
       }
@@ -567,18 +570,23 @@ struct EpiGegluBf16T {  // W rows interleaved 32 gate / 32 up: even row-fragment
     for (int jb = 0; jb < FN; jb += 2) {
 #pragma unroll
       for (int jj = 0; jj < 2 && jb + jj < FN; ++jj) {
-        const float sc = scv[jb + jj];
+        const GegluConsts gc(scv[jb + jj]);  // the token's scale folded into the activation's constants (rp_util.h: geglu2)
 #pragma unroll
         for (int i = 0; i < FM; i += 2)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             float y[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
 #ifdef RP_ABL_NOGELU  // (probe builds only)
-              y[e] = RP_ABL_NOGELU_BODY(acc[i][jb + jj][4 * g + e], acc[i + 1][jb + jj][4 * g + e]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = RP_ABL_NOGELU_BODY(acc[i][jb + jj][4 * g + e], acc[i + 1][jb + jj][4 * g + e]);
 #else
-              y[e] = gelu_new(acc[i][jb + jj][4 * g + e] * sc) * (acc[i + 1][jb + jj][4 * g + e] * sc);
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+              const f32x2 yy = geglu2(f32x2{acc[i][jb + jj][4 * g + e], acc[i][jb + jj][4 * g + e + 1]},
+                                      f32x2{acc[i + 1][jb + jj][4 * g + e], acc[i + 1][jb + jj][4 * g + e + 1]}, gc);
+              y[e] = yy.x;
+              y[e + 1] = yy.y;
+            }
 #endif
             uint2 v;
             v.x = pack_bf2(y[0], y[1]);

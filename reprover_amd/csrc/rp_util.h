@@ -106,6 +106,40 @@ __device__ __forceinline__ float gelu_new(float u) {
   return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
 }
 
+// Two outputs of the row-scaled gated GELU  y = gelu_new(sc ag) (sc au)  (ag / au = the gate / up accumulators, sc = the
+// token's RMSNorm factor, constant per lane in the GEMM epilogues) with the scale folded into per-lane constants (round 6):
+//     y = ag au sc^2 / (1 + 2^(ag (K2 ag^2 + K1))),   K1 = k1 sc, K2 = k2 sc^3,   sc^2 / (1 + e) = 1 / (e / sc^2 + 1 / sc^2)
+// = 4 multiplies + 2 fmas + exp2 + rcp per output, all but the two transcendentals as PACKED fp32 instructions (v_pk_mul_f32
+// / v_pk_fma_f32: two outputs each) - 5.5 instructions per output where the unfolded form took 8 (the gated-GELU epilogue is
+// issue-bound: ~5 us of VALU work per 256 x 256 tile).  Same limits as gelu_new: ag -> -inf gives e = inf, rcp = 0, y = -0.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+struct GegluConsts {
+  f32x2 K1, K2, inv_s2;
+  __device__ __forceinline__ explicit GegluConsts(float sc) {
+    constexpr float k1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+    constexpr float k2 = k1 * 0.044715f;
+    const float s2 = sc * sc, i2 = __builtin_amdgcn_rcpf(s2);
+    K1 = f32x2{k1 * sc, k1 * sc};
+    K2 = f32x2{k2 * s2 * sc, k2 * s2 * sc};
+    inv_s2 = f32x2{i2, i2};
+  }
+};
+__device__ __forceinline__ f32x2 geglu2(f32x2 ag, f32x2 au, const GegluConsts& c) {
+  const f32x2 a = ag * __builtin_elementwise_fma(c.K2, ag * ag, c.K1);
+  const f32x2 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+  const f32x2 d = __builtin_elementwise_fma(e, c.inv_s2, c.inv_s2);
+  const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  return (ag * au) * r;
+}
+
+// v of the lane a DPP control word names (quad_perm / row_half_mirror ...): ONE VALU instruction where __shfl_xor goes through
+// the LDS crossbar (xor, shift, ds_bpermute_b32, compare, select: five).  0xB1 = quad_perm(1,0,3,2) = lane ^ 1,
+// 0x4E = quad_perm(2,3,0,1) = lane ^ 2, 0x141 = row_half_mirror = lane 7 - i of each group of 8.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
