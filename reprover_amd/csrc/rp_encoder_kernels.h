@@ -121,35 +121,52 @@ __device__ __forceinline__ void hilo_update2(uint32_t h2, uint32_t l2, float d0,
 // units of 2^-8 ulp(hi): e is simply bits 8..15 of the rounded word read as int8.  A residual update reads 3 B and writes 3 B per element where the two bf16 planes move 4 + 4: the
 // read-modify-write of x bounds the attention-out projection and the FFN-out epilogue (tools/probes/rmw_probe.hip:
 // 0.144 -> 0.122 ms for [70144, 1472] in 256 x 256 tiles; in the step -0.5 ms).  The training step keeps the bf16 pair.
-// One updated element pair: decode, add, round, re-split; ss accumulates the squares of the values as stored.
-__device__ __forceinline__ void x24_update2(uint32_t h2, int e0, int e1, float d0, float d1, uint32_t& oh, uint32_t& b0,
-                                            uint32_t& b1, float& ss) {
-  const float v0 = __uint_as_float((h2 << 16) + ((uint32_t)e0 << 8)) + d0;  // (e sign-extended: the add borrows from hi)
-  const float v1 = __uint_as_float((h2 & 0xffff0000u) + ((uint32_t)e1 << 8)) + d1;
+// Round 6 - the extension byte is stored BIASED: u = e + 128 = bits 8..15 of (the rounded word + 0x8000).  The same values, hi
+// plane and rounding as before, and fewer instructions in the two residual epilogues, which are bound by their own
+// instruction stream (profiles/r06_raw/exp4): decoding is ONE byte permute + ONE subtract per element -
+// x = float(((hi << 16) | (u << 8)) - 0x8000) - where the signed byte took a sign-extending extract, a shift and an add; and
+// encoding shares one add between the two planes: q = bits(v) + 0x8080 holds hi in its top half and u in byte 1.
+// A zero is (hi 0, u 0x80): X24_ZERO_EXT.
+constexpr uint32_t X24_ZERO_EXT = 0x80808080u;
+// One updated element pair (bf16 pair h2; extension bytes K and K + 1 of word lw): decode, add, round, re-split; q0 / q1 carry
+// the new extension bytes in their byte 1 (x24_pack_ext); ss accumulates the squares of the values as stored.
+template <int K>
+__device__ __forceinline__ void x24_update2(uint32_t h2, uint32_t lw, float d0, float d1, uint32_t& oh, uint32_t& q0,
+                                            uint32_t& q1, float& ss) {
+  // v_perm_b32: bytes 7..4 = h2, 3..0 = lw; selector 0x0c = the constant 0
+  const uint32_t w0 = __builtin_amdgcn_perm(h2, lw, 0x05040000u | ((uint32_t)K << 8) | 0x0cu) - 0x8000u;
+  const uint32_t w1 = __builtin_amdgcn_perm(h2, lw, 0x07060000u | ((uint32_t)(K + 1) << 8) | 0x0cu) - 0x8000u;
+  const float v0 = __uint_as_float(w0) + d0, v1 = __uint_as_float(w1) + d1;
   const uint32_t r0 = __float_as_uint(v0) + 0x80u, r1 = __float_as_uint(v1) + 0x80u;  // to 24 bits, half away from zero
-  b0 = (r0 >> 8) & 0xffu;
-  b1 = (r1 >> 8) & 0xffu;
-  oh = ((r0 + 0x8000u) >> 16) | ((r1 + 0x8000u) & 0xffff0000u);  // hi = the 24-bit word to 16 bits, half away from zero
+  q0 = r0 + 0x8000u;  // top half: the 24-bit word to 16 bits, half away from zero; byte 1: the biased extension byte
+  q1 = r1 + 0x8000u;
+  oh = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
   const float x0 = __uint_as_float(r0 & 0xffffff00u), x1 = __uint_as_float(r1 & 0xffffff00u);
   ss = __fmaf_rn(x1, x1, __fmaf_rn(x0, x0, ss));  // explicit fma chain: the same rounding sequence for every token
 }
+// byte 1 of four words -> one word (element i = byte i)
+__device__ __forceinline__ uint32_t x24_pack_ext(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3) {
+  const uint32_t lo = __builtin_amdgcn_perm(q1, q0, 0x0c0c0501u), hi = __builtin_amdgcn_perm(q3, q2, 0x0c0c0501u);
+  return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
 // (hi by the hardware's nearest-even conversion + an explicit remainder was measured too: the same margins, and 6 % more
 // time in the two residual epilogues - they are VALU-sensitive: two waves per SIMD, 128 elements per lane and tile.)
-// eight elements: h = 8 bf16, l = 8 int8 (element i = byte i), d[0..7] added
+// eight elements: h = 8 bf16, l = 8 biased extension bytes (element i = byte i), d[0..7] added
 __device__ __forceinline__ void x24_update8(const uint4 h, const uint2 l, const float4 d0, const float4 d1, uint4& oh, uint2& ol,
                                             float& ss) {
-  uint32_t b[8];
-  x24_update2(h.x, __builtin_amdgcn_sbfe((int)l.x, 0, 8), __builtin_amdgcn_sbfe((int)l.x, 8, 8), d0.x, d0.y, oh.x, b[0], b[1], ss);
-  x24_update2(h.y, __builtin_amdgcn_sbfe((int)l.x, 16, 8), __builtin_amdgcn_sbfe((int)l.x, 24, 8), d0.z, d0.w, oh.y, b[2], b[3], ss);
-  x24_update2(h.z, __builtin_amdgcn_sbfe((int)l.y, 0, 8), __builtin_amdgcn_sbfe((int)l.y, 8, 8), d1.x, d1.y, oh.z, b[4], b[5], ss);
-  x24_update2(h.w, __builtin_amdgcn_sbfe((int)l.y, 16, 8), __builtin_amdgcn_sbfe((int)l.y, 24, 8), d1.z, d1.w, oh.w, b[6], b[7], ss);
-  ol.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-  ol.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+  uint32_t q[8];
+  x24_update2<0>(h.x, l.x, d0.x, d0.y, oh.x, q[0], q[1], ss);
+  x24_update2<2>(h.y, l.x, d0.z, d0.w, oh.y, q[2], q[3], ss);
+  x24_update2<0>(h.z, l.y, d1.x, d1.y, oh.z, q[4], q[5], ss);
+  x24_update2<2>(h.w, l.y, d1.z, d1.w, oh.w, q[6], q[7], ss);
+  ol.x = x24_pack_ext(q[0], q[1], q[2], q[3]);
+  ol.y = x24_pack_ext(q[4], q[5], q[6], q[7]);
 }
-// decode only (the pooling pass): elements 2 j, 2 j + 1 of an 8-element group
+// decode only (the pooling pass): elements 2 j, 2 j + 1 of an 8-element group (lw = the group's word holding their bytes)
 __device__ __forceinline__ void x24_decode2(uint32_t h2, uint32_t lw, int j, float& x0, float& x1) {
-  x0 = __uint_as_float((h2 << 16) + ((uint32_t)__builtin_amdgcn_sbfe((int)lw, 16 * j, 8) << 8));
-  x1 = __uint_as_float((h2 & 0xffff0000u) + ((uint32_t)__builtin_amdgcn_sbfe((int)lw, 16 * j + 8, 8) << 8));
+  const uint32_t s0 = j ? 0x0504020cu : 0x0504000cu, s1 = j ? 0x0706030cu : 0x0706010cu;
+  x0 = __uint_as_float(__builtin_amdgcn_perm(h2, lw, s0) - 0x8000u);
+  x1 = __uint_as_float(__builtin_amdgcn_perm(h2, lw, s1) - 0x8000u);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -184,7 +201,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ 
     if constexpr (LO8) {
       uint4 oh;
       uint2 ol;
-      x24_update8(make_uint4(0u, 0u, 0u, 0u), make_uint2(0u, 0u), a, b, oh, ol, ss);
+      x24_update8(make_uint4(0u, 0u, 0u, 0u), make_uint2(X24_ZERO_EXT, X24_ZERO_EXT), a, b, oh, ol, ss);
       dh[c] = oh;
       dl8[c] = ol;
     } else {

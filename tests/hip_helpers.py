@@ -24,23 +24,24 @@ def merge_planes(planes):
 def split_x24(x):
     """fp32 [M, N] -> the inference pass's 24-bit form of the residual stream (rp_encoder_kernels.h, x24_update2): the
     fp32 word rounded to its top 24 bits (half away from zero), as (hi bf16 [M, N] = that word rounded to 16 bits, half
-    away from zero; ext int8 [M, N] = bits 8..15 of the rounded word read as a signed byte).  Returned as ONE uint8
-    buffer [M * N * 3] laid out [hi plane | ext plane] (what RP_EPI_RESID8 takes) plus the two views."""
+    away from zero; ext uint8 [M, N] = the signed remainder in units of 2^-8 ulp(hi) stored BIASED by 128 = bits 8..15 of
+    (the rounded word + 0x8000): round 6).  Returned as ONE uint8 buffer [M * N * 3] laid out [hi plane | ext plane] (what
+    RP_EPI_RESID8 takes) plus the two views."""
     bits = x.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
-    r = (bits + 0x80) & 0xFFFFFFFF
-    ext = ((r >> 8) & 0xFF).to(torch.uint8)
-    hi16 = (((r + 0x8000) & 0xFFFFFFFF) >> 16).to(torch.int32).to(torch.int16)  # (wraps like uint16)
+    q = (bits + 0x8080) & 0xFFFFFFFF
+    ext = ((q >> 8) & 0xFF).to(torch.uint8)
+    hi16 = (q >> 16).to(torch.int32).to(torch.int16)  # (wraps like uint16)
     M, N = x.shape
     buf = torch.empty(M * N * 3, dtype=torch.uint8, device=x.device)
     buf[: M * N * 2].view(torch.int16).view(M, N).copy_(hi16)
     buf[M * N * 2 :].view(M, N).copy_(ext)
-    return buf, buf[: M * N * 2].view(torch.bfloat16).view(M, N), buf[M * N * 2 :].view(torch.int8).view(M, N)
+    return buf, buf[: M * N * 2].view(torch.bfloat16).view(M, N), buf[M * N * 2 :].view(M, N)
 
 
 def merge_x24(hi, ext):
-    """x = float((hi << 16) + (ext << 8)) as 32-bit words."""
+    """x = float(((hi << 16) | (ext << 8)) - 0x8000) as 32-bit words."""
     w = (hi.contiguous().view(torch.int16).to(torch.int64) & 0xFFFF) << 16
-    w = (w + (ext.to(torch.int64) << 8)) & 0xFFFFFFFF
+    w = (w + (ext.to(torch.int64) << 8) - 0x8000) & 0xFFFFFFFF
     w = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
     return w.view(torch.float32)
 

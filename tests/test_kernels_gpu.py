@@ -72,8 +72,8 @@ def test_gemm_residual_two_planes(gen):
 
 
 def test_gemm_residual_24_bit_form(gen):
-    """The inference pass's residual stream: a bf16 plane + an int8 extension plane, x = float((hi << 16) + (ext << 8)),
-    i.e. the fp32 word of x rounded to its top 24 bits (x24_update2).  The representation is specified to the bit: the
+    """The inference pass's residual stream: a bf16 plane + a one-byte extension plane (stored biased by 128 since round 6),
+    x = float(((hi << 16) | (ext << 8)) - 0x8000), i.e. the fp32 word of x rounded to its top 24 bits (x24_update2).  The representation is specified to the bit: the
     update must equal the host's restatement of it EXACTLY wherever the fp32 sums agree, hi must be the 24-bit word rounded
     to 16 bits (half away from zero), and the sums of squares must be those of the values as stored."""
     M, N, K = 256, 1472, 384
