@@ -28,7 +28,7 @@ ids_d, cu_d = torch.from_numpy(ids_np).to(dev), torch.from_numpy(cu_np).to(dev)
 out = torch.empty((B, cfg["d_model"]), dtype=torch.bfloat16, device=dev)
 print(f"{model} B={B} tokens={T}", flush=True)
 
-DEFAULTS = {"gemm_variant_all": -1, "gemm_tail_split": 1, "gemm_group_m": 8, "gemm_persist": 9, "gemm_rs_lds": 0, "pool_chunk": 64, "gemm_edge_layout": 1, "gemm_tail_variant": 30, "gemm_mixed": 20, "gemm_o_pingpong": 0}
+DEFAULTS = {"gemm_variant_all": -1, "gemm_tail_split": 1, "gemm_group_m": 8, "gemm_persist": 9, "gemm_rs_lds": 0, "pool_chunk": 64, "gemm_edge_layout": 1, "gemm_tail_variant": 30, "gemm_mixed": 20}
 confs = []
 for a in sys.argv[1:]:
     name, _, rest = a.partition(":")
