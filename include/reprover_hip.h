@@ -380,15 +380,16 @@ RpStatus rp_profile_read(int32_t kernel_class, double* total_ms, int64_t* launch
  * HIP kernel against the oracle in isolation.  Same conventions as above.
  * ------------------------------------------------------------------------------------------- */
 enum { RP_EPI_STORE_BF16 = 0, RP_EPI_RESID = 1, RP_EPI_GEGLU_BF16 = 2,
-       RP_EPI_RESID8 = 3 /* the inference pass's residual stream: out = bf16 plane [M, n_valid], then int8 extension plane [M, n_valid] */ };
+       RP_EPI_RESID8 = 3 /* the inference pass's residual stream: out = bf16 plane [M, n_valid], then one-byte extension plane [M, n_valid] */ };
 /* C = A[M,K] (bf16) x W[N,K]^T (bf16); M, N multiples of 128 (N may exceed n_valid: only the
  * first n_valid columns are written), K multiple of 32.
  *   STORE_BF16: out bf16 [M, n_valid]
  *   RESID:      out = the residual stream's two bf16 planes [2, M, n_valid] (hi = bf16(x), lo = bf16(x - hi));
  *               x += C, re-split (n_valid multiple of 8) - the training step's form
- *   RESID8:     out = bf16 plane [M, n_valid] followed by an int8 plane [M, n_valid]: x = float((hi << 16) + (ext << 8)), the
- *               fp32 word of x rounded to its top 24 bits (hi = that word rounded to 16 bits, half away from zero; ext =
- *               bits 8..15 of the rounded word as a signed byte); x += C, re-split - the inference pass's form
+ *   RESID8:     out = bf16 plane [M, n_valid] followed by a uint8 plane [M, n_valid]: x = float(((hi << 16) | (ext << 8)) -
+ *               0x8000), the fp32 word of x rounded to its top 24 bits (hi = that word rounded to 16 bits, half away from
+ *               zero; ext = the signed remainder stored biased by 128 = bits 8..15 of (the rounded word + 0x8000); ABI 6);
+ *               x += C, re-split - the inference pass's form
  *   GEGLU_BF16: W rows interleaved 32 gate / 32 up; out bf16 [M, n_valid/2] = gelu_new(g)*u  */
 RpStatus rp_dbg_gemm(const void* A, const void* W, void* out, int32_t M, int32_t N, int32_t K,
                      int32_t n_valid, int32_t epilogue, void* stream);
