@@ -8,8 +8,10 @@ if len(sys.argv) >= 3 and sys.argv[1] != "--child":
     res = {l: [] for l in libs}
     for r in range(rounds):
         for l in libs:
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", l, f"/tmp/lib_ab_{libs.index(l)}.pt"],
-                                 capture_output=True, text=True, timeout=600)
+            path, _, envs = l.partition("@")  # "lib.so@VAR=value,VAR2=value": the same build under another environment
+            env = dict(os.environ, **dict(kv.split("=") for kv in envs.split(",") if kv))
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", path, f"/tmp/lib_ab_{libs.index(l)}.pt"],
+                                 capture_output=True, text=True, timeout=600, env=env)
             line = [x for x in out.stdout.splitlines() if x.startswith("{")]
             if not line:
                 print(out.stdout[-2000:], out.stderr[-2000:]); sys.exit(1)
