@@ -229,6 +229,11 @@ constexpr int RMS_MAX_V4 = 8;
 // fp32 table row - 413 MB through L2 per pass - encodes, and scatters 23 four-byte statistic slots per row).
 // rs_out given: the row's RMSNorm factor is written directly (rowscale_kernel's arithmetic on slot 0 + zeros: the same
 // bits) and the pass skips the first rowscale launch; else the statistic goes to the slots as embed_kernel writes it.
+// NV = 16-byte pieces per lane covering a row of the bf16 plane (ceil(D / 512): 3 for d_model 1472 / 1536, 4 up to 2048);
+// R = token rows per wave, all their loads requested before the first store (round 6: the 4-step form issued a fourth,
+// clamped load of every plane for d_model 1472 - a quarter of the load instructions for nothing - and kept one row per wave
+// in flight).
+template <int NV, int R>
 static __global__ __launch_bounds__(256) void embed_copy_kernel(const int32_t* __restrict__ ids, const bf16_t* __restrict__ thi,
                                                          const uint8_t* __restrict__ tlo, const float* __restrict__ tss,
                                                          bf16_t* __restrict__ xhi, uint8_t* __restrict__ xlo,
@@ -236,42 +241,51 @@ static __global__ __launch_bounds__(256) void embed_copy_kernel(const int32_t* _
                                                          float inv_d, float eps, int T, int Tp, int D, int vocab,
                                                          const int32_t* __restrict__ t_dev) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
   int rows = Tp;
   if (t_dev) {  // token count known on the device only (rp_encode_padded): T / Tp are upper bounds
     T = *t_dev;
     rows = min(Tp, (T + 255) & ~255);
   }
-  if (row >= rows) return;
-  int id = (row < T) ? ids[row] : 0;
-  id = min(max(id, 0), vocab - 1);
-  const uint4* sh = reinterpret_cast<const uint4*>(thi + (size_t)id * D);
-  const uint2* sl = reinterpret_cast<const uint2*>(tlo + (size_t)id * D);
-  uint4* dh = reinterpret_cast<uint4*>(xhi + (size_t)row * D);
-  uint2* dl = reinterpret_cast<uint2*>(xlo + (size_t)row * D);
+  if (row0 >= rows) return;
   const int nv = D >> 3;
-  constexpr int NV = RMS_MAX_V4 / 2;  // up to 4 steps of 64 lanes x 8 features: d_model <= 2048
-  uint4 vh[NV];
-  uint2 vl[NV];
+  uint4 vh[R][NV];
+  uint2 vl[R][NV];
+  int idv[R];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {  // every load of the row requested before the first store
-    const int c = min(lane + 64 * i, nv - 1);
-    vh[i] = sh[c];
-    vl[i] = sl[c];
-  }
+  for (int u = 0; u < R; ++u) {
+    const int row = min(row0 + u, rows - 1);
+    int id = (row < T) ? ids[row] : 0;
+    idv[u] = id = min(max(id, 0), vocab - 1);
+    const uint4* sh = reinterpret_cast<const uint4*>(thi + (size_t)id * D);
+    const uint2* sl = reinterpret_cast<const uint2*>(tlo + (size_t)id * D);
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nv) {
-      dh[c] = vh[i];
-      dl[c] = vl[i];
+    for (int i = 0; i < NV; ++i) {  // every load of the wave's rows requested before the first store
+      const int c = min(lane + 64 * i, nv - 1);
+      vh[u][i] = sh[c];
+      vl[u][i] = sl[c];
     }
   }
-  const float ss = tss[id];
-  if (rs_out) {
-    if (lane == 0) rs_out[row] = rsqrtf(ss * inv_d + eps);
-  } else {
-    for (int p = lane; p < np; p += 64) ssp[(size_t)p * Tp + row] = (p == 0) ? ss : 0.f;
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const int row = row0 + u;
+    if (row >= rows) break;
+    uint4* dh = reinterpret_cast<uint4*>(xhi + (size_t)row * D);
+    uint2* dl = reinterpret_cast<uint2*>(xlo + (size_t)row * D);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv) {
+        dh[c] = vh[u][i];
+        dl[c] = vl[u][i];
+      }
+    }
+    const float ss = tss[idv[u]];
+    if (rs_out) {
+      if (lane == 0) rs_out[row] = rsqrtf(ss * inv_d + eps);
+    } else {
+      for (int p = lane; p < np; p += 64) ssp[(size_t)p * Tp + row] = (p == 0) ? ss : 0.f;
+    }
   }
 }
 
@@ -1462,7 +1476,7 @@ static void launch_pool_partial(dim3 grid, hipStream_t stream, const bf16_t* xhi
                                 const int4* pwork, float* partial, int D, int chunk, const float* w, void* out, int out_bf16,
                                 int fuse, bool lo8) {
   if (lo8) {
-    if (D <= 3 * 512)
+    if (D <= 3 * 512)  // (eight rows in flight per wave instead of four: 71 vs 73 us, round 6 exp10 - not kept)
       hipLaunchKernelGGL((pool_partial_kernel<3, 4, true>), grid, dim3(256), 0, stream, xhi, xlo, rs, pwork, partial, D, chunk, w, out,
                          out_bf16, fuse);
     else
