@@ -104,13 +104,17 @@ class RetrievalDataset:
         for i in range(0, len(self.data), batch_size):
             yield self.collate(self.data[i : i + batch_size])
 
-    def train_batches(self, batch_size: int) -> Iterator[Batch]:
+    def train_batches(self, batch_size: int, skip: int = 0) -> Iterator[Batch]:
         """One epoch as the reference's train DataLoader yields it (datamodule.py:255-264: shuffle=True,
-        drop_last=True), negatives drawn per example as it is fetched."""
+        drop_last=True), negatives drawn per example as it is fetched.  ``skip``: the first ``skip`` batches (a resumed
+        run's batches already trained on) are consumed at the INDEX level - their examples fetched, so the negative
+        draws advance ``random`` exactly as an uninterrupted epoch does, but neither collated nor tokenised nor yielded."""
         order = list(range(len(self.data)))
         random.shuffle(order)
-        for i in range(0, len(order) - batch_size + 1, batch_size):
-            yield self.collate([self[j] for j in order[i : i + batch_size]])
+        for n, i in enumerate(range(0, len(order) - batch_size + 1, batch_size)):
+            examples = [self[j] for j in order[i : i + batch_size]]
+            if n >= skip:
+                yield self.collate(examples)
 
 
 def label_matrix(examples: List[Example], num_negatives: int):
@@ -186,8 +190,8 @@ class RetrievalDataModule:
             self.ds_pred = RetrievalDataset([split(s) for s in ("train", "val", "test")], self.corpus,
                                             self.max_seq_len, self.tokenizer)
 
-    def train_dataloader(self) -> Iterator[Batch]:
-        return self.ds_train.train_batches(self.batch_size)
+    def train_dataloader(self, skip: int = 0) -> Iterator[Batch]:
+        return self.ds_train.train_batches(self.batch_size, skip)
 
     def val_dataloader(self) -> Iterator[Batch]:
         return self.ds_val.batches(self.eval_batch_size)

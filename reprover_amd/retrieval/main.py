@@ -119,12 +119,12 @@ def _fit_loop(model, dm, max_steps, val_every, log, ckpt_dir, ckpt_every, seed, 
     import random
 
     while step < max_steps:
-        n_epoch = 0
         random.seed(_epoch_seed(seed, epoch))
-        for batch in dm.train_dataloader():
+        # batches trained on before the checkpoint: their examples are drawn again (the same draws) at the index level -
+        # not collated, not tokenised, not stepped again (a late-epoch resume cost O(skip) tokenised batches)
+        n_epoch = skip
+        for batch in dm.train_dataloader(skip=skip):
             n_epoch += 1
-            if n_epoch <= skip:
-                continue  # trained on before the checkpoint: drawn again (the same draws), not stepped again
             loss = model.training_step(batch, step)
             optimizer.step()
             scheduler.step()

@@ -381,3 +381,42 @@ def test_bench_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "WORLD_SIZE=2" in str(e.value.code)
+
+
+def test_resumed_epoch_skips_batches_at_the_index_level():
+    """A resumed `fit` consumes the batches it already trained on without collating / tokenising them, and the
+    batches that follow - order AND negative draws - are those of an uninterrupted epoch."""
+    import random
+
+    from reprover_amd.retrieval.datamodule import RetrievalDataModule
+
+    files = synth.synth_corpus_records(30, 500, seed=131, max_imports=5)
+    d = tempfile.mkdtemp()
+    cpath = os.path.join(d, "corpus.jsonl")
+    synth.write_corpus_jsonl(cpath, files)
+    dd = os.path.join(d, "data")
+    os.makedirs(dd)
+    for name, seed in (("train", 132), ("val", 134), ("test", 135)):
+        json.dump(synth.synth_split(files, 40, seed=seed, min_file=12), open(os.path.join(dd, f"{name}.json"), "w"))
+    calls = []
+
+    class CountingTokenizer(tokenizer.ByT5Tokenizer):
+        def __call__(self, *a, **kw):
+            calls.append(1)
+            return super().__call__(*a, **kw)
+
+    dm = RetrievalDataModule(dd, cpath, 16, 256, CountingTokenizer(), num_negatives=3, num_in_file_negatives=1, batch_size=8)
+    dm.setup("fit")
+    dm.ds_train.data = [ex for ex in dm.ds_train.data if len(dm.ds_train.negative_pools(ex)[1]) >= 3]
+
+    def sig(b):
+        return [c.state for c in b["context"]], [[p.full_name for p in n] for n in b["neg_premises"]]
+
+    random.seed(7)
+    full = [sig(b) for b in dm.train_dataloader()]
+    per_batch = len(calls) // len(full)
+    calls.clear()
+    random.seed(7)
+    tail = [sig(b) for b in dm.train_dataloader(skip=3)]
+    assert len(full) >= 6 and tail == full[3:]
+    assert len(calls) == per_batch * len(tail)  # the three skipped batches were never tokenised
