@@ -73,6 +73,36 @@ def test_index_cli_writes_reference_style_pickle(workdir):
         PremiseRetriever.load_hf(os.path.join(d, "no_such_ckpt"), 256, "cuda:0")
 
 
+def test_index_cli_reference_pickle_flag(workdir):
+    """`index.py --reference-pickle`: the same index under the REFERENCE's class names (common.IndexedCorpus / Corpus / File /
+    Premise, lean_dojo.data_extraction.lean.Pos, a networkx closure graph), the file the reference's prover unpickles
+    (prover/tactic_generator.py:273-276; verified against the imported reference by fixture G17).  Here: the CLI writes it, the
+    stream names no class of this package, and it reads back to the index the plain flag-less run writes."""
+    d, ckpt, cpath, sdir, splits, cfg, sd = workdir
+    plain, ref = os.path.join(d, "plain.pickle"), os.path.join(d, "for_reference.pickle")
+    index_cli.main(["--ckpt_path", ckpt, "--corpus-path", cpath, "--output-path", plain, "--batch-size", "32"])
+    index_cli.main(["--ckpt_path", ckpt, "--corpus-path", cpath, "--output-path", ref, "--batch-size", "32", "--reference-pickle"])
+    named = set()
+
+    class Spy(pickle.Unpickler):
+        def find_class(self, module, name):
+            named.add((module, name))
+            return type(name, (), {"__setstate__": lambda self, st: None}) if module.split(".")[0] in (
+                "common", "lean_dojo", "networkx") else super().find_class(module, name)
+
+    Spy(open(ref, "rb")).load()
+    assert ("common", "IndexedCorpus") in named and ("lean_dojo.data_extraction.lean", "Pos") in named
+    assert not any(m.startswith("reprover_amd") for m, _ in named)
+    from reprover_amd.common import load_indexed_corpus_pickle
+
+    c1, e1 = load_indexed_corpus_pickle(plain)
+    c2, e2 = load_indexed_corpus_pickle(ref)
+    assert c1.all_premises == c2.all_premises and torch.equal(e1, e2)
+    m = PremiseRetriever.load_hf(ckpt, 256, "cuda:0")
+    m.load_corpus(ref)  # and the retriever takes it like any indexed corpus
+    assert not m.embeddings_staled and len(m.corpus) == len(c1)
+
+
 def test_predict_validate_and_evaluate(workdir):
     d, ckpt, cpath, sdir, splits, cfg, sd = workdir
     log_dir = os.path.join(d, "logs")
