@@ -325,13 +325,24 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
   RpStatus st;
   const Drop drop = tr->drop;
   const dim3 att_grid(H, T / ATT_Q + batch);
-  // behind a residual-branch dropout the branch sees mask * dx: one bf16 copy, the operand of its dgrad and wgrad GEMMs
-  auto branch_grad = [&](uint32_t site) -> const bf16_t* {
-    if (!drop.thresh) return w.dxhi;
+  // Behind a residual-branch dropout the branch sees mask * dx: one bf16 copy (dxm), the operand of its dgrad and wgrad
+  // GEMMs.  The first branch's copy is a pass of its own (mask_first, behind the pooling backward); every later one is
+  // written by the RMSNorm-backward epilogue that produces the gradient it masks (EpiRmsBwdResidT<true>, next_site).
+  const bf16_t* const dxb = drop.thresh ? (const bf16_t*)w.dxm : (const bf16_t*)w.dxhi;
+  auto mask_first = [&](uint32_t site) {
+    if (!drop.thresh) return;
     ProfScope ps(stream, RP_K_BWD_OTHER);
     hipLaunchKernelGGL(mask_dx_kernel, dim3((Tp + 3) / 4), dim3(256), 0, stream, (const bf16_t*)w.dxhi, (const bf16_t*)w.dxlo,
                        w.dxm, Tp, D, drop, site);
-    return w.dxm;
+  };
+  // dx += A W - x rcoef (RMSNorm backward in the epilogue), and dxm for the branch whose backward comes next (0 = none)
+  auto rms_bwd_gemm = [&](const bf16_t* A, int K, const bf16_t* Wt, const bf16_t* x_saved, uint32_t next_site) -> RpStatus {
+    if (drop.thresh && next_site)
+      return launch_gemm(A, K, Tp, Wt, K, D, K,
+                         EpiRmsBwdResidT<true>{w.dxhi, w.dxlo, D, D, x_saved, w.rcoef, w.dxm, drop, next_site}, stream,
+                         RP_K_BWD_DGRAD, 0, nullptr, bwd_variant(D, K, Tp));
+    return launch_gemm(A, K, Tp, Wt, K, D, K, EpiRmsBwdResid{w.dxhi, w.dxlo, D, D, x_saved, w.rcoef}, stream, RP_K_BWD_DGRAD, 0,
+                       nullptr, bwd_variant(D, K, Tp));
   };
   RP_HIP(hipMemsetAsync(w.dxhi, 0, (size_t)Tp * D * 2, stream));
   RP_HIP(hipMemsetAsync(w.dxlo, 0, (size_t)Tp * D * 2, stream));
@@ -342,7 +353,7 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
     ProfScope ps(stream, RP_K_BWD_OTHER);
     hipLaunchKernelGGL(pool_bwd_seq_kernel, dim3(batch), dim3(256), 0, stream, (const float*)w.pool, (const float*)e->final_ln, cu,
                        d_emb, w.ds_seq, w.dwf_seq, D);
-    hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(256), 0, stream, (const float*)w.dwf_seq, batch, D,
+    hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(64 * COLSUM_WAVES), 0, stream, (const float*)w.dwf_seq, batch, D,
                        grads + lay.final_ln());
     const dim3 pg(T / POOL_CHUNK + batch);
     if (D <= 3 * 512)
@@ -354,12 +365,12 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
     RP_CHECK_LAUNCH();
   }
 
+  mask_first(DROP_SITE_LAYER0 + 8u * (uint32_t)(L - 1) + 3);
   for (int i = L - 1; i >= 0; --i) {
     const LayerT& Lt = tr->lt[i];
     const uint32_t site = DROP_SITE_LAYER0 + 8u * (uint32_t)i;
     // ---------------- feed-forward sub-layer:  x_out = x + ff Wo2^T,  ff = gelu(g) u,  [g | u] = rs (x Wi'^T)
     // dWo2 = dx^T ff  (dx: the hi plane of the residual gradient; mask * dx under dropout)
-    const bf16_t* dxb = branch_grad(site + 3);
     {
       const int S = wgrad_splits(D, F, nk);
       float* dst = grads + lay.layer(i, P_WO);
@@ -392,16 +403,13 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
       a.ln = params + lay.layer(i, P_LN_FF); a.dln_part = w.dln_part;
       if ((st = run_unfold(a, stream))) return st;
       ProfScope ps(stream, RP_K_BWD_OTHER);
-      hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(256), 0, stream, (const float*)w.dln_part, (2 * F + 31) / 32,
+      hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(64 * COLSUM_WAVES), 0, stream, (const float*)w.dln_part, (2 * F + 31) / 32,
                          D, grads + lay.layer(i, P_LN_FF));
     }
     // dx += dzs Wi' - x rcoef   (RMSNorm backward in the epilogue)
-    if ((st = launch_gemm(w.dzs, 2 * F, Tp, Lt.wi_t, 2 * F, D, 2 * F, EpiRmsBwdResid{w.dxhi, w.dxlo, D, D, w.xf[i], w.rcoef},
-                          stream, RP_K_BWD_DGRAD, 0, nullptr, bwd_variant(D, 2 * F, Tp))))
-      return st;
+    if ((st = rms_bwd_gemm(w.dzs, 2 * F, Lt.wi_t, w.xf[i], site + 1))) return st;
 
     // ---------------- attention sub-layer:  x_out = x + att Wo^T,  att = Attn(q, k, v),  [q | k | v] = rs (x Wqkv'^T)
-    dxb = branch_grad(site + 1);
     {
       const int S = wgrad_splits(D, inner, nk);
       float* dst = grads + lay.layer(i, P_O);
@@ -448,13 +456,10 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
       a.ln = params + lay.layer(i, P_LN_ATTN); a.dln_part = w.dln_part;
       if ((st = run_unfold(a, stream))) return st;
       ProfScope ps(stream, RP_K_BWD_OTHER);
-      hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(256), 0, stream, (const float*)w.dln_part, (3 * inner + 31) / 32,
+      hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(64 * COLSUM_WAVES), 0, stream, (const float*)w.dln_part, (3 * inner + 31) / 32,
                          D, grads + lay.layer(i, P_LN_ATTN));
     }
-    if ((st = launch_gemm(w.dqkv, 3 * inner, Tp, Lt.wqkv_t, 3 * inner, D, 3 * inner,
-                          EpiRmsBwdResid{w.dxhi, w.dxlo, D, D, w.xa[i], w.rcoef}, stream, RP_K_BWD_DGRAD, 0, nullptr,
-                          bwd_variant(D, 3 * inner, Tp))))
-      return st;
+    if ((st = rms_bwd_gemm(w.dqkv, 3 * inner, Lt.wqkv_t, w.xa[i], i > 0 ? site - 8u + 3u : 0u))) return st;
   }
   {
     ProfScope ps(stream, RP_K_BWD_OTHER);
@@ -550,17 +555,23 @@ extern "C" RpStatus rp_trainer_create(const RpT5Config* cfg, const float* params
 
 extern "C" RpEncoder* rp_trainer_encoder(RpTrainer* tr) { return tr ? tr->enc : nullptr; }
 
+// 16-bit threshold of the column-pair hash (rp_encoder_kernels.h::drop_mul2): at least 1 for p > 0 (0 switches dropout off)
+static Drop make_drop(float p, uint32_t seed) {
+  if (!(p > 0.f)) return Drop{seed, 0u, 1.f};
+  const long t = std::lround((double)p * 65536.0);
+  return Drop{seed, (uint32_t)std::min(std::max(t, 1L), 65535L), 1.f / (1.f - p)};
+}
+
 extern "C" RpStatus rp_trainer_set_dropout(RpTrainer* tr, float p, uint32_t seed) {
   RP_REQUIRE(tr && p >= 0.f && p < 1.f, "dropout probability %g", (double)p);
-  const double th = (double)p * 4294967296.0;
-  tr->drop = Drop{seed, p > 0.f ? (uint32_t)std::min(th, 4294967295.0) : 0u, p > 0.f ? 1.f / (1.f - p) : 1.f};
+  tr->drop = make_drop(p, seed);
   return RP_OK;
 }
 
 extern "C" RpStatus rp_dbg_dropout_mask(float p, uint32_t seed, uint32_t site, uint32_t row0, uint32_t col0, int32_t rows,
                                         int32_t cols, uint8_t* out, void* stream_) {
   RP_REQUIRE(out && rows > 0 && cols > 0 && p > 0.f && p < 1.f, "bad argument");
-  const Drop d{seed, (uint32_t)std::min((double)p * 4294967296.0, 4294967295.0), 1.f / (1.f - p)};
+  const Drop d = make_drop(p, seed);
   hipLaunchKernelGGL(dropout_mask_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, (hipStream_t)stream_, d, site, row0, col0,
                      rows, cols, out);
   RP_CHECK_LAUNCH();

@@ -267,7 +267,12 @@ struct EpiGegluBwd {
         float dff[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
         if (drop.thresh) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) dff[e] *= drop_mul(drop, drop_site, (uint32_t)token, (uint32_t)(f0 + sub * 8 + e));
+          for (int e = 0; e < 8; e += 2) {
+            float m0, m1;
+            drop_mul2(drop, drop_site, (uint32_t)token, (uint32_t)(f0 + sub * 8 + e), m0, m1);
+            dff[e] *= m0;
+            dff[e + 1] *= m1;
+          }
         }
         const uint4 gq = gg[b & 1][c], uq = uu[b & 1][c];
         const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w}, uw[4] = {uq.x, uq.y, uq.z, uq.w};
@@ -309,12 +314,19 @@ struct EpiGegluBwd {
 
 // dx += v - x * rcoef[token]  on the two planes of the residual-stream gradient (v = the dgrad accumulators,
 // x = the sub-layer's saved input, bf16; rcoef = rs^2 * rowdot / D): RMSNorm backward fused into the dgrad GEMM.
-struct EpiRmsBwdResid {
+// MASK (round 6): the updated gradient is the input of the NEXT branch's backward, which under dropout wants bf16(mask dx)
+// as the operand of its two GEMMs - written here from the words just stored (mask_dx_kernel's arithmetic on the same
+// inputs: the same bits) instead of a separate pass over both planes per branch (24 launches of 14 us per step).
+template <bool MASK>
+struct EpiRmsBwdResidT {
   bf16_t* __restrict__ dxhi;
   bf16_t* __restrict__ dxlo;
   int ldx, n_valid;  // n_valid % 8 == 0
   const bf16_t* __restrict__ xs;
   const float* __restrict__ rcoef;
+  bf16_t* __restrict__ dxm = nullptr;  // MASK: [tokens, ldx] = bf16(mask(next_site) * (hi + lo))
+  Drop drop = Drop{0u, 0u, 1.f};
+  uint32_t next_site = 0;
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
     static_assert(FM % 2 == 0, "blocks of 64 features");
@@ -367,11 +379,23 @@ struct EpiRmsBwdResid {
           hilo_update2(h.w, l.w, __builtin_fmaf(-rc, lo16(x.w), d1.z), __builtin_fmaf(-rc, hi16(x.w), d1.w), oh.w, ol.w, ss);
           *reinterpret_cast<uint4*>(dxhi + off) = oh;
           *reinterpret_cast<uint4*>(dxlo + off) = ol;
+          if constexpr (MASK) {
+            const uint32_t hw[4] = {oh.x, oh.y, oh.z, oh.w}, lw[4] = {ol.x, ol.y, ol.z, ol.w};
+            uint32_t ow[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float m0, m1;
+              drop_mul2(drop, next_site, (uint32_t)token, (uint32_t)(f + 2 * e), m0, m1);
+              ow[e] = pack_bf2((lo16(hw[e]) + lo16(lw[e])) * m0, (hi16(hw[e]) + hi16(lw[e])) * m1);
+            }
+            *reinterpret_cast<uint4*>(dxm + off) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+          }
         }
       }
     }
   }
 };
+using EpiRmsBwdResid = EpiRmsBwdResidT<false>;
 
 // training forward, FFN-in: the row-scaled pre-activations (packed order) the backward needs AND the gated-GELU output with
 // the dropout that sits between it and wo (HF:110).  The product part is EpiGegluBf16T's, plus the mask.
@@ -406,9 +430,15 @@ struct EpiGegluTrainT {
           for (int g = 0; g < 4; ++g) {
             float y[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              y[e] = gelu_new(acc[i][jb + jj][4 * g + e] * sc) * (acc[i + 1][jb + jj][4 * g + e] * sc);
-              if constexpr (DROP) y[e] *= drop_mul(drop, drop_site, row, (uint32_t)((m_base >> 1) + (i >> 1) * 32 + 8 * g + 4 * hi + e));
+            for (int e = 0; e < 4; ++e) y[e] = gelu_new(acc[i][jb + jj][4 * g + e] * sc) * (acc[i + 1][jb + jj][4 * g + e] * sc);
+            if constexpr (DROP) {
+#pragma unroll
+              for (int e = 0; e < 4; e += 2) {
+                float m0, m1;
+                drop_mul2(drop, drop_site, row, (uint32_t)((m_base >> 1) + (i >> 1) * 32 + 8 * g + 4 * hi + e), m0, m1);
+                y[e] *= m0;
+                y[e + 1] *= m1;
+              }
             }
             uint2 v;
             v.x = pack_bf2(y[0], y[1]);
@@ -601,6 +631,17 @@ __global__ __launch_bounds__(256, (DROP && MODE == 1) ? 1 : 2) void attn_bwd_ker
           lse_m[0] = lv.x; lse_m[1] = lv.y; lse_m[2] = lv.z; lse_m[3] = lv.w;
           del_m[0] = dv.x; del_m[1] = dv.y; del_m[2] = dv.z; del_m[3] = dv.w;
         }
+        float dmul[4];
+        if constexpr (DROP) {
+          const int jg = c0 + 8 * g + 4 * hi;  // even: the lane's four streamed indices are jg .. jg + 3
+          if (MODE == 0) {  // streamed keys: two column pairs of the query's row
+            drop_mul2(drop, drop_site, (uint32_t)(s0 + ni), ((uint32_t)h << 20) | (uint32_t)jg, dmul[0], dmul[1]);
+            drop_mul2(drop, drop_site, (uint32_t)(s0 + ni), ((uint32_t)h << 20) | (uint32_t)(jg + 2), dmul[2], dmul[3]);
+          } else {  // streamed queries: the lane's key picks the field, the row advances
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dmul[e] = drop_mul(drop, drop_site, (uint32_t)(s0 + jg + e), ((uint32_t)h << 20) | (uint32_t)ni);
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
@@ -616,10 +657,8 @@ __global__ __launch_bounds__(256, (DROP && MODE == 1) ? 1 : 2) void attn_bwd_ker
           // delta = dO . O already carries the mask
           float pm = p, dpv = dp[mb][r];
           if constexpr (DROP) {
-            const uint32_t qrow = (uint32_t)(s0 + ((MODE == 0) ? ni : j)), kcol = (uint32_t)((MODE == 0) ? j : ni);
-            const float m = drop_mul(drop, drop_site, qrow, ((uint32_t)h << 20) | kcol);
-            pm *= m;
-            dpv *= m;
+            pm *= dmul[e];
+            dpv *= dmul[e];
           }
           const float ds = p * (dpv - del);
           s[mb][r] = pm;
@@ -817,8 +856,9 @@ __global__ __launch_bounds__(256) void mask_dx_kernel(const bf16_t* __restrict__
     for (int e = 0; e < 4; ++e) {
       const float x0 = __uint_as_float(hw[e] << 16) + __uint_as_float(lw[e] << 16);
       const float x1 = __uint_as_float(hw[e] & 0xffff0000u) + __uint_as_float(lw[e] & 0xffff0000u);
-      ow[e] = pack_bf2(x0 * drop_mul(drop, site, (uint32_t)row, (uint32_t)(c * 8 + 2 * e)),
-                       x1 * drop_mul(drop, site, (uint32_t)row, (uint32_t)(c * 8 + 2 * e + 1)));
+      float m0, m1;
+      drop_mul2(drop, site, (uint32_t)row, (uint32_t)(c * 8 + 2 * e), m0, m1);
+      ow[e] = pack_bf2(x0 * m0, x1 * m1);
     }
     dm[c] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
   }
@@ -841,8 +881,16 @@ __global__ __launch_bounds__(64) void rowdot_finish_kernel(const float* __restri
                                                            float* __restrict__ rcoef, int rows) {
   const int t = blockIdx.x * 64 + threadIdx.x;
   if (t >= rows) return;
+  // 32 slots requested at a time, then added in index order (round 6: the plain loop waited for each of the 56 slots of the
+  // FFN projection in turn - 19 us for 10 k tokens)
   float s = 0.f;
-  for (int p = 0; p < np; ++p) s += rdp[(size_t)p * ld + t];
+  for (int p0 = 0; p0 < np; p0 += 32) {
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = (p0 + i < np) ? rdp[(size_t)(p0 + i) * ld + t] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += v[i];
+  }
   const float r = rs[t];
   rcoef[t] = r * r * s * inv_d;
 }
@@ -1113,19 +1161,40 @@ __global__ __launch_bounds__(256) void unfold_kernel(UnfoldArgs a) {
   }
 }
 
-// out[c] = sum_r part[r][c]: 64 columns per workgroup, wave w sums rows w, w + 4, ... in order, then the four wave sums
-// in wave order (fixed association: deterministic)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int rows, int C,
-                                                     float* __restrict__ out) {
-  __shared__ float red[4][64];
+// out[c] = sum_r part[r][c]: 64 columns per workgroup of 16 waves, wave w sums rows w, w + 16, ... in order (eight loads in
+// flight), then the sixteen wave sums pairwise in a fixed tree (deterministic).  Round 6: four waves per workgroup walked 56
+// rows each one load at a time - 9.5 us per launch, 25 launches per step.
+constexpr int COLSUM_WAVES = 16;
+__global__ __launch_bounds__(64 * COLSUM_WAVES) void colsum_kernel(const float* __restrict__ part, int rows, int C,
+                                                                   float* __restrict__ out) {
+  __shared__ float red[COLSUM_WAVES][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   float s = 0.f;
-  if (c < C)
-    for (int r = wave; r < rows; r += 4) s += part[(size_t)r * C + c];
+  if (c < C) {
+    for (int r0 = wave; r0 < rows; r0 += 8 * COLSUM_WAVES) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = r0 + i * COLSUM_WAVES;
+        v[i] = (r < rows) ? part[(size_t)r * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[i];
+    }
+  }
   red[wave][lane] = s;
   __syncthreads();
-  if (wave == 0 && c < C) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (wave == 0 && c < C) {
+    float t[COLSUM_WAVES];
+#pragma unroll
+    for (int i = 0; i < COLSUM_WAVES; ++i) t[i] = red[i][lane];
+#pragma unroll
+    for (int w = 1; w < COLSUM_WAVES; w *= 2)
+#pragma unroll
+      for (int i = 0; i < COLSUM_WAVES; i += 2 * w) t[i] += t[i + w];
+    out[c] = t[0];
+  }
 }
 
 // relative_attention_bias.weight's gradient: column sums of the workgroups' table rows, then offsets -> buckets
