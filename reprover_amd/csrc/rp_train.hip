@@ -22,7 +22,7 @@
 using namespace rp;
 
 namespace rp {
-int g_train_dbg = 0;  // experiments (rp_set_option "train_dbg"): bit 0 = skip the bias-table gradient's LDS atomics
+int g_train_dbg = 0;  // experiments (rp_set_option "train_dbg"): bit 0 = skip the bias-table gradient's LDS atomics, bit 1 = the two feed-forward weight gradients as separate launches
 }
 
 namespace {
@@ -106,27 +106,40 @@ struct TrainWs {
 // kernel).  Deterministic in (rows, cols, nk): the same plan sizes the workspace and drives the launch.
 struct WgradPlan {
   int cfg, splits;
+  double t;  // modelled seconds
 };
+constexpr double WGRAD_CU_RATE = 1.0e15 / 256;  // sustained MFMA rate of one CU on these loops, FLOP/s
+constexpr double WGRAD_PART_BW = 4.0e12;        // partial-matrix traffic, B/s
 WgradPlan plan_wgrad(int rows, int cols, int nk) {
-  const double cu_rate = 1.0e15 / 256;       // sustained MFMA rate of one CU on these loops, FLOP/s
-  const double hbm = 4.0e12;                 // partial-matrix traffic, B/s
-  WgradPlan best{0, 1};
-  double best_t = 1e30;
+  WgradPlan best{0, 1, 1e30};
   for (int cfg = 0; cfg < 2; ++cfg) {
     const int b = cfg == 0 ? 256 : 128;
     const int slots = cfg == 0 ? 256 : 512;
-    const double rate = cfg == 0 ? cu_rate : cu_rate * 0.7 / 2;  // per workgroup
+    const double rate = cfg == 0 ? WGRAD_CU_RATE : WGRAD_CU_RATE * 0.7 / 2;  // per workgroup
     const int tiles = ((rows + b - 1) / b) * ((cols + b - 1) / b);
     for (int s = 1; s <= 32 && s * 4 <= std::max(nk, 4); ++s) {
       const int rounds = (tiles * s + slots - 1) / slots;
       const double t_wg = 2.0 * b * b * 64.0 * ((nk + s - 1) / s) / rate;
-      const double t_part = s > 1 ? 2.0 * s * (double)rows * cols * 4 / hbm : 0.0;
+      const double t_part = s > 1 ? 2.0 * s * (double)rows * cols * 4 / WGRAD_PART_BW : 0.0;
       const double tt = rounds * t_wg + t_part + 3e-6;
-      if (tt < best_t) {
-        best_t = tt;
-        best = WgradPlan{cfg, s};
-      }
+      if (tt < best.t) best = WgradPlan{cfg, s, tt};
     }
+  }
+  return best;
+}
+// Two products over the same tokens in ONE launch of 256 x 256 tiles with a common split count (wgrad_kernel's second
+// problem): the union of their tiles fills the rounds better than either alone - at the reference's training batch the two
+// feed-forward gradients are 168 + 84 = 252 tiles, one round of 256 CUs with no split at all.  splits = 0: launch them
+// separately (the model prefers it).  Same determinism as plan_wgrad.
+WgradPlan plan_wgrad_pair(int rows0, int cols0, int rows1, int cols1, int nk) {
+  const int tiles = ((rows0 + 255) / 256) * ((cols0 + 255) / 256) + ((rows1 + 255) / 256) * ((cols1 + 255) / 256);
+  WgradPlan best{0, 0, plan_wgrad(rows0, cols0, nk).t + plan_wgrad(rows1, cols1, nk).t};
+  for (int s = 1; s <= 32 && s * 4 <= std::max(nk, 4); ++s) {
+    const int rounds = (tiles * s + 255) / 256;
+    const double t_wg = 2.0 * 256 * 256 * 64.0 * ((nk + s - 1) / s) / WGRAD_CU_RATE;
+    const double t_part = s > 1 ? 2.0 * s * ((double)rows0 * cols0 + (double)rows1 * cols1) * 4 / WGRAD_PART_BW : 0.0;
+    const double tt = rounds * t_wg + t_part + 3e-6;
+    if (tt < best.t) best = WgradPlan{0, s, tt};
   }
   return best;
 }
@@ -179,6 +192,9 @@ TrainWs carve_train(const RpTrainer* tr, int T, int batch, char* base) {
   need(D, inner);
   need(2 * F, D);
   need(D, F);
+  // the feed-forward pair in one launch: both partial sets live side by side
+  wp = std::max(wp, (size_t)std::max(1, plan_wgrad_pair((int)(2 * F), (int)D, (int)D, (int)F, nk).splits) * (2 * F * D + D * F) * 4);
+  wp = std::max(wp, (size_t)std::max(1, plan_wgrad_pair((int)(3 * inner), (int)D, (int)D, (int)inner, nk).splits) * (3 * inner * D + D * inner) * 4);
   w.wpart_bytes = wp;
   w.wpart = (float*)take(wp);
   w.dtab_part = (float*)take((Tp / ATT_Q + (size_t)batch + 1) * H * (2 * tr->enc->maxd + 1) * 4);
@@ -197,30 +213,44 @@ int bwd_variant(int n_rows_w, int K, int Tp) {
   return tiles >= 192 ? 26 : 0;
 }
 
+// One product of a wgrad launch: dW[ny, nx] (fp32, ldc = nx) = Y[:Tp, :ny]^T X[:Tp, :nx], `splits` partial matrices at
+// out + s * ny * nx
+struct WgradOperands {
+  const bf16_t* Y;
+  int ldy, ny;
+  const bf16_t* X;
+  int ldx, nx;
+  float* out;
+};
 template <class C>
-RpStatus launch_wgrad_cfg(const bf16_t* Y, int ldy, int ny, const bf16_t* X, int ldx, int nx, int nk, int splits, float* out,
-                          int ldc, size_t split_stride, hipStream_t stream) {
+RpStatus launch_wgrad_cfg(const WgradOperands& a, const WgradOperands* b, int nk, int splits, hipStream_t stream) {
   auto kern = wgrad_kernel<C>;
   static LdsAttrOnce attr;
   RP_HIP(attr.ensure((const void*)kern, C::LDS_BYTES));
-  const int tiles_m = (ny + C::BM - 1) / C::BM, tiles_n = (nx + C::BN - 1) / C::BN;
+  auto problem = [](const WgradOperands& o) {
+    return WgradProblem{o.Y, o.ldy, o.ny, o.X, o.ldx, o.nx, (o.ny + C::BM - 1) / C::BM, (o.nx + C::BN - 1) / C::BN,
+                        o.out, o.nx, (size_t)o.ny * o.nx};
+  };
+  const WgradProblem p0 = problem(a), p1 = b ? problem(*b) : WgradProblem{};
+  const int blocks0 = splits * p0.tiles_m * p0.tiles_n, blocks1 = b ? splits * p1.tiles_m * p1.tiles_n : 0;
   ProfScope ps(stream, RP_K_BWD_WGRAD);
-  hipLaunchKernelGGL(kern, dim3(splits * tiles_m * tiles_n), dim3(C::THREADS), C::LDS_BYTES, stream, Y, ldy, ny, X, ldx, nx,
-                     nk, splits, tiles_m, tiles_n, out, ldc, split_stride);
+  hipLaunchKernelGGL(kern, dim3(blocks0 + blocks1), dim3(C::THREADS), C::LDS_BYTES, stream, p0, p1, blocks0, nk, splits);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
 
-// dW[ny, nx] (fp32, ldc = nx) = Y[:Tp, :ny]^T X[:Tp, :nx]; `splits` partial matrices at out + s * ny * nx
 RpStatus launch_wgrad(const bf16_t* Y, int ldy, int ny, const bf16_t* X, int ldx, int nx, int Tp, int splits, float* out,
                       hipStream_t stream, int force_cfg = -1) {
   RP_REQUIRE(Tp % 64 == 0 && ny % 8 == 0 && nx % 8 == 0 && ny >= 8 && nx >= 8, "wgrad: Tp=%d ny=%d nx=%d", Tp, ny, nx);
   const int cfg = force_cfg >= 0 ? force_cfg : plan_wgrad(ny, nx, Tp / 64).cfg;
-  if (cfg == 1)
-    return launch_wgrad_cfg<WgradCfg<128, 128, 2, 2, 2>>(Y, ldy, ny, X, ldx, nx, Tp / 64, splits, out, nx, (size_t)ny * nx,
-                                                         stream);
-  return launch_wgrad_cfg<WgradCfg<256, 256, 4, 2, 2>>(Y, ldy, ny, X, ldx, nx, Tp / 64, splits, out, nx, (size_t)ny * nx,
-                                                       stream);
+  const WgradOperands a{Y, ldy, ny, X, ldx, nx, out};
+  if (cfg == 1) return launch_wgrad_cfg<WgradCfg<128, 128, 2, 2, 2>>(a, nullptr, Tp / 64, splits, stream);
+  return launch_wgrad_cfg<WgradCfg<256, 256, 4, 2, 2>>(a, nullptr, Tp / 64, splits, stream);
+}
+// two products over the same token rows in one launch of 256 x 256 tiles (plan_wgrad_pair)
+RpStatus launch_wgrad_pair(const WgradOperands& a, const WgradOperands& b, int Tp, int splits, hipStream_t stream) {
+  RP_REQUIRE(Tp % 64 == 0 && a.ny % 8 == 0 && a.nx % 8 == 0 && b.ny % 8 == 0 && b.nx % 8 == 0 && splits >= 1, "wgrad pair");
+  return launch_wgrad_cfg<WgradCfg<256, 256, 4, 2, 2>>(a, &b, Tp / 64, splits, stream);
 }
 
 RpStatus run_unfold(const UnfoldArgs& a, hipStream_t stream) {
@@ -371,15 +401,18 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
     const uint32_t site = DROP_SITE_LAYER0 + 8u * (uint32_t)i;
     // ---------------- feed-forward sub-layer:  x_out = x + ff Wo2^T,  ff = gelu(g) u,  [g | u] = rs (x Wi'^T)
     // dWo2 = dx^T ff  (dx: the hi plane of the residual gradient; mask * dx under dropout)
-    {
+    const WgradPlan pair = ((g_train_dbg >> 1) & 1) ? WgradPlan{0, 0, 0.0} : plan_wgrad_pair(2 * F, D, D, F, nk);  // bit 1: separate launches
+    auto wo_unfold = [&](int S) -> RpStatus {
+      if (S == 1) return RP_OK;
+      UnfoldArgs a{};
+      a.part = w.wpart + (pair.splits ? (size_t)S * 2 * F * D : 0); a.split_stride = (size_t)D * F; a.splits = S; a.rows = D; a.C = F;
+      a.mode = UNFOLD_PLAIN; a.g0 = grads + lay.layer(i, P_WO);
+      return run_unfold(a, stream);
+    };
+    if (!pair.splits) {
       const int S = wgrad_splits(D, F, nk);
-      float* dst = grads + lay.layer(i, P_WO);
-      if ((st = launch_wgrad(dxb, D, D, w.ff[i], F, F, Tp, S, S == 1 ? dst : w.wpart, stream))) return st;
-      if (S > 1) {
-        UnfoldArgs a{};
-        a.part = w.wpart; a.split_stride = (size_t)D * F; a.splits = S; a.rows = D; a.C = F; a.mode = UNFOLD_PLAIN; a.g0 = dst;
-        if ((st = run_unfold(a, stream))) return st;
-      }
+      if ((st = launch_wgrad(dxb, D, D, w.ff[i], F, F, Tp, S, S == 1 ? grads + lay.layer(i, P_WO) : w.wpart, stream))) return st;
+      if ((st = wo_unfold(S))) return st;
     }
     // dff = dx Wo2 -> gated-GELU backward -> dzs = rs [dg | du] (packed order), row dots
     if ((st = launch_gemm(dxb, D, Tp, Lt.wo2_t, D, F, D,
@@ -392,10 +425,18 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
       hipLaunchKernelGGL(rowdot_finish_kernel, dim3((Tp + 63) / 64), dim3(64), 0, stream, (const float*)w.rdp, (F + 63) / 64, Tp,
                          (const float*)w.rsf[i], inv_d, w.rcoef, Tp);
     }
-    // dWi' = dzs^T x  -> unfold (de-interleave gate / up, x ln_ff, d ln_ff)
+    // dWi' = dzs^T x  -> unfold (de-interleave gate / up, x ln_ff, d ln_ff); with the pair plan dWo2 rides in the same launch
+    // (dxb is still the branch's masked gradient: the epilogue that overwrites it comes below)
     {
-      const int S = wgrad_splits(2 * F, D, nk);
-      if ((st = launch_wgrad(w.dzs, 2 * F, 2 * F, w.xf[i], D, D, Tp, S, w.wpart, stream))) return st;
+      const int S = pair.splits ? pair.splits : wgrad_splits(2 * F, D, nk);
+      if (pair.splits) {
+        const WgradOperands wi_ops{w.dzs, 2 * F, 2 * F, w.xf[i], D, D, w.wpart};
+        const WgradOperands wo_ops{dxb, D, D, w.ff[i], F, F, S == 1 ? grads + lay.layer(i, P_WO) : w.wpart + (size_t)S * 2 * F * D};
+        if ((st = launch_wgrad_pair(wi_ops, wo_ops, Tp, S, stream))) return st;
+        if ((st = wo_unfold(S))) return st;
+      } else if ((st = launch_wgrad(w.dzs, 2 * F, 2 * F, w.xf[i], D, D, Tp, S, w.wpart, stream))) {
+        return st;
+      }
       UnfoldArgs a{};
       a.part = w.wpart; a.split_stride = (size_t)2 * F * D; a.splits = S; a.rows = 2 * F; a.C = D; a.mode = UNFOLD_GEGLU;
       a.g0 = grads + lay.layer(i, P_WI0); a.g1 = grads + lay.layer(i, P_WI1);
@@ -410,16 +451,20 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
     if ((st = rms_bwd_gemm(w.dzs, 2 * F, Lt.wi_t, w.xf[i], site + 1))) return st;
 
     // ---------------- attention sub-layer:  x_out = x + att Wo^T,  att = Attn(q, k, v),  [q | k | v] = rs (x Wqkv'^T)
-    {
+    // the two weight gradients of the sub-layer (dWo = dx^T att, dWqkv' = dzs^T x) as one launch when the model prefers it
+    // (30 + 12 tiles: a common split count fills the round)
+    const WgradPlan apair = ((g_train_dbg >> 1) & 1) ? WgradPlan{0, 0, 0.0} : plan_wgrad_pair(3 * inner, D, D, inner, nk);
+    auto o_unfold = [&](int S) -> RpStatus {
+      if (S == 1) return RP_OK;
+      UnfoldArgs a{};
+      a.part = w.wpart + (apair.splits ? (size_t)S * 3 * inner * D : 0); a.split_stride = (size_t)D * inner; a.splits = S; a.rows = D;
+      a.C = inner; a.mode = UNFOLD_PLAIN; a.g0 = grads + lay.layer(i, P_O);
+      return run_unfold(a, stream);
+    };
+    if (!apair.splits) {
       const int S = wgrad_splits(D, inner, nk);
-      float* dst = grads + lay.layer(i, P_O);
-      if ((st = launch_wgrad(dxb, D, D, w.att[i], inner, inner, Tp, S, S == 1 ? dst : w.wpart, stream))) return st;
-      if (S > 1) {
-        UnfoldArgs a{};
-        a.part = w.wpart; a.split_stride = (size_t)D * inner; a.splits = S; a.rows = D; a.C = inner; a.mode = UNFOLD_PLAIN;
-        a.g0 = dst;
-        if ((st = run_unfold(a, stream))) return st;
-      }
+      if ((st = launch_wgrad(dxb, D, D, w.att[i], inner, inner, Tp, S, S == 1 ? grads + lay.layer(i, P_O) : w.wpart, stream))) return st;
+      if ((st = o_unfold(S))) return st;
     }
     if ((st = launch_gemm(dxb, D, Tp, Lt.wo_t, D, inner, D, EpiStoreBf16{w.datt, inner, inner, RowScale{nullptr}}, stream,
                           RP_K_BWD_DGRAD, 0, nullptr, bwd_variant(inner, D, Tp))))
@@ -446,8 +491,16 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
                          (const float*)w.rsa[i], w.rcoef, T, Tp, 3 * inner, inv_d);
     }
     {
-      const int S = wgrad_splits(3 * inner, D, nk);
-      if ((st = launch_wgrad(w.dqkv, 3 * inner, 3 * inner, w.xa[i], D, D, Tp, S, w.wpart, stream))) return st;
+      const int S = apair.splits ? apair.splits : wgrad_splits(3 * inner, D, nk);
+      if (apair.splits) {
+        const WgradOperands qkv_ops{w.dqkv, 3 * inner, 3 * inner, w.xa[i], D, D, w.wpart};
+        const WgradOperands o_ops{dxb, D, D, w.att[i], inner, inner,
+                                  S == 1 ? grads + lay.layer(i, P_O) : w.wpart + (size_t)S * 3 * inner * D};
+        if ((st = launch_wgrad_pair(qkv_ops, o_ops, Tp, S, stream))) return st;
+        if ((st = o_unfold(S))) return st;
+      } else if ((st = launch_wgrad(w.dqkv, 3 * inner, 3 * inner, w.xa[i], D, D, Tp, S, w.wpart, stream))) {
+        return st;
+      }
       UnfoldArgs a{};
       a.part = w.wpart; a.split_stride = (size_t)3 * inner * D; a.splits = S; a.rows = 3 * inner; a.C = D; a.mode = UNFOLD_QKV;
       a.n = inner;

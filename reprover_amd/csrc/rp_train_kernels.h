@@ -191,15 +191,36 @@ __device__ __forceinline__ void wgrad_tile(const bf16_t* __restrict__ Y, int ldy
   epi.template run<FM, FN>(acc, tile_m * C::BM + wave_row * (FM * 32), tile_n * C::BN + wave_col * (FN * 32), lane);
 }
 
-// grid = splits * tiles_m * tiles_n; split s reduces token tiles [s nk / S, (s + 1) nk / S) into its own fp32 matrix
+// One launch carries up to TWO products over the same token range (round 6: the two weight gradients of a feed-forward
+// sub-layer - 168 + 84 tiles of 256 x 256 at d_model 1472 - fill one round of 256 CUs WITHOUT split-K, where each alone
+// ran three splits and a finishing pass over its partial matrices).  grid = splits * (tiles of p0 + tiles of p1): the
+// first blocks0 logical ids belong to p0.  Split s reduces token tiles [s nk / S, (s + 1) nk / S) into its own fp32 matrix
 // out + s * split_stride (summed in split order by the finishing kernel: no atomics).
+struct WgradProblem {
+  const bf16_t* Y;  // [T, ny]
+  int ldy, ny;
+  const bf16_t* X;  // [T, nx]
+  int ldx, nx;
+  int tiles_m, tiles_n;
+  float* out;  // [splits][ny, ldc]
+  int ldc;
+  size_t split_stride;
+};
 template <class C>
-__global__ __launch_bounds__(C::THREADS) void wgrad_kernel(const bf16_t* __restrict__ Y, int ldy, int ny,
-                                                           const bf16_t* __restrict__ X, int ldx, int nx, int nk_total,
-                                                           int splits, int tiles_m, int tiles_n, float* __restrict__ out,
-                                                           int ldc, size_t split_stride) {
+__global__ __launch_bounds__(C::THREADS) void wgrad_kernel(WgradProblem p0, WgradProblem p1, int blocks0, int nk_total,
+                                                           int splits) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const bool second = logical >= blocks0;  // uniform across the workgroup
+  if (second) logical -= blocks0;
+  const bf16_t* Y = second ? p1.Y : p0.Y;
+  const bf16_t* X = second ? p1.X : p0.X;
+  const int ldy = second ? p1.ldy : p0.ldy, ny = second ? p1.ny : p0.ny;
+  const int ldx = second ? p1.ldx : p0.ldx, nx = second ? p1.nx : p0.nx;
+  const int tiles_m = second ? p1.tiles_m : p0.tiles_m, tiles_n = second ? p1.tiles_n : p0.tiles_n;
+  float* out = second ? p1.out : p0.out;
+  const int ldc = second ? p1.ldc : p0.ldc;
+  const size_t split_stride = second ? p1.split_stride : p0.split_stride;
   const int per_split = tiles_m * tiles_n;
   const int s = logical / per_split, t = logical - s * per_split;
   const int tm = t / tiles_n, tn = t - tm * tiles_n;
@@ -476,7 +497,7 @@ constexpr int AB_TILE = 64 * 128;                  // 64 rows x 64 d, bf16
 constexpr int AB_STAGE = 2 * AB_TILE + 2 * 256;    // X1, X2, two vectors of 64 floats (MODE 1: lse2, delta)
 
 template <int MODE, bool DROP>
-__global__ __launch_bounds__(256, (DROP && MODE == 1) ? 1 : 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ att,
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ att,
                                                           const bf16_t* __restrict__ datt, const float* __restrict__ lse2,
                                                           float* __restrict__ delta, const int4* __restrict__ work,
                                                           const float* __restrict__ bias_tab, bf16_t* __restrict__ dqkv,
