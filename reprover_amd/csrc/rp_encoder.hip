@@ -50,6 +50,7 @@ int g_gemm_persist = 9;   // persistent workgroups (gemm_tiles_persist) per proj
 int g_pool_chunk = 64;      // tokens per workgroup of the pooling pass (32 / 64 / 128; round 5 A/B at 70 k tokens: 98 / 100 / 104 us)
 int g_gemm_edge_layout = 1;  // big tiles: the last feature tile of 1152 / 1472 features on a wave grid over its valid features only
 int g_gemm_mixed = 20;  // full and half tiles in ONE launch (gemm_kernel_mixed) per projection: 1 QKV, 4 attention-out, 16 FFN-out
+int g_gemm_mixed_bwd = 1;  // the same for the training step's dgrad GEMMs whose tile count leaves a short last round (plan_mixed_loose)
 int g_gemm_tail_variant = 30;  // tile configuration of that tail round: 30 = 256 x 128 x 64 half tiles, 0 = 128 x 128 x 32 quarter tiles
 int g_gemm_tail_split = 1;  // big passes without a mixed launch: the last partial round of 256 x 256 tiles as one round of smaller tiles
 int g_debug_skip_ffn = 0;  // parity debugging: stop each block after the attention sub-layer
@@ -174,6 +175,10 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   if (!strcmp(name, "gemm_mixed")) {
     RP_REQUIRE(value >= 0 && value <= 31, "gemm_mixed: bit mask 0..31");
     g_gemm_mixed = value;
+    return RP_OK;
+  }
+  if (!strcmp(name, "gemm_mixed_bwd")) {
+    g_gemm_mixed_bwd = value != 0;
     return RP_OK;
   }
   if (!strcmp(name, "gemm_tail_variant")) {

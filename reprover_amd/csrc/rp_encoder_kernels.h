@@ -12,7 +12,7 @@ namespace rp {
 
 // tuning knobs (defined in rp_encoder.hip, set through rp_set_option)
 extern int g_gemm_group_m, g_gemm_variant, g_gemm_variant_qkv, g_gemm_variant_wo, g_gemm_variant_o, g_gemm_tail_split,
-    g_debug_skip_ffn, g_gemm_skinny, g_gemm_skinny_variant, g_gemm_rs_lds, g_gemm_small_pipe, g_gemm_helpers, g_gemm_persist, g_pool_chunk, g_gemm_edge_layout, g_gemm_tail_variant, g_gemm_mixed;
+    g_debug_skip_ffn, g_gemm_skinny, g_gemm_skinny_variant, g_gemm_rs_lds, g_gemm_small_pipe, g_gemm_helpers, g_gemm_persist, g_pool_chunk, g_gemm_edge_layout, g_gemm_tail_variant, g_gemm_mixed, g_gemm_mixed_bwd;
 extern int g_gemm_stagger_us[RP_K_COUNT];
 
 // ------------------------------------------------------------------------------------------
@@ -833,6 +833,25 @@ inline MixedPlan plan_mixed(int tiles_f, int tiles_t, int n_cus) {
   return p;
 }
 
+// The same hand-out for a tile count that has no whole rounds of whole token rows (round 6, the training step's dgrad
+// GEMMs: 14 x 41 = 574 tiles are 2.24 rounds of 256 CUs - three tile periods): as many whole token rows of full tiles as fit
+// floor(tiles / CUs) rounds, the remaining rows as half tiles if they fit one round - 2.5 periods.
+inline MixedPlan plan_mixed_loose(int tiles_f, int tiles_t, int n_cus) {
+  MixedPlan p;
+  const int total = tiles_f * tiles_t, rounds = total / n_cus;
+  if (rounds == 0 || total % n_cus == 0) return p;
+  const int full_rows = rounds * n_cus / tiles_f, rest = tiles_t - full_rows;
+  if (full_rows <= 0 || rest <= 0 || 2 * rest * tiles_f > n_cus) return p;
+  p.full_rows = full_rows;
+  p.half_first = std::min(2 * rest, (n_cus / 2) / tiles_f);
+  p.half_last = 2 * rest - p.half_first;
+  return p;
+}
+template <class C, class Epi>
+constexpr bool mixed_capable() {
+  return C::PIPE != 0 && C::FP8 == 0 && C::BM == 256 && C::BN == 256 && C::NWAVES == 8 && C::OCC == 0 && epi_extra_lds<Epi>::value == 0;
+}
+
 // One workgroup per CU walking its share of the tiles (gemm_tiles_persist).  Workgroup b runs on XCD b % 8 (observed, speed
 // only) and takes the tiles j, j + 32, j + 64, ... of that XCD's contiguous range of logical tile ids (j = b / 8): at any
 // moment the 32 workgroups of an XCD sit on 32 consecutive logical ids, exactly as the one-tile-per-workgroup launch has them.
@@ -913,10 +932,12 @@ static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hi
   // token rows beyond the valid count are read as copies of the last valid row (the operand clamps at `rows`): the 27
   // padding rows of a 101-token state cost one cache line per DMA piece instead of eight
   a.rows = rows_needed;
-  if constexpr (edge_layouts<C, Epi>() && epi_extra_lds<Epi>::value == 0) {
-    if (prof_class >= RP_K_GEMM_QKV && prof_class <= RP_K_GEMM_WO && ((g_gemm_mixed >> (prof_class - RP_K_GEMM_QKV)) & 1) &&
-        n_helpers == 0 && !t_dev && K >= 2 * C::BK) {
-      const MixedPlan mp = plan_mixed(tiles_f, tiles_t, n_cus);
+  if constexpr (mixed_capable<C, Epi>()) {
+    const bool fwd_mixed = edge_layouts<C, Epi>() && prof_class >= RP_K_GEMM_QKV && prof_class <= RP_K_GEMM_WO &&
+                           ((g_gemm_mixed >> (prof_class - RP_K_GEMM_QKV)) & 1);
+    const bool bwd_mixed = prof_class == RP_K_BWD_DGRAD && g_gemm_mixed_bwd;  // the training step's dgrad GEMMs
+    if ((fwd_mixed || bwd_mixed) && n_helpers == 0 && !t_dev && K >= 2 * C::BK) {
+      const MixedPlan mp = fwd_mixed ? plan_mixed(tiles_f, tiles_t, n_cus) : plan_mixed_loose(tiles_f, tiles_t, n_cus);
       if (mp.full_rows) {
         using CH = GemmCfg<C::BM, C::BN / 2, C::BK, C::WM, C::WN, C::NSTAGE, C::PIPE>;
         auto mk = gemm_kernel_mixed<C, CH, Epi>;

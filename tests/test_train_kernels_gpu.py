@@ -43,6 +43,16 @@ def test_geglu_backward_epilogue(gen, M, F, K, variant):
     assert r["dot_err"] <= 2e-3 * r["dot_max"] + 1e-3
 
 
+def test_geglu_backward_mixed_launch_is_the_same_bits():
+    """The reference's training batch gives this GEMM 14 x 41 = 574 tiles of 256 x 256 - 2.24 rounds of 256 CUs - and it
+    runs as 36 token rows of full tiles + 10 rows of half tiles in one launch (plan_mixed_loose, option gemm_mixed_bwd):
+    the same K-ascending chain per output element, so not a bit differs from one workgroup per full tile."""
+    a = th.geglu_bwd_outputs(5, 41 * 256, 3584, 1472, 26, mixed=True)
+    b = th.geglu_bwd_outputs(5, 41 * 256, 3584, 1472, 26, mixed=False)
+    assert not torch.isnan(a[0].float()).any() and not torch.isnan(a[1]).any()
+    assert torch.equal(a[0].view(torch.int16), b[0].view(torch.int16)) and torch.equal(a[1].view(torch.int32), b[1].view(torch.int32))
+
+
 @pytest.mark.parametrize("M,N,K,variant", [(256, 128, 384, 0), (512, 1472, 7168, 26), (256, 1472, 1152, 26), (256, 128, 96, 0)])
 def test_rmsnorm_backward_residual_epilogue(gen, M, N, K, variant):
     r = th.check_rms_bwd_resid(gen, M, N, K, variant)

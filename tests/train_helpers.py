@@ -85,6 +85,25 @@ def check_geglu_bwd(gen, M, F, K, variant):
             "nan": int(torch.isnan(dzs.float()).sum().item() + torch.isnan(dots).sum().item())}
 
 
+def geglu_bwd_outputs(gen_seed, M, F, K, variant, mixed):
+    """dzs / row dots of one gated-GELU backward GEMM with the mixed launch (full + half tiles) switched on or off."""
+    lib = _lib.load()
+    gen = torch.Generator(device="cuda").manual_seed(gen_seed)
+    dx, W = rand_bf16(gen, M, K), rand_bf16(gen, F, K, scale=K ** -0.5)
+    gu = rand_bf16(gen, M, 2 * F, scale=1.5)
+    rs = torch.rand(M, generator=gen, device="cuda") + 0.5
+    dzs = torch.full((M, 2 * F), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dots = torch.full((M,), float("nan"), dtype=torch.float32, device="cuda")
+    _lib.check(lib.rp_set_option(b"gemm_mixed_bwd", int(mixed)), "opt")
+    try:
+        _lib.check(lib.rp_dbg_dgrad(_lib.ptr(dx), _lib.ptr(W), M, F, K, 0, _lib.ptr(gu), _lib.ptr(rs), _lib.ptr(dzs),
+                                    _lib.ptr(dots), variant, _lib.current_stream()), "rp_dbg_dgrad(0)")
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(lib.rp_set_option(b"gemm_mixed_bwd", 1), "opt")
+    return dzs, dots
+
+
 def check_rms_bwd_resid(gen, M, N, K, variant):
     import hip_helpers as hh
 
