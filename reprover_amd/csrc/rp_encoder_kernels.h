@@ -4,6 +4,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
+#include <functional>
 #include <vector>
 
 #include "rp_gemm.h"
@@ -833,20 +835,66 @@ inline MixedPlan plan_mixed(int tiles_f, int tiles_t, int n_cus) {
   return p;
 }
 
-// The same hand-out for a tile count that has no whole rounds of whole token rows (round 6, the training step's dgrad
-// GEMMs: 14 x 41 = 574 tiles are 2.24 rounds of 256 CUs - three tile periods): as many whole token rows of full tiles as fit
-// floor(tiles / CUs) rounds, the remaining rows as half tiles if they fit one round - 2.5 periods.
+// The same hand-out for a tile count that has no whole rounds of whole token rows (round 6, the training step: the
+// gated-GELU backward GEMM is 14 x 41 = 574 tiles - 2.24 rounds of 256 CUs, three tile periods; the FFN-in forward 28 x 41 =
+// 1148 - 4.48 rounds, five periods).  Candidate plans - the token rows that fit floor(tiles / CUs) rounds (or one / two rows
+// fewer) as full tiles, the rest as half tiles - are list-scheduled in the launch's block order (a half tile = 0.55
+// periods) and the best is taken if it saves more than a quarter period: 2.5 and 4.5 periods here.  Cached per shape.
 inline MixedPlan plan_mixed_loose(int tiles_f, int tiles_t, int n_cus) {
-  MixedPlan p;
+  struct Entry {
+    int tf, tt, cus;
+    MixedPlan p;
+  };
+  thread_local Entry cache[8] = {};
+  thread_local int next = 0;
+  for (const Entry& e : cache)
+    if (e.tf == tiles_f && e.tt == tiles_t && e.cus == n_cus) return e.p;
+  MixedPlan best;
   const int total = tiles_f * tiles_t, rounds = total / n_cus;
-  if (rounds == 0 || total % n_cus == 0) return p;
-  const int full_rows = rounds * n_cus / tiles_f, rest = tiles_t - full_rows;
-  if (full_rows <= 0 || rest <= 0 || 2 * rest * tiles_f > n_cus) return p;
-  p.full_rows = full_rows;
-  p.half_first = std::min(2 * rest, (n_cus / 2) / tiles_f);
-  p.half_last = 2 * rest - p.half_first;
-  return p;
+  if (rounds > 0 && total % n_cus != 0 && n_cus <= 1024) {
+    double best_t = (double)(rounds + 1) - 0.26;
+    std::vector<double> cu(n_cus);
+    auto makespan = [&](const MixedPlan& p) {
+      std::fill(cu.begin(), cu.end(), 0.0);
+      std::make_heap(cu.begin(), cu.end(), std::greater<double>());
+      double end = 0.0;
+      auto run = [&](int n, double d) {
+        for (int i = 0; i < n; ++i) {
+          std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
+          cu.back() += d;
+          end = std::max(end, cu.back());
+          std::push_heap(cu.begin(), cu.end(), std::greater<double>());
+        }
+      };
+      run(p.half_first * tiles_f, 0.55);
+      run(p.full_rows * tiles_f, 1.0);
+      run(p.half_last * tiles_f, 0.55);
+      return end;
+    };
+    const int top = rounds * n_cus / tiles_f;
+    for (int full_rows = top; full_rows >= std::max(1, top - 2); --full_rows) {
+      const int rest = tiles_t - full_rows;
+      if (rest <= 0) continue;
+      MixedPlan p;
+      p.full_rows = full_rows;
+      p.half_first = std::min(2 * rest, (n_cus / 2) / tiles_f);
+      p.half_last = 2 * rest - p.half_first;
+      const double t = makespan(p);
+      if (t < best_t) {
+        best_t = t;
+        best = p;
+      }
+    }
+  }
+  cache[next] = Entry{tiles_f, tiles_t, n_cus, best};
+  next = (next + 1) % 8;
+  return best;
 }
+// epilogues of the training step declare `loose_mixed`: their GEMMs take plan_mixed_loose whatever the projection class
+template <class E, class = void>
+struct epi_loose_mixed : std::false_type {};
+template <class E>
+struct epi_loose_mixed<E, std::void_t<decltype(E::loose_mixed)>> : std::true_type {};
 template <class C, class Epi>
 constexpr bool mixed_capable() {
   return C::PIPE != 0 && C::FP8 == 0 && C::BM == 256 && C::BN == 256 && C::NWAVES == 8 && C::OCC == 0 && epi_extra_lds<Epi>::value == 0;
@@ -933,9 +981,9 @@ static RpStatus launch_gemm_cfg(GemmOperand w, GemmOperand a, int K, Epi epi, hi
   // padding rows of a 101-token state cost one cache line per DMA piece instead of eight
   a.rows = rows_needed;
   if constexpr (mixed_capable<C, Epi>()) {
-    const bool fwd_mixed = edge_layouts<C, Epi>() && prof_class >= RP_K_GEMM_QKV && prof_class <= RP_K_GEMM_WO &&
+    const bool fwd_mixed = !epi_loose_mixed<Epi>::value && edge_layouts<C, Epi>() && prof_class >= RP_K_GEMM_QKV && prof_class <= RP_K_GEMM_WO &&
                            ((g_gemm_mixed >> (prof_class - RP_K_GEMM_QKV)) & 1);
-    const bool bwd_mixed = prof_class == RP_K_BWD_DGRAD && g_gemm_mixed_bwd;  // the training step's dgrad GEMMs
+    const bool bwd_mixed = epi_loose_mixed<Epi>::value && g_gemm_mixed_bwd;  // the training step's GEMMs
     if ((fwd_mixed || bwd_mixed) && n_helpers == 0 && !t_dev && K >= 2 * C::BK) {
       const MixedPlan mp = fwd_mixed ? plan_mixed(tiles_f, tiles_t, n_cus) : plan_mixed_loose(tiles_f, tiles_t, n_cus);
       if (mp.full_rows) {

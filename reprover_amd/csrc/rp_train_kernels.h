@@ -237,6 +237,7 @@ __global__ __launch_bounds__(C::THREADS) void wgrad_kernel(WgradProblem p0, Wgra
 //   rdp[slot][token] = sum over the slot's 64 features f of (dy_g g + dy_u u)      (RMSNorm backward's row dot)
 // g, u are the saved row-scaled pre-activations (bf16, packed order as the forward's weight interleave produced them).
 struct EpiGegluBwd {
+  static constexpr bool loose_mixed = true;
   const bf16_t* __restrict__ gu;  // [tokens, ld2]
   bf16_t* __restrict__ dzs;       // [tokens, ld2]
   int ld2, n_valid;               // ld2 = 2 d_ff, n_valid = d_ff (multiple of 64)
@@ -422,6 +423,8 @@ using EpiRmsBwdResid = EpiRmsBwdResidT<false>;
 // the dropout that sits between it and wo (HF:110).  The product part is EpiGegluBf16T's, plus the mask.
 template <bool DROP>
 struct EpiGegluTrainT {
+  // (not `loose_mixed`: 28 x 41 = 1148 tiles plan as 4.5 instead of 5 periods, but the persistent form this launch takes
+  // otherwise measured faster - 2.73 vs 2.80 ms per step)
   EpiStoreBf16 st;  // gu [tokens, 2 d_ff]
   bf16_t* out;      // ff [tokens, d_ff] = mask * gelu_new(g) * u
   int ldo, n_valid;
