@@ -341,6 +341,7 @@ struct EpiGegluBwd {
 // inputs: the same bits) instead of a separate pass over both planes per branch (24 launches of 14 us per step).
 template <bool MASK>
 struct EpiRmsBwdResidT {
+  static constexpr bool any_layout = true;  // blocks of 64 features per wave, whatever the wave grid (the edge tile of d_model 1472)
   bf16_t* __restrict__ dxhi;
   bf16_t* __restrict__ dxlo;
   int ldx, n_valid;  // n_valid % 8 == 0
