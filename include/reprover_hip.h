@@ -424,6 +424,10 @@ RpStatus rp_dbg_attention(const void* qkv_bf16, const int32_t* cu_seqlens, const
  *     variant: tile configuration (0 = 128x128x32, 26 = 256x256x64 pipelined). */
 RpStatus rp_dbg_wgrad(const void* Y, const void* X, float* out, int32_t T, int32_t ny, int32_t nx, int32_t splits,
                       void* stream);
+/* two products over the same T token rows in ONE launch of 256 x 256 tiles with a common split count (the training step's
+ * weight-gradient pairs): out0 f32 [splits, ny0, nx0], out1 f32 [splits, ny1, nx1] as rp_dbg_wgrad writes them. */
+RpStatus rp_dbg_wgrad_pair(const void* Y0, const void* X0, float* out0, int32_t ny0, int32_t nx0, const void* Y1,
+                           const void* X1, float* out1, int32_t ny1, int32_t nx1, int32_t T, int32_t splits, void* stream);
 RpStatus rp_dbg_attention_bwd(const void* qkv, const void* att, const void* datt, const int32_t* cu_seqlens,
                               const float* bias_tab, int32_t batch, int32_t num_heads, int32_t rows_total, void* lse_out,
                               void* att_out, void* dqkv, float* dtab, void* stream);

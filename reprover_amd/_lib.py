@@ -169,6 +169,8 @@ SIGNATURES = {
     ),
     "rp_grad_norm": (C.c_int32, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rp_dbg_wgrad": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "rp_dbg_wgrad_pair": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "rp_dbg_attention_bwd": (
         C.c_int32,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

@@ -717,6 +717,15 @@ extern "C" RpStatus rp_dbg_wgrad(const void* Y, const void* X, float* out, int32
                       (hipStream_t)stream_, splits < 0 ? 1 : 0);
 }
 
+extern "C" RpStatus rp_dbg_wgrad_pair(const void* Y0, const void* X0, float* out0, int32_t ny0, int32_t nx0, const void* Y1,
+                                      const void* X1, float* out1, int32_t ny1, int32_t nx1, int32_t T, int32_t splits,
+                                      void* stream_) {
+  RP_REQUIRE(Y0 && X0 && out0 && Y1 && X1 && out1 && splits > 0, "bad argument");
+  const WgradOperands a{(const bf16_t*)Y0, ny0, ny0, (const bf16_t*)X0, nx0, nx0, out0};
+  const WgradOperands b{(const bf16_t*)Y1, ny1, ny1, (const bf16_t*)X1, nx1, nx1, out1};
+  return launch_wgrad_pair(a, b, T, splits, (hipStream_t)stream_);
+}
+
 extern "C" RpStatus rp_dbg_attention_bwd(const void* qkv, const void* att, const void* datt, const int32_t* cu,
                                          const float* bias_tab, int32_t batch, int32_t H, int32_t rows_total, void* lse_out,
                                          void* att_out, void* dqkv, float* dtab /* [H, 257] */, void* stream_) {

@@ -30,6 +30,17 @@ def test_wgrad(gen, T, ny, nx, splits):
     assert r["max_err"] <= 2e-6 * T ** 0.5 * r["ref_max"] + 1e-4 and r["worst_split_err"] <= 2e-6 * T ** 0.5 * r["ref_max"] + 1e-4
 
 
+@pytest.mark.parametrize("T,shapes,splits", [(1024, ((7168, 1472), (1472, 3584)), 1), (640, ((1152, 1472), (1472, 384)), 5),
+                                             (256, ((64, 72), (200, 8)), 2)])
+def test_wgrad_pair_launch_equals_the_single_launches(gen, T, shapes, splits):
+    """The training step's weight-gradient pairs (dWi' + dWo2, dWqkv' + dWo) share one launch: per split and element the
+    same K-ascending MFMA chain as the product launched alone, so the partial matrices are the same bits."""
+    r = th.check_wgrad_pair(gen, T, shapes, splits)
+    print(r)
+    assert r["same_bits"]
+    assert r["max_err"] <= 2e-6 * T ** 0.5 * r["ref_max"] + 1e-4
+
+
 def test_wgrad_detects_permutations():
     assert th.check_wgrad_structured()["exact"]
 

@@ -40,6 +40,24 @@ def check_wgrad(gen, T, ny, nx, splits):
             "worst_split_err": worst_split, "nan": int(torch.isnan(out).sum().item())}
 
 
+def check_wgrad_pair(gen, T, shapes, splits):
+    """Two products in one launch (rp_dbg_wgrad_pair) against the same products launched one by one: the same bits per split."""
+    lib = _lib.load()
+    (ny0, nx0), (ny1, nx1) = shapes
+    Y0, X0, Y1, X1 = rand_bf16(gen, T, ny0), rand_bf16(gen, T, nx0), rand_bf16(gen, T, ny1), rand_bf16(gen, T, nx1)
+    out0 = torch.full((splits, ny0, nx0), float("nan"), dtype=torch.float32, device="cuda")
+    out1 = torch.full((splits, ny1, nx1), float("nan"), dtype=torch.float32, device="cuda")
+    _lib.check(lib.rp_dbg_wgrad_pair(_lib.ptr(Y0), _lib.ptr(X0), _lib.ptr(out0), ny0, nx0, _lib.ptr(Y1), _lib.ptr(X1),
+                                     _lib.ptr(out1), ny1, nx1, T, splits, _lib.current_stream()), "rp_dbg_wgrad_pair")
+    torch.cuda.synchronize()
+    one0, one1 = wgrad(Y0, X0, splits), wgrad(Y1, X1, splits)
+    ref0, ref1 = Y0.float().T @ X0.float(), Y1.float().T @ X1.float()
+    return {"same_bits": bool(torch.equal(out0.view(torch.int32), one0.view(torch.int32)) and
+                              torch.equal(out1.view(torch.int32), one1.view(torch.int32))),
+            "max_err": max((out0.sum(0) - ref0).abs().max().item(), (out1.sum(0) - ref1).abs().max().item()),
+            "ref_max": max(ref0.abs().max().item(), ref1.abs().max().item())}
+
+
 def check_wgrad_structured():
     """Operands that make any token / feature permutation visible: Y[t, o] = (t % 5 == o % 5), X[t, c] = t % 7 + c % 3."""
     T, ny, nx = 256, 256, 128
