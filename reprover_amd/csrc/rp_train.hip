@@ -22,7 +22,7 @@
 using namespace rp;
 
 namespace rp {
-int g_train_dbg = 0;  // experiments (rp_set_option "train_dbg"): bit 0 = skip the bias-table gradient's LDS atomics, bit 1 = the two feed-forward weight gradients as separate launches
+int g_train_dbg = 0;  // experiments (rp_set_option "train_dbg"): bit 0 = skip the bias-table gradient's LDS atomics, bit 1 = the weight gradients of a sub-layer as separate launches, bit 2 = dWi' finished by unfold_kernel even when its launch has no split
 }
 
 namespace {
@@ -221,6 +221,7 @@ struct WgradOperands {
   const bf16_t* X;
   int ldx, nx;
   float* out;
+  WgradFinish fin = WgradFinish{};  // first product of a split-free launch only
 };
 template <class C>
 RpStatus launch_wgrad_cfg(const WgradOperands& a, const WgradOperands* b, int nk, int splits, hipStream_t stream) {
@@ -229,9 +230,10 @@ RpStatus launch_wgrad_cfg(const WgradOperands& a, const WgradOperands* b, int nk
   RP_HIP(attr.ensure((const void*)kern, C::LDS_BYTES));
   auto problem = [](const WgradOperands& o) {
     return WgradProblem{o.Y, o.ldy, o.ny, o.X, o.ldx, o.nx, (o.ny + C::BM - 1) / C::BM, (o.nx + C::BN - 1) / C::BN,
-                        o.out, o.nx, (size_t)o.ny * o.nx};
+                        o.out, o.nx, (size_t)o.ny * o.nx, o.fin};
   };
   const WgradProblem p0 = problem(a), p1 = b ? problem(*b) : WgradProblem{};
+  RP_REQUIRE(!a.fin.geglu || (splits == 1 && a.ny % 64 == 0), "a finishing wgrad epilogue needs a split-free launch");
   const int blocks0 = splits * p0.tiles_m * p0.tiles_n, blocks1 = b ? splits * p1.tiles_m * p1.tiles_n : 0;
   ProfScope ps(stream, RP_K_BWD_WGRAD);
   hipLaunchKernelGGL(kern, dim3(blocks0 + blocks1), dim3(C::THREADS), C::LDS_BYTES, stream, p0, p1, blocks0, nk, splits);
@@ -429,20 +431,30 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
     // (dxb is still the branch's masked gradient: the epilogue that overwrites it comes below)
     {
       const int S = pair.splits ? pair.splits : wgrad_splits(2 * F, D, nk);
+      // split-free pair: the epilogue finishes dWi' itself (WgradFinish: no partial matrix, no unfold pass); bit 2 of
+      // train_dbg keeps the separate pass
+      const bool finish_in_epilogue = pair.splits == 1 && (2 * F) % 64 == 0 && !((g_train_dbg >> 2) & 1);
       if (pair.splits) {
-        const WgradOperands wi_ops{w.dzs, 2 * F, 2 * F, w.xf[i], D, D, w.wpart};
+        WgradOperands wi_ops{w.dzs, 2 * F, 2 * F, w.xf[i], D, D, w.wpart};
+        if (finish_in_epilogue) {
+          wi_ops.out = grads + lay.layer(i, P_WI0);
+          wi_ops.fin = WgradFinish{1, grads + lay.layer(i, P_WI1), params + lay.layer(i, P_WI0), params + lay.layer(i, P_WI1),
+                                   params + lay.layer(i, P_LN_FF), w.dln_part};
+        }
         const WgradOperands wo_ops{dxb, D, D, w.ff[i], F, F, S == 1 ? grads + lay.layer(i, P_WO) : w.wpart + (size_t)S * 2 * F * D};
         if ((st = launch_wgrad_pair(wi_ops, wo_ops, Tp, S, stream))) return st;
         if ((st = wo_unfold(S))) return st;
       } else if ((st = launch_wgrad(w.dzs, 2 * F, 2 * F, w.xf[i], D, D, Tp, S, w.wpart, stream))) {
         return st;
       }
-      UnfoldArgs a{};
-      a.part = w.wpart; a.split_stride = (size_t)2 * F * D; a.splits = S; a.rows = 2 * F; a.C = D; a.mode = UNFOLD_GEGLU;
-      a.g0 = grads + lay.layer(i, P_WI0); a.g1 = grads + lay.layer(i, P_WI1);
-      a.w0 = params + lay.layer(i, P_WI0); a.w1 = params + lay.layer(i, P_WI1);
-      a.ln = params + lay.layer(i, P_LN_FF); a.dln_part = w.dln_part;
-      if ((st = run_unfold(a, stream))) return st;
+      if (!finish_in_epilogue) {
+        UnfoldArgs a{};
+        a.part = w.wpart; a.split_stride = (size_t)2 * F * D; a.splits = S; a.rows = 2 * F; a.C = D; a.mode = UNFOLD_GEGLU;
+        a.g0 = grads + lay.layer(i, P_WI0); a.g1 = grads + lay.layer(i, P_WI1);
+        a.w0 = params + lay.layer(i, P_WI0); a.w1 = params + lay.layer(i, P_WI1);
+        a.ln = params + lay.layer(i, P_LN_FF); a.dln_part = w.dln_part;
+        if ((st = run_unfold(a, stream))) return st;
+      }
       ProfScope ps(stream, RP_K_BWD_OTHER);
       hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(64 * COLSUM_WAVES), 0, stream, (const float*)w.dln_part, (2 * F + 31) / 32,
                          D, grads + lay.layer(i, P_LN_FF));

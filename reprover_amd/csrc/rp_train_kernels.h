@@ -35,12 +35,55 @@ struct WgradCfg {
   static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tiling");
 };
 
+// A product that runs WITHOUT split-K can finish its gradient in the epilogue (round 6: the feed-forward pair's dWi'): what
+// unfold_kernel's GEGLU mode does on the partial matrices - de-interleave the packed gate | up rows, x ln, the 32-row-block
+// partials of d ln = colsum(dW' .* W) - on the accumulators as they stand, so the 42-MB matrix is neither written as a
+// partial nor read back.
+struct WgradFinish {
+  int geglu = 0;                    // 1: rows are the packed [32 gate | 32 up] order of wi_0 / wi_1
+  float* g1 = nullptr;              // wi_1's gradient (wi_0's is the product's `out`)
+  const float* w0 = nullptr;        // master weights [d_ff, C]
+  const float* w1 = nullptr;
+  const float* ln = nullptr;        // [C]
+  float* dln_part = nullptr;        // [rows / 32][C]
+};
 struct EpiStoreF32 {  // out[o, c] = acc (rows o < n_o, columns c < n_c); 32 lanes cover 128 contiguous bytes
   float* out;
   int ldc, n_o, n_c;
+  WgradFinish fin;
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane) {
     const int hi = lane >> 5, cl = lane & 31;
+    if (fin.geglu) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int ob = m_base + i * 32;  // a 32-row fragment = 32 gate rows or 32 up rows of one 64-row group
+        if (ob >= n_o) continue;
+        const bool up = (ob >> 5) & 1;
+        const int sr0 = (ob >> 6) * 32;
+        float* g = up ? fin.g1 : out;
+        const float* w = up ? fin.w1 : fin.w0;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int c = n_base + j * 32 + cl;
+          const bool live = c < n_c;
+          const float lnv = live ? fin.ln[c] : 0.f;
+          float wv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) wv[r] = live ? w[(size_t)(sr0 + mfma32_row(r, hi)) * ldc + c] : 0.f;
+          float dl = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[i][j][r];
+            if (live) g[(size_t)(sr0 + mfma32_row(r, hi)) * ldc + c] = v * lnv;
+            dl = __builtin_fmaf(v, wv[r], dl);
+          }
+          dl += __shfl_xor(dl, 32, 64);  // the fragment's other sixteen rows
+          if (hi == 0 && live) fin.dln_part[(size_t)(ob >> 5) * ldc + c] = dl;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -205,6 +248,7 @@ struct WgradProblem {
   float* out;  // [splits][ny, ldc]
   int ldc;
   size_t split_stride;
+  WgradFinish fin;  // splits == 1 only
 };
 template <class C>
 __global__ __launch_bounds__(C::THREADS) void wgrad_kernel(WgradProblem p0, WgradProblem p1, int blocks0, int nk_total,
@@ -225,7 +269,8 @@ __global__ __launch_bounds__(C::THREADS) void wgrad_kernel(WgradProblem p0, Wgra
   const int s = logical / per_split, t = logical - s * per_split;
   const int tm = t / tiles_n, tn = t - tm * tiles_n;
   const int kt0 = (int)((long long)s * nk_total / splits), kt1 = (int)((long long)(s + 1) * nk_total / splits);
-  EpiStoreF32 epi{out + (size_t)s * split_stride, ldc, ny, nx};
+  EpiStoreF32 epi{out + (size_t)s * split_stride, ldc, ny, nx, WgradFinish{}};
+  if (!second) epi.fin = p0.fin;  // (a finishing epilogue rides on the first product only)
   wgrad_tile<C>(Y, ldy, ny, X, ldx, nx, kt0, kt1 - kt0, tm, tn, epi, smem);
 }
 
