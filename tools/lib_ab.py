@@ -31,6 +31,11 @@ import bench
 from reprover_amd import _lib, synth, tokenizer
 from reprover_amd.encoder import HipT5Encoder
 _lib.LIB_PATH = os.path.abspath(lib_path)
+import ctypes
+_probe = ctypes.CDLL(_lib.LIB_PATH)  # an OLDER build may lack debug entry points added since: bind what it has
+for _name in [n for n in _lib.SIGNATURES if not hasattr(_probe, n)]:
+    assert _name.startswith("rp_dbg_"), _name
+    del _lib.SIGNATURES[_name]
 lib = _lib.load()
 dev = torch.device("cuda", 0)
 cfg = synth.t5_config("byt5-small")
