@@ -432,9 +432,10 @@ RpStatus rp_dbg_attention_bwd(const void* qkv, const void* att, const void* datt
                               const float* bias_tab, int32_t batch, int32_t num_heads, int32_t rows_total, void* lse_out,
                               void* att_out, void* dqkv, float* dtab, void* stream);
 /* out u8 [rows, cols]: 1 where element (site, row0 + r, col0 + c) is kept.  Sites: 0 embeddings, 1 final norm output,
- * 16 + 8 i + {0 attention probabilities (row = the query's packed token index, col = (head << 12) | key offset in its
+ * 16 + 8 i + {0 attention probabilities (row = the query's packed token index, col = (head << 20) | key offset in its
  * sequence), 1 attention residual branch, 2 gated product inside the FFN, 3 FFN residual branch} (row = packed token
- * index, col = feature). */
+ * index, col = feature).  Element (site, row, col) is kept iff the 16-bit field (col & 1) of hash(seed, site, row, col >> 1)
+ * is >= round(p * 65536): one hash per column pair (rp_encoder_kernels.h::drop_mul2). */
 RpStatus rp_dbg_dropout_mask(float p, uint32_t seed, uint32_t site, uint32_t row0, uint32_t col0, int32_t rows,
                              int32_t cols, uint8_t* out, void* stream);
 RpStatus rp_dbg_dgrad(const void* A, const void* W, int32_t M, int32_t N, int32_t K, int32_t mode, const void* aux0,
