@@ -467,12 +467,22 @@ static RpStatus encode_pass(RpEncoder* e, const int32_t* ids, const int32_t* cu_
   {
     ProfScope ps(stream, RP_K_EMBED);
     // four token rows per wave, all their loads in flight before the first store (round 6, exp10: 66 -> 57 us at 70 k tokens;
-    // one row per wave 66, two 61 - 63, eight 61)
-    constexpr int ER = 4;
-    if (D <= 1536)
-      hipLaunchKernelGGL((embed_copy_kernel<3, ER>), dim3((Tp + 4 * ER - 1) / (4 * ER)), dim3(256), 0, stream, ids, (const bf16_t*)e->embed_hi, (const uint8_t*)e->embed_lo, (const float*)e->embed_ss, w.xb, reinterpret_cast<uint8_t*>(w.xlo), w.ssp, np, embed_rs ? w.rs : (float*)nullptr, 1.f / (float)D, c.layer_norm_eps, T, Tp, D, c.vocab_size, t_dev);
-    else
-      hipLaunchKernelGGL((embed_copy_kernel<4, ER>), dim3((Tp + 4 * ER - 1) / (4 * ER)), dim3(256), 0, stream, ids, (const bf16_t*)e->embed_hi, (const uint8_t*)e->embed_lo, (const float*)e->embed_ss, w.xb, reinterpret_cast<uint8_t*>(w.xlo), w.ssp, np, embed_rs ? w.rs : (float*)nullptr, 1.f / (float)D, c.layer_norm_eps, T, Tp, D, c.vocab_size, t_dev);
+    // one row per wave 66, two 61 - 63, eight 61).  Few tokens (a single proof state: 8 workgroups of four rows per wave
+    // took 11.4 us, 32 of one row 5.2): one row per wave, as many workgroups as there are rows to spread.
+    auto launch_embed = [&](auto kern, int rows_per_wave) {
+      hipLaunchKernelGGL(kern, dim3((Tp + 4 * rows_per_wave - 1) / (4 * rows_per_wave)), dim3(256), 0, stream, ids,
+                         (const bf16_t*)e->embed_hi, (const uint8_t*)e->embed_lo, (const float*)e->embed_ss, w.xb,
+                         reinterpret_cast<uint8_t*>(w.xlo), w.ssp, np, embed_rs ? w.rs : (float*)nullptr, 1.f / (float)D,
+                         c.layer_norm_eps, T, Tp, D, c.vocab_size, t_dev);
+    };
+    const bool few = Tp < 8192;
+    if (D <= 1536) {
+      if (few) launch_embed(embed_copy_kernel<3, 1>, 1);
+      else launch_embed(embed_copy_kernel<3, 4>, 4);
+    } else {
+      if (few) launch_embed(embed_copy_kernel<4, 1>, 1);
+      else launch_embed(embed_copy_kernel<4, 4>, 4);
+    }
   }
   RP_CHECK_LAUNCH();
   const dim3 att_grid(H, T / ATT_Q + batch);  // upper bound of the number of 128-query blocks

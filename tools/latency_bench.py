@@ -8,6 +8,8 @@ from reprover_amd.retrieval.model import PremiseRetriever
 import importlib.util
 spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
 bench = importlib.util.module_from_spec(spec); sys.argv = ["x"]; spec.loader.exec_module(bench)
+if os.environ.get("RP_LIB_PATH"):  # another build of the library (A/B runs)
+    _lib.LIB_PATH = os.path.abspath(os.environ["RP_LIB_PATH"])
 dev = torch.device("cuda:0")
 cfg = synth.t5_config("byt5-small")
 sd = bench.random_init_state_dict(cfg, dev, 1)
