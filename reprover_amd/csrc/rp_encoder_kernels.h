@@ -411,6 +411,8 @@ struct EpiStoreBf16T {  // out[token, feature] = bf16(acc * rs[token])
   bf16_t* out;
   int ldo, n_valid;  // n_valid = number of real output features (multiple of 8)
   RS rs;
+  // (the preload hook of the gated-GELU epilogue below was measured here too - the persistent QKV launch: 2.874 vs 2.880 ms
+  // per step, nothing - and is not carried)
   template <int FM, int FN>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
     const int hi = lane >> 5, cl = lane & 31;
@@ -582,6 +584,9 @@ struct EpiResidT {  // x[token, feature] += acc on the two planes of the residua
 typedef EpiResidT<false> EpiResid;          // the two bf16 planes (kernel tests; the training step's SPLIT_IN form)
 typedef EpiResidT<false, true> EpiResid8;   // bf16 plane + int8 extension plane: the inference pass
 
+#ifndef RP_GEGLU_PRELOAD  // (0: the factors are requested by the epilogue's first instructions, as until round 6)
+#define RP_GEGLU_PRELOAD 1
+#endif
 template <class RS>
 struct EpiGegluBf16T {  // W rows interleaved 32 gate / 32 up: even row-fragments gate, odd up
   // full tiles of the 8-wave 256 x 256 configuration run as 2 x 4 waves of 128 features x 64 tokens: a wave's 64 outputs per
@@ -591,7 +596,16 @@ struct EpiGegluBf16T {  // W rows interleaved 32 gate / 32 up: even row-fragment
   bf16_t* out;         // [tokens, n_valid/2]
   int ldo, n_valid;    // n_valid counts interleaved rows (= 2 * d_ff)
   RS rs;
-  template <int FM, int FN>
+  // persistent launches: the tokens' RMSNorm factors requested in front of the tile's last k-tile (rp_gemm.h has_preload)
+  static constexpr bool preload_hook = std::is_same<RS, RowScale>::value && RP_GEGLU_PRELOAD;
+  float pre[4] = {0.f, 0.f, 0.f, 0.f};
+  template <int FN>
+  __device__ __forceinline__ void preload(int n_base, int lane) {
+    static_assert(FN <= 4, "pre[]");
+#pragma unroll
+    for (int j = 0; j < FN; ++j) pre[j] = rs.get(n_base + j * 32 + (lane & 31));
+  }
+  template <int FM, int FN, bool PRE = false>
   __device__ __forceinline__ void run(f32x16 (&acc)[FM][FN], int m_base, int n_base, int lane, char* stage) {
     static_assert(FM % 2 == 0, "gate/up fragment pairs");
     const int hi = lane >> 5, cl = lane & 31;
@@ -603,7 +617,12 @@ struct EpiGegluBf16T {  // W rows interleaved 32 gate / 32 up: even row-fragment
     const int f = (m_base >> 1) + sub * 8;
     float scv[FN];
 #pragma unroll
-    for (int j = 0; j < FN; ++j) scv[j] = rs.get(n_base + j * 32 + cl);
+    for (int j = 0; j < FN; ++j) {
+      if constexpr (PRE)
+        scv[j] = pre[j];
+      else
+        scv[j] = rs.get(n_base + j * 32 + cl);
+    }
 #pragma unroll
     for (int jb = 0; jb < FN; jb += 2) {
 #pragma unroll

@@ -122,6 +122,15 @@ struct has_prologue<E, std::void_t<decltype(&E::prologue)>> : std::true_type {};
 
 // ... and `void reduce(int tid)`: called once the main loop is over (the metadata has landed and every wave is past the
 // barrier), followed by a barrier - turns the metadata into what the epilogue reads.
+// An epilogue may ask for `template <int FN> void preload(int n_base, int lane)` (static constexpr bool preload_hook = true):
+// the persistent tile loop calls it in front of a tile's LAST k-tile - nothing of the wave's is in flight there - so that
+// per-token operands of the epilogue (the RMSNorm factors) are in registers when the epilogue starts instead of being
+// requested by its first instructions (round 6: a round trip to another XCD's write, ~1 us per tile, 30 tiles per workgroup);
+// the epilogue then runs as run<FM, FN, true>.
+template <class E, class = void>
+struct has_preload : std::false_type {};
+template <class E>
+struct has_preload<E, std::enable_if_t<E::preload_hook>> : std::true_type {};
 template <class E, class = void>
 struct has_reduce : std::false_type {};
 template <class E>
@@ -696,7 +705,9 @@ __device__ __forceinline__ void gemm_tiles_persist(const GemmOperand A, const Ge
       ++kt;
     }
     for (; kt + 1 < nk; ++kt) tile_body(kt, I1(), I0());
+    if constexpr (has_preload<Epilogue>::value) epi.template preload<FN>(tile_n * C::BN + wave_col * (FN * 32), lane);
     tile_body(kt, I0(), I0());
+    if constexpr (has_preload<Epilogue>::value) wait_vmcnt<0>();  // (landed under the k-tile; the next tile's requests come below)
     __syncthreads();  // every wave is done with the ring (nothing of this wave's is in flight here)
     if constexpr (has_reduce<Epilogue>::value) epi.reduce(tid);  // (the barrier behind it: below, after the next tile's requests)
     RP_PTS(p_t2);
@@ -713,7 +724,10 @@ __device__ __forceinline__ void gemm_tiles_persist(const GemmOperand A, const Ge
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // the reduced metadata is visible to every wave (raw: the requests above stay in flight)
     }
-    epi.template run<FM, FN>(acc, em, en, lane, smem + PERSIST_EPI_OFF + wave * EPI_STAGE_BYTES);
+    if constexpr (has_preload<Epilogue>::value)
+      epi.template run<FM, FN, true>(acc, em, en, lane, smem + PERSIST_EPI_OFF + wave * EPI_STAGE_BYTES);
+    else
+      epi.template run<FM, FN>(acc, em, en, lane, smem + PERSIST_EPI_OFF + wave * EPI_STAGE_BYTES);
     return more;
   };
 
