@@ -344,35 +344,46 @@ struct EpiGegluBwd {
         const uint4 gq = gg[b & 1][c], uq = uu[b & 1][c];
         const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w}, uw[4] = {uq.x, uq.y, uq.z, uq.w};
         const float rsv = rs[token];
-        float og[8], ou[8], dot = 0.f;
+        // gelu_new(g) = g * sg, sg = sigmoid(2 z), 2 z = 2 sqrt(2/pi) (g + 0.044715 g^3); element pairs as 2-vectors so that
+        // everything but v_exp_f32 / v_rcp_f32 is a packed fp32 instruction (round 6; rp_util.h::geglu2 is the forward's)
+        constexpr float k1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+        constexpr float k2 = k1 * 0.044715f;
+        constexpr float d2 = 2.0f * 0.7978845608028654f, d2c3 = d2 * 3.0f * 0.044715f;
+        const f32x2 K1 = {k1, k1}, K2 = {k2, k2}, D2 = {d2, d2}, D2C3 = {d2c3, d2c3}, ONE = {1.f, 1.f}, RS = {rsv, rsv};
+        f32x2 dot2 = {0.f, 0.f};
+        uint32_t ogw[4], ouw[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float gv = __uint_as_float((e & 1) ? (gw[e >> 1] & 0xffff0000u) : (gw[e >> 1] << 16));
-          const float uv = __uint_as_float((e & 1) ? (uw[e >> 1] & 0xffff0000u) : (uw[e >> 1] << 16));
-          // gelu_new(g) = g * sg, sg = sigmoid(2 z), 2 z = 2 sqrt(2/pi) (g + 0.044715 g^3)
-          constexpr float k1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
-          constexpr float k2 = k1 * 0.044715f;
-          const float a = gv * __builtin_fmaf(k2, gv * gv, k1);
-          const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
-          const float d2z = 2.0f * 0.7978845608028654f * __builtin_fmaf(3.0f * 0.044715f, gv * gv, 1.0f);
-          const float dgelu = sg + gv * sg * (1.0f - sg) * d2z;
-          const float dyg = dff[e] * uv * dgelu, dyu = dff[e] * (gv * sg);
-          dot = __builtin_fmaf(dyg, gv, __builtin_fmaf(dyu, uv, dot));
-          og[e] = dyg * rsv;
-          ou[e] = dyu * rsv;
+        for (int e2 = 0; e2 < 4; ++e2) {
+          const f32x2 gv = {__uint_as_float(gw[e2] << 16), __uint_as_float(gw[e2] & 0xffff0000u)};
+          const f32x2 uv = {__uint_as_float(uw[e2] << 16), __uint_as_float(uw[e2] & 0xffff0000u)};
+          const f32x2 df = {dff[2 * e2], dff[2 * e2 + 1]};
+          const f32x2 g2 = gv * gv;
+          const f32x2 a = gv * __builtin_elementwise_fma(K2, g2, K1);
+          const f32x2 den = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)} + ONE;
+          const f32x2 sg = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+          const f32x2 d2z = __builtin_elementwise_fma(D2C3, g2, D2);
+          const f32x2 gs = gv * sg;                                   // gelu_new(g)
+          const f32x2 t = __builtin_elementwise_fma(-sg, sg, sg);     // sg (1 - sg)
+          const f32x2 dgelu = __builtin_elementwise_fma(gv * t, d2z, sg);
+          const f32x2 dyg = (df * uv) * dgelu, dyu = df * gs;
+          dot2 = __builtin_elementwise_fma(dyg, gv, __builtin_elementwise_fma(dyu, uv, dot2));
+          const f32x2 og = dyg * RS, ou = dyu * RS;
+          ogw[e2] = pack_bf2(og.x, og.y);
+          ouw[e2] = pack_bf2(ou.x, ou.y);
         }
+        float dot = dot2.x + dot2.y;
         if (f0 < n_valid) {
           const size_t off = (size_t)token * ld2 + 2 * f0 + pcol_in;
-          *reinterpret_cast<uint4*>(dzs + off) =
-              make_uint4(pack_bf2(og[0], og[1]), pack_bf2(og[2], og[3]), pack_bf2(og[4], og[5]), pack_bf2(og[6], og[7]));
-          *reinterpret_cast<uint4*>(dzs + off + 32) =
-              make_uint4(pack_bf2(ou[0], ou[1]), pack_bf2(ou[2], ou[3]), pack_bf2(ou[4], ou[5]), pack_bf2(ou[6], ou[7]));
+          *reinterpret_cast<uint4*>(dzs + off) = make_uint4(ogw[0], ogw[1], ogw[2], ogw[3]);
+          *reinterpret_cast<uint4*>(dzs + off + 32) = make_uint4(ouw[0], ouw[1], ouw[2], ouw[3]);
         } else {
           dot = 0.f;
         }
-        dot += __shfl_xor(dot, 1, 64);
-        dot += __shfl_xor(dot, 2, 64);
-        dot += __shfl_xor(dot, 4, 64);
+        // the token's 64 features sit on 8 neighbouring lanes: three DPP adds (quad_perm(1,0,3,2), quad_perm(2,3,0,1),
+        // row_half_mirror) leave the sum on every one of them
+        dot += dpp_f32<0xB1>(dot);
+        dot += dpp_f32<0x4E>(dot);
+        dot += dpp_f32<0x141>(dot);
         if (sub == 0 && slot < np) rdp[(size_t)slot * ld_t + token] = dot;
       }
     }
@@ -492,7 +503,7 @@ struct EpiGegluTrainT {
     for (int jb = 0; jb < FN; jb += 2) {
 #pragma unroll
       for (int jj = 0; jj < 2 && jb + jj < FN; ++jj) {
-        const float sc = scv[jb + jj];
+        const GegluConsts gc(scv[jb + jj]);  // the token's RMSNorm factor folded into the activation's constants
         const uint32_t row = (uint32_t)(n_base + (jb + jj) * 32 + cl);
 #pragma unroll
         for (int i = 0; i < FM; i += 2)
@@ -500,7 +511,12 @@ struct EpiGegluTrainT {
           for (int g = 0; g < 4; ++g) {
             float y[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = gelu_new(acc[i][jb + jj][4 * g + e] * sc) * (acc[i + 1][jb + jj][4 * g + e] * sc);
+            for (int e = 0; e < 4; e += 2) {  // the inference epilogue's packed form (rp_util.h::geglu2): the same bits as it
+              const f32x2 yy = geglu2(f32x2{acc[i][jb + jj][4 * g + e], acc[i][jb + jj][4 * g + e + 1]},
+                                      f32x2{acc[i + 1][jb + jj][4 * g + e], acc[i + 1][jb + jj][4 * g + e + 1]}, gc);
+              y[e] = yy.x;
+              y[e + 1] = yy.y;
+            }
             if constexpr (DROP) {
 #pragma unroll
               for (int e = 0; e < 4; e += 2) {
