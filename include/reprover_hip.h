@@ -331,9 +331,10 @@ void     rp_trainer_destroy(RpTrainer* tr);
 RpEncoder* rp_trainer_encoder(RpTrainer* tr);
 /* Dropout of the following rp_train_forward / rp_train_backward pairs (T5's dropout_rate, 0.1 in the reference's training:
  * transformers modeling_t5.py :725 embeddings, :168/:360 attention probabilities, :400 / :140 the two residual branches, :110
- * inside the gated FFN, :745 after the final norm).  Counter-based: element (site, row, column) is kept iff
- * hash(seed, site, row, column) >= p * 2^32 and scaled by 1 / (1 - p); the backward regenerates the masks of the forward that
- * ran with the same seed, nothing is stored.  p = 0 (the default) switches it off; pass a fresh seed per step. */
+ * inside the gated FFN, :745 after the final norm).  Counter-based: element (site, row, column) is kept iff the 16-bit field
+ * (column & 1) of hash(seed, site, row, column >> 1) is >= round(p * 2^16), and scaled by 1 / (1 - p); the backward
+ * regenerates the masks of the forward that ran with the same seed, nothing is stored.  p = 0 (the default) switches it off;
+ * pass a fresh seed per step. */
 RpStatus rp_trainer_set_dropout(RpTrainer* tr, float p, uint32_t seed);
 /* Refresh every compute copy from the fp32 masters (call after each optimizer step); launch-only. */
 RpStatus rp_trainer_load_params(RpTrainer* tr, const float* params, void* stream);
