@@ -24,7 +24,7 @@ thread_local std::string g_last_error;
 // options
 // ------------------------------------------------------------------------------------------
 extern int g_scan_cfg, g_scan_impl, g_scan_filter_cfg, g_scan_sample_cfg, g_scan_stride, g_scan_no_epilogue, g_scan_impl_force_new,
-    g_scan_cap, g_train_dbg;
+    g_scan_cap, g_train_dbg, g_train_wgrad_form;
 int g_gemm_group_m = 8;
 // Tile configuration per encoder GEMM (see launch_gemm()), measured at 65536 tokens (tools/gemm_bench.py,
 // profiles/).  20 / 26 = the software-pipelined 256 x 256 x 64 tile with 4 / 8 waves: the same main
@@ -214,6 +214,11 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   if (!strcmp(name, "train_dbg")) { g_train_dbg = value; return RP_OK; }
   if (!strcmp(name, "scan_no_epilogue")) { g_scan_no_epilogue = value; return RP_OK; }
 #endif
+  if (!strcmp(name, "train_wgrad_form")) {  // tests: the weight-gradient launch forms of the training step (rp_train.hip)
+    RP_REQUIRE(value >= 0 && value <= 3, "train_wgrad_form: bit mask 0..3");
+    g_train_wgrad_form = value;
+    return RP_OK;
+  }
   if (!strcmp(name, "scan_cap")) { g_scan_cap = value; return RP_OK; }  // tests: forces the overflow -> dense contract
   if (!strcmp(name, "scan_force_new")) { g_scan_impl_force_new = value; return RP_OK; }
   if (!strcmp(name, "scan_impl")) {

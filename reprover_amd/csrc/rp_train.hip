@@ -22,7 +22,10 @@
 using namespace rp;
 
 namespace rp {
-int g_train_dbg = 0;  // experiments (rp_set_option "train_dbg"): bit 0 = skip the bias-table gradient's LDS atomics, bit 1 = the weight gradients of a sub-layer as separate launches, bit 2 = dWi' finished by unfold_kernel even when its launch has no split
+int g_train_dbg = 0;  // experiments (rp_set_option "train_dbg", probe builds): bit 0 = skip the bias-table gradient's LDS atomics
+// rp_set_option "train_wgrad_form" (tests): bit 0 = the weight gradients of a sub-layer as separate launches (rounds 3-5),
+// bit 1 = dWi' finished by unfold_kernel even when its launch has no split
+int g_train_wgrad_form = 0;
 }
 
 namespace {
@@ -403,7 +406,7 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
     const uint32_t site = DROP_SITE_LAYER0 + 8u * (uint32_t)i;
     // ---------------- feed-forward sub-layer:  x_out = x + ff Wo2^T,  ff = gelu(g) u,  [g | u] = rs (x Wi'^T)
     // dWo2 = dx^T ff  (dx: the hi plane of the residual gradient; mask * dx under dropout)
-    const WgradPlan pair = ((g_train_dbg >> 1) & 1) ? WgradPlan{0, 0, 0.0} : plan_wgrad_pair(2 * F, D, D, F, nk);  // bit 1: separate launches
+    const WgradPlan pair = (g_train_wgrad_form & 1) ? WgradPlan{0, 0, 0.0} : plan_wgrad_pair(2 * F, D, D, F, nk);
     auto wo_unfold = [&](int S) -> RpStatus {
       if (S == 1) return RP_OK;
       UnfoldArgs a{};
@@ -431,9 +434,9 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
     // (dxb is still the branch's masked gradient: the epilogue that overwrites it comes below)
     {
       const int S = pair.splits ? pair.splits : wgrad_splits(2 * F, D, nk);
-      // split-free pair: the epilogue finishes dWi' itself (WgradFinish: no partial matrix, no unfold pass); bit 2 of
-      // train_dbg keeps the separate pass
-      const bool finish_in_epilogue = pair.splits == 1 && (2 * F) % 64 == 0 && !((g_train_dbg >> 2) & 1);
+      // split-free pair: the epilogue finishes dWi' itself (WgradFinish: no partial matrix, no unfold pass); bit 1 of
+      // train_wgrad_form keeps the separate pass
+      const bool finish_in_epilogue = pair.splits == 1 && (2 * F) % 64 == 0 && !(g_train_wgrad_form & 2);
       if (pair.splits) {
         WgradOperands wi_ops{w.dzs, 2 * F, 2 * F, w.xf[i], D, D, w.wpart};
         if (finish_in_epilogue) {
@@ -465,7 +468,7 @@ RpStatus train_backward(RpTrainer* tr, const float* params, const int32_t* ids, 
     // ---------------- attention sub-layer:  x_out = x + att Wo^T,  att = Attn(q, k, v),  [q | k | v] = rs (x Wqkv'^T)
     // the two weight gradients of the sub-layer (dWo = dx^T att, dWqkv' = dzs^T x) as one launch when the model prefers it
     // (30 + 12 tiles: a common split count fills the round)
-    const WgradPlan apair = ((g_train_dbg >> 1) & 1) ? WgradPlan{0, 0, 0.0} : plan_wgrad_pair(3 * inner, D, D, inner, nk);
+    const WgradPlan apair = (g_train_wgrad_form & 1) ? WgradPlan{0, 0, 0.0} : plan_wgrad_pair(3 * inner, D, D, inner, nk);
     auto o_unfold = [&](int S) -> RpStatus {
       if (S == 1) return RP_OK;
       UnfoldArgs a{};

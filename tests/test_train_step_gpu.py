@@ -301,6 +301,46 @@ def test_dropout_step_equals_the_oracle_with_the_same_masks(golden_dir):
     assert float(loss2) == float(loss) and torch.equal(tr2.grads, first)
 
 
+def test_paired_weight_gradient_launches_and_the_finishing_epilogue_equal_the_separate_passes():
+    """Round 6's weight-gradient launches - the two products of a sub-layer in one launch with a common split count, dWi'
+    finished by the wgrad epilogue when that launch has no split - against the forms they replace (option train_wgrad_form: bit 0 =
+    one launch per product, bit 1 = unfold_kernel finishes dWi'): the same step under dropout (the branch mask from the
+    epilogue both times), gradients equal up to the fp32 summation order of the split partials."""
+    from reprover_amd import _lib, synth
+    from reprover_amd.tokenizer import ByT5Tokenizer
+    from reprover_amd.train import HipT5Trainer
+
+    cfg = dict(synth.t5_config("byt5-small"), num_layers=2)
+    sd = synth.synth_state_dict(cfg, seed=41, scale="hf")
+    rng = np.random.default_rng(42)
+    tok = ByT5Tokenizer()
+
+    def enc(n_texts, lo, hi):
+        texts = [synth.synth_text(rng, int(n)) for n in rng.integers(lo, hi, size=n_texts)]
+        b = tok(texts, padding="longest", max_length=1024, truncation=True, return_tensors="pt")
+        return b.input_ids, b.attention_mask
+
+    groups = [enc(6, 100, 900), enc(6, 100, 900), enc(6, 50, 600)]  # ~ 8 k tokens: the pair plans of a real batch
+    label = torch.from_numpy((rng.random((6, 12)) < 0.25).astype(np.float32))
+    lib = _lib.load()
+    got = {}
+    try:
+        for name, form in (("paired", 0), ("separate", 1), ("paired_unfold", 2)):
+            _lib.check(lib.rp_set_option(b"train_wgrad_form", form), "opt")
+            tr = HipT5Trainer(cfg, sd, "cuda:0", lr=1e-4, dropout_rate=0.1, dropout_seed=5)
+            loss, _ = tr.contrastive_step(groups, label)
+            got[name] = (float(loss), {k: v.clone() for k, v in tr.named_gradients()})
+    finally:
+        _lib.check(lib.rp_set_option(b"train_wgrad_form", 0), "opt")
+    for other in ("separate", "paired_unfold"):
+        assert got[other][0] == got["paired"][0]  # (the forward is the same launches)
+        for k, g in got["paired"][1].items():
+            ref = got[other][1][k]
+            assert torch.isfinite(g).all()
+            rel = ((g - ref).norm() / (ref.norm() + 1e-30)).item()
+            assert rel <= 2e-5, (other, k, rel)
+
+
 def test_backward_at_block_and_tile_boundaries():
     """Sequence lengths on every boundary of the backward's tiling (1 token = EOS alone, 2, 63/64/65 = a streamed tile,
     127/128/129 = a query block, 255/256/257 = the GEMM row padding, a 700-token sequence whose offsets saturate the
