@@ -1521,10 +1521,18 @@ __global__ __launch_bounds__(256) void mse_backward_kernel(const float* __restri
   float* dst = (is_ctx ? d_ctx : d_prem) + (size_t)r * D;
   for (int c = threadIdx.x; c < D; c += 256) {
     float acc = 0.f;
-    for (int o = 0; o < n_other; ++o) {
-      const int j = is_ctx ? r : o, k = is_ctx ? o : r;
-      const float ds = (sim[(size_t)j * P + k] - label[(size_t)j * P + k]) * scale;
-      acc = fmaf(ds, other[(size_t)o * D + c], acc);
+    for (int o0 = 0; o0 < n_other; o0 += 8) {  // eight rows of the other side requested, then accumulated in index order
+      float ds[8], ov[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int o = min(o0 + u, n_other - 1);
+        const int j = is_ctx ? r : o, k = is_ctx ? o : r;
+        ds[u] = (sim[(size_t)j * P + k] - label[(size_t)j * P + k]) * scale;
+        ov[u] = other[(size_t)o * D + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (o0 + u < n_other) acc = fmaf(ds[u], ov[u], acc);
     }
     dst[c] = acc;
   }
