@@ -816,22 +816,7 @@ __global__ __launch_bounds__(C::THREADS) void gemm_kernel_mixed(GemmOperand A, G
     gemm_tile_pipe<CH>(A, W, K, h % tiles_m, 2 * full_rows + h / tiles_m, epi, smem);
   }
 }
-// CUs of the current device: an attribute query (not the slow property struct), cached per device.  ONE source for the
-// planners below and for encode_pass's main_rows(): plans computed in two places must agree on a part that does not have
-// 256 CUs.
-inline int device_cu_count() {
-  static int cached_dev = -1, cached = 256;
-  int dev = 0, v = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 256;
-  if (dev == cached_dev) return cached;
-  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) {
-    cached_dev = dev;
-    cached = v;
-    return v;
-  }
-  return 256;
-}
-
+// (device_cu_count(): rp_util.h)
 struct MixedPlan {
   int full_rows = 0, half_first = 0, half_last = 0;  // token tiles of 256 | rows of 128 tokens handed out first | last
 };

@@ -592,9 +592,14 @@ __device__ __forceinline__ void gemm_tiles_persist(const GemmOperand A, const Ge
     char* base = smem + buf * C::STAGE_BYTES;
     if (half == 0) {
 #pragma unroll
-      for (int d = 0; d < C::A_DMA; ++d)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + A.k_off(kt, BK)), (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024),
-                                         16, 0, 0);
+      for (int d = 0; d < C::A_DMA; ++d) {
+        if constexpr (C::AAUX == 2)  // (the scan's premise stream: nt policy)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + A.k_off(kt, BK)), (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024),
+                                           16, 0, 2);
+        else
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + A.k_off(kt, BK)), (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024),
+                                           16, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int d = 0; d < C::W_DMA; ++d)

@@ -54,15 +54,21 @@ typedef GemmCfg<128, 64, 64, 2, 2, 3> SimCfgSampleK64;
 typedef GemmCfg<256, 128, 64, 4, 2, 2, 1> SimCfgSampleBig;
 // default: the premise stream (read once, by one CU) carries the nt cache policy: -7 % filter time
 typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 0, 2> SimCfgFilterNt;
+// the same tile on EIGHT waves, 2 x 4 (128 premises x 64 queries per wave: the epilogue's runs - 64 scores per lane and query,
+// part = 2 x premise half + lane half - do not change): two waves per SIMD, one multiplies while the other waits
+typedef GemmCfg<256, 256, 64, 2, 4, 2, 1, 0, 2> SimCfgFilterNt8;
+// (the e4m3 tile stays on four waves: its 32-byte fragments, double-buffered, do not fit 256 registers beside 128 accumulators)
 constexpr int SIM_FILTER_META_BYTES = 5120;  // per-tile metadata behind the ring (EpiSimFilter::prologue)
 int g_scan_cfg = 0;   // 0: auto; 1: force 128-query tiles in the dense path
 int g_scan_impl = 0;  // 0: auto (pipelined filter kernel when the shape allows); 1: first-generation filter kernel
 int g_scan_impl_force_new = 0;  // experiments: second-generation filter for every batch size
-int g_scan_filter_cfg = 0;   // experiments: 0 = nt premise stream (default), 1 = 256x256x32 4-stage, 2 = default cache policy
+int g_scan_filter_cfg = 0;   // experiments: 0 = 8 waves, nt premise stream (default), 1 = 256x256x32 4-stage, 2 = 4 waves, default cache policy,
+                             // 4 = 4 waves (the default until round 6)
 int g_scan_sample_cfg = 0;   // experiments: 0 = 128x64x64 3-stage when D % 64 == 0 (default), 1 = 128x64x32 6-stage
                              // (a 6-stage 64-wide ring - five slices in flight - measured the same 23.5 us: not the depth)
 int g_scan_stride = 0;       // experiments: > 0 overrides the sampling stride (power of two)
 int g_scan_cap = 0;          // tests: > 0 overrides the candidate-list capacity (forces the overflow -> dense contract)
+int g_scan_persist = 1;      // 0: the bf16 filter pass as one workgroup per tile whatever the tile count (tests: the two forms write the same bits)
 int g_scan_no_epilogue = 0;  // timing only: the filter pass drops every score (main loop in isolation)
 
 __device__ __forceinline__ uint64_t make_key(float score, int32_t id) {
@@ -265,19 +271,20 @@ struct EpiSimFilter {
   uint2* slots;          // [workgroup tiles][256][4][64]
   int32_t* scnt;         // [tiles_q * 256][filter_blocks][4]
   int filter_blocks;
+  int stride, tiles_q;   // the plan's (a tile's filter block and slot area follow from its coordinates)
   // per workgroup
   char* smem;
   int meta_off;  // byte offset of the metadata behind the ring
-  int p0, q0;    // first premise / query of this workgroup's tile
-  int wg_tile, fb;
+  int p0;        // first premise of this workgroup's tile (prologue of the e4m3 form: one tile per workgroup)
   int debug_drop_all;
 
   static constexpr int M_TAU = 0, M_QS = 1024, M_ES = 2048, M_AS = 3072, M_AI = 4096;  // metadata layout (bytes from meta_off)
 
-  __device__ __forceinline__ void prologue(char* meta, int wave, int lane, int /*n0*/) {
+  __device__ __forceinline__ void prologue(char* meta, int wave, int lane, int q0) {  // (q0 = first query of the tile)
     auto dma4 = [&](const void* g, char* dst) {
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)dst, 4, 0, 0);
     };
+    if (wave >= 4) return;           // (an 8-wave tile: the first four waves bring the 256 entries)
     const int e = wave * 64 + lane;  // wave w brings entries [64 w, 64 w + 64)
     const int q = min(q0 + e, B - 1), p = min(p0 + e, N - 1);
     dma4(tau + q, meta + M_TAU + wave * 256);
@@ -299,12 +306,23 @@ struct EpiSimFilter {
     const float* s_tau = reinterpret_cast<const float*>(meta + M_TAU);
     const float* s_qs = reinterpret_cast<const float*>(meta + M_QS);
     const float* s_es = reinterpret_cast<const float*>(meta + M_ES);
-    const int pl0 = m_base - p0, ql0 = n_base - q0;  // this wave's first premise / query inside the tile
+    // the tile from the wave's coordinates (the persistent launch walks several tiles per workgroup): premise block pb is the
+    // fb-th block that is not a multiple of stride
+    const int pb = m_base >> 8, qt = n_base >> 8;
+    const int fb = pb - pb / stride - 1, wg_tile = fb * tiles_q + qt, q0 = qt << 8;
+    const int pl0 = m_base - (pb << 8), ql0 = n_base - q0;  // this wave's first premise / query inside the tile
     const int part = (pl0 >> 7) * 2 + hi;
 
+    // Append without a branch: ~5 % of the scores pass (k * stride accessible rows above the bound, ~3 x that before the
+    // predicate), so for nearly every score SOME lane of the wave appends, and a compiler-built `if` costs a saveexec, two taken
+    // branches to an out-of-line block and back and a 64-bit address computation per score (6.3 us of epilogue per tile for
+    // 128 compares per lane).  Here the compare narrows exec itself and the store + the cursor bump run under it:
+    // compare, exec <- vcc, store, add, exec <- all - straight-line code.  The run's cursor is a 32-bit byte offset from the
+    // tile's slot area (a uniform base in SGPRs); the count is what the cursor moved.  (exec is all ones on entry: the
+    // epilogue runs in uniform control flow of full waves.)
     float tauv[FN], qsv[FN], upv[FN];
-    uint2* run_ptr[FN];
-    int n[FN];
+    uint32_t off[FN], off0[FN];
+    const uint2* const tile_slots = slots + (size_t)wg_tile * 256 * (4 * SLOT_RUN);
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int ql = ql0 + j * 32 + cl;
@@ -315,9 +333,33 @@ struct EpiSimFilter {
         if (reinterpret_cast<const int*>(meta + M_AI)[ql] >= 0) upv[j] = as;
       }
       qsv[j] = FP8 ? s_qs[ql] : 1.f;
-      run_ptr[j] = slots + ((size_t)wg_tile * 256 + ql) * (4 * SLOT_RUN) + part;
-      n[j] = 0;
+      off0[j] = off[j] = (uint32_t)((ql * (4 * SLOT_RUN) + part) * (int)sizeof(uint2));
     }
+    auto append = [&](float sc, uint32_t code, int j) {
+      const uint64_t entry = ((uint64_t)code << 32) | __float_as_uint(sc);  // {score bits, 16 i + r} as the uint2 the reader takes
+      if constexpr (PAGED)
+        asm volatile(
+            "v_cmp_ge_f32_e32 vcc, %2, %3\n\t"
+            "s_mov_b64 exec, vcc\n\t"
+            "v_cmp_le_f32_e32 vcc, %2, %5\n\t"
+            "s_mov_b64 exec, vcc\n\t"
+            "global_store_dwordx2 %0, %1, %4\n\t"
+            "v_add_u32_e32 %0, 32, %0\n\t"  // entry stride: the four parts of a query interleave
+            "s_mov_b64 exec, -1"
+            : "+v"(off[j])
+            : "v"(entry), "v"(sc), "v"(tauv[j]), "s"(tile_slots), "v"(upv[j])
+            : "vcc", "memory");
+      else
+        asm volatile(
+            "v_cmp_ge_f32_e32 vcc, %2, %3\n\t"
+            "s_mov_b64 exec, vcc\n\t"
+            "global_store_dwordx2 %0, %1, %4\n\t"
+            "v_add_u32_e32 %0, 32, %0\n\t"
+            "s_mov_b64 exec, -1"
+            : "+v"(off[j])
+            : "v"(entry), "v"(sc), "v"(tauv[j]), "s"(tile_slots)
+            : "vcc", "memory");
+    };
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       float esv[16];
@@ -331,19 +373,21 @@ struct EpiSimFilter {
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
+        // the entry codes 16 i + r count up from a register written HERE: as compile-time constants the persistent tile loop
+        // hoisted all 64 of them out of the loop, live across it (spills)
+        // (the e4m3 form has one tile per workgroup, no loop, and no register to spare: constants there)
+        uint32_t code0 = (uint32_t)(i * 16);
+        if constexpr (FP8 == 0) asm volatile("v_mov_b32_e32 %0, %1" : "=v"(code0) : "n"(i * 16));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float sc = FP8 ? (acc[i][j][r] * qsv[j]) * esv[r] : acc[i][j][r];
-          if (sc >= tauv[j] && (!PAGED || sc <= upv[j])) {
-            run_ptr[j][n[j]] = make_uint2(__float_as_uint(sc), (uint32_t)(i * 16 + r));
-            n[j] += 4;  // entry stride: the four parts of a query interleave
-          }
+          append(sc, code0 + (uint32_t)r, j);
         }
       }
     }
 #pragma unroll
     for (int j = 0; j < FN; ++j)
-      scnt[((size_t)(q0 + ql0 + j * 32 + cl) * filter_blocks + fb) * 4 + part] = n[j] >> 2;
+      scnt[((size_t)(q0 + ql0 + j * 32 + cl) * filter_blocks + fb) * 4 + part] = (int)((off[j] - off0[j]) >> 5);
   }
 };
 
@@ -351,7 +395,7 @@ template <class C, bool PAGED>
 __global__ __launch_bounds__(C::THREADS) void sim_filter_kernel(GemmOperand Eop, GemmOperand Qop, int K, int tiles_q,
                                                                 int stride, EpiSimFilter<C::FP8, PAGED> epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert(C::BM == SIM_PB && C::BN == 256 && C::NWAVES == 4, "filter tile geometry");
+  static_assert(C::BM == SIM_PB && C::BN == 256 && C::WM == 2, "filter tile geometry");
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int qt = logical % tiles_q;
   const int fb = logical / tiles_q;
@@ -359,10 +403,37 @@ __global__ __launch_bounds__(C::THREADS) void sim_filter_kernel(GemmOperand Eop,
   epi.smem = smem;
   epi.meta_off = C::RING_BYTES;
   epi.p0 = pb * C::BM;
-  epi.q0 = qt * C::BN;
-  epi.wg_tile = logical;
-  epi.fb = fb;
   gemm_tile_pipe<C>(Eop, Qop, K, pb, qt, epi, smem);
+}
+
+// The same pass as ONE workgroup per CU walking its share of the tiles (gemm_tiles_persist; bf16 index): the 476 tiles of
+// C2 are two per CU, and the second tile's first k-tile is requested under the first tile's epilogue - neither the turn-over
+// of the CU to a new workgroup (~3.5 us between a first-round workgroup's last stamp and its successor's first) nor the
+// wait for a first k-tile with nothing else to do (~3 us) is paid a second time.  Workgroup b (XCD b % 8) takes entries
+// b / 8, b / 8 + 32, ... of its XCD's contiguous range of tile ids, as the encoder's persistent launches do.  Same MFMA
+// chain per score: not a bit differs.
+template <class C, bool PAGED>
+__global__ __launch_bounds__(C::THREADS) void sim_filter_persist_kernel(GemmOperand Eop, GemmOperand Qop, int K, int n_tiles,
+                                                                        EpiSimFilter<0, PAGED> epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(C::BM == SIM_PB && C::BN == 256 && C::WM == 2 && C::FP8 == 0, "filter tile geometry");
+  const int xcd = blockIdx.x & 7, per = (int)gridDim.x >> 3;  // (the grid is a multiple of 8)
+  const int q = n_tiles >> 3, r = n_tiles & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, cnt = q + (xcd < r ? 1 : 0);
+  int i = blockIdx.x >> 3;
+  const int tiles_q = epi.tiles_q, stride = epi.stride;
+  auto next_tile = [&](int& tm, int& tn) {
+    if (i >= cnt) return false;
+    const int logical = base + i, fb = logical / tiles_q;
+    i += per;
+    tm = fb + fb / (stride - 1) + 1;
+    tn = logical - fb * tiles_q;
+    return true;
+  };
+  epi.smem = smem;
+  epi.meta_off = PERSIST_META_OFF;
+  epi.p0 = 0;
+  gemm_tiles_persist<C>(Eop, Qop, K, next_tile, epi, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1070,6 +1141,18 @@ static RpStatus launch_filter_cfg(GemmOperand e, GemmOperand q, int D2, int n_bl
   RP_HIP(attr.ensure((const void*)sim_filter_kernel<C, PAGED>, LDS));
   const int tiles_q = (epi.B + C::BN - 1) / C::BN;
   ProfScope ps(stream, RP_K_SCAN);
+  if constexpr (C::FP8 == 0 && C::NSTAGE == 2 && C::BK == 64) {
+    // more tiles than CUs: one persistent workgroup per CU (K >= two k-tiles: its loop requests ring slot 1 unconditionally)
+    const int slots = device_cu_count() & ~7;
+    if (g_scan_persist && tiles_q * n_blocks > slots && slots >= 8 && D2 >= 2 * C::BK) {
+      static LdsAttrOnce pattr;
+      RP_HIP(pattr.ensure((const void*)sim_filter_persist_kernel<C, PAGED>, PERSIST_LDS_BYTES));
+      hipLaunchKernelGGL((sim_filter_persist_kernel<C, PAGED>), dim3(slots), dim3(C::THREADS), PERSIST_LDS_BYTES, stream, e, q, D2,
+                         tiles_q * n_blocks, epi);
+      RP_CHECK_LAUNCH();
+      return RP_OK;
+    }
+  }
   hipLaunchKernelGGL((sim_filter_kernel<C, PAGED>), dim3(tiles_q * n_blocks), dim3(C::THREADS), LDS, stream, e, q, D2, tiles_q,
                      stride, epi);
   RP_CHECK_LAUNCH();
@@ -1213,11 +1296,14 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
       ef.slots = (uint2*)(ws + p.off_slots);
       ef.scnt = (int32_t*)(ws + p.off_scnt);
       ef.filter_blocks = p.filter_blocks;
+      ef.stride = p.stride;
+      ef.tiles_q = (B + 255) / 256;
       ef.smem = nullptr;
       ef.meta_off = 0;
-      ef.p0 = ef.q0 = ef.wg_tile = ef.fb = 0;
+      ef.p0 = 0;
       ef.debug_drop_all = g_scan_no_epilogue;
     };
+    // (bf16 index: the 8-wave tile; the 4-wave forms it replaced stay selectable in probe builds, scan_filter_cfg)
     if (fp8 && after_id) {  // a later page: the bound joins the pre-test (EpiSimFilter<., PAGED>)
       EpiSimFilter<1, true> ef;
       fill(ef);
@@ -1235,7 +1321,7 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
       fill(ef);
       ef.after_score = after_score;
       ef.after_id = after_id;
-      st = launch_filter_cfg<SimCfgFilterNt, true>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+      st = launch_filter_cfg<SimCfgFilterNt8, true>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
     } else {
       EpiSimFilter<0> ef;
       fill(ef);
@@ -1244,9 +1330,11 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
         st = launch_filter_cfg<SimCfgFilterK32, false>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
       else if (g_scan_filter_cfg == 2)
         st = launch_filter_cfg<SimCfgFilter, false>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+      else if (g_scan_filter_cfg == 4)
+        st = launch_filter_cfg<SimCfgFilterNt, false>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
       else
 #endif
-        st = launch_filter_cfg<SimCfgFilterNt, false>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+        st = launch_filter_cfg<SimCfgFilterNt8, false>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
     }
   } else {
     epi.filter = 1;
@@ -1692,3 +1780,8 @@ static RpStatus topk_merge_impl(const float* scores, const int32_t* ids, const i
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
+
+#ifdef RP_PHASE_PROBE  // probe builds only (tools/probes/scan_phase.py): the host-side reader of the filter pass's phase timestamps
+#define RP_PROBE_EXPORT_SCAN
+#include "probes/rp_probe_exports.h"
+#endif

@@ -167,4 +167,20 @@ __host__ __device__ __forceinline__ float ord2f(uint32_t o) {
 #endif
 }
 
+// CUs of the current device: an attribute query (not the slow property struct), cached per device.  ONE source for the
+// planners below and for encode_pass's main_rows(): plans computed in two places must agree on a part that does not have
+// 256 CUs.
+inline int device_cu_count() {
+  static int cached_dev = -1, cached = 256;
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (dev == cached_dev) return cached;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) {
+    cached_dev = dev;
+    cached = v;
+    return v;
+  }
+  return 256;
+}
+
 }  // namespace rp

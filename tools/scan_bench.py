@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from reprover_amd import _lib
 import hip_helpers as hh
+if os.environ.get("RP_LIB"):  # a probe / experiment build instead of the product library
+    _lib.LIB_PATH = os.path.abspath(os.environ["RP_LIB"])
 lib = _lib.load()
 N, D, k = int(os.environ.get("N", 130000)), int(os.environ.get("D", 1472)), 100
 Bs = [int(b) for b in os.environ.get("BS", "256,128,1").split(",")]
