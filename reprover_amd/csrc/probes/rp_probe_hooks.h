@@ -22,6 +22,13 @@ __device__ unsigned long long g_handover_ts[8 * 64 * 3];  // [wave][kt][0..2]
   do {                                                                                                 \
     if (threadIdx.x == 0 && blockIdx.x < 16384) g_phase_ts[blockIdx.x * 4 + (slot)] = wall_clock64();  \
   } while (0)
+// the plain loop (gemm_tile) stamps like the pipelined one unless -DRP_PROBE_NO_PLAIN_TS (the scan's sample pass would
+// overwrite the per-workgroup sums of a persistent filter pass)
+#ifdef RP_PROBE_NO_PLAIN_TS
+#define RP_TS_PLAIN(slot) ((void)0)
+#else
+#define RP_TS_PLAIN(slot) RP_TS(slot)
+#endif
 #define RP_HTS(kt, which)                                                              \
   do {                                                                                 \
     if (blockIdx.x == 1000 && (threadIdx.x & 63) == 0 && (kt) < 64)                     \

@@ -23,7 +23,6 @@ thread_local std::string g_last_error;
 // ------------------------------------------------------------------------------------------
 // options
 // ------------------------------------------------------------------------------------------
-extern int g_scan_persist;
 extern int g_scan_cfg, g_scan_impl, g_scan_filter_cfg, g_scan_sample_cfg, g_scan_stride, g_scan_no_epilogue, g_scan_impl_force_new,
     g_scan_cap, g_train_dbg, g_train_wgrad_form;
 int g_gemm_group_m = 8;
@@ -220,7 +219,6 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
     g_train_wgrad_form = value;
     return RP_OK;
   }
-  if (!strcmp(name, "scan_persist")) { g_scan_persist = value != 0; return RP_OK; }  // tests: bf16 filter pass, one workgroup per tile
   if (!strcmp(name, "scan_cap")) { g_scan_cap = value; return RP_OK; }  // tests: forces the overflow -> dense contract
   if (!strcmp(name, "scan_force_new")) { g_scan_impl_force_new = value; return RP_OK; }
   if (!strcmp(name, "scan_impl")) {

@@ -36,6 +36,7 @@ namespace rp {
 #include "probes/rp_probe_hooks.h"
 #else
 #define RP_TS(slot) ((void)0)
+#define RP_TS_PLAIN(slot) ((void)0)
 #define RP_HTS(kt, which) ((void)0)
 #define RP_PROBE_STAGE_FILTER(kt, half) ((void)0)
 #define RP_PROBE_READS_DECL ((void)0)
@@ -149,7 +150,7 @@ template <class C, class Epilogue>
 __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand W, int K, int tile_m,
                                           int tile_n, Epilogue& epi, char* smem) {
   constexpr int BK = C::BK, NSTAGE = C::NSTAGE, FM = C::FM, FN = C::FN;
-  RP_TS(0);
+  RP_TS_PLAIN(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -219,7 +220,7 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
     else
       wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // every wave's share of tile kt is in LDS; tile kt-1 fully consumed
-    if (kt == 0) RP_TS(1);
+    if (kt == 0) RP_TS_PLAIN(1);
     if (kt + NSTAGE - 1 < nk) {
       int nb = buf + NSTAGE - 1;
       if (nb >= NSTAGE) nb -= NSTAGE;
@@ -273,11 +274,11 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
     if (++buf == NSTAGE) buf = 0;
   }
   __syncthreads();  // all waves done with LDS before an epilogue reuses it
-  RP_TS(2);
+  RP_TS_PLAIN(2);
 
   epi.template run<FM, FN>(acc, tile_m * C::BM + wave_row * (FM * 32), tile_n * C::BN + wave_col * (FN * 32), lane,
                            smem + wave * EPI_STAGE_BYTES);
-  RP_TS(3);
+  RP_TS_PLAIN(3);
 }
 
 // One-wave-per-SIMD variant (WM*WN = 4 waves, 128x128 per wave at BM = BN = 256): each fragment
@@ -592,14 +593,9 @@ __device__ __forceinline__ void gemm_tiles_persist(const GemmOperand A, const Ge
     char* base = smem + buf * C::STAGE_BYTES;
     if (half == 0) {
 #pragma unroll
-      for (int d = 0; d < C::A_DMA; ++d) {
-        if constexpr (C::AAUX == 2)  // (the scan's premise stream: nt policy)
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + A.k_off(kt, BK)), (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024),
-                                           16, 0, 2);
-        else
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + A.k_off(kt, BK)), (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024),
-                                           16, 0, 0);
-      }
+      for (int d = 0; d < C::A_DMA; ++d)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + A.k_off(kt, BK)), (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024),
+                                         16, 0, 0);
     } else {
 #pragma unroll
       for (int d = 0; d < C::W_DMA; ++d)

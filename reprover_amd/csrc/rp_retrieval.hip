@@ -68,7 +68,6 @@ int g_scan_sample_cfg = 0;   // experiments: 0 = 128x64x64 3-stage when D % 64 =
                              // (a 6-stage 64-wide ring - five slices in flight - measured the same 23.5 us: not the depth)
 int g_scan_stride = 0;       // experiments: > 0 overrides the sampling stride (power of two)
 int g_scan_cap = 0;          // tests: > 0 overrides the candidate-list capacity (forces the overflow -> dense contract)
-int g_scan_persist = 1;      // 0: the bf16 filter pass as one workgroup per tile whatever the tile count (tests: the two forms write the same bits)
 int g_scan_no_epilogue = 0;  // timing only: the filter pass drops every score (main loop in isolation)
 
 __device__ __forceinline__ uint64_t make_key(float score, int32_t id) {
@@ -306,8 +305,7 @@ struct EpiSimFilter {
     const float* s_tau = reinterpret_cast<const float*>(meta + M_TAU);
     const float* s_qs = reinterpret_cast<const float*>(meta + M_QS);
     const float* s_es = reinterpret_cast<const float*>(meta + M_ES);
-    // the tile from the wave's coordinates (the persistent launch walks several tiles per workgroup): premise block pb is the
-    // fb-th block that is not a multiple of stride
+    // the tile from the wave's coordinates: premise block pb is the fb-th block that is not a multiple of stride
     const int pb = m_base >> 8, qt = n_base >> 8;
     const int fb = pb - pb / stride - 1, wg_tile = fb * tiles_q + qt, q0 = qt << 8;
     const int pl0 = m_base - (pb << 8), ql0 = n_base - q0;  // this wave's first premise / query inside the tile
@@ -373,15 +371,10 @@ struct EpiSimFilter {
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        // the entry codes 16 i + r count up from a register written HERE: as compile-time constants the persistent tile loop
-        // hoisted all 64 of them out of the loop, live across it (spills)
-        // (the e4m3 form has one tile per workgroup, no loop, and no register to spare: constants there)
-        uint32_t code0 = (uint32_t)(i * 16);
-        if constexpr (FP8 == 0) asm volatile("v_mov_b32_e32 %0, %1" : "=v"(code0) : "n"(i * 16));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float sc = FP8 ? (acc[i][j][r] * qsv[j]) * esv[r] : acc[i][j][r];
-          append(sc, code0 + (uint32_t)r, j);
+          append(sc, (uint32_t)(i * 16 + r), j);
         }
       }
     }
@@ -404,36 +397,6 @@ __global__ __launch_bounds__(C::THREADS) void sim_filter_kernel(GemmOperand Eop,
   epi.meta_off = C::RING_BYTES;
   epi.p0 = pb * C::BM;
   gemm_tile_pipe<C>(Eop, Qop, K, pb, qt, epi, smem);
-}
-
-// The same pass as ONE workgroup per CU walking its share of the tiles (gemm_tiles_persist; bf16 index): the 476 tiles of
-// C2 are two per CU, and the second tile's first k-tile is requested under the first tile's epilogue - neither the turn-over
-// of the CU to a new workgroup (~3.5 us between a first-round workgroup's last stamp and its successor's first) nor the
-// wait for a first k-tile with nothing else to do (~3 us) is paid a second time.  Workgroup b (XCD b % 8) takes entries
-// b / 8, b / 8 + 32, ... of its XCD's contiguous range of tile ids, as the encoder's persistent launches do.  Same MFMA
-// chain per score: not a bit differs.
-template <class C, bool PAGED>
-__global__ __launch_bounds__(C::THREADS) void sim_filter_persist_kernel(GemmOperand Eop, GemmOperand Qop, int K, int n_tiles,
-                                                                        EpiSimFilter<0, PAGED> epi) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert(C::BM == SIM_PB && C::BN == 256 && C::WM == 2 && C::FP8 == 0, "filter tile geometry");
-  const int xcd = blockIdx.x & 7, per = (int)gridDim.x >> 3;  // (the grid is a multiple of 8)
-  const int q = n_tiles >> 3, r = n_tiles & 7;
-  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, cnt = q + (xcd < r ? 1 : 0);
-  int i = blockIdx.x >> 3;
-  const int tiles_q = epi.tiles_q, stride = epi.stride;
-  auto next_tile = [&](int& tm, int& tn) {
-    if (i >= cnt) return false;
-    const int logical = base + i, fb = logical / tiles_q;
-    i += per;
-    tm = fb + fb / (stride - 1) + 1;
-    tn = logical - fb * tiles_q;
-    return true;
-  };
-  epi.smem = smem;
-  epi.meta_off = PERSIST_META_OFF;
-  epi.p0 = 0;
-  gemm_tiles_persist<C>(Eop, Qop, K, next_tile, epi, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1141,18 +1104,6 @@ static RpStatus launch_filter_cfg(GemmOperand e, GemmOperand q, int D2, int n_bl
   RP_HIP(attr.ensure((const void*)sim_filter_kernel<C, PAGED>, LDS));
   const int tiles_q = (epi.B + C::BN - 1) / C::BN;
   ProfScope ps(stream, RP_K_SCAN);
-  if constexpr (C::FP8 == 0 && C::NSTAGE == 2 && C::BK == 64) {
-    // more tiles than CUs: one persistent workgroup per CU (K >= two k-tiles: its loop requests ring slot 1 unconditionally)
-    const int slots = device_cu_count() & ~7;
-    if (g_scan_persist && tiles_q * n_blocks > slots && slots >= 8 && D2 >= 2 * C::BK) {
-      static LdsAttrOnce pattr;
-      RP_HIP(pattr.ensure((const void*)sim_filter_persist_kernel<C, PAGED>, PERSIST_LDS_BYTES));
-      hipLaunchKernelGGL((sim_filter_persist_kernel<C, PAGED>), dim3(slots), dim3(C::THREADS), PERSIST_LDS_BYTES, stream, e, q, D2,
-                         tiles_q * n_blocks, epi);
-      RP_CHECK_LAUNCH();
-      return RP_OK;
-    }
-  }
   hipLaunchKernelGGL((sim_filter_kernel<C, PAGED>), dim3(tiles_q * n_blocks), dim3(C::THREADS), LDS, stream, e, q, D2, tiles_q,
                      stride, epi);
   RP_CHECK_LAUNCH();

@@ -496,30 +496,6 @@ def test_sim_topk_multi_gpu_shard_shape(gen, B, N):
     assert torch.equal(ids, ids2) and torch.equal(sc, sc2) and torch.equal(cnt, cnt2)
 
 
-@pytest.mark.parametrize("B,N,D", [(256, 130000, 1472), (2048, 16250, 1472), (300, 140000, 128), (512, 70000, 192)])
-def test_sim_topk_persistent_filter_pass_is_the_same_bits(gen, B, N, D):
-    """More filter tiles than CUs: the bf16 filter pass runs as one persistent workgroup per CU walking its tiles (the
-    next tile's first k-tile requested under the epilogue).  Option scan_persist = 0 launches one workgroup per tile:
-    ids, scores and counts must be identical - and equal to the dense plan's."""
-    rng = np.random.default_rng(B + N + D)
-    k = 100
-    E = torch.nn.functional.normalize(torch.randn(N, D, generator=gen, device="cuda"), dim=1).to(torch.bfloat16)
-    Q = torch.nn.functional.normalize(torch.randn(B, D, generator=gen, device="cuda"), dim=1).to(torch.bfloat16)
-    m, acc = hh.synth_masks(rng, N, B, F=900)
-    dm = hh.masks_to_device(m, Q.device)
-    lib = _lib.load()
-    a = hh.sim_topk(Q, E, k, dm, id_offset=7)
-    _lib.check(lib.rp_set_option(b"scan_persist", 0), "opt")
-    try:
-        b = hh.sim_topk(Q, E, k, dm, id_offset=7)
-    finally:
-        _lib.check(lib.rp_set_option(b"scan_persist", 1), "opt")
-    c = hh.sim_topk(Q, E, k, dm, id_offset=7, flags=_lib.RP_TOPK_DENSE)
-    for x, y, z in zip(a, b, c):
-        assert torch.equal(x, y) and torch.equal(x, z)
-    assert bool((a[2] == k).all())
-
-
 def test_build_file_bits_equals_host_transposition():
     """rp_build_file_bits (the per-batch accessibility operand built from the device-resident import closure and 4
     bytes per query) against Corpus.query_masks (the host-side transposition it replaces), incl. B not a multiple of 32."""
