@@ -23,6 +23,7 @@ thread_local std::string g_last_error;
 // ------------------------------------------------------------------------------------------
 // options
 // ------------------------------------------------------------------------------------------
+extern int g_scan_waves;
 extern int g_scan_cfg, g_scan_impl, g_scan_filter_cfg, g_scan_sample_cfg, g_scan_stride, g_scan_no_epilogue, g_scan_impl_force_new,
     g_scan_cap, g_train_dbg, g_train_wgrad_form;
 int g_gemm_group_m = 8;
@@ -210,6 +211,7 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   }
   if (!strcmp(name, "scan_filter_cfg")) { g_scan_filter_cfg = value; return RP_OK; }
   if (!strcmp(name, "scan_sample_cfg")) { g_scan_sample_cfg = value; return RP_OK; }
+  if (!strcmp(name, "scan_waves")) { g_scan_waves = value; return RP_OK; }
   if (!strcmp(name, "scan_stride")) { g_scan_stride = value; return RP_OK; }
   if (!strcmp(name, "train_dbg")) { g_train_dbg = value; return RP_OK; }
   if (!strcmp(name, "scan_no_epilogue")) { g_scan_no_epilogue = value; return RP_OK; }

@@ -50,6 +50,15 @@ typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 1, 0, 1> SimCfg8FilterTail;
 // one (32 KB) - the premise operand streams from HBM, not from L2 like an encoder GEMM's weights
 typedef GemmCfg<256, 256, 32, 2, 2, 4, 1> SimCfgFilterK32;
 typedef GemmCfg<128, 64, 64, 2, 2, 3> SimCfgSampleK64;
+// Round 6: the plain-loop tiles of this kernel run on EIGHT waves where their DMA split allows it (4 x 2: 32 queries per wave).
+// One wave per SIMD waited out every LDS round trip of its k-steps by itself (~900 cycles per 64-wide k-tile for 256 of MFMA);
+// with two per SIMD one multiplies while the other waits: sample pass at C2 23.3 -> 20.6 us, the first-generation filter pass
+// 90.7 -> 83.9 us for a single query and 129 -> 109 us at 64 queries, the same bits (profiles/r06_raw/exp24*).  The four-wave
+// forms stay selectable in probe builds (scan_waves = 4).
+typedef GemmCfg<128, 128, 64, 4, 2, 2> SimCfgQ128W8;
+typedef GemmCfg<128, 128, 32, 4, 2, 3> SimCfgQ128K32W8;
+typedef GemmCfg<128, 128, 32, 4, 2, 3, 0, 1> SimCfg8Q128W8;
+typedef GemmCfg<128, 64, 64, 4, 2, 3> SimCfgSampleK64W8;
 // the sample pass when MANY queries share few rows (its 256 x 128 tiles fill the chip): MFMA-bound there, on the pipelined loop
 typedef GemmCfg<256, 128, 64, 4, 2, 2, 1> SimCfgSampleBig;
 // default: the premise stream (read once, by one CU) carries the nt cache policy: -7 % filter time
@@ -64,6 +73,7 @@ int g_scan_impl = 0;  // 0: auto (pipelined filter kernel when the shape allows)
 int g_scan_impl_force_new = 0;  // experiments: second-generation filter for every batch size
 int g_scan_filter_cfg = 0;   // experiments: 0 = 8 waves, nt premise stream (default), 1 = 256x256x32 4-stage, 2 = 4 waves, default cache policy,
                              // 4 = 4 waves (the default until round 6)
+int g_scan_waves = 8;        // experiments: 4 = the four-wave forms of the plain-loop tiles
 int g_scan_sample_cfg = 0;   // experiments: 0 = 128x64x64 3-stage when D % 64 == 0 (default), 1 = 128x64x32 6-stage
                              // (a 6-stage 64-wide ring - five slices in flight - measured the same 23.5 us: not the depth)
 int g_scan_stride = 0;       // experiments: > 0 overrides the sampling stride (power of two)
@@ -1095,6 +1105,16 @@ static RpStatus launch_scan_cfg(GemmOperand q, GemmOperand e, int D2, int n_tile
   return RP_OK;
 }
 
+// the eight-wave form of a plain-loop tile (the four-wave one only in probe builds)
+template <class C4, class C8>
+static RpStatus launch_scan_w(GemmOperand q, GemmOperand e, int D2, int n_tiles, int stride, const EpiSim& epi, hipStream_t stream) {
+  static_assert(C4::BM == C8::BM && C4::BN == C8::BN && C4::BK == C8::BK && C4::FP8 == C8::FP8, "the same tile");
+#ifdef RP_EXPERIMENTS
+  if (g_scan_waves == 4) return launch_scan_cfg<C4>(q, e, D2, n_tiles, stride, epi, stream);
+#endif
+  return launch_scan_cfg<C8>(q, e, D2, n_tiles, stride, epi, stream);
+}
+
 template <class C, bool PAGED>
 static RpStatus launch_filter_cfg(GemmOperand e, GemmOperand q, int D2, int n_blocks, int stride,
                                   const EpiSimFilter<C::FP8, PAGED>& epi, hipStream_t stream) {
@@ -1192,12 +1212,12 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
     // single pass: dense keys of every premise tile, then one select
     if (fp8)
       st = (p.bm == 256) ? launch_scan_cfg<SimCfg8Q256>(qop, eop, D2, p.tiles_p, 1, epi, stream)
-                         : launch_scan_cfg<SimCfg8Q128>(qop, eop, D2, p.tiles_p, 1, epi, stream);
+                         : launch_scan_w<SimCfg8Q128, SimCfg8Q128W8>(qop, eop, D2, p.tiles_p, 1, epi, stream);
     else if (p.bm == 256)
       st = launch_scan_cfg<SimCfgQ256>(qop, eop, D2, p.tiles_p, 1, epi, stream);
     else
-      st = (D2 % 64 == 0) ? launch_scan_cfg<SimCfgQ128>(qop, eop, D2, p.tiles_p, 1, epi, stream)
-                          : launch_scan_cfg<SimCfgQ128K32>(qop, eop, D2, p.tiles_p, 1, epi, stream);
+      st = (D2 % 64 == 0) ? launch_scan_w<SimCfgQ128, SimCfgQ128W8>(qop, eop, D2, p.tiles_p, 1, epi, stream)
+                          : launch_scan_w<SimCfgQ128K32, SimCfgQ128K32W8>(qop, eop, D2, p.tiles_p, 1, epi, stream);
     if (st) return st;
     sa.out_keys = nullptr;
     sa.out_ld = 0;
@@ -1222,7 +1242,7 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
                              : launch_scan_cfg<SimCfgQ256>(qop, eop, D2, p.sample_blocks * (SIM_PB / SimCfgQ256::BN), p.stride, epi, stream))
        : fp8 ? launch_scan_cfg<SimCfg8Sample>(qop, eop, D2, n_sub, p.stride, epi, stream)
        : (g_scan_sample_cfg == 0 && D2 % 64 == 0)
-           ? launch_scan_cfg<SimCfgSampleK64>(qop, eop, D2, n_sub, p.stride, epi, stream)
+           ? launch_scan_w<SimCfgSampleK64, SimCfgSampleK64W8>(qop, eop, D2, n_sub, p.stride, epi, stream)
            : launch_scan_cfg<SimCfgSample>(qop, eop, D2, n_sub, p.stride, epi, stream);  // (D % 64 != 0: 32-wide K slices)
   if (st) return st;
   sa.out_keys = cand;
@@ -1292,12 +1312,12 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
     const int n_t = p.filter_blocks * (SIM_PB / 128);
     if (fp8)
       st = (p.bm == 256) ? launch_scan_cfg<SimCfg8Q256>(qop, eop, D2, n_t, p.stride, epi, stream)
-                         : launch_scan_cfg<SimCfg8Q128>(qop, eop, D2, n_t, p.stride, epi, stream);
+                         : launch_scan_w<SimCfg8Q128, SimCfg8Q128W8>(qop, eop, D2, n_t, p.stride, epi, stream);
     else if (p.bm == 256)
       st = launch_scan_cfg<SimCfgQ256>(qop, eop, D2, n_t, p.stride, epi, stream);
     else
-      st = (D2 % 64 == 0) ? launch_scan_cfg<SimCfgQ128>(qop, eop, D2, n_t, p.stride, epi, stream)
-                          : launch_scan_cfg<SimCfgQ128K32>(qop, eop, D2, n_t, p.stride, epi, stream);
+      st = (D2 % 64 == 0) ? launch_scan_w<SimCfgQ128, SimCfgQ128W8>(qop, eop, D2, n_t, p.stride, epi, stream)
+                          : launch_scan_w<SimCfgQ128K32, SimCfgQ128K32W8>(qop, eop, D2, n_t, p.stride, epi, stream);
   }
   if (st) return st;
   GatherArgs ga;
