@@ -1335,6 +1335,11 @@ def main():
             # the WHOLE rp_sim_topk call (sample + its select + filter + gather/select: four launches) over the same bytes
             "whole_call_ms": whole_scan_ms,
             "whole_call_frac": (scan_bytes / (whole_scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if whole_scan_ms else None,
+            # the same call timed WITHOUT the per-launch event pairs (calls back to back between two events, the 1-GPU entry of
+            # shard_call_us): what a caller waits for; the figure above carries ~3 us of event overhead per launch
+            "whole_call_ms_back_to_back": (shard_call_us or {}).get("1_gpus_256q_x_%drows" % N, 0.0) * 1e-3 or None,
+            "whole_call_frac_back_to_back": (scan_bytes / ((shard_call_us or {}).get("1_gpus_256q_x_%drows" % N) * 1e-6) / 1e9 / PEAK_HBM_GBS)
+            if (shard_call_us or {}).get("1_gpus_256q_x_%drows" % N) else None,
         },
         "roofline_hbm": roofline_hbm,
         "roofline_b1": roofline_b1,
