@@ -53,7 +53,7 @@ typedef GemmCfg<128, 64, 64, 2, 2, 3> SimCfgSampleK64;
 // Round 6: the plain-loop tiles of this kernel run on EIGHT waves where their DMA split allows it (4 x 2: 32 queries per wave).
 // One wave per SIMD waited out every LDS round trip of its k-steps by itself (~900 cycles per 64-wide k-tile for 256 of MFMA);
 // with two per SIMD one multiplies while the other waits: sample pass at C2 23.3 -> 20.6 us, the first-generation filter pass
-// 90.7 -> 83.9 us for a single query and 129 -> 109 us at 64 queries, the same bits (profiles/r06_raw/exp24*).  The four-wave
+// 90.7 -> 83.9 us for a single query and 129 -> 109 us at 64 queries, the same bits (profiles/r06_raw/exp28*).  The four-wave
 // forms stay selectable in probe builds (scan_waves = 4).
 typedef GemmCfg<128, 128, 64, 4, 2, 2> SimCfgQ128W8;
 typedef GemmCfg<128, 128, 32, 4, 2, 3> SimCfgQ128K32W8;
