@@ -182,18 +182,31 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
     const int kc = (lane % C::SLOTS) ^ C::swz(row);
     w_src[d] = W.ptr + W.row_off(tile_n * C::BN + row, kc);
   }
-  const int nk = K / BK;
+  // KTAIL (as in gemm_tile_pipe): K % BK is 0 or BK / 2; in the half tile the lanes whose 16-byte chunk lies beyond K fetch the
+  // chunk 64 bytes earlier (a duplicate, never out of bounds) and the upper k-steps' A fragments are zeroed by selects
+  static_assert(C::KTAIL == 0 || (BK == 64 && C::SLOTS == 8 && C::ROWS_PER_DMA == 8 && C::FP8 != 0), "KTAIL: 128-byte e4m3 rows");
+  const int nk = C::KTAIL != 0 ? (K + BK / 2) / BK : K / BK;
+  const bool has_tail = C::KTAIL != 0 && nk * BK != K;
+  const int fix_lane = (lane >> 2) & 1;
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * C::STAGE_BYTES;
     const int ke = kt;
+    const int fix_mask = (C::KTAIL != 0 && has_tail && kt == nk - 1) ? -1 : 0;  // (scalar)
 #pragma unroll
-    for (int d = 0; d < C::A_DMA; ++d)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[d] + A.k_off(ke, BK)),
-                                       (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024), 16, 0, 0);
+    for (int d = 0; d < C::A_DMA; ++d) {
+      const bf16_t* src = a_src[d] + A.k_off(ke, BK);
+      if constexpr (C::KTAIL != 0) src += ((((fix_lane ^ (wave * C::A_DMA + d)) & 1) ? -(BK / 2) : 0) & fix_mask);
+      if constexpr (C::AAUX == 2)  // (nt policy on a streamed A operand)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024), 16, 0, 2);
+      else
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + (wave * C::A_DMA + d) * 1024), 16, 0, 0);
+    }
 #pragma unroll
-    for (int d = 0; d < C::W_DMA; ++d)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[d] + W.k_off(ke, BK)),
-                                       (lds_ptr_t)(base + C::A_BYTES + (wave * C::W_DMA + d) * 1024), 16, 0, 0);
+    for (int d = 0; d < C::W_DMA; ++d) {
+      const bf16_t* src = w_src[d] + W.k_off(ke, BK);
+      if constexpr (C::KTAIL != 0) src += ((((fix_lane ^ (wave * C::W_DMA + d)) & 1) ? -(BK / 2) : 0) & fix_mask);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + C::A_BYTES + (wave * C::W_DMA + d) * 1024), 16, 0, 0);
+    }
   };
   constexpr int DMA_PER_STAGE = C::A_DMA + C::W_DMA;  // per wave
 
@@ -207,6 +220,7 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
     for (int f = 0; f < FN; ++f) b_off[f][ks] = C::off(wave_col * (FN * 32) + f * 32 + (lane & 31), ks * 2 + hi);
   }
 
+  if constexpr (has_prologue<Epilogue>::value) epi.prologue(smem + C::RING_BYTES, wave, lane, tile_n * C::BN);
   // prologue: NSTAGE-1 tiles in flight
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
@@ -241,6 +255,11 @@ __device__ __forceinline__ void gemm_tile(const GemmOperand A, const GemmOperand
           const i32x4 lo = *reinterpret_cast<const i32x4*>(sa + C::off(row, ks * 4 + hi * 2));
           const i32x4 up = *reinterpret_cast<const i32x4*>(sa + C::off(row, ks * 4 + hi * 2 + 1));
           af8[f] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+          if constexpr (C::KTAIL != 0) {  // the half tile multiplies its lower k-steps only: acc + (+0 x b) is acc bit for bit
+            const bool z = has_tail && kt == nk - 1 && ks >= C::ROW_BYTES / 128;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) af8[f][e] = z ? 0 : af8[f][e];
+          }
         }
 #pragma unroll
         for (int f = 0; f < FN; ++f) {

@@ -66,7 +66,14 @@ typedef GemmCfg<256, 256, 64, 2, 2, 2, 1, 0, 2> SimCfgFilterNt;
 // the same tile on EIGHT waves, 2 x 4 (128 premises x 64 queries per wave: the epilogue's runs - 64 scores per lane and query,
 // part = 2 x premise half + lane half - do not change): two waves per SIMD, one multiplies while the other waits
 typedef GemmCfg<256, 256, 64, 2, 4, 2, 1, 0, 2> SimCfgFilterNt8;
-// (the e4m3 tile stays on four waves: its 32-byte fragments, double-buffered, do not fit 256 registers beside 128 accumulators)
+// The e4m3 tile on eight waves runs the PLAIN loop: the pipelined loop's double-buffered 32-byte fragments do not fit 256
+// registers beside 128 accumulators (192 bytes of scratch), one fragment set does (188 registers) - and with two waves per SIMD
+// the compiler-scheduled loop beats the hand-pipelined four-wave one: filter pass at 256 queries x 130 k rows of 1536 e4m3
+// bytes 76.7 -> 64.1 us, x 1 M rows 545 -> 487 us (configs[4]), 2048 queries x 16 k rows 65 -> 57 us, the same bits
+// (profiles/r06_raw/exp29*); rows that end half a k-tile early (1472 bytes): SimCfg8FilterTailW8, the same half-tile handling
+// as the pipelined loop's (GemmCfg::KTAIL).
+typedef GemmCfg<256, 256, 64, 2, 4, 2, 0, 1> SimCfg8FilterW8;
+typedef GemmCfg<256, 256, 64, 2, 4, 2, 0, 1, 0, 1> SimCfg8FilterTailW8;  // rows that end half a k-tile early (1472 e4m3 bytes)
 constexpr int SIM_FILTER_META_BYTES = 5120;  // per-tile metadata behind the ring (EpiSimFilter::prologue)
 int g_scan_cfg = 0;   // 0: auto; 1: force 128-query tiles in the dense path
 int g_scan_impl = 0;  // 0: auto (pipelined filter kernel when the shape allows); 1: first-generation filter kernel
@@ -406,7 +413,10 @@ __global__ __launch_bounds__(C::THREADS) void sim_filter_kernel(GemmOperand Eop,
   epi.smem = smem;
   epi.meta_off = C::RING_BYTES;
   epi.p0 = pb * C::BM;
-  gemm_tile_pipe<C>(Eop, Qop, K, pb, qt, epi, smem);
+  if constexpr (C::PIPE != 0)
+    gemm_tile_pipe<C>(Eop, Qop, K, pb, qt, epi, smem);
+  else
+    gemm_tile<C>(Eop, Qop, K, pb, qt, epi, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1280,13 +1290,20 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
       fill(ef);
       ef.after_score = after_score;
       ef.after_id = after_id;
-      st = (D2 % 64 == 0) ? launch_filter_cfg<SimCfg8Filter, true>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
-                          : launch_filter_cfg<SimCfg8FilterTail, true>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+      st = (D2 % 64 == 0) ? launch_filter_cfg<SimCfg8FilterW8, true>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
+                          : launch_filter_cfg<SimCfg8FilterTailW8, true>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
     } else if (fp8) {
       EpiSimFilter<1> ef;
       fill(ef);
-      st = (D2 % 64 == 0) ? launch_filter_cfg<SimCfg8Filter, false>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
-                          : launch_filter_cfg<SimCfg8FilterTail, false>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+#ifdef RP_EXPERIMENTS
+      if (g_scan_filter_cfg == 4 && D2 % 64 == 0)
+        st = launch_filter_cfg<SimCfg8Filter, false>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+      else if (g_scan_filter_cfg == 4 && D2 % 64 != 0)
+        st = launch_filter_cfg<SimCfg8FilterTail, false>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
+      else
+#endif
+      st = (D2 % 64 == 0) ? launch_filter_cfg<SimCfg8FilterW8, false>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream)
+                          : launch_filter_cfg<SimCfg8FilterTailW8, false>(eop, qop, D2, p.filter_blocks, p.stride, ef, stream);
     } else if (after_id) {
       EpiSimFilter<0, true> ef;
       fill(ef);
