@@ -59,6 +59,8 @@ typedef GemmCfg<128, 128, 64, 4, 2, 2> SimCfgQ128W8;
 typedef GemmCfg<128, 128, 32, 4, 2, 3> SimCfgQ128K32W8;
 typedef GemmCfg<128, 128, 32, 4, 2, 3, 0, 1> SimCfg8Q128W8;
 typedef GemmCfg<128, 64, 64, 4, 2, 3> SimCfgSampleK64W8;
+typedef GemmCfg<128, 64, 64, 4, 2, 3, 0, 1> SimCfg8SampleK64W8;            // e4m3 rows of whole 128-byte k-tiles
+typedef GemmCfg<128, 64, 64, 4, 2, 3, 0, 1, 0, 1> SimCfg8SampleK64TailW8;  // ... ending half a k-tile early (1472 bytes)
 // the sample pass when MANY queries share few rows (its 256 x 128 tiles fill the chip): MFMA-bound there, on the pipelined loop
 typedef GemmCfg<256, 128, 64, 4, 2, 2, 1> SimCfgSampleBig;
 // default: the premise stream (read once, by one CU) carries the nt cache policy: -7 % filter time
@@ -1118,7 +1120,7 @@ static RpStatus launch_scan_cfg(GemmOperand q, GemmOperand e, int D2, int n_tile
 // the eight-wave form of a plain-loop tile (the four-wave one only in probe builds)
 template <class C4, class C8>
 static RpStatus launch_scan_w(GemmOperand q, GemmOperand e, int D2, int n_tiles, int stride, const EpiSim& epi, hipStream_t stream) {
-  static_assert(C4::BM == C8::BM && C4::BN == C8::BN && C4::BK == C8::BK && C4::FP8 == C8::FP8, "the same tile");
+  static_assert(C4::BM == C8::BM && C4::BN == C8::BN && C4::FP8 == C8::FP8, "the same tile");
 #ifdef RP_EXPERIMENTS
   if (g_scan_waves == 4) return launch_scan_cfg<C4>(q, e, D2, n_tiles, stride, epi, stream);
 #endif
@@ -1250,6 +1252,8 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
                          : (D2 % 64 == 0)
                              ? launch_scan_cfg<SimCfgSampleBig>(qop, eop, D2, p.sample_blocks * (SIM_PB / SimCfgSampleBig::BN), p.stride, epi, stream)
                              : launch_scan_cfg<SimCfgQ256>(qop, eop, D2, p.sample_blocks * (SIM_PB / SimCfgQ256::BN), p.stride, epi, stream))
+       : (fp8 && D2 % 64 == 0) ? launch_scan_w<SimCfg8Sample, SimCfg8SampleK64W8>(qop, eop, D2, n_sub, p.stride, epi, stream)
+       : (fp8 && D2 % 64 == 32 && D2 > 64) ? launch_scan_w<SimCfg8Sample, SimCfg8SampleK64TailW8>(qop, eop, D2, n_sub, p.stride, epi, stream)
        : fp8 ? launch_scan_cfg<SimCfg8Sample>(qop, eop, D2, n_sub, p.stride, epi, stream)
        : (g_scan_sample_cfg == 0 && D2 % 64 == 0)
            ? launch_scan_w<SimCfgSampleK64, SimCfgSampleK64W8>(qop, eop, D2, n_sub, p.stride, epi, stream)
