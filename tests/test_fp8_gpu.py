@@ -74,13 +74,15 @@ def test_sim_topk_fp8_exact_small_integers(B):
 
 
 @pytest.mark.parametrize("B,N,D,tol", [(256, 60000, 1536, 2e-6), (3, 20000, 1472, 2e-6), (130, 16000, 64, 2e-5),
-                                       (256, 60000, 1472, 2e-6), (300, 40000, 192, 1e-5)])
+                                       (256, 60000, 1472, 2e-6), (300, 40000, 192, 1e-5), (130, 16000, 128, 2e-5),
+                                       (40, 30000, 320, 1e-5)])
 def test_sim_topk_fp8_vs_oracle_scores(B, N, D, tol):
     """ByT5-base width (1536), ByT5-small width (1472 = 23 x 64: odd K-step count), minimum width (one
     K-step; unit vectors of 64 entries have a few large products that absorb the small ones in the fp32
     accumulator, hence the wider tolerance there).  B > 128 at D = 1472 / 192: e4m3 rows that end HALF a 128-byte k-tile
     early take the pipelined filter with its half last tile (GemmCfg::KTAIL); the dense plan (first-generation kernel, plain
-    K-ascending loop) must give the same bits."""
+    K-ascending loop) must give the same bits.  D = 128 / 320: the eight-wave sample tile of round 6 (128-byte k-tiles in a
+    3-deep ring) with ONE whole k-tile, and with two and a half at B <= 128 (first-generation filter behind it)."""
     rng = np.random.default_rng(6)
     k = 100
     E, Q = _unit_rows(rng, N, D), _unit_rows(rng, B, D)
