@@ -23,7 +23,7 @@ thread_local std::string g_last_error;
 // ------------------------------------------------------------------------------------------
 // options
 // ------------------------------------------------------------------------------------------
-extern int g_scan_waves;
+extern int g_scan_waves, g_scan_small_tiles;
 extern int g_scan_cfg, g_scan_impl, g_scan_filter_cfg, g_scan_sample_cfg, g_scan_stride, g_scan_no_epilogue, g_scan_impl_force_new,
     g_scan_cap, g_train_dbg, g_train_wgrad_form;
 int g_gemm_group_m = 8;
@@ -223,6 +223,11 @@ extern "C" RpStatus rp_set_option(const char* name, int32_t value) {
   }
   if (!strcmp(name, "scan_cap")) { g_scan_cap = value; return RP_OK; }  // tests: forces the overflow -> dense contract
   if (!strcmp(name, "scan_force_new")) { g_scan_impl_force_new = value; return RP_OK; }
+  if (!strcmp(name, "scan_small_tiles")) {  // tests: 0 = at most 32 queries on the 128-query tiles (must be the same bits)
+    RP_REQUIRE(value >= 0 && value <= 1, "scan_small_tiles out of range");
+    g_scan_small_tiles = value;
+    return RP_OK;
+  }
   if (!strcmp(name, "scan_impl")) {
     RP_REQUIRE(value >= 0 && value <= 1, "scan_impl out of range");
     g_scan_impl = value;

@@ -61,6 +61,19 @@ typedef GemmCfg<128, 128, 32, 4, 2, 3, 0, 1> SimCfg8Q128W8;
 typedef GemmCfg<128, 64, 64, 4, 2, 3> SimCfgSampleK64W8;
 typedef GemmCfg<128, 64, 64, 4, 2, 3, 0, 1> SimCfg8SampleK64W8;            // e4m3 rows of whole 128-byte k-tiles
 typedef GemmCfg<128, 64, 64, 4, 2, 3, 0, 1, 0, 1> SimCfg8SampleK64TailW8;  // ... ending half a k-tile early (1472 bytes)
+// At most 32 queries (a single proof state: retrieve()): 32 queries x 128 premises.  The 128-query tile spent half of every stage's
+// LDS-DMA on a query panel of which one row is a query, and kept one 16-KB premise slice per workgroup in flight - 32 KB per CU
+// where HBM at its latency wants ~64 (8 TB/s x 2 us / 256 CUs).  Here a stage is 4 KB of queries + 16 KB of premises, the ring is
+// four deep and two workgroups share a CU: ~96 KB of the premise stream in flight per CU.  Same MFMA, same K order: the same bits.
+typedef GemmCfg<32, 128, 64, 1, 4, 4> SimCfgQ32;
+typedef GemmCfg<32, 128, 64, 1, 4, 4, 0, 1> SimCfg8Q32;            // e4m3 rows of whole 128-byte k-tiles
+typedef GemmCfg<32, 128, 64, 1, 4, 4, 0, 1, 0, 1> SimCfg8Q32Tail;  // ... ending half a k-tile early (1472 bytes)
+// the sample pass of such a call: 32 queries x 64 premises on two waves, six stages of 12 KB
+typedef GemmCfg<32, 64, 64, 1, 2, 6> SimCfgSampleQ32;
+typedef GemmCfg<32, 64, 64, 1, 2, 6, 0, 1> SimCfg8SampleQ32;
+typedef GemmCfg<32, 64, 64, 1, 2, 6, 0, 1, 0, 1> SimCfg8SampleQ32Tail;
+typedef GemmCfg<32, 128, 64, 1, 4, 3> SimCfgQ32S3;   // (probe builds: three stages)
+typedef GemmCfg<32, 256, 64, 1, 4, 4> SimCfgQ32P256;  // (probe builds: 256 premises per tile, one workgroup per CU)
 // the sample pass when MANY queries share few rows (its 256 x 128 tiles fill the chip): MFMA-bound there, on the pipelined loop
 typedef GemmCfg<256, 128, 64, 4, 2, 2, 1> SimCfgSampleBig;
 // default: the premise stream (read once, by one CU) carries the nt cache policy: -7 % filter time
@@ -82,8 +95,9 @@ int g_scan_impl = 0;  // 0: auto (pipelined filter kernel when the shape allows)
 int g_scan_impl_force_new = 0;  // experiments: second-generation filter for every batch size
 int g_scan_filter_cfg = 0;   // experiments: 0 = 8 waves, nt premise stream (default), 1 = 256x256x32 4-stage, 2 = 4 waves, default cache policy,
                              // 4 = 4 waves (the default until round 6)
+int g_scan_small_tiles = 1;  // tests / A-B runs: 0 = calls of at most 32 queries on the 128-query sample and filter tiles, as before round 6
 int g_scan_waves = 8;        // experiments: 4 = the four-wave forms of the plain-loop tiles
-int g_scan_sample_cfg = 0;   // experiments: 0 = 128x64x64 3-stage when D % 64 == 0 (default), 1 = 128x64x32 6-stage
+int g_scan_sample_cfg = 0;   // experiments: 0 = 128x64x64 3-stage when D % 64 == 0, 32x64x64 at <= 32 queries (default), 1 = 128x64x32 6-stage
                              // (a 6-stage 64-wide ring - five slices in flight - measured the same 23.5 us: not the depth)
 int g_scan_stride = 0;       // experiments: > 0 overrides the sampling stride (power of two)
 int g_scan_cap = 0;          // tests: > 0 overrides the candidate-list capacity (forces the overflow -> dense contract)
@@ -1252,9 +1266,13 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
                          : (D2 % 64 == 0)
                              ? launch_scan_cfg<SimCfgSampleBig>(qop, eop, D2, p.sample_blocks * (SIM_PB / SimCfgSampleBig::BN), p.stride, epi, stream)
                              : launch_scan_cfg<SimCfgQ256>(qop, eop, D2, p.sample_blocks * (SIM_PB / SimCfgQ256::BN), p.stride, epi, stream))
+       : (fp8 && B <= 32 && D2 % 64 == 0 && g_scan_small_tiles) ? launch_scan_cfg<SimCfg8SampleQ32>(qop, eop, D2, n_sub, p.stride, epi, stream)
+       : (fp8 && B <= 32 && D2 % 64 == 32 && D2 > 64 && g_scan_small_tiles)
+           ? launch_scan_cfg<SimCfg8SampleQ32Tail>(qop, eop, D2, n_sub, p.stride, epi, stream)
        : (fp8 && D2 % 64 == 0) ? launch_scan_w<SimCfg8Sample, SimCfg8SampleK64W8>(qop, eop, D2, n_sub, p.stride, epi, stream)
        : (fp8 && D2 % 64 == 32 && D2 > 64) ? launch_scan_w<SimCfg8Sample, SimCfg8SampleK64TailW8>(qop, eop, D2, n_sub, p.stride, epi, stream)
        : fp8 ? launch_scan_cfg<SimCfg8Sample>(qop, eop, D2, n_sub, p.stride, epi, stream)
+       : (g_scan_sample_cfg == 0 && g_scan_small_tiles && B <= 32 && D2 % 64 == 0) ? launch_scan_cfg<SimCfgSampleQ32>(qop, eop, D2, n_sub, p.stride, epi, stream)
        : (g_scan_sample_cfg == 0 && D2 % 64 == 0)
            ? launch_scan_w<SimCfgSampleK64, SimCfgSampleK64W8>(qop, eop, D2, n_sub, p.stride, epi, stream)
            : launch_scan_cfg<SimCfgSample>(qop, eop, D2, n_sub, p.stride, epi, stream);  // (D % 64 != 0: 32-wide K slices)
@@ -1331,11 +1349,23 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
   } else {
     epi.filter = 1;
     const int n_t = p.filter_blocks * (SIM_PB / 128);
-    if (fp8)
+    if (fp8 && B <= 32 && D2 % 64 == 0 && g_scan_small_tiles)
+      st = launch_scan_cfg<SimCfg8Q32>(qop, eop, D2, n_t, p.stride, epi, stream);
+    else if (fp8 && B <= 32 && D2 % 64 == 32 && D2 > 64 && g_scan_small_tiles)
+      st = launch_scan_cfg<SimCfg8Q32Tail>(qop, eop, D2, n_t, p.stride, epi, stream);
+    else if (fp8)
       st = (p.bm == 256) ? launch_scan_cfg<SimCfg8Q256>(qop, eop, D2, n_t, p.stride, epi, stream)
                          : launch_scan_w<SimCfg8Q128, SimCfg8Q128W8>(qop, eop, D2, n_t, p.stride, epi, stream);
     else if (p.bm == 256)
       st = launch_scan_cfg<SimCfgQ256>(qop, eop, D2, n_t, p.stride, epi, stream);
+#ifdef RP_EXPERIMENTS
+    else if (B <= 32 && D2 % 64 == 0 && g_scan_filter_cfg == 9)
+      st = launch_scan_cfg<SimCfgQ32S3>(qop, eop, D2, n_t, p.stride, epi, stream);
+    else if (B <= 32 && D2 % 64 == 0 && g_scan_filter_cfg == 10)
+      st = launch_scan_cfg<SimCfgQ32P256>(qop, eop, D2, p.filter_blocks, p.stride, epi, stream);
+#endif
+    else if (B <= 32 && D2 % 64 == 0 && g_scan_small_tiles)
+      st = launch_scan_cfg<SimCfgQ32>(qop, eop, D2, n_t, p.stride, epi, stream);
     else
       st = (D2 % 64 == 0) ? launch_scan_w<SimCfgQ128, SimCfgQ128W8>(qop, eop, D2, n_t, p.stride, epi, stream)
                           : launch_scan_w<SimCfgQ128K32, SimCfgQ128K32W8>(qop, eop, D2, n_t, p.stride, epi, stream);

@@ -354,6 +354,38 @@ def test_sim_topk_sample_gives_no_bound(gen):
     assert torch.equal(mi, ids) and torch.equal(ms, sc) and torch.equal(mc, cnt)
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("B,N,D,k", [(1, 130000, 1472, 100), (7, 60000, 1536, 100), (32, 45000, 192, 10), (19, 30000, 128, 100),
+                                     (33, 30000, 1472, 100)])
+def test_sim_topk_small_query_tiles_are_the_same_bits(gen, fp8, B, N, D, k):
+    """At most 32 queries (a single proof state): the 32-query sample / filter tiles of round 6 (32 x 64 on two waves, 32 x 128 on
+    four waves with a 4-deep ring; e4m3 rows of 1472 bytes end half a k-tile early) against the 128-query tiles every batch ran on
+    before (option scan_small_tiles = 0): identical ids, scores and counts, and the properties of an exact masked
+    top-k.  B = 33 is the first size that stays on the 128-query tiles either way."""
+    rng = np.random.default_rng(B + N + D)
+    E, Q = _rand_bf16(gen, N, D, scale=D ** -0.5), _rand_bf16(gen, B, D, scale=D ** -0.5)
+    m, acc = hh.synth_masks(rng, N, B, F=max(2, N // 40))
+    dm = hh.masks_to_device(m, Q.device)
+    lib = _lib.load()
+    if fp8:
+        E8, es = hh.quantize_e4m3(E)
+        Q8, qs = hh.quantize_e4m3(Q)
+        run = lambda: hh.sim_topk_fp8(Q8, qs, E8, es, k, dm, id_offset=7)  # noqa: E731
+    else:
+        run = lambda: hh.sim_topk(Q, E, k, dm, id_offset=7)  # noqa: E731
+    a = run()
+    try:
+        _lib.check(lib.rp_set_option(b"scan_small_tiles", 0), "opt")
+        b = run()
+    finally:
+        _lib.check(lib.rp_set_option(b"scan_small_tiles", 1), "opt")
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    if not fp8:
+        hh.check_topk_against_scores(a[0].cpu().numpy() - 7, a[1].cpu().numpy(), a[2].cpu().numpy(), _scores(Q, E), acc, k,
+                                     tol=1e-4)
+
+
 @pytest.mark.parametrize("B,N,D,k", [(256, 50000, 1472, 100), (300, 33000, 64, 10), (1, 40000, 192, 100),
                                      (37, 70000, 128, 1000), (600, 20000, 256, 3)])
 def test_sim_topk_filter_generations_agree(gen, B, N, D, k):

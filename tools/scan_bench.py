@@ -13,7 +13,7 @@ N, D, k = int(os.environ.get("N", 130000)), int(os.environ.get("D", 1472)), 100
 Bs = [int(b) for b in os.environ.get("BS", "256,128,1").split(",")]
 cfgs = [int(c) for c in os.environ.get("CFGS", "0").split(",")]
 impls = [int(c) for c in os.environ.get("IMPLS", "0,1").split(",")]  # scan_impl: 0 = pipelined filter kernel, 1 = first generation
-# CASES="name=val,name=val|name=val|..." : extra rp_set_option settings, one timing line per case (reset to 0 afterwards)
+# CASES="name=val,name=val|name=val|..." : extra rp_set_option settings, one timing line per case (reset to the option's default afterwards)
 cases = [c for c in os.environ.get("CASES", "").split("|")] if os.environ.get("CASES") is not None else [""]
 dense_too = os.environ.get("DENSE", "1") == "1"
 modes = [int(c) for c in os.environ.get("FP8", "0,1").split(",")]
@@ -72,4 +72,4 @@ for B in Bs:
                       f"E-stream {byts/scan_s/1e9:7.1f} GB/s  MFMA {2.0*B*N*D/scan_s/1e12:6.1f} TFLOP/s  QPS {B/(tot*1e-3):10.0f}  "
                       f"cnt_ok {bool((out_c == k).all())}  [{case}]{' BLOCKED' if bl else ''} chk {int(out_i.sum())}", flush=True)
                 for kv in filter(None, case.split(",")):
-                    _lib.check(lib.rp_set_option(kv.split("=")[0].encode(), 0), "opt")
+                    _lib.check(lib.rp_set_option(kv.split("=")[0].encode(), {"scan_small_tiles": 1, "scan_waves": 8}.get(kv.split("=")[0], 0)), "opt")
