@@ -72,6 +72,11 @@ typedef GemmCfg<32, 128, 64, 1, 4, 4, 0, 1, 0, 1> SimCfg8Q32Tail;  // ... ending
 typedef GemmCfg<32, 64, 64, 1, 2, 6> SimCfgSampleQ32;
 typedef GemmCfg<32, 64, 64, 1, 2, 6, 0, 1> SimCfg8SampleQ32;
 typedef GemmCfg<32, 64, 64, 1, 2, 6, 0, 1, 0, 1> SimCfg8SampleQ32Tail;
+// 33 .. 64 queries (the reference's evaluation batch, datamodule.py's eval_batch_size 64): 64 queries x 128 premises on eight waves,
+// 24-KB stages three deep, two workgroups per CU - 64 KB of premises in flight per CU where the 128-query tile keeps 32
+typedef GemmCfg<64, 128, 64, 2, 4, 3> SimCfgQ64;
+typedef GemmCfg<64, 128, 64, 2, 4, 3, 0, 1> SimCfg8Q64;
+typedef GemmCfg<64, 128, 64, 2, 4, 3, 0, 1, 0, 1> SimCfg8Q64Tail;
 typedef GemmCfg<32, 128, 64, 1, 4, 3> SimCfgQ32S3;   // (probe builds: three stages)
 typedef GemmCfg<32, 256, 64, 1, 4, 4> SimCfgQ32P256;  // (probe builds: 256 premises per tile, one workgroup per CU)
 // the sample pass when MANY queries share few rows (its 256 x 128 tiles fill the chip): MFMA-bound there, on the pipelined loop
@@ -95,7 +100,7 @@ int g_scan_impl = 0;  // 0: auto (pipelined filter kernel when the shape allows)
 int g_scan_impl_force_new = 0;  // experiments: second-generation filter for every batch size
 int g_scan_filter_cfg = 0;   // experiments: 0 = 8 waves, nt premise stream (default), 1 = 256x256x32 4-stage, 2 = 4 waves, default cache policy,
                              // 4 = 4 waves (the default until round 6)
-int g_scan_small_tiles = 1;  // tests / A-B runs: 0 = calls of at most 32 queries on the 128-query sample and filter tiles, as before round 6
+int g_scan_small_tiles = 1;  // tests / A-B runs: 0 = calls of at most 64 queries on the 128-query sample and filter tiles, as before round 6
 int g_scan_waves = 8;        // experiments: 4 = the four-wave forms of the plain-loop tiles
 int g_scan_sample_cfg = 0;   // experiments: 0 = 128x64x64 3-stage when D % 64 == 0, 32x64x64 at <= 32 queries (default), 1 = 128x64x32 6-stage
                              // (a 6-stage 64-wide ring - five slices in flight - measured the same 23.5 us: not the depth)
@@ -1353,6 +1358,10 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
       st = launch_scan_cfg<SimCfg8Q32>(qop, eop, D2, n_t, p.stride, epi, stream);
     else if (fp8 && B <= 32 && D2 % 64 == 32 && D2 > 64 && g_scan_small_tiles)
       st = launch_scan_cfg<SimCfg8Q32Tail>(qop, eop, D2, n_t, p.stride, epi, stream);
+    else if (fp8 && B <= 64 && D2 % 64 == 0 && g_scan_small_tiles)
+      st = launch_scan_cfg<SimCfg8Q64>(qop, eop, D2, n_t, p.stride, epi, stream);
+    else if (fp8 && B <= 64 && D2 % 64 == 32 && D2 > 64 && g_scan_small_tiles)
+      st = launch_scan_cfg<SimCfg8Q64Tail>(qop, eop, D2, n_t, p.stride, epi, stream);
     else if (fp8)
       st = (p.bm == 256) ? launch_scan_cfg<SimCfg8Q256>(qop, eop, D2, n_t, p.stride, epi, stream)
                          : launch_scan_w<SimCfg8Q128, SimCfg8Q128W8>(qop, eop, D2, n_t, p.stride, epi, stream);
@@ -1366,6 +1375,8 @@ static RpStatus sim_topk_impl(const void* Q, const void* E, const float* q_scale
 #endif
     else if (B <= 32 && D2 % 64 == 0 && g_scan_small_tiles)
       st = launch_scan_cfg<SimCfgQ32>(qop, eop, D2, n_t, p.stride, epi, stream);
+    else if (B <= 64 && D2 % 64 == 0 && g_scan_small_tiles)
+      st = launch_scan_cfg<SimCfgQ64>(qop, eop, D2, n_t, p.stride, epi, stream);
     else
       st = (D2 % 64 == 0) ? launch_scan_w<SimCfgQ128, SimCfgQ128W8>(qop, eop, D2, n_t, p.stride, epi, stream)
                           : launch_scan_w<SimCfgQ128K32, SimCfgQ128K32W8>(qop, eop, D2, n_t, p.stride, epi, stream);

@@ -356,12 +356,12 @@ def test_sim_topk_sample_gives_no_bound(gen):
 
 @pytest.mark.parametrize("fp8", [False, True])
 @pytest.mark.parametrize("B,N,D,k", [(1, 130000, 1472, 100), (7, 60000, 1536, 100), (32, 45000, 192, 10), (19, 30000, 128, 100),
-                                     (33, 30000, 1472, 100)])
+                                     (33, 30000, 1472, 100), (64, 130000, 1472, 100), (50, 20000, 192, 10), (65, 30000, 1536, 100)])
 def test_sim_topk_small_query_tiles_are_the_same_bits(gen, fp8, B, N, D, k):
     """At most 32 queries (a single proof state): the 32-query sample / filter tiles of round 6 (32 x 64 on two waves, 32 x 128 on
     four waves with a 4-deep ring; e4m3 rows of 1472 bytes end half a k-tile early) against the 128-query tiles every batch ran on
     before (option scan_small_tiles = 0): identical ids, scores and counts, and the properties of an exact masked
-    top-k.  B = 33 is the first size that stays on the 128-query tiles either way."""
+    top-k.  33 .. 64 queries take the 64-query filter tile (eight waves, three stages); B = 65 stays on the 128-query tiles either way."""
     rng = np.random.default_rng(B + N + D)
     E, Q = _rand_bf16(gen, N, D, scale=D ** -0.5), _rand_bf16(gen, B, D, scale=D ** -0.5)
     m, acc = hh.synth_masks(rng, N, B, F=max(2, N // 40))
